@@ -1,0 +1,144 @@
+"""ctypes binding of libbore_hip.so (C-ABI: include/bore_hip.h).
+
+The shared library is built IN-TREE (bore_amd/csrc/libbore_hip.so) by
+``build_native()`` / ``__graft_entry__.build()`` with ``hipcc --offload-arch=gfx950``.
+There is no CPU fallback: if the library is missing, every compute entry point
+raises ``RuntimeError`` -- the product path never routes around the HIP kernels.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import shutil
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "libbore_hip.so")
+SOURCES = ["bore_hip.hip"]
+HEADER = os.path.join(os.path.dirname(_HERE), "include", "bore_hip.h")
+
+MAX_LAYERS = 8
+BATCH_MAX = 64
+
+ACT = dict(linear=0, relu=1, elu=2, sigmoid=3, tanh=4)
+TRANSFORM = dict(identity=0, sigmoid=1, exp=2)
+
+# every symbol include/bore_hip.h declares (tests check the .so exports them all)
+EXPORTS = [
+    "bore_abi_version", "bore_last_error", "bore_param_count", "bore_mlp_forward",
+    "bore_mlp_value_and_input_grad", "bore_mlp_fit", "bore_mlp_evaluate",
+    "bore_shuffle_perm",
+]
+
+
+class MlpDesc(C.Structure):
+    _fields_ = [("input_dim", C.c_int32), ("n_layers", C.c_int32),
+                ("units", C.c_int32 * MAX_LAYERS), ("act", C.c_int32 * MAX_LAYERS),
+                ("l2_kernel", C.c_float * MAX_LAYERS), ("l2_bias", C.c_float * MAX_LAYERS)]
+
+
+class AdamCfg(C.Structure):
+    _fields_ = [("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float),
+                ("eps", C.c_float)]
+
+
+def hipcc_path():
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    return None
+
+
+def build_native(force=False, verbose=False):
+    """Compile libbore_hip.so for gfx950.  Cross-compiles without a GPU."""
+    srcs = [os.path.join(CSRC, s) for s in SOURCES]
+    deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [HEADER]
+    if (not force and os.path.exists(LIB_PATH)
+            and os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(d) for d in deps)):
+        return LIB_PATH
+    hipcc = hipcc_path()
+    if hipcc is None:
+        raise RuntimeError("hipcc not found: cannot build libbore_hip.so")
+    cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC",
+           "-Wall", "-Wextra", *srcs, "-o", LIB_PATH]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True, cwd=CSRC)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    """The loaded library (loads on first use; raises if it was never built)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
+            "g.build()'` (hipcc --offload-arch=gfx950).  bore_amd has no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp, i32, i64, u64 = C.c_void_p, C.c_int, C.c_int64, C.c_uint64
+    dp = C.POINTER(MlpDesc)
+    L.bore_abi_version.restype = i32
+    L.bore_last_error.restype = C.c_char_p
+    L.bore_param_count.restype = i64
+    L.bore_param_count.argtypes = [dp]
+    L.bore_mlp_forward.argtypes = [dp, i32, vp, vp, i64, i32, vp, vp]
+    L.bore_mlp_value_and_input_grad.argtypes = [dp, i32, vp, vp, i64, i32, i32, vp, vp, vp]
+    L.bore_mlp_fit.argtypes = [dp, i32, vp, vp, vp, vp, vp, vp, i64, i32, i32, vp, u64, i64,
+                               i64, C.POINTER(AdamCfg), vp, vp]
+    L.bore_mlp_evaluate.argtypes = [dp, i32, vp, vp, vp, i64, vp, vp, vp]
+    L.bore_shuffle_perm.argtypes = [u64, i64, i32, i64, i32, i64, vp, vp]
+    for name in EXPORTS:
+        if name not in ("bore_last_error", "bore_param_count"):
+            getattr(L, name).restype = i32
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        raise RuntimeError(f"libbore_hip: {lib().bore_last_error().decode()} (code {rc})")
+
+
+def make_desc(input_dim, units, acts, l2_kernel=None, l2_bias=None):
+    n = len(units)
+    if not 1 <= n <= MAX_LAYERS:
+        raise ValueError(f"1..{MAX_LAYERS} Dense layers supported, got {n}")
+    d = MlpDesc()
+    d.input_dim = int(input_dim)
+    d.n_layers = n
+    for i in range(n):
+        d.units[i] = int(units[i])
+        a = acts[i] if acts[i] is not None else "linear"
+        if a not in ACT:
+            raise ValueError(f"unsupported activation {a!r}; supported: {sorted(ACT)}")
+        d.act[i] = ACT[a]
+        d.l2_kernel[i] = float(l2_kernel[i]) if l2_kernel and l2_kernel[i] else 0.0
+        d.l2_bias[i] = float(l2_bias[i]) if l2_bias and l2_bias[i] else 0.0
+    return d
+
+
+def require_gpu():
+    import torch
+    if not torch.cuda.is_available():
+        raise RuntimeError("bore_amd needs a ROCm GPU (MI355X / gfx950): torch.cuda.is_available() "
+                           "is False and there is no CPU fallback")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """Device pointer of a contiguous torch tensor (None -> NULL)."""
+    if t is None:
+        return C.c_void_p(0)
+    assert t.is_cuda and t.is_contiguous()
+    return C.c_void_p(t.data_ptr())

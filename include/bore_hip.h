@@ -1,0 +1,151 @@
+/*
+ * bore_hip.h -- C-ABI of libbore_hip.so, the MI355X (gfx950) implementation of the
+ * BORE density-ratio classifier hot path: MLP fit (BCE + Adam) and the batched
+ * value / input-gradient operator used by the multi-start argmax.
+ *
+ * The reference (ltiao/bore v1.5.0) is pure Python over TensorFlow/Keras and SciPy;
+ * it has no FFI of its own.  Each entry point below replaces the TF op sequence a
+ * reference call site triggers; the Python host (bore_amd/) binds them with ctypes
+ * (INTEGRATION.md shows the stub a reference maintainer would add).
+ *
+ * Conventions
+ *   - plain C, no C++/torch types; every pointer marked "device" is a HIP device
+ *     pointer owned by the caller (torch.Tensor.data_ptr()); `stream` is a
+ *     hipStream_t passed as void* (NULL = default stream).  Calls only ENQUEUE
+ *     work; the caller synchronises the stream.
+ *   - return 0 on success, <0 on error (BORE_E_*); bore_last_error() returns the
+ *     message for the calling thread.  Nothing throws across the boundary.
+ *   - row-major; network arithmetic is fp32; coordinates crossing the SciPy
+ *     boundary are fp64 (bore/decorators.py:54-61).
+ *   - parameters are ONE packed fp32 vector per model in Keras get_weights()
+ *     order [W1 (in,out), b1, W2, b2, ...]; `n_models` models are stored back to
+ *     back (leading replica dimension: independent BO loops).
+ */
+#ifndef BORE_HIP_H
+#define BORE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BORE_ABI_VERSION 1
+#define BORE_MAX_LAYERS 8
+#define BORE_BATCH_MAX 64 /* rows per tile == wavefront width */
+
+enum bore_status {
+  BORE_OK = 0,
+  BORE_E_INVALID = -1,   /* bad argument */
+  BORE_E_UNSUPPORTED = -2, /* shape does not fit this build's kernels (e.g. LDS budget) */
+  BORE_E_HIP = -3        /* HIP runtime error (message has hipGetErrorString) */
+};
+
+/* Keras activation names accepted by Dense(activation=...) on this path
+ * (README.rst:61-63 relu/sigmoid; plugins/hpbandster/base.py:27 elu). */
+enum bore_activation {
+  BORE_ACT_LINEAR = 0,
+  BORE_ACT_RELU = 1,
+  BORE_ACT_ELU = 2,
+  BORE_ACT_SIGMOID = 3,
+  BORE_ACT_TANH = 4
+};
+
+/* TRANSFORMS of bore/plugins/hpbandster/base.py:18; the objective handed to
+ * L-BFGS-B is transform(-f(x)) (bore/mixins.py:20). */
+enum bore_transform {
+  BORE_T_IDENTITY = 0,
+  BORE_T_SIGMOID = 1,
+  BORE_T_EXP = 2
+};
+
+/* A stack of Dense layers (bore/models.py:9-33; README.rst:60-63). */
+typedef struct bore_mlp_desc {
+  int32_t input_dim;                 /* D */
+  int32_t n_layers;                  /* number of Dense layers, 1..BORE_MAX_LAYERS */
+  int32_t units[BORE_MAX_LAYERS];    /* output width of each layer */
+  int32_t act[BORE_MAX_LAYERS];      /* enum bore_activation */
+  float l2_kernel[BORE_MAX_LAYERS];  /* kernel_regularizer=l2(f): f (0 = none) */
+  float l2_bias[BORE_MAX_LAYERS];    /* bias_regularizer=l2(f) */
+} bore_mlp_desc;
+
+/* tf.keras.optimizers.Adam hyper-parameters (README.rst:66 optimizer="adam":
+ * lr 1e-3, beta 0.9/0.999, epsilon 1e-7). */
+typedef struct bore_adam_cfg {
+  float lr, beta1, beta2, eps;
+} bore_adam_cfg;
+
+int bore_abi_version(void);
+const char *bore_last_error(void);
+
+/* Number of fp32 parameters P of the packed vector; <0 on a bad descriptor. */
+int64_t bore_param_count(const bore_mlp_desc *desc);
+
+/*
+ * Keras predict / model(x)  (bore/mixins.py:50 screening; bore/base.py:40).
+ *   theta  device [n_models][P]
+ *   X      device fp32 [n_models][n_rows][D], or [n_rows][D] shared by every
+ *          model when x_shared != 0
+ *   out    device fp32 [n_models][n_rows]  (units[last] must be 1)
+ */
+int bore_mlp_forward(const bore_mlp_desc *desc, int n_models, const float *theta,
+                     const float *X, int64_t n_rows, int x_shared, float *out,
+                     void *stream);
+
+/*
+ * convert(model, transform) evaluated on a batch of points (bore/base.py:7-42,
+ * bore/decorators.py:24-79).  negate != 0 gives the minimisation form
+ * transform(-f(x)) that MaximizableMixin hands to SciPy (bore/mixins.py:20);
+ * negate == 0 gives transform(f(x)) (BatchMaximizableMixin._func_max,
+ * bore/mixins.py:98).
+ *   X     device fp64 [n_models][n_rows][D]
+ *   val   device fp32 [n_models][n_rows]
+ *   grad  device fp64 [n_models][n_rows][D]     d val / d x (dtype of the watched input)
+ */
+int bore_mlp_value_and_input_grad(const bore_mlp_desc *desc, int n_models,
+                                  const float *theta, const double *X,
+                                  int64_t n_rows, int transform, int negate,
+                                  float *val, double *grad, void *stream);
+
+/*
+ * Keras fit(X, z, epochs, batch_size) for n_models independent models in ONE
+ * launch (README.rst:93; bore/plugins/hpbandster/base.py:184): per epoch one
+ * shuffle, ceil(N/batch) steps of {forward, mean BCE-from-logits, backward,
+ * Adam}; the last partial batch still steps (bore/math.py:12-13).
+ *   theta, adam_m, adam_v  device fp32 [n_models][P], updated in place
+ *   adam_t   device int64 [n_models], Adam iteration counters, advanced by
+ *            epochs*ceil(N/batch) (state persists across calls: warm start)
+ *   X        device fp32 [n_models][N][D];  z device fp32 [n_models][N] in {0,1}
+ *   perm     device int32 [n_models][epochs][N] explicit shuffles, or NULL to
+ *            draw them in-kernel from (seed, model_index0+model, epoch0+epoch)
+ *            -- the same stream bore_shuffle_perm() writes out
+ *   epoch_loss  device fp32 [n_models][epochs] or NULL: Keras' logged loss
+ *   batch_size  1..BORE_BATCH_MAX
+ */
+int bore_mlp_fit(const bore_mlp_desc *desc, int n_models, float *theta,
+                 float *adam_m, float *adam_v, int64_t *adam_t, const float *X,
+                 const float *z, int64_t N, int epochs, int batch_size,
+                 const int32_t *perm, uint64_t seed, int64_t model_index0,
+                 int64_t epoch0, const bore_adam_cfg *adam, float *epoch_loss,
+                 void *stream);
+
+/*
+ * Keras evaluate(X, z): mean BCE(+l2) and binary accuracy (threshold 0.5 on the
+ * model output) over all N rows (bore/plugins/hpbandster/base.py:186).
+ *   loss, acc  device fp32 [n_models]
+ */
+int bore_mlp_evaluate(const bore_mlp_desc *desc, int n_models, const float *theta,
+                      const float *X, const float *z, int64_t N, float *loss,
+                      float *acc, void *stream);
+
+/* The in-kernel shuffle stream of bore_mlp_fit, written out:
+ * perm device int32 [n_models][epochs][N]. */
+int bore_shuffle_perm(uint64_t seed, int64_t model_index0, int n_models,
+                      int64_t epoch0, int epochs, int64_t N, int32_t *perm,
+                      void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BORE_HIP_H */

@@ -1,0 +1,48 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden_labels():
+    return np.load(os.path.join(GOLDEN, "ref_labels.npz"))
+
+
+@pytest.fixture(scope="session")
+def golden_misc():
+    import json
+    with open(os.path.join(GOLDEN, "ref_misc.json")) as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="session")
+def golden_mlp():
+    import json
+    with open(os.path.join(GOLDEN, "mlp_golden.json")) as f:
+        meta = json.load(f)
+    return meta, np.load(os.path.join(GOLDEN, "mlp_golden.npz"))
+
+
+def golden_params(npz, name, key, n_layers):
+    return [npz[f"{name}_{key}_{i}"].copy() for i in range(2 * n_layers)]
+
+
+@pytest.fixture(scope="session")
+def gpu():
+    """Device + loaded HIP library; GPU tests fail (not skip) if either is missing."""
+    import torch
+    from bore_amd import _lib
+    assert torch.cuda.is_available(), "GPU test on a box without a GPU"
+    _lib.lib()
+    return torch.device("cuda", 0)

@@ -1,0 +1,60 @@
+"""The C-ABI library builds for gfx950, loads, and exports every symbol the header
+declares.  No compute call is made (no GPU needed)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from bore_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def built():
+    if not os.path.exists(_lib.LIB_PATH):
+        if _lib.hipcc_path() is None:
+            pytest.fail("libbore_hip.so missing and no hipcc to build it")
+        _lib.build_native()
+    return _lib.lib()
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, "include", "bore_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(bore_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_header_and_binding_agree():
+    assert header_functions() == sorted(_lib.EXPORTS)
+
+
+def test_library_exports_every_declared_symbol(built):
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    for name in header_functions():
+        assert hasattr(raw, name), name
+    assert built.bore_abi_version() == 1
+
+
+def test_param_count_and_descriptor_validation(built):
+    d = _lib.make_desc(2, [16, 16, 1], ["relu", "relu", "sigmoid"])
+    assert built.bore_param_count(ctypes.byref(d)) == 337
+    d = _lib.make_desc(6, [32, 32, 1], ["relu", "relu", None])
+    assert built.bore_param_count(ctypes.byref(d)) == 1313
+    d = _lib.make_desc(16, [64, 64, 64, 1], ["relu"] * 3 + [None])
+    assert built.bore_param_count(ctypes.byref(d)) == 9473
+    d = _lib.make_desc(32, [128, 128, 1], ["relu"] * 2 + [None])
+    assert built.bore_param_count(ctypes.byref(d)) == 20865
+    bad = _lib.MlpDesc()
+    assert built.bore_param_count(ctypes.byref(bad)) < 0
+    assert b"bore_mlp_desc" in built.bore_last_error()
+    with pytest.raises(ValueError):
+        _lib.make_desc(2, [4] * 9, ["relu"] * 9)
+    with pytest.raises(ValueError):
+        _lib.make_desc(2, [4, 1], ["swish", None])
+
+
+def test_struct_layout_matches_header():
+    assert ctypes.sizeof(_lib.MlpDesc) == 4 * (2 + 4 * _lib.MAX_LAYERS)
+    assert ctypes.sizeof(_lib.AdamCfg) == 16

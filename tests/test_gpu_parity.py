@@ -1,0 +1,299 @@
+"""HIP path vs the CPU oracle on the same seeded inputs, through the C-ABI
+(bore_amd.ops -> libbore_hip.so).  Everything here needs an MI355X.
+
+Stated tolerances (fp32 network arithmetic, different summation order than numpy/BLAS):
+  forward / value     |hip - oracle32| <= 2e-6 + 2e-5*|ref|   (and vs the float64 goldens 2e-5)
+  input gradient      <= 2e-5 + 2e-4*|ref|
+  fit, few steps      weights/m/v within 5e-6 + 1e-4*|ref| of the float64 trajectory
+  integer work (shuffle stream, Adam step counter): bit-exact
+"""
+import numpy as np
+import pytest
+import torch
+
+from bore_amd import _lib, ops, shuffle
+from conftest import golden_params
+from oracle import bore_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def pack(params):
+    return np.concatenate([np.asarray(p, dtype=np.float32).reshape(-1) for p in params])
+
+
+def unpack(flat, D, units):
+    out, off, k = [], 0, D
+    for u in units:
+        out.append(flat[off:off + k * u].reshape(k, u)); off += k * u
+        out.append(flat[off:off + u]); off += u
+        k = u
+    return out
+
+
+def dev(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.cuda().contiguous()
+
+
+def rand_model(rs, D, units):
+    p = O.glorot_uniform_params(D, units, rs)
+    for i in range(1, len(p), 2):
+        p[i] = rs.normal(scale=0.1, size=p[i].shape).astype(np.float32)
+    return p
+
+
+CONFIGS = [  # BASELINE.json configs 1-3 and 5 (fp32), plus ragged shapes
+    (2, [16, 16, 1], ["relu", "relu", "sigmoid"]),
+    (6, [32, 32, 1], ["relu", "relu", "linear"]),
+    (16, [64, 64, 64, 1], ["relu", "relu", "relu", "linear"]),
+    (32, [128, 128, 1], ["relu", "relu", "linear"]),
+    (3, [32, 32, 32, 1], ["elu", "elu", "elu", "linear"]),
+    (1, [1], ["sigmoid"]),
+    (5, [7, 3, 1], ["tanh", "sigmoid", "linear"]),
+]
+
+
+@pytest.mark.parametrize("D,units,acts", CONFIGS)
+@pytest.mark.parametrize("n_rows", [1, 63, 64, 65, 1024])
+def test_forward_matches_oracle(gpu, D, units, acts, n_rows):
+    rs = np.random.RandomState(D * 1000 + n_rows)
+    p = rand_model(rs, D, units)
+    X = rs.uniform(-1, 1, size=(n_rows, D)).astype(np.float32)
+    desc = _lib.make_desc(D, units, acts)
+    out = ops.mlp_forward(desc, dev(pack(p)).reshape(1, -1), dev(X)).cpu().numpy()[0]
+    ref = O.predict(p, acts, X)[:, 0]
+    ref64 = O.predict(p, acts, X, dtype=np.float64)[:, 0]
+    np.testing.assert_allclose(out, ref, rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(out, ref64, rtol=2e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize("D,units,acts", CONFIGS)
+@pytest.mark.parametrize("transform,negate", [("identity", True), ("sigmoid", True),
+                                               ("exp", True), ("sigmoid", False)])
+def test_value_and_input_grad_matches_oracle(gpu, D, units, acts, transform, negate):
+    rs = np.random.RandomState(D)
+    p = rand_model(rs, D, units)
+    R = 131
+    X = rs.uniform(0, 1, size=(R, D))
+    desc = _lib.make_desc(D, units, acts)
+    val, grad = ops.mlp_value_and_input_grad(desc, dev(pack(p)).reshape(1, -1),
+                                             dev(X).reshape(1, R, D), transform, negate)
+    assert val.dtype == torch.float32 and grad.dtype == torch.float64
+    val, grad = val.cpu().numpy()[0], grad.cpu().numpy()[0]
+    if negate:
+        rv, rg = O.value_and_input_grad(p, acts, X, transform, dtype=np.float64)
+    else:  # T(f) (the SVGD form): closed-form value, central differences for the gradient
+        sig = lambda f: 1 / (1 + np.exp(-f))
+        f64 = lambda Z: O.predict(p, acts, Z, dtype=np.float64)[:, 0]
+        rv = sig(f64(X))
+        h = 1e-6
+        rg = np.zeros_like(X)
+        for j in range(D):
+            e = np.zeros(D)
+            e[j] = h
+            rg[:, j] = (sig(f64(X + e)) - sig(f64(X - e))) / (2 * h)
+    np.testing.assert_allclose(val, rv, rtol=2e-5, atol=2e-6)
+    tol = dict(rtol=2e-4, atol=2e-5) if negate else dict(rtol=2e-3, atol=2e-4)
+    np.testing.assert_allclose(grad, rg, **tol)
+    # rows are independent: a single row evaluates to the same bits as inside the batch
+    v1, g1 = ops.mlp_value_and_input_grad(desc, dev(pack(p)).reshape(1, -1),
+                                          dev(X[5:6]).reshape(1, 1, D), transform, negate)
+    assert v1.cpu().numpy()[0, 0] == val[5] and np.array_equal(g1.cpu().numpy()[0, 0], grad[5])
+
+
+@pytest.mark.parametrize("name", ["branin", "hartmann", "plugin", "hpo16"])
+def test_fit_reproduces_float64_golden_trajectory(gpu, golden_mlp, name):
+    meta, g = golden_mlp
+    c = meta[name]
+    n = len(c["units"])
+    l2 = [c["l2"] or 0.0] * (n - 1) + [0.0]
+    desc = _lib.make_desc(c["D"], c["units"], c["acts"], l2, l2)
+    p0 = golden_params(g, name, "p0", n)
+    theta = dev(pack(p0)).reshape(1, -1)
+    m, v = torch.zeros_like(theta), torch.zeros_like(theta)
+    t = torch.zeros(1, dtype=torch.int64, device="cuda")
+    X = dev(g[f"{name}_X"], torch.float32).reshape(1, c["N"], c["D"])
+    z = dev(g[f"{name}_z"].astype(np.float32)).reshape(1, c["N"])
+    perm = dev(g[f"{name}_perms"].astype(np.int32)).reshape(1, c["epochs"], c["N"])
+    hist = ops.mlp_fit(desc, theta, m, v, t, X, z, c["epochs"], c["batch"], perm=perm)
+    assert int(t[0]) == int(g[f"{name}_t"])                      # bit-exact step counter
+    np.testing.assert_allclose(hist.cpu().numpy()[0], g[f"{name}_hist"], rtol=2e-5)
+    got = unpack(theta.cpu().numpy()[0], c["D"], c["units"])
+    gm = unpack(m.cpu().numpy()[0], c["D"], c["units"])
+    gv = unpack(v.cpu().numpy()[0], c["D"], c["units"])
+    for i in range(2 * n):
+        np.testing.assert_allclose(got[i], g[f"{name}_p1_{i}"], rtol=1e-4, atol=5e-6, err_msg=f"theta {i}")
+        np.testing.assert_allclose(gm[i], g[f"{name}_m_{i}"], rtol=1e-3, atol=1e-7, err_msg=f"m {i}")
+        np.testing.assert_allclose(gv[i], g[f"{name}_v_{i}"], rtol=1e-3, atol=1e-10, err_msg=f"v {i}")
+    # evaluate / predict / value+grad at the golden trained weights
+    p1 = golden_params(g, name, "p1", n)
+    th1 = dev(pack(p1)).reshape(1, -1)
+    loss, acc = ops.mlp_evaluate(desc, th1, X, z)
+    assert float(loss[0]) == pytest.approx(g[f"{name}_eval"][0], rel=2e-5)
+    assert float(acc[0]) == pytest.approx(g[f"{name}_eval"][1], abs=1e-6)
+    Xq = g[f"{name}_Xq"]
+    pred = ops.mlp_forward(desc, th1, dev(Xq, torch.float32)).cpu().numpy()[0]
+    np.testing.assert_allclose(pred, g[f"{name}_pred"][:, 0], rtol=2e-5, atol=2e-6)
+    val, grad = ops.mlp_value_and_input_grad(desc, th1, dev(Xq).reshape(1, *Xq.shape), c["transform"])
+    np.testing.assert_allclose(val.cpu().numpy()[0], g[f"{name}_val"], rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(grad.cpu().numpy()[0], g[f"{name}_grad"], rtol=2e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("N,B", [(1, 64), (10, 64), (64, 64), (65, 64), (110, 64), (7, 1), (100, 32),
+                                 (129, 64)])
+def test_fit_edge_shapes_against_oracle(gpu, N, B):
+    """Empty-ish and ragged inputs: single row, exact batch, batch + 1 (a 1-row partial
+    batch still steps, bore/math.py:12-13), batch_size 1."""
+    rs = np.random.RandomState(N * 7 + B)
+    D, units, acts = 2, [16, 16, 1], ["relu", "relu", "sigmoid"]
+    p = rand_model(rs, D, units)
+    X = rs.uniform(size=(N, D))
+    z = rs.uniform(size=N) < 0.3
+    E = 4
+    perms = np.stack([rs.permutation(N) for _ in range(E)])
+    p64 = [a.astype(np.float64) for a in p]
+    st = O.AdamState(p64)
+    hist = O.fit(p64, acts, st, X.astype(np.float32), z, perms, batch_size=B, dtype=np.float64)
+    desc = _lib.make_desc(D, units, acts)
+    theta = dev(pack(p)).reshape(1, -1)
+    m, v = torch.zeros_like(theta), torch.zeros_like(theta)
+    t = torch.zeros(1, dtype=torch.int64, device="cuda")
+    h = ops.mlp_fit(desc, theta, m, v, t, dev(X, torch.float32).reshape(1, N, D),
+                    dev(z.astype(np.float32)).reshape(1, N), E, B,
+                    perm=dev(perms.astype(np.int32)).reshape(1, E, N))
+    assert int(t[0]) == st.t == E * O.steps_per_epoch(N, B)
+    np.testing.assert_allclose(h.cpu().numpy()[0], hist, rtol=5e-5)
+    np.testing.assert_allclose(theta.cpu().numpy()[0], pack(p64), rtol=2e-4, atol=1e-5)
+
+
+def test_warm_start_equals_one_long_fit(gpu):
+    """Adam slots and the step counter persist across calls."""
+    rs = np.random.RandomState(4)
+    D, units, acts = 2, [16, 16, 1], ["relu", "relu", "sigmoid"]
+    desc = _lib.make_desc(D, units, acts)
+    p = pack(rand_model(rs, D, units))
+    N, E = 80, 6
+    X = dev(rs.uniform(size=(1, N, D)), torch.float32)
+    z = dev((rs.uniform(size=(1, N)) < 0.25).astype(np.float32))
+    perm = dev(np.stack([rs.permutation(N) for _ in range(E)]).astype(np.int32)).reshape(1, E, N)
+
+    def run(splits):
+        th = dev(p).reshape(1, -1)
+        m, v = torch.zeros_like(th), torch.zeros_like(th)
+        t = torch.zeros(1, dtype=torch.int64, device="cuda")
+        e0 = 0
+        for e in splits:
+            ops.mlp_fit(desc, th, m, v, t, X, z, e, 64, perm=perm[:, e0:e0 + e].contiguous())
+            e0 += e
+        return th.cpu().numpy(), m.cpu().numpy(), v.cpu().numpy(), int(t[0])
+
+    a, b = run([E]), run([2, 1, 3])
+    assert a[3] == b[3] == 12
+    for x, y in zip(a[:3], b[:3]):
+        # identical arithmetic except beta^t restarts from pow() instead of a running product
+        np.testing.assert_allclose(x, y, rtol=1e-6, atol=1e-9)
+
+
+def test_shuffle_stream_is_bit_exact_and_drives_fit(gpu):
+    for N in (1, 10, 64, 65, 110, 300):
+        d = ops.shuffle_perm(1234, 3, 5, N, model_index0=2, epoch0=7).cpu().numpy()
+        h = shuffle.permutations(1234, 3, 5, N, model_index0=2, epoch0=7)
+        assert np.array_equal(d, h), N
+    # perm=None inside fit == the same stream passed explicitly (same kernel arithmetic)
+    rs = np.random.RandomState(0)
+    D, units, acts = 2, [16, 16, 1], ["relu", "relu", "sigmoid"]
+    desc = _lib.make_desc(D, units, acts)
+    L, N, E = 3, 110, 5
+    th0 = np.stack([pack(rand_model(rs, D, units)) for _ in range(L)])
+    X = dev(rs.uniform(size=(L, N, D)), torch.float32)
+    z = dev((rs.uniform(size=(L, N)) < 0.25).astype(np.float32))
+    outs = []
+    for explicit in (False, True):
+        th = dev(th0)
+        m, v = torch.zeros_like(th), torch.zeros_like(th)
+        t = torch.zeros(L, dtype=torch.int64, device="cuda")
+        perm = ops.shuffle_perm(99, L, E, N, model_index0=4, epoch0=20) if explicit else None
+        loss = ops.mlp_fit(desc, th, m, v, t, X, z, E, 64, perm=perm, seed=99, model_index0=4,
+                           epoch0=20)
+        outs.append((th.cpu().numpy(), loss.cpu().numpy()))
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+
+
+def test_replicas_are_independent_and_equal_single_model_runs(gpu):
+    """The leading n_models dimension: L models in one launch == L launches of one."""
+    rs = np.random.RandomState(1)
+    D, units, acts = 6, [32, 32, 1], ["relu", "relu", "linear"]
+    desc = _lib.make_desc(D, units, acts)
+    L, N, E = 5, 100, 3
+    th0 = np.stack([pack(rand_model(rs, D, units)) for _ in range(L)])
+    X = rs.uniform(size=(L, N, D)).astype(np.float32)
+    z = (rs.uniform(size=(L, N)) < 0.3).astype(np.float32)
+    perm = np.stack([[rs.permutation(N) for _ in range(E)] for _ in range(L)]).astype(np.int32)
+    th = dev(th0); m = torch.zeros_like(th); v = torch.zeros_like(th)
+    t = torch.zeros(L, dtype=torch.int64, device="cuda")
+    ops.mlp_fit(desc, th, m, v, t, dev(X), dev(z), E, 64, perm=dev(perm))
+    Xq = rs.uniform(size=(L, 70, D))
+    val, grad = ops.mlp_value_and_input_grad(desc, th, dev(Xq), "sigmoid")
+    pred = ops.mlp_forward(desc, th, dev(Xq.astype(np.float32)))
+    shared = ops.mlp_forward(desc, th, dev(Xq[0].astype(np.float32)))
+    for l in range(L):
+        th1 = dev(th0[l:l + 1]); m1 = torch.zeros_like(th1); v1 = torch.zeros_like(th1)
+        t1 = torch.zeros(1, dtype=torch.int64, device="cuda")
+        ops.mlp_fit(desc, th1, m1, v1, t1, dev(X[l:l + 1]), dev(z[l:l + 1]), E, 64,
+                    perm=dev(perm[l:l + 1]))
+        assert torch.equal(th1[0], th[l]) and torch.equal(m1[0], m[l]) and torch.equal(v1[0], v[l])
+        v_, g_ = ops.mlp_value_and_input_grad(desc, th1, dev(Xq[l:l + 1]), "sigmoid")
+        assert torch.equal(v_[0], val[l]) and torch.equal(g_[0], grad[l])
+        assert torch.equal(ops.mlp_forward(desc, th1, dev(Xq[l].astype(np.float32)))[0], pred[l])
+        assert torch.equal(ops.mlp_forward(desc, th1, dev(Xq[0].astype(np.float32)))[0], shared[l])
+
+
+def test_long_fit_learns_and_tracks_oracle_loss(gpu):
+    """BASELINE config 1 shape: 200 epochs, batch 64, N = 110 (400 Adam steps)."""
+    rs = np.random.RandomState(0)
+    D, units, acts = 2, [16, 16, 1], ["relu", "relu", "sigmoid"]
+    desc = _lib.make_desc(D, units, acts)
+    p = rand_model(rs, D, units)
+    N, E = 110, 200
+    X = rs.uniform(size=(N, D))
+    y = np.sum((X - 0.3) ** 2, axis=1)
+    z, _ = O.labels(y, 0.25)
+    perms = shuffle.permutations(5, 1, E, N)[0]
+    p32 = [a.copy() for a in p]
+    st = O.AdamState(p32)
+    hist = O.fit(p32, acts, st, X, z, perms, batch_size=64)
+    th = dev(pack(p)).reshape(1, -1); m = torch.zeros_like(th); v = torch.zeros_like(th)
+    t = torch.zeros(1, dtype=torch.int64, device="cuda")
+    h = ops.mlp_fit(desc, th, m, v, t, dev(X, torch.float32).reshape(1, N, D),
+                    dev(z.astype(np.float32)).reshape(1, N), E, 64, seed=5).cpu().numpy()[0]
+    assert int(t[0]) == 400
+    assert h[-1] < 0.6 * h[0]
+    np.testing.assert_allclose(h, hist, rtol=2e-3, atol=2e-4)       # 400 chained fp32 steps
+    pred = ops.mlp_forward(desc, th, dev(X, torch.float32)).cpu().numpy()[0]
+    np.testing.assert_allclose(pred, O.predict(p32, acts, X)[:, 0], atol=5e-3)
+
+
+def test_bad_arguments_fail_loudly(gpu):
+    desc = _lib.make_desc(2, [4, 1], ["relu", "sigmoid"])
+    P = ops.param_count(desc)
+    th = torch.zeros(1, P, device="cuda")
+    with pytest.raises(ValueError):
+        ops.mlp_forward(desc, th, torch.zeros(5, 3, device="cuda"))
+    with pytest.raises(TypeError):
+        ops.mlp_forward(desc, th, torch.zeros(5, 2, device="cuda", dtype=torch.float64))
+    with pytest.raises(TypeError):
+        ops.mlp_forward(desc, th.cpu(), torch.zeros(5, 2))
+    X = torch.zeros(1, 5, 2, device="cuda"); z = torch.zeros(1, 5, device="cuda")
+    t = torch.zeros(1, dtype=torch.int64, device="cuda")
+    with pytest.raises(ValueError, match="perm"):
+        ops.mlp_fit(desc, th, th.clone(), th.clone(), t, X, z, 1, 64,
+                    perm=torch.full((1, 1, 5), 7, dtype=torch.int32, device="cuda"))
+    with pytest.raises(RuntimeError, match="batch_size"):
+        ops.mlp_fit(desc, th, th.clone(), th.clone(), t, X, z, 1, 128)
+    d2 = _lib.make_desc(2, [4, 2], ["relu", None])
+    with pytest.raises(RuntimeError, match="1 unit"):
+        ops.mlp_forward(d2, torch.zeros(1, ops.param_count(d2), device="cuda"), X[0])
+    assert ops.mlp_forward(desc, th, torch.zeros(0, 2, device="cuda")).shape == (1, 0)

@@ -1,0 +1,149 @@
+"""Host-side mirror of the reference interface: everything that runs without a GPU."""
+import numpy as np
+import pytest
+
+import bore_amd
+from bore_amd import shuffle, transforms
+from bore_amd.data import Record, classification_labels
+from bore_amd.layers import Adam, BinaryCrossentropy, Dense, l2, resolve_loss, resolve_optimizer
+from bore_amd.math import ceil_divide, epochs_per_iteration, steps_per_epoch
+from bore_amd.models import (DenseSequential, MaximizableDenseSequential, MaximizableSequential,
+                             Sequential)
+from bore_amd.optimizers.utils import from_bounds
+
+
+def test_record_matches_reference_vectors(golden_labels, golden_misc):
+    g = golden_labels
+    for k, case in enumerate(golden_misc["label_cases"]):
+        rec = Record()
+        for xi, yi in zip(g[f"X{k}"], g[f"y{k}"]):
+            rec.append(x=xi, y=yi)
+        assert rec.size() == case["n"]
+        X, z = rec.load_classification_data(case["gamma"])
+        assert X.dtype == np.float64 and z.dtype == np.bool_
+        assert np.array_equal(X, g[f"Xo{k}"]) and np.array_equal(z, g[f"z{k}"])
+        assert np.array_equal(classification_labels(g[f"y{k}"], case["gamma"]), g[f"z{k}"])
+        dup = np.array([rec.is_duplicate(p) for p in g[f"probe{k}"]])
+        assert np.array_equal(dup, g[f"dup{k}"])
+
+
+def test_math_matches_reference_vectors(golden_misc):
+    for n, b, s in golden_misc["steps_per_epoch"]:
+        assert steps_per_epoch(n, b) == s
+    assert ceil_divide(7, 2) == 4 and ceil_divide(8, 2) == 4
+    assert epochs_per_iteration(1000, 10, 64) == 1000 and epochs_per_iteration(1000, 100, 64) == 500
+
+
+def test_from_bounds_matches_reference_vectors(golden_misc):
+    from scipy.optimize import Bounds
+    for c in golden_misc["from_bounds"]:
+        (lo, hi), dim = from_bounds([tuple(b) for b in c["bounds"]])
+        assert list(lo) == c["low"] and list(hi) == c["high"] and dim == c["dim"]
+        assert isinstance(lo, tuple)
+        (lo, hi), dim = from_bounds(Bounds(np.array(c["low"]), np.array(c["high"])))
+        assert list(lo) == c["low_b"] and dim == c["dim_b"]
+
+
+def test_transforms_registry():
+    assert set(bore_amd.TRANSFORMS) == {"identity", "sigmoid", "exp"}
+    t = transforms.resolve("sigmoid")
+    assert t.name == "sigmoid" and not t.negate and t.negated().negate
+    assert transforms.resolve(None) is transforms.identity
+    assert transforms.resolve(np.exp).name == "exp"
+    np.testing.assert_allclose(transforms.exp.negated()(1.0), np.exp(-1.0))
+    with pytest.raises(ValueError):
+        transforms.resolve("softplus")
+    with pytest.raises(TypeError):
+        transforms.resolve(lambda u: u * 2)
+
+
+def test_dense_descriptor_and_compile_arguments():
+    d = Dense(16, activation="relu", input_dim=2, kernel_regularizer=l2(1e-3),
+              bias_regularizer=l2(1e-4))
+    assert (d.units, d.activation, d.input_dim) == (16, "relu", 2)
+    assert d.l2_kernel == pytest.approx(1e-3) and d.l2_bias == pytest.approx(1e-4)
+    assert Dense(3).activation == "linear"
+    with pytest.raises(ValueError):
+        Dense(4, activation="gelu")
+    assert resolve_optimizer("adam") == Adam()
+    assert Adam().epsilon == 1e-7                     # Keras, not torch (1e-8)
+    assert resolve_loss("binary_crossentropy").from_logits is False
+    assert resolve_loss(BinaryCrossentropy(from_logits=True)).from_logits is True
+    with pytest.raises(NotImplementedError):
+        resolve_optimizer("sgd")
+    with pytest.raises(NotImplementedError):
+        resolve_loss("mse")
+
+
+def test_dense_sequential_reproduces_the_reference_off_by_one():
+    m = DenseSequential(input_dim=2, output_dim=1, num_layers=2, num_units=32)
+    assert [l.units for l in m.layers] == [32, 32, 32, 1]       # bore/models.py:16-19
+    assert m.count_params() == 2 * 32 + 32 + 2 * (32 * 32 + 32) + 33
+    m = MaximizableDenseSequential(transform="exp", input_dim=3, output_dim=1, num_layers=1,
+                                   num_units=8, layer_kws=dict(activation="elu"))
+    assert [l.units for l in m.layers] == [8, 8, 1] and m.transform.name == "exp"
+    assert m.layers[0].activation == "elu" and m.layers[-1].activation == "linear"
+    assert m._func_min.transform.negate and m._func_min.transform.name == "exp"
+
+
+def test_first_positional_argument_is_transform():
+    # bore/mixins.py:16: MaximizableMixin.__init__(self, transform=..., *args, **kwargs)
+    m = MaximizableSequential("sigmoid")
+    assert m.transform.name == "sigmoid"
+    m.add(Dense(16, activation="relu"))
+    m.add(Dense(1, activation="sigmoid"))
+    lines = []
+    m.summary(print_fn=lines.append)
+    assert any("dense_1" in s for s in lines)
+
+
+def test_compile_loss_consistency_errors():
+    m = Sequential([Dense(4, activation="relu", input_dim=2), Dense(1)])
+    m.compile(optimizer="adam", loss="binary_crossentropy")
+    with pytest.raises(NotImplementedError):
+        m._check_loss()                    # probabilities loss on a linear output
+    m.compile(optimizer="adam", loss=BinaryCrossentropy(from_logits=True), metrics=["accuracy"])
+    m._check_loss()
+    with pytest.raises(NotImplementedError):
+        m.compile(metrics=["auc"])
+    with pytest.raises(TypeError):
+        m.add("not a layer")
+
+
+def test_maxima_argument_asserts_fire_before_any_gpu_work():
+    from scipy.optimize import Bounds
+    m = MaximizableSequential()
+    b = Bounds(np.zeros(2), np.ones(2))
+    with pytest.raises(AssertionError):
+        m.maxima(b, num_starts=5, num_samples=4)
+    with pytest.raises(AssertionError):
+        m.maxima(b, num_starts=-1)
+    with pytest.raises(AssertionError):
+        m.maxima(b, num_samples=0)
+    with pytest.raises(TypeError):
+        m.maxima(b, num_start_points=3)    # README.rst:96's keyword is not a parameter
+
+
+def test_shuffle_stream_properties():
+    for N in (1, 2, 63, 64, 65, 110):
+        p = shuffle.epoch_permutation(7, 3, 11, N)
+        assert p.dtype == np.int32 and np.array_equal(np.sort(p), np.arange(N))
+    a = shuffle.permutations(1, 2, 3, 50)
+    assert a.shape == (2, 3, 50)
+    assert not np.array_equal(a[0, 0], a[0, 1]) and not np.array_equal(a[0, 0], a[1, 0])
+    assert np.array_equal(a[1, 2], shuffle.epoch_permutation(1, 1, 2, 50))
+    assert np.array_equal(shuffle.permutations(1, 1, 1, 50, model_index0=1, epoch0=2)[0, 0], a[1, 2])
+    # rough uniformity of the first position
+    first = np.array([shuffle.epoch_permutation(0, 0, e, 8)[0] for e in range(800)])
+    assert np.bincount(first, minlength=8).min() > 60
+
+
+def test_no_cpu_fallback_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    m = MaximizableSequential()
+    m.add(Dense(4, activation="relu"))
+    m.add(Dense(1, activation="sigmoid"))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m.predict(np.zeros((3, 2)))
