@@ -1,0 +1,153 @@
+#!/usr/bin/env python
+"""bench.py -- BO-iterations/sec (fit + argmax) for the 16-16-1 classifier on MI355X.
+
+Workload (BASELINE.json config 4 per GPU = config 1 replicated): `--loops` independent
+Branin BO loops per GPU (default 64 = 512 loops / 8 GPUs), 16-16-1 MLP, gamma 0.25,
+fit(epochs=200, batch_size=64) warm-started every iteration, argmax with 3 L-BFGS-B
+restarts from 1024 uniform samples (maxiter 1000, ftol 1e-9), 10 initial points.  One
+"step" is one BO iteration of EVERY loop on the GPU; the data set grows by one point per
+step.  Loops are sharded over ranks (weak scaling, no data-path collective; one gather of
+the results at the end, outside the timed region).
+
+Prints ONE JSON line on rank 0 (see the driver contract in the task statement) with the
+`roofline` of the dominant kernel (fit_kernel; algorithmic bytes per SURVEY.md §8d
+divided by its HIP-event duration) and a `cpu_baseline` (the numpy/scipy oracle, which
+mirrors the reference's per-step structure, timed on this host for a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def cpu_baseline(seconds, seed=0):
+    """Oracle BO loop (config 1) on one host core: label -> per-step eager fit -> predict ->
+    sequential scipy L-BFGS-B with one single-point f/g call per evaluation."""
+    from scipy.optimize import Bounds
+    from oracle import bore_oracle as O
+    from bore_amd.engine import branin01
+    try:
+        from threadpoolctl import threadpool_limits
+        ctx = threadpool_limits(limits=1)
+    except Exception:          # pragma: no cover
+        import contextlib
+        ctx = contextlib.nullcontext()
+    with ctx:
+        rs = np.random.RandomState(seed)
+        acts = ["relu", "relu", "sigmoid"]
+        p = O.glorot_uniform_params(2, [16, 16, 1], rs)
+        st = O.AdamState(p)
+        X = rs.uniform(size=(10, 2))
+        y = branin01(X)
+        bounds = Bounds(np.zeros(2), np.ones(2))
+        it, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < seconds:
+            z, _ = O.labels(y, 0.25)
+            perms = np.stack([rs.permutation(len(y)) for _ in range(200)])
+            O.fit(p, acts, st, X, z, perms, batch_size=64)
+            res = O.argmax(p, acts, bounds, num_starts=3, num_samples=1024, random_state=rs)
+            x = res.x if res is not None else rs.uniform(size=2)
+            X = np.vstack([X, x])
+            y = np.append(y, branin01(x))
+            it += 1
+        dt = time.perf_counter() - t0
+    return dict(value=it / dt, unit="BO-iterations/s", cores=1, kind="port",
+                sample=f"{it} BO iterations of one Branin loop (N 10->{10 + it}) in {dt:.1f} s, "
+                       "numpy fp32 oracle + scipy L-BFGS-B, 1 thread")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--loops", type=int, default=64, help="BO loops per GPU")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from bore_amd.engine import ReplicaEngine, gather_results
+
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    loop_ids = np.arange(args.loops) * world + rank        # loop l lives on rank l % world
+    eng = ReplicaEngine(loop_ids)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        eng.step()
+    eng.finish_timing()
+    for k in ("fit_ms", "fit_bytes"):
+        eng.stats[k] = []
+    eng.stats["n_fg_rows"] = eng.stats["n_rounds"] = 0
+    n_start = eng.N
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.step()
+    barrier()
+    dt = time.perf_counter() - t0
+    eng.finish_timing()
+
+    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax[0])
+    results = gather_results(eng, world)            # the path's only collective (RCCL gather)
+
+    if rank == 0:
+        total_iters = args.loops * world * args.steps
+        fit_ms = np.array(eng.stats["fit_ms"])
+        fit_bytes = np.array(eng.stats["fit_bytes"], dtype=np.float64)
+        achieved = fit_bytes.sum() / (fit_ms.sum() * 1e-3) / 1e9
+        out = {
+            "metric": "BO-iterations/sec (fit+argmax), 16-16-1 MLP",
+            "value": total_iters / dt, "unit": "BO-iterations/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE config 4 shard = config 1 x loops: Branin-2D, "
+                                   "16-16-1 MLP, q=0.25, 200 epochs, batch 64, 3 L-BFGS-B "
+                                   "restarts from 1024 samples",
+                       "loops_per_gpu": args.loops, "N_start": int(n_start),
+                       "N_end": int(eng.N), "parallelism": f"replica-shard x{world}"},
+            "roofline": {"bound": "hbm", "kernel": "fit_kernel", "achieved": achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None,
+                         "avg_launch_ms": float(fit_ms.mean()),
+                         "algorithmic_bytes_per_launch": float(fit_bytes.mean())},
+            "phases": {"fit_ms_per_step": float(fit_ms.mean()),
+                       "fg_rows_per_step": eng.stats["n_fg_rows"] / args.steps,
+                       "fg_rounds_per_step": eng.stats["n_rounds"] / args.steps,
+                       "none_results": eng.stats["none_results"]},
+            "best_y_median": float(np.median(results[:, -1])),
+        }
+        out["cpu_baseline"] = cpu_baseline(args.cpu_seconds) if args.cpu_seconds > 0 else None
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -80,6 +80,10 @@ def lib():
         raise RuntimeError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
             "g.build()'` (hipcc --offload-arch=gfx950).  bore_amd has no CPU fallback.")
+    # torch bundles its own libamdhip64 (SONAME libamdhip64.so.7).  It must be in the
+    # process BEFORE this library is opened so that both resolve to ONE HIP runtime --
+    # device pointers from torch tensors are only valid in the runtime that made them.
+    import torch  # noqa: F401
     L = C.CDLL(LIB_PATH)
     vp, i32, i64, u64 = C.c_void_p, C.c_int, C.c_int64, C.c_uint64
     dp = C.POINTER(MlpDesc)

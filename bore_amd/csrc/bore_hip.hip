@@ -35,7 +35,7 @@ extern "C" const char *bore_last_error(void) { return g_err; }
 
 extern "C" int64_t bore_param_count(const bore_mlp_desc *desc) {
   MlpLayout L;
-  if (bore_make_layout(desc, 0, &L)) return fail(BORE_E_INVALID, "bad bore_mlp_desc");
+  if (bore_make_layout(desc, 0, 1, &L)) return fail(BORE_E_INVALID, "bad bore_mlp_desc");
   return L.P;
 }
 
@@ -236,11 +236,11 @@ __global__ __launch_bounds__(BORE_THREADS) void forward_kernel(const RowArgs a) 
   load_theta(L, a.theta + model * L.P, th);
   const float *X = a.Xf + (a.x_shared ? 0 : model * a.n_rows * D);
   float *out = a.out + model * a.n_rows;
-  const long long n_tiles = (a.n_rows + BORE_BATCH_MAX - 1) / BORE_BATCH_MAX;
+  const long long n_tiles = (a.n_rows + L.tb - 1) / L.tb;
   __syncthreads();
   for (long long t = blockIdx.y; t < n_tiles; t += gridDim.y) {
-    const long long row0 = t * BORE_BATCH_MAX;
-    const int nb = (int)min((long long)BORE_BATCH_MAX, a.n_rows - row0);
+    const long long row0 = t * L.tb;
+    const int nb = (int)min((long long)L.tb, a.n_rows - row0);
     float *A0 = tile + L.aoff[0];
     for (int idx = tid; idx < nb * D; idx += nthr) {
       const int b = idx / D, d = idx - b * D;
@@ -267,11 +267,11 @@ __global__ __launch_bounds__(BORE_THREADS) void value_grad_kernel(const RowArgs 
   const double *X = a.Xd + model * a.n_rows * D;
   float *val = a.out + model * a.n_rows;
   double *grad = a.grad + model * a.n_rows * D;
-  const long long n_tiles = (a.n_rows + BORE_BATCH_MAX - 1) / BORE_BATCH_MAX;
+  const long long n_tiles = (a.n_rows + L.tb - 1) / L.tb;
   __syncthreads();
   for (long long t = blockIdx.y; t < n_tiles; t += gridDim.y) {
-    const long long row0 = t * BORE_BATCH_MAX;
-    const int nb = (int)min((long long)BORE_BATCH_MAX, a.n_rows - row0);
+    const long long row0 = t * L.tb;
+    const int nb = (int)min((long long)L.tb, a.n_rows - row0);
     float *A0 = tile + L.aoff[0];
     for (int idx = tid; idx < nb * D; idx += nthr) {
       const int b = idx / D, d = idx - b * D;
@@ -335,12 +335,12 @@ __global__ __launch_bounds__(BORE_THREADS) void evaluate_kernel(const EvalArgs a
   if (tid == 0) misc[0] = 0.f;
   const float *X = a.X + model * a.N * D;
   const float *z = a.z + model * a.N;
-  const long long n_tiles = (a.N + BORE_BATCH_MAX - 1) / BORE_BATCH_MAX;
+  const long long n_tiles = (a.N + L.tb - 1) / L.tb;
   float lsum = 0.f, csum = 0.f;
   __syncthreads();
   for (long long t = 0; t < n_tiles; ++t) {
-    const long long row0 = t * BORE_BATCH_MAX;
-    const int nb = (int)min((long long)BORE_BATCH_MAX, a.N - row0);
+    const long long row0 = t * L.tb;
+    const int nb = (int)min((long long)L.tb, a.N - row0);
     float *A0 = tile + L.aoff[0];
     for (int idx = tid; idx < nb * D; idx += nthr) {
       const int b = idx / D, d = idx - b * D;
@@ -406,10 +406,21 @@ static int allow_lds(K kernel, size_t bytes) {
   return 0;
 }
 
-static int check_common(const bore_mlp_desc *desc, int n_models, int with_deltas, MlpLayout *L) {
-  if (bore_make_layout(desc, with_deltas, L)) return fail(BORE_E_INVALID, "bad bore_mlp_desc");
+// Builds the layout with the largest tile (<= max_rows rows, halving) whose theta + tile +
+// `extra_floats` fit the CU's LDS; a tile may shrink only when `may_shrink`.
+static int check_common(const bore_mlp_desc *desc, int n_models, int with_deltas, int max_rows,
+                        bool may_shrink, size_t extra_floats, MlpLayout *L) {
   if (n_models < 1) return fail(BORE_E_INVALID, "n_models must be >= 1 (got %d)", n_models);
-  return 0;
+  for (int tb = max_rows;; tb >>= 1) {
+    if (tb < 1 || bore_make_layout(desc, with_deltas, tb, L))
+      return fail(BORE_E_INVALID, "bad bore_mlp_desc");
+    const size_t need = ((size_t)L->P_lds + L->tile_floats + extra_floats) * 4;
+    if (need <= BORE_LDS_BYTES) return 0;
+    if (!may_shrink || tb == 1)
+      return fail(BORE_E_UNSUPPORTED,
+                  "model needs %zu B of LDS per workgroup (> %d) at %d rows per tile", need,
+                  BORE_LDS_BYTES, tb);
+  }
 }
 
 extern "C" int bore_mlp_fit(const bore_mlp_desc *desc, int n_models, float *theta, float *adam_m,
@@ -418,7 +429,13 @@ extern "C" int bore_mlp_fit(const bore_mlp_desc *desc, int n_models, float *thet
                             uint64_t seed, int64_t model_index0, int64_t epoch0,
                             const bore_adam_cfg *adam, float *epoch_loss, void *stream) {
   FitArgs a;
-  int rc = check_common(desc, n_models, 1, &a.L);
+  if (batch_size < 1 || batch_size > BORE_BATCH_MAX)
+    return fail(BORE_E_UNSUPPORTED, "fit: batch_size must be 1..%d (got %d)", BORE_BATCH_MAX,
+                batch_size);
+  if (N < 1 || N > (1 << 20)) return fail(BORE_E_INVALID, "fit: N=%lld out of range", (long long)N);
+  // the whole mini-batch is one tile; perm (+ keys) and the batch targets ride along
+  int rc = check_common(desc, n_models, 1, batch_size, false,
+                        BORE_BATCH_MAX + 8 + (size_t)N * (perm ? 1 : 2), &a.L);
   if (rc) return rc;
   const MlpLayout &L = a.L;
   if (L.w[L.n_layers] != 1)
@@ -427,11 +444,7 @@ extern "C" int bore_mlp_fit(const bore_mlp_desc *desc, int n_models, float *thet
     return fail(BORE_E_INVALID, "fit: BCE needs a sigmoid or linear (from_logits) output layer");
   if (!theta || !adam_m || !adam_v || !adam_t || !X || !z || !adam)
     return fail(BORE_E_INVALID, "fit: null pointer");
-  if (N < 1 || N > (1 << 20)) return fail(BORE_E_INVALID, "fit: N=%lld out of range", (long long)N);
   if (epochs < 0) return fail(BORE_E_INVALID, "fit: epochs < 0");
-  if (batch_size < 1 || batch_size > BORE_BATCH_MAX)
-    return fail(BORE_E_UNSUPPORTED, "fit: batch_size must be 1..%d (got %d)", BORE_BATCH_MAX,
-                batch_size);
   if (epochs == 0) return 0;
 
   a.theta = theta; a.am = adam_m; a.av = adam_v; a.at = (long long *)adam_t;
@@ -478,7 +491,7 @@ static int row_launch(bool with_grad, const bore_mlp_desc *desc, int n_models, R
   size_t off = L.P_lds;
   a.o_tile = (int)off;
   off += L.tile_floats;
-  const long long n_tiles = (a.n_rows + BORE_BATCH_MAX - 1) / BORE_BATCH_MAX;
+  const long long n_tiles = (a.n_rows + L.tb - 1) / L.tb;
   // enough workgroups to fill 256 CUs a few times over, never more than tiles
   long long gy = n_tiles;
   const long long cap = (2048 + n_models - 1) / n_models;
@@ -505,7 +518,7 @@ extern "C" int bore_mlp_forward(const bore_mlp_desc *desc, int n_models, const f
                                 const float *X, int64_t n_rows, int x_shared, float *out,
                                 void *stream) {
   RowArgs a;
-  int rc = check_common(desc, n_models, 0, &a.L);
+  int rc = check_common(desc, n_models, 0, BORE_BATCH_MAX, true, 0, &a.L);
   if (rc) return rc;
   if (a.L.w[a.L.n_layers] != 1)
     return fail(BORE_E_INVALID, "forward: the last Dense layer must have 1 unit");
@@ -522,7 +535,7 @@ extern "C" int bore_mlp_value_and_input_grad(const bore_mlp_desc *desc, int n_mo
                                              int transform, int negate, float *val,
                                              double *grad, void *stream) {
   RowArgs a;
-  int rc = check_common(desc, n_models, 2, &a.L);
+  int rc = check_common(desc, n_models, 2, BORE_BATCH_MAX, true, 0, &a.L);
   if (rc) return rc;
   if (a.L.w[a.L.n_layers] != 1)
     return fail(BORE_E_INVALID, "value_and_input_grad: the last Dense layer must have 1 unit");
@@ -540,7 +553,7 @@ extern "C" int bore_mlp_evaluate(const bore_mlp_desc *desc, int n_models, const 
                                  const float *X, const float *z, int64_t N, float *loss,
                                  float *acc, void *stream) {
   EvalArgs a;
-  int rc = check_common(desc, n_models, 0, &a.L);
+  int rc = check_common(desc, n_models, 0, BORE_BATCH_MAX, true, 8, &a.L);
   if (rc) return rc;
   if (a.L.w[a.L.n_layers] != 1)
     return fail(BORE_E_INVALID, "evaluate: the last Dense layer must have 1 unit");

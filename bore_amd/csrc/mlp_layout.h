@@ -24,6 +24,7 @@ struct MlpLayout {
   int lda[BORE_MAX_LAYERS + 1];   // row stride of A_l and D_l (odd)
   int aoff[BORE_MAX_LAYERS + 1];  // offset of A_l inside the tile region
   int doff[BORE_MAX_LAYERS + 1];  // offset of D_l inside the tile region
+  int tb;                         // rows per tile (<= BORE_BATCH_MAX)
   int tile_floats;                // floats of A_0..A_n (+ D_* when with_deltas)
   float l2_w[BORE_MAX_LAYERS + 1], l2_b[BORE_MAX_LAYERS + 1];
   int any_l2;
@@ -32,9 +33,12 @@ struct MlpLayout {
 static inline int bore_odd(int x) { return x | 1; }
 
 // Returns 0 on success.  with_deltas: 0 = forward only, 1 = deltas D_1..D_n (fit),
-// 2 = deltas D_0..D_n (input gradient).
-static inline int bore_make_layout(const bore_mlp_desc *d, int with_deltas, MlpLayout *L) {
+// 2 = deltas D_0..D_n (input gradient).  tile_rows: rows held per tile, 1..BORE_BATCH_MAX.
+static inline int bore_make_layout(const bore_mlp_desc *d, int with_deltas, int tile_rows,
+                                   MlpLayout *L) {
   if (!d || d->n_layers < 1 || d->n_layers > BORE_MAX_LAYERS || d->input_dim < 1) return -1;
+  if (tile_rows < 1 || tile_rows > BORE_BATCH_MAX) return -1;
+  L->tb = tile_rows;
   L->n_layers = d->n_layers;
   L->w[0] = d->input_dim;
   L->act[0] = 0;
@@ -63,11 +67,11 @@ static inline int bore_make_layout(const bore_mlp_desc *d, int with_deltas, MlpL
   int t = 0;
   for (int l = 0; l <= d->n_layers; ++l) {
     L->lda[l] = bore_odd(L->w[l]);
-    L->aoff[l] = t; t += BORE_BATCH_MAX * L->lda[l];
+    L->aoff[l] = t; t += tile_rows * L->lda[l];
   }
   for (int l = 0; l <= d->n_layers; ++l) {
     L->doff[l] = t;
-    if ((with_deltas == 1 && l >= 1) || with_deltas == 2) t += BORE_BATCH_MAX * L->lda[l];
+    if ((with_deltas == 1 && l >= 1) || with_deltas == 2) t += tile_rows * L->lda[l];
   }
   L->tile_floats = t;
   return 0;

@@ -44,6 +44,8 @@ def mlp_forward(desc, theta, X, out=None):
         out = torch.empty((L, N), dtype=torch.float32, device=theta.device)
     else:
         _chk(out, torch.float32, (L, N), "out")
+    if N == 0:
+        return out
     _lib.check(_lib.lib().bore_mlp_forward(C.byref(desc), L, _lib.ptr(theta), _lib.ptr(X), N,
                                            int(shared), _lib.ptr(out), _lib.stream_ptr()))
     return out
@@ -69,6 +71,8 @@ def mlp_value_and_input_grad(desc, theta, X, transform="identity", negate=True, 
         _chk(grad, torch.float64, (L, R, D), "grad")
     if transform not in _lib.TRANSFORM:
         raise ValueError(f"unknown transform {transform!r}")
+    if R == 0:
+        return val, grad
     _lib.check(_lib.lib().bore_mlp_value_and_input_grad(
         C.byref(desc), L, _lib.ptr(theta), _lib.ptr(X), R, _lib.TRANSFORM[transform],
         int(bool(negate)), _lib.ptr(val), _lib.ptr(grad), _lib.stream_ptr()))

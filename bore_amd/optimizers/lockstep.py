@@ -39,10 +39,13 @@ class _Problem:
 
 
 def minimize_lockstep(fg_batch, X0, bounds=None, maxcor=10, ftol=2.2204460492503131e-09,
-                      gtol=1e-5, maxfun=15000, maxiter=15000, maxls=20, **unknown):
+                      gtol=1e-5, maxfun=15000, maxiter=15000, maxls=20, with_index=False,
+                      **unknown):
     """Minimise R problems sharing one objective.  ``fg_batch(X (k, D) f64) -> (val (k,),
-    grad (k, D))``.  ``bounds``: anything ``minimize`` accepts.  Returns a list of R
-    ``OptimizeResult`` with the fields ``_minimize_lbfgsb`` fills."""
+    grad (k, D))``; with ``with_index`` it is called as ``fg_batch(X, idx)`` where ``idx`` are
+    the problem numbers of the rows (callers that keep a fixed [R, D] device buffer).
+    ``bounds``: anything ``minimize`` accepts.  Returns a list of R ``OptimizeResult`` with
+    the fields ``_minimize_lbfgsb`` fills."""
     if unknown:
         raise TypeError(f"unknown L-BFGS-B options: {sorted(unknown)}")
     if not available():
@@ -97,7 +100,7 @@ def minimize_lockstep(fg_batch, X0, bounds=None, maxcor=10, ftol=2.2204460492503
 
     # ScalarFunction evaluates x0 when it is constructed (nfev = 1) and then serves the
     # first FG request at the same point from its cache.
-    val, grad = fg_batch(X0)
+    val, grad = fg_batch(X0, np.arange(R)) if with_index else fg_batch(X0)
     for r, p in enumerate(probs):
         p.last_x = p.x.copy()
         p.last_f = float(val[r])
@@ -130,7 +133,7 @@ def minimize_lockstep(fg_batch, X0, bounds=None, maxcor=10, ftol=2.2204460492503
                     break
         if pending:
             Xp = np.stack([probs[r].x for r in pending])
-            val, grad = fg_batch(Xp)
+            val, grad = fg_batch(Xp, np.asarray(pending)) if with_index else fg_batch(Xp)
             for i, r in enumerate(pending):
                 p = probs[r]
                 p.nfev += 1
