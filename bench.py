@@ -71,6 +71,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--loops", type=int, default=64, help="BO loops per GPU")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--mode", default="device", choices=["device", "lockstep"],
+                    help="device: L-BFGS-B restarts inside one kernel; lockstep: scipy on the host")
     args = ap.parse_args()
 
     import torch
@@ -85,8 +87,8 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
-    loop_ids = np.arange(args.loops) * world + rank        # loop l lives on rank l % world
-    eng = ReplicaEngine(loop_ids)
+    loop_ids = rank * args.loops + np.arange(args.loops)   # contiguous shard per rank
+    eng = ReplicaEngine(loop_ids, mode=args.mode)
 
     def barrier():
         torch.cuda.synchronize()
@@ -130,7 +132,7 @@ def main():
             "config": {"workload": "BASELINE config 4 shard = config 1 x loops: Branin-2D, "
                                    "16-16-1 MLP, q=0.25, 200 epochs, batch 64, 3 L-BFGS-B "
                                    "restarts from 1024 samples",
-                       "loops_per_gpu": args.loops, "N_start": int(n_start),
+                       "loops_per_gpu": args.loops, "restarts": args.mode, "N_start": int(n_start),
                        "N_end": int(eng.N), "parallelism": f"replica-shard x{world}"},
             "roofline": {"bound": "hbm", "kernel": "fit_kernel", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

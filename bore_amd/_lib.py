@@ -15,7 +15,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libbore_hip.so")
-SOURCES = ["bore_hip.hip"]
+SOURCES = ["bore_hip.hip", "bore_argmax.hip"]
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "bore_hip.h")
 
 MAX_LAYERS = 8
@@ -28,7 +28,8 @@ TRANSFORM = dict(identity=0, sigmoid=1, exp=2)
 EXPORTS = [
     "bore_abi_version", "bore_last_error", "bore_param_count", "bore_mlp_forward",
     "bore_mlp_value_and_input_grad", "bore_mlp_fit", "bore_mlp_evaluate",
-    "bore_shuffle_perm",
+    "bore_shuffle_perm", "bore_labels", "bore_uniform_candidates", "bore_screen_topk",
+    "bore_lbfgsb_minimize",
 ]
 
 
@@ -36,6 +37,11 @@ class MlpDesc(C.Structure):
     _fields_ = [("input_dim", C.c_int32), ("n_layers", C.c_int32),
                 ("units", C.c_int32 * MAX_LAYERS), ("act", C.c_int32 * MAX_LAYERS),
                 ("l2_kernel", C.c_float * MAX_LAYERS), ("l2_bias", C.c_float * MAX_LAYERS)]
+
+
+class LbfgsbOpts(C.Structure):
+    _fields_ = [("maxcor", C.c_int32), ("maxiter", C.c_int32), ("maxfun", C.c_int32),
+                ("maxls", C.c_int32), ("ftol", C.c_double), ("gtol", C.c_double)]
 
 
 class AdamCfg(C.Structure):
@@ -60,8 +66,11 @@ def build_native(force=False, verbose=False):
     hipcc = hipcc_path()
     if hipcc is None:
         raise RuntimeError("hipcc not found: cannot build libbore_hip.so")
+    # -ffp-contract=off: no implicit FMA formation.  The fp32 network code spells its FMAs
+    # out (fmaf); the fp64 L-BFGS-B then rounds exactly like its host build (tests compare
+    # the two bit for bit) and like the unfused numpy/scipy arithmetic of the oracle.
     cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC",
-           "-Wall", "-Wextra", *srcs, "-o", LIB_PATH]
+           "-ffp-contract=off", "-Wall", "-Wextra", *srcs, "-o", LIB_PATH]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True, cwd=CSRC)
@@ -97,6 +106,12 @@ def lib():
                                i64, C.POINTER(AdamCfg), vp, vp]
     L.bore_mlp_evaluate.argtypes = [dp, i32, vp, vp, vp, i64, vp, vp, vp]
     L.bore_shuffle_perm.argtypes = [u64, i64, i32, i64, i32, i64, vp, vp]
+    L.bore_labels.argtypes = [i32, vp, i64, C.c_double, vp, vp, vp]
+    dpp = C.POINTER(C.c_double)
+    L.bore_uniform_candidates.argtypes = [u64, i64, i32, i64, i64, i32, dpp, dpp, vp, vp]
+    L.bore_screen_topk.argtypes = [dp, i32, vp, vp, i64, i32, i32, vp, vp, vp, vp]
+    L.bore_lbfgsb_minimize.argtypes = [dp, i32, vp, i32, i32, vp, i32, dpp, dpp,
+                                       C.POINTER(LbfgsbOpts), vp, vp, vp, vp, vp]
     for name in EXPORTS:
         if name not in ("bore_last_error", "bore_param_count"):
             getattr(L, name).restype = i32

@@ -1,0 +1,440 @@
+// bore_argmax.hip -- the acquisition side of the hot path on the device: label step,
+// candidate sampling, screening + top-k, and the multi-start L-BFGS-B itself.
+// gfx950 (MI355X) only.  C-ABI: include/bore_hip.h.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstring>
+
+#include "host_common.h"
+#include "lbfgsb.h"
+#include "mlp_device.h"
+
+using namespace bore;
+
+// ---------------------------------------------------------------------------
+// labels: tau = np.quantile(y, gamma) (linear interpolation), z = y < tau
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(BORE_THREADS) void labels_kernel(const double *y, int N, double vi,
+                                                              float *z, double *tau_out) {
+  extern __shared__ float smem[];
+  double *ys = reinterpret_cast<double *>(smem);  // [N] + 2 (a, b)
+  const long long model = blockIdx.x;
+  const double *ym = y + model * (long long)N;
+  for (int i = threadIdx.x; i < N; i += blockDim.x) ys[i] = ym[i];
+  // numpy's _get_indexes: floor/ceil neighbours of the virtual index, clamped to the ends
+  int lo, hi;
+  if (vi >= (double)(N - 1)) {
+    lo = hi = N - 1;
+  } else if (vi < 0.0) {
+    lo = hi = 0;
+  } else {
+    lo = (int)floor(vi);
+    hi = lo + 1;
+  }
+  const double gam = (vi >= (double)(N - 1)) ? vi - (-1.0) : (vi < 0.0 ? vi : vi - floor(vi));
+  __syncthreads();
+  for (int i = threadIdx.x; i < N; i += blockDim.x) {
+    const double yi = ys[i];
+    int r = 0;
+    for (int j = 0; j < N; ++j) {
+      const double yj = ys[j];
+      r += (yj < yi) || (yj == yi && j < i);
+    }
+    if (r == lo) ys[N] = yi;
+    if (r == hi) ys[N + 1] = yi;
+  }
+  __syncthreads();
+  // numpy's _lerp
+  const double a = ys[N], b = ys[N + 1];
+  const double diff = b - a;
+  double tau = a + diff * gam;
+  if (gam >= 0.5) tau = b - diff * (1.0 - gam);
+  for (int i = threadIdx.x; i < N; i += blockDim.x) z[model * (long long)N + i] = ys[i] < tau ? 1.f : 0.f;
+  if (threadIdx.x == 0 && tau_out) tau_out[model] = tau;
+}
+
+extern "C" int bore_labels(int n_models, const double *y, int64_t N, double gamma, float *z,
+                           double *tau, void *stream) {
+  if (n_models < 1 || !y || !z) return fail(BORE_E_INVALID, "labels: bad argument");
+  if (N < 1 || N > 16384) return fail(BORE_E_UNSUPPORTED, "labels: N=%lld outside 1..16384", (long long)N);
+  if (!(gamma >= 0.0 && gamma <= 1.0)) return fail(BORE_E_INVALID, "labels: gamma outside [0, 1]");
+  // numpy's virtual index of the default ("linear") method: (n - 1) * q
+  const double vi = (double)(N - 1) * gamma;
+  const size_t bytes = ((size_t)N + 2) * 8;
+  int rc = allow_lds(labels_kernel, bytes);
+  if (rc) return rc;
+  hipLaunchKernelGGL(labels_kernel, dim3(n_models), dim3(BORE_THREADS), bytes, (hipStream_t)stream,
+                     y, (int)N, vi, z, tau);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
+// candidates: X ~ U(low, high) from a counter-based stream
+// ---------------------------------------------------------------------------
+struct BoxArgs {
+  double lo[BORE_DIM_MAX], hi[BORE_DIM_MAX];
+};
+
+__host__ __device__ __forceinline__ unsigned long long candidate_base(unsigned long long seed,
+                                                                      long long model,
+                                                                      long long draw) {
+  unsigned long long h = mix64(seed ^ 0xA0761D6478BD642FULL);  // domain tag: not the shuffle stream
+  h = mix64(h + 0x9E3779B97F4A7C15ULL * (unsigned long long)(model + 1));
+  return mix64(h + 0xD1B54A32D192ED03ULL * (unsigned long long)(draw + 1));
+}
+
+__global__ __launch_bounds__(BORE_THREADS) void candidates_kernel(unsigned long long seed,
+                                                                 long long model0, long long draw,
+                                                                 long long n_samples, int D,
+                                                                 const BoxArgs box, double *X) {
+  const long long model = blockIdx.y;
+  const unsigned long long base = candidate_base(seed, model0 + model, draw);
+  const long long total = n_samples * D;
+  double *Xm = X + model * total;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int d = (int)(i % D);
+    const unsigned long long r = mix64(base + 0x8CB92BA72F3D8DD7ULL * (unsigned long long)(i + 1));
+    const double u = (double)(r >> 11) * (1.0 / 9007199254740992.0);  // 53 bits -> [0, 1)
+    Xm[i] = box.lo[d] + (box.hi[d] - box.lo[d]) * u;
+  }
+}
+
+extern "C" int bore_uniform_candidates(uint64_t seed, int64_t model_index0, int n_models,
+                                       int64_t draw_index, int64_t n_samples, int D,
+                                       const double *low, const double *high, double *X,
+                                       void *stream) {
+  if (n_models < 1 || n_samples < 1 || !low || !high || !X)
+    return fail(BORE_E_INVALID, "uniform_candidates: bad argument");
+  if (D < 1 || D > BORE_DIM_MAX)
+    return fail(BORE_E_UNSUPPORTED, "uniform_candidates: D must be 1..%d", BORE_DIM_MAX);
+  if (n_models > 65535) return fail(BORE_E_UNSUPPORTED, "uniform_candidates: n_models > 65535");
+  BoxArgs box;
+  for (int d = 0; d < D; ++d) {
+    box.lo[d] = low[d];
+    box.hi[d] = high[d];
+  }
+  long long gx = (n_samples * D + BORE_THREADS - 1) / BORE_THREADS;
+  if (gx > 64) gx = 64;
+  hipLaunchKernelGGL(candidates_kernel, dim3((unsigned)gx, n_models), dim3(BORE_THREADS), 0,
+                     (hipStream_t)stream, seed, (long long)model_index0, (long long)draw_index,
+                     (long long)n_samples, D, box, X);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
+// screening + top-k: one workgroup per model
+// ---------------------------------------------------------------------------
+struct ScreenArgs {
+  MlpLayout L;
+  const float *theta;
+  const double *X;
+  double *x0;
+  int *idx;
+  float *pred;
+  long long n_samples;
+  int x_shared, R, n_pad;
+  int o_tile, o_keys;  // float offsets (o_keys is 8-byte aligned)
+};
+
+// float -> unsigned that sorts like the float
+__device__ __forceinline__ unsigned orderable(float f) {
+  const unsigned u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const unsigned long long o = __shfl_xor(v, off, 64);
+    v = o < v ? o : v;
+  }
+  return v;
+}
+
+__global__ __launch_bounds__(BORE_THREADS) void screen_topk_kernel(const ScreenArgs a) {
+  extern __shared__ float smem[];
+  const MlpLayout &L = a.L;
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const long long model = blockIdx.x;
+  const int n = L.n_layers, D = L.w[0];
+  const int Ns = (int)a.n_samples;
+  float *th = smem, *tile = smem + a.o_tile;
+  unsigned long long *keys = reinterpret_cast<unsigned long long *>(smem + a.o_keys);
+  load_theta(L, a.theta + model * L.P, th);
+  const double *X = a.X + (a.x_shared ? 0 : model * a.n_samples * D);
+  __syncthreads();
+  // predictions -> sort keys: ascending key == descending prediction, ties to the lower row
+  const int n_tiles = (Ns + L.tb - 1) / L.tb;
+  for (int t = 0; t < n_tiles; ++t) {
+    const int row0 = t * L.tb;
+    const int nb = min(L.tb, Ns - row0);
+    float *A0 = tile + L.aoff[0];
+    for (int i = tid; i < nb * D; i += nthr) {
+      const int b = i / D, d = i - b * D;
+      A0[b * L.lda[0] + d] = (float)X[(long long)row0 * D + i];
+    }
+    __syncthreads();
+    for (int l = 1; l <= n; ++l) {
+      fwd_layer(L, th, tile, l, nb, false);
+      __syncthreads();
+    }
+    if (tid < nb) {
+      const float p = tile[L.aoff[n] + tid * L.lda[n]];
+      keys[row0 + tid] = ((unsigned long long)(~orderable(p)) << 32) | (unsigned)(row0 + tid);
+      if (a.pred) a.pred[model * a.n_samples + row0 + tid] = p;
+    }
+  }
+  for (int i = Ns + tid; i < a.n_pad; i += nthr) keys[i] = ~0ULL;
+  __syncthreads();
+
+  int *idx_out = a.idx + model * a.R;
+  if (a.R <= 16) {
+    // R passes of "smallest key greater than the previous pick" (keys are distinct)
+    unsigned long long *red = keys + a.n_pad;  // [4] wave minima + [1] the pick; picks at [8..8+R)
+    unsigned long long prev = 0;
+    for (int r = 0; r < a.R; ++r) {
+      unsigned long long best = ~0ULL;
+      for (int i = tid; i < Ns; i += nthr) {
+        const unsigned long long k = keys[i];
+        if ((r == 0 || k > prev) && k < best) best = k;
+      }
+      best = wave_min_u64(best);
+      if ((tid & 63) == 0) red[tid >> 6] = best;
+      __syncthreads();
+      if (tid == 0) {
+        unsigned long long b = red[0];
+        for (int w = 1; w < (nthr >> 6); ++w) b = red[w] < b ? red[w] : b;
+        red[4] = b;
+        red[8 + r] = b;
+        idx_out[r] = (int)(unsigned)(b & 0xFFFFFFFFu);
+      }
+      __syncthreads();
+      prev = red[4];
+    }
+  } else {
+    // bitonic sort of the padded key array
+    for (int k = 2; k <= a.n_pad; k <<= 1)
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        for (int i = tid; i < a.n_pad; i += nthr) {
+          const int ixj = i ^ j;
+          if (ixj > i) {
+            const unsigned long long x = keys[i], y = keys[ixj];
+            const bool up = (i & k) == 0;
+            if ((x > y) == up) {
+              keys[i] = y;
+              keys[ixj] = x;
+            }
+          }
+        }
+        __syncthreads();
+      }
+    for (int r = tid; r < a.R; r += nthr) idx_out[r] = (int)(unsigned)(keys[r] & 0xFFFFFFFFu);
+  }
+  __syncthreads();
+  // gather the chosen rows; the picks are still in LDS
+  const unsigned long long *picks = a.R <= 16 ? keys + a.n_pad + 8 : keys;
+  double *x0 = a.x0 + model * (long long)a.R * D;
+  for (int i = tid; i < a.R * D; i += nthr) {
+    const int r = i / D, d = i - r * D;
+    x0[i] = X[(long long)(unsigned)(picks[r] & 0xFFFFFFFFu) * D + d];
+  }
+}
+
+extern "C" int bore_screen_topk(const bore_mlp_desc *desc, int n_models, const float *theta,
+                                const double *X_init, int64_t n_samples, int x_shared,
+                                int num_starts, double *x0, int32_t *idx, float *pred,
+                                void *stream) {
+  ScreenArgs a;
+  if (n_samples < 1 || n_samples > (1 << 20))
+    return fail(BORE_E_INVALID, "screen_topk: n_samples out of range");
+  if (num_starts < 1 || num_starts > n_samples)
+    return fail(BORE_E_INVALID, "screen_topk: need 1 <= num_starts <= n_samples");
+  int n_pad = 1;
+  while (n_pad < n_samples) n_pad <<= 1;
+  const size_t key_floats = 2 * ((size_t)n_pad + 32) + 1;
+  int rc = check_common(desc, n_models, 0, BORE_BATCH_MAX, true, key_floats, &a.L);
+  if (rc) return rc;
+  if (a.L.w[a.L.n_layers] != 1)
+    return fail(BORE_E_INVALID, "screen_topk: the last Dense layer must have 1 unit");
+  if (!theta || !X_init || !x0 || !idx) return fail(BORE_E_INVALID, "screen_topk: null pointer");
+  a.theta = theta; a.X = X_init; a.x0 = x0; a.idx = idx; a.pred = pred;
+  a.n_samples = n_samples; a.x_shared = x_shared; a.R = num_starts; a.n_pad = n_pad;
+  size_t off = a.L.P_lds;
+  a.o_tile = (int)off; off += a.L.tile_floats;
+  off = (off + 1) & ~(size_t)1;
+  a.o_keys = (int)off; off += 2 * ((size_t)n_pad + 32);
+  rc = allow_lds(screen_topk_kernel, off * 4);
+  if (rc) return rc;
+  hipLaunchKernelGGL(screen_topk_kernel, dim3(n_models), dim3(BORE_THREADS), off * 4,
+                     (hipStream_t)stream, a);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
+// multi-start L-BFGS-B: grid = (models, problem blocks)
+// ---------------------------------------------------------------------------
+struct LbfgsbArgs {
+  MlpLayout L;  // L.tb = problems per workgroup
+  const float *theta;
+  const double *x0;
+  double *x, *fun, *jac;
+  int *info;
+  BoxArgs box;
+  int nbd[BORE_DIM_MAX];
+  lbfgsb::Options opt;
+  int R, transform, max_rounds;
+  float sign;
+  // LDS carve (float offsets; the fp64 regions are 8-byte aligned)
+  int o_tile, o_vals, o_prob, prob_floats, o_state, o_dw, o_iw;
+};
+
+// thread that runs the state machine of the workgroup's problem p: spread over the waves
+// first (each wave has its own program counter, so up to 4 problems advance concurrently
+// without divergence), then over lanes.
+__device__ __forceinline__ int problem_thread(int p) { return (p & 3) * 64 + (p >> 2); }
+
+__global__ __launch_bounds__(BORE_THREADS) void lbfgsb_kernel(const LbfgsbArgs a) {
+  extern __shared__ float smem[];
+  const MlpLayout &L = a.L;
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const long long model = blockIdx.x;
+  const int D = L.w[0];
+  const int p0 = blockIdx.y * L.tb;               // first problem of this workgroup
+  const int np = min(L.tb, a.R - p0);             // problems here (>= 1 by grid construction)
+  float *th = smem, *tile = smem + a.o_tile, *vals = smem + a.o_vals;
+  load_theta(L, a.theta + model * L.P, th);
+
+  // which problem (if any) this thread owns
+  int myp = -1;
+  {
+    const int wv = tid >> 6, ln = tid & 63;
+    const int p = ln * 4 + wv;
+    if (p < np && problem_thread(p) == tid) myp = p;
+  }
+  lbfgsb::State *st = nullptr;
+  lbfgsb::Work wk;
+  if (myp >= 0) {
+    float *base = smem + a.o_prob + (size_t)myp * a.prob_floats;
+    st = reinterpret_cast<lbfgsb::State *>(base + a.o_state);
+    wk = lbfgsb::make_work(reinterpret_cast<double *>(base + a.o_dw),
+                           reinterpret_cast<int *>(base + a.o_iw), D, a.opt.m);
+    const int ndw = lbfgsb::dwork_size(D, a.opt.m);
+    double *dw = reinterpret_cast<double *>(base + a.o_dw);
+    for (int i = 0; i < ndw; ++i) dw[i] = 0.0;
+    const double *x0 = a.x0 + (model * a.R + p0 + myp) * (long long)D;
+    lbfgsb::lbfgsb_init(*st, wk, D, a.opt.m, x0, a.box.lo, a.box.hi, a.nbd);
+  }
+  __syncthreads();
+
+  bool done = (myp < 0);
+  for (int round = 0; round < a.max_rounds; ++round) {
+    int pending = 0;
+    if (!done) {
+      const int rc = lbfgsb::lbfgsb_advance(*st, wk, a.box.lo, a.box.hi, a.nbd, a.opt);
+      if (rc == lbfgsb::LB_NEED_FG) {
+        float *row = tile + L.aoff[0] + myp * L.lda[0];
+        for (int d = 0; d < D; ++d) row[d] = (float)wk.x[d];  // Keras autocast fp64 -> fp32
+        pending = 1;
+      } else {
+        done = true;
+      }
+    }
+    if (!__syncthreads_or(pending)) break;   // every problem of the workgroup has terminated
+    fg_tile(L, th, tile, np, a.transform, a.sign, vals);
+    if (pending) {
+      st->f = (double)vals[myp];
+      const float *g = tile + L.doff[0] + myp * L.lda[0];
+      for (int d = 0; d < D; ++d) wk.g[d] = (double)g[d];
+    }
+    // no barrier needed: the next writes to A_0 / reads of D_0 are by the same threads,
+    // and the cooperative pass starts behind the __syncthreads_or above
+  }
+
+  if (myp >= 0) {
+    const long long q = model * a.R + p0 + myp;
+    if (st->stage != lbfgsb::S_FINISHED) {  // round cap hit (cannot happen with a sane cap)
+      st->status = 2;
+      st->task = lbfgsb::T_STOP;
+      st->msg = lbfgsb::M_MAXFUN;
+    }
+    for (int d = 0; d < D; ++d) {
+      a.x[q * D + d] = wk.x[d];
+      a.jac[q * D + d] = wk.g[d];
+    }
+    a.fun[q] = st->f;
+    int *inf = a.info + q * 5;
+    inf[0] = st->nit; inf[1] = st->nfev; inf[2] = st->status; inf[3] = st->task; inf[4] = st->msg;
+  }
+}
+
+extern "C" int bore_lbfgsb_minimize(const bore_mlp_desc *desc, int n_models, const float *theta,
+                                    int transform, int negate, const double *x0, int num_starts,
+                                    const double *lb, const double *ub,
+                                    const bore_lbfgsb_opts *opts, double *x, double *fun,
+                                    double *jac, int32_t *info, void *stream) {
+  LbfgsbArgs a;
+  if (!desc || !theta || !x0 || !lb || !ub || !opts || !x || !fun || !jac || !info)
+    return fail(BORE_E_INVALID, "lbfgsb_minimize: null pointer");
+  const int D = desc->input_dim;
+  if (D < 1 || D > BORE_DIM_MAX)
+    return fail(BORE_E_UNSUPPORTED, "lbfgsb_minimize: input_dim must be 1..%d", BORE_DIM_MAX);
+  if (num_starts < 1) return fail(BORE_E_INVALID, "lbfgsb_minimize: num_starts < 1");
+  if (transform < BORE_T_IDENTITY || transform > BORE_T_EXP)
+    return fail(BORE_E_INVALID, "lbfgsb_minimize: unknown transform %d", transform);
+  if (opts->maxcor < 1 || opts->maxcor > 32)
+    return fail(BORE_E_UNSUPPORTED, "lbfgsb_minimize: maxcor must be 1..32");
+  if (opts->maxls < 1) return fail(BORE_E_INVALID, "lbfgsb_minimize: maxls must be positive.");
+  if (opts->maxiter < 0 || opts->maxfun < 0 || opts->ftol < 0)
+    return fail(BORE_E_INVALID, "lbfgsb_minimize: negative limit/tolerance");
+  for (int d = 0; d < D; ++d) {
+    const bool lo = std::isfinite(lb[d]), up = std::isfinite(ub[d]);
+    if (lo && up && lb[d] > ub[d])
+      return fail(BORE_E_INVALID,
+                  "LBFGSB - one of the lower bounds is greater than an upper bound.");
+    a.nbd[d] = lo && up ? 2 : lo ? 1 : up ? 3 : 0;
+    a.box.lo[d] = lo ? lb[d] : 0.0;
+    a.box.hi[d] = up ? ub[d] : 0.0;
+  }
+  const int m = opts->maxcor;
+  a.opt.m = m;
+  a.opt.factr = opts->ftol / 2.220446049250313e-16;
+  a.opt.pgtol = opts->gtol;
+  a.opt.maxiter = opts->maxiter;
+  a.opt.maxfun = opts->maxfun;
+  a.opt.maxls = opts->maxls;
+  // per-problem LDS block: State | fp64 workspace | int workspace (all 8-byte aligned)
+  const size_t state_f = (sizeof(lbfgsb::State) + 7) / 8 * 2;
+  const size_t dw_f = 2 * (size_t)lbfgsb::dwork_size(D, m);
+  const size_t iw_f = ((size_t)lbfgsb::iwork_size(D) + 1) & ~(size_t)1;
+  a.o_state = 0;
+  a.o_dw = (int)state_f;
+  a.o_iw = (int)(state_f + dw_f);
+  a.prob_floats = (int)(state_f + dw_f + iw_f);
+  const int max_rows = num_starts < BORE_BATCH_MAX ? num_starts : BORE_BATCH_MAX;
+  int rc = check_common(desc, n_models, 2, max_rows, true, 4, &a.L, a.prob_floats + 1);
+  if (rc) return rc;
+  if (a.L.w[a.L.n_layers] != 1)
+    return fail(BORE_E_INVALID, "lbfgsb_minimize: the last Dense layer must have 1 unit");
+  a.theta = theta; a.x0 = x0; a.x = x; a.fun = fun; a.jac = jac; a.info = info;
+  a.R = num_starts; a.transform = transform; a.sign = negate ? -1.f : 1.f;
+  long long cap = (long long)opts->maxfun + opts->maxls + 64;
+  a.max_rounds = (int)(cap > (1 << 24) ? (1 << 24) : cap);
+  size_t off = a.L.P_lds;
+  a.o_tile = (int)off; off += a.L.tile_floats;
+  a.o_vals = (int)off; off += a.L.tb;
+  off = (off + 1) & ~(size_t)1;
+  a.o_prob = (int)off; off += (size_t)a.prob_floats * a.L.tb;
+  rc = allow_lds(lbfgsb_kernel, off * 4);
+  if (rc) return rc;
+  const int blocks = (num_starts + a.L.tb - 1) / a.L.tb;
+  if (blocks > 65535) return fail(BORE_E_UNSUPPORTED, "lbfgsb_minimize: too many restarts");
+  hipLaunchKernelGGL(lbfgsb_kernel, dim3(n_models, blocks), dim3(BORE_THREADS), off * 4,
+                     (hipStream_t)stream, a);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}

@@ -7,31 +7,13 @@
 #include <cstdio>
 #include <cstring>
 
+#include "host_common.h"
 #include "mlp_device.h"
 
 using namespace bore;
 
-// ---------------------------------------------------------------------------
-// error plumbing
-// ---------------------------------------------------------------------------
-static thread_local char g_err[512] = "";
-
-static int fail(int code, const char *fmt, ...) {
-  va_list ap;
-  va_start(ap, fmt);
-  vsnprintf(g_err, sizeof(g_err), fmt, ap);
-  va_end(ap);
-  return code;
-}
-
-#define HIP_TRY(expr)                                                               \
-  do {                                                                              \
-    hipError_t e_ = (expr);                                                         \
-    if (e_ != hipSuccess) return fail(BORE_E_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
-  } while (0)
-
 extern "C" int bore_abi_version(void) { return BORE_ABI_VERSION; }
-extern "C" const char *bore_last_error(void) { return g_err; }
+extern "C" const char *bore_last_error(void) { return g_bore_err; }
 
 extern "C" int64_t bore_param_count(const bore_mlp_desc *desc) {
   MlpLayout L;
@@ -278,32 +260,7 @@ __global__ __launch_bounds__(BORE_THREADS) void value_grad_kernel(const RowArgs 
       A0[b * L.lda[0] + d] = (float)X[row0 * D + idx];  // Keras autocast fp64 -> fp32
     }
     __syncthreads();
-    for (int l = 1; l <= n; ++l) {
-      fwd_layer(L, th, tile, l, nb, false);
-      __syncthreads();
-    }
-    if (tid < nb) {  // objective T(-f) and its derivative wrt the last pre-activation
-      const float f = tile[L.aoff[n] + tid * L.lda[n]];
-      const float u = a.sign * f;
-      float T, dT;
-      if (a.transform == BORE_T_SIGMOID) {
-        T = sigmoid_stable(u);
-        dT = T * (1.f - T);
-      } else if (a.transform == BORE_T_EXP) {
-        T = expf(u);
-        dT = T;
-      } else {
-        T = u;
-        dT = 1.f;
-      }
-      val[row0 + tid] = T;
-      tile[L.doff[n] + tid * L.lda[n]] = a.sign * dT * act_grad(L.act[n], f);
-    }
-    __syncthreads();
-    for (int l = n; l >= 1; --l) {
-      bwd_delta(L, th, tile, l, nb);
-      __syncthreads();
-    }
+    fg_tile(L, th, tile, nb, a.transform, a.sign, val + row0);
     const float *D0 = tile + L.doff[0];
     for (int idx = tid; idx < nb * D; idx += nthr) {
       const int b = idx / D, d = idx - b * D;
@@ -396,33 +353,6 @@ __global__ __launch_bounds__(BORE_THREADS) void shuffle_kernel(unsigned long lon
 // ---------------------------------------------------------------------------
 // host side of the C-ABI
 // ---------------------------------------------------------------------------
-template <typename K>
-static int allow_lds(K kernel, size_t bytes) {
-  if (bytes > BORE_LDS_BYTES)
-    return fail(BORE_E_UNSUPPORTED, "model needs %zu B of LDS per workgroup (> %d)", bytes,
-                BORE_LDS_BYTES);
-  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-  return 0;
-}
-
-// Builds the layout with the largest tile (<= max_rows rows, halving) whose theta + tile +
-// `extra_floats` fit the CU's LDS; a tile may shrink only when `may_shrink`.
-static int check_common(const bore_mlp_desc *desc, int n_models, int with_deltas, int max_rows,
-                        bool may_shrink, size_t extra_floats, MlpLayout *L) {
-  if (n_models < 1) return fail(BORE_E_INVALID, "n_models must be >= 1 (got %d)", n_models);
-  for (int tb = max_rows;; tb >>= 1) {
-    if (tb < 1 || bore_make_layout(desc, with_deltas, tb, L))
-      return fail(BORE_E_INVALID, "bad bore_mlp_desc");
-    const size_t need = ((size_t)L->P_lds + L->tile_floats + extra_floats) * 4;
-    if (need <= BORE_LDS_BYTES) return 0;
-    if (!may_shrink || tb == 1)
-      return fail(BORE_E_UNSUPPORTED,
-                  "model needs %zu B of LDS per workgroup (> %d) at %d rows per tile", need,
-                  BORE_LDS_BYTES, tb);
-  }
-}
-
 extern "C" int bore_mlp_fit(const bore_mlp_desc *desc, int n_models, float *theta, float *adam_m,
                             float *adam_v, int64_t *adam_t, const float *X, const float *z,
                             int64_t N, int epochs, int batch_size, const int32_t *perm,

@@ -1,0 +1,55 @@
+// host_common.h -- host-side plumbing shared by the translation units of libbore_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+
+#include "mlp_layout.h"
+
+inline thread_local char g_bore_err[512] = "";
+
+inline int fail(int code, const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_bore_err, sizeof(g_bore_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                      \
+  do {                                                                                     \
+    hipError_t e_ = (expr);                                                                \
+    if (e_ != hipSuccess) return fail(BORE_E_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+  } while (0)
+
+// Raise the kernel's dynamic-LDS limit to `bytes` (default cap is 64 KiB).
+template <typename K>
+inline int allow_lds(K kernel, size_t bytes) {
+  if (bytes > BORE_LDS_BYTES)
+    return fail(BORE_E_UNSUPPORTED, "model needs %zu B of LDS per workgroup (> %d)", bytes,
+                BORE_LDS_BYTES);
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  return 0;
+}
+
+// Builds the layout with the largest tile (<= max_rows rows, halving) whose theta + tile +
+// `extra_floats` (+ `extra_floats_per_row` for every tile row) fit the CU's LDS; a tile may
+// shrink only when `may_shrink`.
+inline int check_common(const bore_mlp_desc *desc, int n_models, int with_deltas, int max_rows,
+                        bool may_shrink, size_t extra_floats, MlpLayout *L,
+                        size_t extra_floats_per_row = 0) {
+  if (n_models < 1) return fail(BORE_E_INVALID, "n_models must be >= 1 (got %d)", n_models);
+  for (int tb = max_rows;; tb = (tb > 16 ? tb >> 1 : tb - 1)) {
+    if (tb < 1 || bore_make_layout(desc, with_deltas, tb, L))
+      return fail(BORE_E_INVALID, "bad bore_mlp_desc");
+    const size_t need =
+        ((size_t)L->P_lds + L->tile_floats + extra_floats + extra_floats_per_row * tb) * 4;
+    if (need <= BORE_LDS_BYTES) return 0;
+    if (!may_shrink || tb == 1)
+      return fail(BORE_E_UNSUPPORTED,
+                  "model needs %zu B of LDS per workgroup (> %d) at %d rows per tile", need,
+                  BORE_LDS_BYTES, tb);
+  }
+}

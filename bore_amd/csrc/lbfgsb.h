@@ -1,0 +1,1212 @@
+// lbfgsb.h -- bound-constrained limited-memory BFGS (L-BFGS-B), written from the
+// published algorithm for execution INSIDE a HIP kernel, one problem per lane.
+//
+// What it stands in for: scipy.optimize.minimize(method="L-BFGS-B", jac=True, bounds)
+// as called by the reference at bore/mixins.py:59-60 (SciPy is a third-party dependency
+// of the reference, pinned scipy==1.7.0 in setup.py:15; its core is the Fortran/C code
+// "L-BFGS-B 3.0" of Zhu, Byrd, Lu, Nocedal & Morales).  The algorithm restated here:
+//   Byrd, Lu, Nocedal, Zhu, "A limited memory algorithm for bound constrained
+//   optimization", SIAM J. Sci. Comput. 16 (1995): generalized Cauchy point (sec. 4),
+//   subspace minimisation by the direct primal method (sec. 5.1), compact limited-memory
+//   matrices (sec. 3);
+//   Morales, Nocedal, "Remark on Algorithm 778" (2011): projected subspace step with
+//   backtracking fallback;
+//   More', Thuente, "Line search algorithms with guaranteed sufficient decrease",
+//   ACM TOMS 20 (1994): dcsrch / dcstep, with ftol=1e-3, gtol=0.9, xtol=0.1.
+// Same stopping rules, constants and failure modes as the SciPy driver
+// (_minimize_lbfgsb): projected-gradient test (pgtol), relative-reduction test
+// (factr*epsmch), maxiter / maxfun -> status 1, abnormal line search -> status 2, at
+// most `maxls` function evaluations per line search, memory refresh on a failed
+// factorisation or line search.
+//
+// The routine is a REVERSE-COMMUNICATION state machine: lbfgsb_advance() runs until the
+// problem needs f and g at `x` (returns LB_NEED_FG) or has terminated (LB_DONE).  That is
+// what lets a workgroup evaluate all its problems' points in one cooperative MLP pass.
+//
+// All arithmetic is fp64.  Results are not bit-identical to SciPy (its BLAS sums in a
+// different order) but follow the same trajectory to rounding; tests/test_lbfgsb_host.py
+// compares iterates, iteration and evaluation counts against scipy on the CPU build.
+#pragma once
+#include <math.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define LB_HD __host__ __device__ __forceinline__
+#define LB_HDN __host__ __device__ __forceinline__  // one call site each: no device call stack
+#else
+#define LB_HD inline
+#define LB_HDN
+#endif
+
+namespace lbfgsb {
+
+enum { LB_NEED_FG = 1, LB_DONE = 2 };
+
+// task codes: the (task[0], task[1]) pairs of scipy's status_messages/task_messages
+enum {
+  T_START = 0, T_NEW_X = 1, T_FG = 3, T_CONVERGENCE = 4, T_STOP = 5, T_ERROR = 7, T_ABNORMAL = 8
+};
+enum {
+  M_NONE = 0, M_PGTOL = 401, M_FACTR = 402, M_MAXFUN = 502, M_MAXITER = 504,
+  M_NO_FEASIBLE = 701, M_FACTR_NEG = 702, M_M_LE_0 = 711, M_N_LE_0 = 712, M_INVALID_NBD = 713
+};
+
+// stages of the state machine (where to resume after the caller supplied f and g)
+enum { S_INIT = 0, S_FG_START = 1, S_FG_LNSRCH = 2, S_FINISHED = 3 };
+
+struct Options {
+  int m;          // maxcor
+  double factr;   // ftol / epsmch
+  double pgtol;   // gtol
+  int maxiter, maxfun, maxls;
+};
+
+// Fixed-size scalar state of one problem.  The vectors/matrices live in a caller-provided
+// double/int workspace (sizes from dwork_size()/iwork_size()).
+struct State {
+  // problem
+  int n, m;
+  // mainlb scalars
+  double theta, f, fold, sbgnrm, dnorm, stp, gd, gdold, dtd, xstep, stpmx;
+  int col, head, itail, iupdat, iter, nfgv, ifun, iback, nfree, nact, nenter, ileave, nseg;
+  int info, iword;
+  int prjctd, cnstnd, boxed, updatd, wrk;
+  // dcsrch saved locals
+  int brackt, ls_stage, ls_task;  // ls_task: 0 START, 1 FG, 2 CONVERGENCE, 3 WARNING, 4 ERROR
+  double ginit, gtest, gx, gy, finit, fx, fy, stx, sty, stmin, stmax, width, width1;
+  // driver
+  int stage, task, msg, nit, nfev, status;
+  double flast;
+};
+
+LB_HD int dwork_size(int n, int m) { return 2 * m * n + 11 * m * m + 8 * m + 9 * n; }
+LB_HD int iwork_size(int n) { return 3 * n; }
+
+// Views into the workspaces (all 0-based; matrices column-major like the original).
+struct Work {
+  double *ws, *wy;          // [m][n]: correction j is ws[j*n .. j*n+n)
+  double *sy, *ss, *wt;     // m x m, element (i,j) at [j*m + i]
+  double *wn, *snd;         // 2m x 2m, element (i,j) at [j*2m + i]
+  double *z, *r, *d, *t, *xp, *x, *g;
+  double *xlast, *glast;    // last point actually evaluated (SciPy's ScalarFunction cache)
+  double *wa;               // 8m: p | c | wbp | v
+  int *index, *iwhere, *indx2;
+};
+
+LB_HD Work make_work(double *dw, int *iw, int n, int m) {
+  Work w;
+  w.ws = dw; dw += m * n;
+  w.wy = dw; dw += m * n;
+  w.sy = dw; dw += m * m;
+  w.ss = dw; dw += m * m;
+  w.wt = dw; dw += m * m;
+  w.wn = dw; dw += 4 * m * m;
+  w.snd = dw; dw += 4 * m * m;
+  w.z = dw; dw += n;
+  w.r = dw; dw += n;
+  w.d = dw; dw += n;
+  w.t = dw; dw += n;
+  w.xp = dw; dw += n;
+  w.x = dw; dw += n;
+  w.g = dw; dw += n;
+  w.xlast = dw; dw += n;
+  w.glast = dw; dw += n;
+  w.wa = dw;
+  w.index = iw;
+  w.iwhere = iw + n;
+  w.indx2 = iw + 2 * n;
+  return w;
+}
+
+#define LB_EPSMCH 2.220446049250313e-16
+
+// ---- small dense kernels ------------------------------------------------------
+LB_HD double ddot(int n, const double *a, const double *b) {
+  double s = 0.0;
+  for (int i = 0; i < n; ++i) s += a[i] * b[i];
+  return s;
+}
+
+// Cholesky of the leading n x n block of a (leading dimension ld), upper triangle:
+// A = R'R with R stored in the upper triangle.  Returns 0, or k>0 if the leading minor
+// of order k is not positive definite.
+LB_HD int dpofa(double *a, int ld, int n) {
+  for (int j = 0; j < n; ++j) {
+    double s = 0.0;
+    for (int k = 0; k < j; ++k) {
+      double t = a[j * ld + k] - ddot(k, a + k * ld, a + j * ld);
+      t = t / a[k * ld + k];
+      a[j * ld + k] = t;
+      s += t * t;
+    }
+    s = a[j * ld + j] - s;
+    if (s <= 0.0) return j + 1;
+    a[j * ld + j] = sqrt(s);
+  }
+  return 0;
+}
+
+// Triangular solves with the UPPER triangle of t (leading dimension ld):
+// trans == 0:  T x = b;   trans != 0:  T' x = b.   Returns 0, or k>0 for a zero diagonal.
+LB_HD int dtrsl_upper(const double *t, int ld, int n, double *b, int trans) {
+  for (int j = 0; j < n; ++j)
+    if (t[j * ld + j] == 0.0) return j + 1;
+  if (!trans) {
+    b[n - 1] = b[n - 1] / t[(n - 1) * ld + (n - 1)];
+    for (int j = n - 2; j >= 0; --j) {
+      const double temp = -b[j + 1];
+      const double *col = t + (j + 1) * ld;
+      for (int i = 0; i <= j; ++i) b[i] += temp * col[i];
+      b[j] = b[j] / t[j * ld + j];
+    }
+  } else {
+    b[0] = b[0] / t[0];
+    for (int j = 1; j < n; ++j) {
+      b[j] = b[j] - ddot(j, t + j * ld, b);
+      b[j] = b[j] / t[j * ld + j];
+    }
+  }
+  return 0;
+}
+
+// ---- limited-memory matrix products ---------------------------------------------
+// Product of the 2col x 2col middle matrix of the compact L-BFGS formula with v -> p.
+LB_HD int bmv(int m, const double *sy, const double *wt, int col, const double *v, double *p) {
+  if (col == 0) return 0;
+  // solve [  D^(1/2)      O ] [ p1 ] = [ v1 ]
+  //       [ -L*D^(-1/2)   J ] [ p2 ]   [ v2 ]
+  p[col] = v[col];
+  for (int i = 1; i < col; ++i) {
+    double sum = 0.0;
+    for (int k = 0; k < i; ++k) sum += sy[k * m + i] * v[k] / sy[k * m + k];
+    p[col + i] = v[col + i] + sum;
+  }
+  int info = dtrsl_upper(wt, m, col, p + col, 1);
+  if (info) return info;
+  for (int i = 0; i < col; ++i) p[i] = v[i] / sqrt(sy[i * m + i]);
+  // solve [ -D^(1/2)   D^(-1/2)*L' ] [ p1 ] = [ p1 ]
+  //       [  0         J'          ] [ p2 ]   [ p2 ]
+  info = dtrsl_upper(wt, m, col, p + col, 0);
+  if (info) return info;
+  for (int i = 0; i < col; ++i) p[i] = -p[i] / sqrt(sy[i * m + i]);
+  for (int i = 0; i < col; ++i) {
+    double sum = 0.0;
+    for (int k = i + 1; k < col; ++k) sum += sy[i * m + k] * p[col + k] / sy[i * m + i];
+    p[i] += sum;
+  }
+  return 0;
+}
+
+// T = theta*SS + L*D^(-1)*L' (upper triangle), then its Cholesky factor J' in wt.
+LB_HD int formt(int m, double *wt, const double *sy, const double *ss, int col, double theta) {
+  for (int j = 0; j < col; ++j) wt[j * m] = theta * ss[j * m];
+  for (int i = 1; i < col; ++i)
+    for (int j = i; j < col; ++j) {
+      const int k1 = (i < j ? i : j);
+      double ddum = 0.0;
+      for (int k = 0; k < k1; ++k) ddum += sy[k * m + i] * sy[k * m + j] / sy[k * m + k];
+      wt[j * m + i] = ddum + theta * ss[j * m + i];
+    }
+  return dpofa(wt, m, col) ? -3 : 0;
+}
+
+// ---- projected gradient norm -------------------------------------------------------
+LB_HD double projgr(int n, const double *l, const double *u, const int *nbd, const double *x,
+                    const double *g) {
+  double sb = 0.0;
+  for (int i = 0; i < n; ++i) {
+    double gi = g[i];
+    if (nbd[i] != 0) {
+      if (gi < 0.0) {
+        if (nbd[i] >= 2) gi = fmax(x[i] - u[i], gi);
+      } else {
+        if (nbd[i] <= 2) gi = fmin(x[i] - l[i], gi);
+      }
+    }
+    sb = fmax(sb, fabs(gi));
+  }
+  return sb;
+}
+
+// ---- heap of breakpoints -------------------------------------------------------------
+// t[0..n) with companion iorder; iheap == 0 builds the heap first.  On exit the least
+// element sits in t[n-1] and t[0..n-1) is a heap again.
+LB_HD void hpsolb(int n, double *t, int *iorder, int iheap) {
+  if (iheap == 0) {
+    for (int k = 2; k <= n; ++k) {
+      const double ddum = t[k - 1];
+      const int indxin = iorder[k - 1];
+      int i = k;
+      while (i > 1) {
+        const int j = i / 2;
+        if (ddum < t[j - 1]) {
+          t[i - 1] = t[j - 1];
+          iorder[i - 1] = iorder[j - 1];
+          i = j;
+        } else {
+          break;
+        }
+      }
+      t[i - 1] = ddum;
+      iorder[i - 1] = indxin;
+    }
+  }
+  if (n > 1) {
+    int i = 1;
+    const double out = t[0];
+    const int indxou = iorder[0];
+    const double ddum = t[n - 1];
+    const int indxin = iorder[n - 1];
+    for (;;) {
+      int j = i + i;
+      if (j <= n - 1) {
+        if (t[j] < t[j - 1]) j = j + 1;
+        if (t[j - 1] < ddum) {
+          t[i - 1] = t[j - 1];
+          iorder[i - 1] = iorder[j - 1];
+          i = j;
+          continue;
+        }
+      }
+      break;
+    }
+    t[i - 1] = ddum;
+    iorder[i - 1] = indxin;
+    t[n - 1] = out;
+    iorder[n - 1] = indxou;
+  }
+}
+
+// ---- generalized Cauchy point ----------------------------------------------------------
+// xcp = w.z, breakpoints in w.t, search direction in w.d, iorder = w.indx2,
+// p | c | wbp | v = w.wa.
+LB_HDN int cauchy(State &s, const Work &w, const double *l, const double *u, const int *nbd) {
+  const int n = s.n, m = s.m, col = s.col, col2 = 2 * s.col;
+  double *x = w.x, *g = w.g, *t = w.t, *d = w.d, *xcp = w.z;
+  double *p = w.wa, *c = w.wa + 2 * m, *wbp = w.wa + 4 * m, *v = w.wa + 6 * m;
+  int *iorder = w.indx2, *iwhere = w.iwhere;
+  const double theta = s.theta;
+
+  if (s.sbgnrm <= 0.0) {
+    for (int i = 0; i < n; ++i) xcp[i] = x[i];
+    return 0;
+  }
+  bool bnded = true;
+  int nfree = n + 1, nbreak = 0, ibkmin = 0;
+  double bkmin = 0.0, f1 = 0.0;
+  for (int i = 0; i < col2; ++i) p[i] = 0.0;
+
+  for (int i = 1; i <= n; ++i) {
+    const double neggi = -g[i - 1];
+    double tl = 0.0, tu = 0.0;
+    if (iwhere[i - 1] != 3 && iwhere[i - 1] != -1) {
+      if (nbd[i - 1] <= 2) tl = x[i - 1] - l[i - 1];
+      if (nbd[i - 1] >= 2) tu = u[i - 1] - x[i - 1];
+      const bool xlower = nbd[i - 1] <= 2 && tl <= 0.0;
+      const bool xupper = nbd[i - 1] >= 2 && tu <= 0.0;
+      iwhere[i - 1] = 0;
+      if (xlower) {
+        if (neggi <= 0.0) iwhere[i - 1] = 1;
+      } else if (xupper) {
+        if (neggi >= 0.0) iwhere[i - 1] = 2;
+      } else {
+        if (fabs(neggi) <= 0.0) iwhere[i - 1] = -3;
+      }
+    }
+    int pointr = s.head;
+    if (iwhere[i - 1] != 0 && iwhere[i - 1] != -1) {
+      d[i - 1] = 0.0;
+    } else {
+      d[i - 1] = neggi;
+      f1 -= neggi * neggi;
+      for (int j = 0; j < col; ++j) {
+        p[j] += w.wy[pointr * n + (i - 1)] * neggi;
+        p[col + j] += w.ws[pointr * n + (i - 1)] * neggi;
+        pointr = (pointr + 1) % m;
+      }
+      if (nbd[i - 1] <= 2 && nbd[i - 1] != 0 && neggi < 0.0) {
+        ++nbreak;
+        iorder[nbreak - 1] = i;
+        t[nbreak - 1] = tl / (-neggi);
+        if (nbreak == 1 || t[nbreak - 1] < bkmin) {
+          bkmin = t[nbreak - 1];
+          ibkmin = nbreak;
+        }
+      } else if (nbd[i - 1] >= 2 && neggi > 0.0) {
+        ++nbreak;
+        iorder[nbreak - 1] = i;
+        t[nbreak - 1] = tu / neggi;
+        if (nbreak == 1 || t[nbreak - 1] < bkmin) {
+          bkmin = t[nbreak - 1];
+          ibkmin = nbreak;
+        }
+      } else {
+        --nfree;
+        iorder[nfree - 1] = i;
+        if (fabs(neggi) > 0.0) bnded = false;
+      }
+    }
+  }
+  if (theta != 1.0)
+    for (int j = 0; j < col; ++j) p[col + j] *= theta;
+  for (int i = 0; i < n; ++i) xcp[i] = x[i];
+  if (nbreak == 0 && nfree == n + 1) return 0;  // d is zero: GCP = x
+  for (int j = 0; j < col2; ++j) c[j] = 0.0;
+
+  double f2 = -theta * f1;
+  const double f2_org = f2;
+  if (col > 0) {
+    const int info = bmv(m, w.sy, w.wt, col, p, v);
+    if (info) return info;
+    f2 -= ddot(col2, v, p);
+  }
+  double dtm = -f1 / f2;
+  double tsum = 0.0;
+  s.nseg = 1;
+  bool skip_to_999 = false;
+
+  if (nbreak > 0) {
+    int nleft = nbreak, iter = 1, ibp = 0;
+    double tj = 0.0;
+    for (;;) {
+      const double tj0 = tj;
+      if (iter == 1) {
+        tj = bkmin;
+        ibp = iorder[ibkmin - 1];
+      } else {
+        if (iter == 2) {
+          if (ibkmin != nbreak) {
+            t[ibkmin - 1] = t[nbreak - 1];
+            iorder[ibkmin - 1] = iorder[nbreak - 1];
+          }
+        }
+        hpsolb(nleft, t, iorder, iter - 2);
+        tj = t[nleft - 1];
+        ibp = iorder[nleft - 1];
+      }
+      const double dt = tj - tj0;
+      if (dtm < dt) break;  // the minimiser lies in this segment
+      tsum += dt;
+      --nleft;
+      ++iter;
+      const double dibp = d[ibp - 1];
+      d[ibp - 1] = 0.0;
+      double zibp;
+      if (dibp > 0.0) {
+        zibp = u[ibp - 1] - x[ibp - 1];
+        xcp[ibp - 1] = u[ibp - 1];
+        iwhere[ibp - 1] = 2;
+      } else {
+        zibp = l[ibp - 1] - x[ibp - 1];
+        xcp[ibp - 1] = l[ibp - 1];
+        iwhere[ibp - 1] = 1;
+      }
+      if (nleft == 0 && nbreak == n) {  // every variable is fixed
+        dtm = dt;
+        skip_to_999 = true;
+        break;
+      }
+      ++s.nseg;
+      const double dibp2 = dibp * dibp;
+      f1 = f1 + dt * f2 + dibp2 - theta * dibp * zibp;
+      f2 = f2 - theta * dibp2;
+      if (col > 0) {
+        for (int j = 0; j < col2; ++j) c[j] += dt * p[j];
+        int pointr = s.head;
+        for (int j = 0; j < col; ++j) {
+          wbp[j] = w.wy[pointr * n + (ibp - 1)];
+          wbp[col + j] = theta * w.ws[pointr * n + (ibp - 1)];
+          pointr = (pointr + 1) % m;
+        }
+        const int info = bmv(m, w.sy, w.wt, col, wbp, v);
+        if (info) return info;
+        const double wmc = ddot(col2, c, v);
+        const double wmp = ddot(col2, p, v);
+        const double wmw = ddot(col2, wbp, v);
+        for (int j = 0; j < col2; ++j) p[j] -= dibp * wbp[j];
+        f1 += dibp * wmc;
+        f2 += 2.0 * dibp * wmp - dibp2 * wmw;
+      }
+      f2 = fmax(LB_EPSMCH * f2_org, f2);
+      if (nleft > 0) {
+        dtm = -f1 / f2;
+        continue;
+      } else if (bnded) {
+        f1 = 0.0;
+        f2 = 0.0;
+        dtm = 0.0;
+      } else {
+        dtm = -f1 / f2;
+      }
+      break;
+    }
+  }
+  if (!skip_to_999) {
+    if (dtm <= 0.0) dtm = 0.0;
+    tsum += dtm;
+    for (int i = 0; i < n; ++i) xcp[i] += tsum * d[i];
+  }
+  if (col > 0)
+    for (int j = 0; j < col2; ++j) c[j] += dtm * p[j];
+  return 0;
+}
+
+// ---- free / active bookkeeping at the GCP ------------------------------------------------
+LB_HD void freev(State &s, const Work &w) {
+  const int n = s.n;
+  s.nenter = 0;
+  s.ileave = n + 1;
+  if (s.iter > 0 && s.cnstnd) {
+    for (int i = 1; i <= s.nfree; ++i) {
+      const int k = w.index[i - 1];
+      if (w.iwhere[k - 1] > 0) {
+        --s.ileave;
+        w.indx2[s.ileave - 1] = k;
+      }
+    }
+    for (int i = 1 + s.nfree; i <= n; ++i) {
+      const int k = w.index[i - 1];
+      if (w.iwhere[k - 1] <= 0) {
+        ++s.nenter;
+        w.indx2[s.nenter - 1] = k;
+      }
+    }
+  }
+  s.wrk = (s.ileave < n + 1) || (s.nenter > 0) || s.updatd;
+  s.nfree = 0;
+  int iact = n + 1;
+  for (int i = 1; i <= n; ++i) {
+    if (w.iwhere[i - 1] <= 0) {
+      ++s.nfree;
+      w.index[s.nfree - 1] = i;
+    } else {
+      --iact;
+      w.index[iact - 1] = i;
+    }
+  }
+}
+
+// ---- LEL^T factorisation of the reduced middle matrix (subspace minimisation) ---------------
+LB_HDN int formk(State &s, const Work &w) {
+  const int n = s.n, m = s.m, col = s.col, nsub = s.nfree, m2 = 2 * s.m;
+  double *wn = w.wn, *wn1 = w.snd;
+  const int *ind = w.index, *indx2 = w.indx2;
+#define WN(i, j) wn[(j) * m2 + (i)]
+#define WN1(i, j) wn1[(j) * m2 + (i)]
+#define WS(k, p) w.ws[(p) * n + (k)]
+#define WY(k, p) w.wy[(p) * n + (k)]
+  int upcl;
+  if (s.updatd) {
+    if (s.iupdat > m) {  // shift the old part of WN1
+      for (int jy = 0; jy < m - 1; ++jy) {
+        const int js = m + jy;
+        for (int i = 0; i < m - 1 - jy; ++i) {
+          WN1(jy + i, jy) = WN1(jy + 1 + i, jy + 1);
+          WN1(js + i, js) = WN1(js + 1 + i, js + 1);
+        }
+        for (int i = 0; i < m - 1; ++i) WN1(m + i, jy) = WN1(m + 1 + i, jy + 1);
+      }
+    }
+    // new rows in blocks (1,1), (2,1), (2,2)
+    int ipntr = (s.head + col - 1) % m;
+    const int iy = col - 1, is = m + col - 1;
+    int jpntr = s.head;
+    for (int jy = 0; jy < col; ++jy) {
+      const int js = m + jy;
+      double temp1 = 0.0, temp2 = 0.0, temp3 = 0.0;
+      for (int k = 0; k < nsub; ++k) {
+        const int k1 = ind[k] - 1;
+        temp1 += WY(k1, ipntr) * WY(k1, jpntr);
+      }
+      for (int k = nsub; k < n; ++k) {
+        const int k1 = ind[k] - 1;
+        temp2 += WS(k1, ipntr) * WS(k1, jpntr);
+        temp3 += WS(k1, ipntr) * WY(k1, jpntr);
+      }
+      WN1(iy, jy) = temp1;
+      WN1(is, js) = temp2;
+      WN1(is, jy) = temp3;
+      jpntr = (jpntr + 1) % m;
+    }
+    // new column in block (2,1)
+    const int jy = col - 1;
+    jpntr = (s.head + col - 1) % m;
+    ipntr = s.head;
+    for (int i = 0; i < col; ++i) {
+      const int is2 = m + i;
+      double temp3 = 0.0;
+      for (int k = 0; k < nsub; ++k) {
+        const int k1 = ind[k] - 1;
+        temp3 += WS(k1, ipntr) * WY(k1, jpntr);
+      }
+      ipntr = (ipntr + 1) % m;
+      WN1(is2, jy) = temp3;
+    }
+    upcl = col - 1;
+  } else {
+    upcl = col;
+  }
+  // old parts of blocks (1,1) and (2,2): variables that entered / left the free set
+  {
+    int ipntr = s.head;
+    for (int iy = 0; iy < upcl; ++iy) {
+      const int is = m + iy;
+      int jpntr = s.head;
+      for (int jy = 0; jy <= iy; ++jy) {
+        const int js = m + jy;
+        double temp1 = 0.0, temp2 = 0.0, temp3 = 0.0, temp4 = 0.0;
+        for (int k = 0; k < s.nenter; ++k) {
+          const int k1 = indx2[k] - 1;
+          temp1 += WY(k1, ipntr) * WY(k1, jpntr);
+          temp2 += WS(k1, ipntr) * WS(k1, jpntr);
+        }
+        for (int k = s.ileave - 1; k < n; ++k) {
+          const int k1 = indx2[k] - 1;
+          temp3 += WY(k1, ipntr) * WY(k1, jpntr);
+          temp4 += WS(k1, ipntr) * WS(k1, jpntr);
+        }
+        WN1(iy, jy) += temp1 - temp3;
+        WN1(is, js) += -temp2 + temp4;
+        jpntr = (jpntr + 1) % m;
+      }
+      ipntr = (ipntr + 1) % m;
+    }
+  }
+  // old part of block (2,1)
+  {
+    int ipntr = s.head;
+    for (int is = m; is < m + upcl; ++is) {
+      int jpntr = s.head;
+      for (int jy = 0; jy < upcl; ++jy) {
+        double temp1 = 0.0, temp3 = 0.0;
+        for (int k = 0; k < s.nenter; ++k) {
+          const int k1 = indx2[k] - 1;
+          temp1 += WS(k1, ipntr) * WY(k1, jpntr);
+        }
+        for (int k = s.ileave - 1; k < n; ++k) {
+          const int k1 = indx2[k] - 1;
+          temp3 += WS(k1, ipntr) * WY(k1, jpntr);
+        }
+        if (is <= jy + m)
+          WN1(is, jy) += temp1 - temp3;
+        else
+          WN1(is, jy) += -temp1 + temp3;
+        jpntr = (jpntr + 1) % m;
+      }
+      ipntr = (ipntr + 1) % m;
+    }
+  }
+  // upper triangle of WN = [D+Y'ZZ'Y/theta   -L_a'+R_z'] [-L_a+R_z   S'AA'S*theta]
+  const double theta = s.theta;
+  for (int iy = 0; iy < col; ++iy) {
+    const int is = col + iy, is1 = m + iy;
+    for (int jy = 0; jy <= iy; ++jy) {
+      const int js = col + jy, js1 = m + jy;
+      WN(jy, iy) = WN1(iy, jy) / theta;
+      WN(js, is) = WN1(is1, js1) * theta;
+    }
+    for (int jy = 0; jy < iy; ++jy) WN(jy, is) = -WN1(is1, jy);
+    for (int jy = iy; jy < col; ++jy) WN(jy, is) = WN1(is1, jy);
+    WN(iy, iy) += w.sy[iy * m + iy];
+  }
+  // Cholesky of the (1,1) block, then L^-1(-L_a'+R_z') in the (1,2) block
+  if (dpofa(wn, m2, col)) return -1;
+  const int col2 = 2 * col;
+  for (int js = col; js < col2; ++js)
+    if (dtrsl_upper(wn, m2, col, wn + js * m2, 1)) return -1;
+  // (2,2) block: S'AA'S*theta + (L^-1(-L_a'+R_z'))'(L^-1(-L_a'+R_z')), then its Cholesky
+  for (int is = col; is < col2; ++is)
+    for (int js = is; js < col2; ++js) WN(is, js) += ddot(col, wn + is * m2, wn + js * m2);
+  if (dpofa(wn + col * m2 + col, m2, col)) return -2;
+  return 0;
+#undef WN
+#undef WN1
+#undef WS
+#undef WY
+}
+
+// r = -Z'B(xcp - x) - Z'g   (uses c = wa[2m..4m) from cauchy; p = wa[0..2m) as scratch)
+LB_HD int cmprlb(State &s, const Work &w) {
+  const int n = s.n, m = s.m, col = s.col;
+  if (!s.cnstnd && col > 0) {
+    for (int i = 0; i < n; ++i) w.r[i] = -w.g[i];
+    return 0;
+  }
+  for (int i = 0; i < s.nfree; ++i) {
+    const int k = w.index[i] - 1;
+    w.r[i] = -s.theta * (w.z[k] - w.x[k]) - w.g[k];
+  }
+  if (bmv(m, w.sy, w.wt, col, w.wa + 2 * m, w.wa)) return -8;
+  int pointr = s.head;
+  for (int j = 0; j < col; ++j) {
+    const double a1 = w.wa[j], a2 = s.theta * w.wa[col + j];
+    for (int i = 0; i < s.nfree; ++i) {
+      const int k = w.index[i] - 1;
+      w.r[i] += w.wy[pointr * n + k] * a1 + w.ws[pointr * n + k] * a2;
+    }
+    pointr = (pointr + 1) % m;
+  }
+  return 0;
+}
+
+// Subspace minimisation: on entry w.z = xcp and w.r = reduced gradient; on exit w.z is
+// the (projected) subspace minimiser.  wv = wa[0..2m).
+LB_HDN int subsm(State &s, const Work &w, const double *l, const double *u, const int *nbd) {
+  const int n = s.n, m = s.m, col = s.col, nsub = s.nfree, m2 = 2 * s.m, col2 = 2 * s.col;
+  double *x = w.z, *d = w.r, *xp = w.xp, *wv = w.wa;
+  const double *xx = w.x, *gg = w.g;
+  const int *ind = w.index;
+  const double theta = s.theta;
+  if (nsub <= 0) return 0;
+  int pointr = s.head;
+  for (int i = 0; i < col; ++i) {
+    double temp1 = 0.0, temp2 = 0.0;
+    for (int j = 0; j < nsub; ++j) {
+      const int k = ind[j] - 1;
+      temp1 += w.wy[pointr * n + k] * d[j];
+      temp2 += w.ws[pointr * n + k] * d[j];
+    }
+    wv[i] = temp1;
+    wv[col + i] = theta * temp2;
+    pointr = (pointr + 1) % m;
+  }
+  if (dtrsl_upper(w.wn, m2, col2, wv, 1)) return 1;
+  for (int i = 0; i < col; ++i) wv[i] = -wv[i];
+  if (dtrsl_upper(w.wn, m2, col2, wv, 0)) return 1;
+  pointr = s.head;
+  for (int jy = 0; jy < col; ++jy) {
+    const int js = col + jy;
+    for (int i = 0; i < nsub; ++i) {
+      const int k = ind[i] - 1;
+      d[i] += w.wy[pointr * n + k] * wv[jy] / theta + w.ws[pointr * n + k] * wv[js];
+    }
+    pointr = (pointr + 1) % m;
+  }
+  for (int i = 0; i < nsub; ++i) d[i] *= 1.0 / theta;
+  // projected Newton step
+  s.iword = 0;
+  for (int i = 0; i < n; ++i) xp[i] = x[i];
+  for (int i = 0; i < nsub; ++i) {
+    const int k = ind[i] - 1;
+    const double dk = d[i], xk = x[k];
+    if (nbd[k] != 0) {
+      if (nbd[k] == 1) {
+        x[k] = fmax(l[k], xk + dk);
+        if (x[k] == l[k]) s.iword = 1;
+      } else if (nbd[k] == 2) {
+        const double xk2 = fmax(l[k], xk + dk);
+        x[k] = fmin(u[k], xk2);
+        if (x[k] == l[k] || x[k] == u[k]) s.iword = 1;
+      } else if (nbd[k] == 3) {
+        x[k] = fmin(u[k], xk + dk);
+        if (x[k] == u[k]) s.iword = 1;
+      }
+    } else {
+      x[k] = xk + dk;
+    }
+  }
+  if (s.iword == 0) return 0;
+  // sign of the directional derivative along the projected step
+  double dd_p = 0.0;
+  for (int i = 0; i < n; ++i) dd_p += (x[i] - xx[i]) * gg[i];
+  if (dd_p > 0.0) {  // not a descent direction: fall back to the backtracking step
+    for (int i = 0; i < n; ++i) x[i] = xp[i];
+    double alpha = 1.0, temp1 = alpha;
+    int ibd = 0;
+    for (int i = 0; i < nsub; ++i) {
+      const int k = ind[i] - 1;
+      const double dk = d[i];
+      if (nbd[k] != 0) {
+        if (dk < 0.0 && nbd[k] <= 2) {
+          const double temp2 = l[k] - x[k];
+          if (temp2 >= 0.0) temp1 = 0.0;
+          else if (dk * alpha < temp2) temp1 = temp2 / dk;
+        } else if (dk > 0.0 && nbd[k] >= 2) {
+          const double temp2 = u[k] - x[k];
+          if (temp2 <= 0.0) temp1 = 0.0;
+          else if (dk * alpha > temp2) temp1 = temp2 / dk;
+        }
+        if (temp1 < alpha) {
+          alpha = temp1;
+          ibd = i;
+        }
+      }
+    }
+    if (alpha < 1.0) {
+      const double dk = d[ibd];
+      const int k = ind[ibd] - 1;
+      if (dk > 0.0) {
+        x[k] = u[k];
+        d[ibd] = 0.0;
+      } else if (dk < 0.0) {
+        x[k] = l[k];
+        d[ibd] = 0.0;
+      }
+    }
+    for (int i = 0; i < nsub; ++i) {
+      const int k = ind[i] - 1;
+      x[k] += alpha * d[i];
+    }
+  }
+  return 0;
+}
+
+// ---- More'-Thuente line search -------------------------------------------------------------
+LB_HD void dcstep(double &stx, double &fx, double &dx, double &sty, double &fy, double &dy,
+                  double &stp, double fp, double dp, int &brackt, double stpmin, double stpmax) {
+  const double p66 = 0.66;
+  const double sgnd = dp * (dx / fabs(dx));
+  double stpf;
+  if (fp > fx) {  // higher function value: bracketed
+    const double theta = 3.0 * (fx - fp) / (stp - stx) + dx + dp;
+    const double sc = fmax(fabs(theta), fmax(fabs(dx), fabs(dp)));
+    double gamma = sc * sqrt((theta / sc) * (theta / sc) - (dx / sc) * (dp / sc));
+    if (stp < stx) gamma = -gamma;
+    const double p = (gamma - dx) + theta, q = ((gamma - dx) + gamma) + dp, r = p / q;
+    const double stpc = stx + r * (stp - stx);
+    const double stpq = stx + ((dx / ((fx - fp) / (stp - stx) + dx)) / 2.0) * (stp - stx);
+    if (fabs(stpc - stx) < fabs(stpq - stx)) stpf = stpc;
+    else stpf = stpc + (stpq - stpc) / 2.0;
+    brackt = 1;
+  } else if (sgnd < 0.0) {  // lower value, derivatives of opposite sign: bracketed
+    const double theta = 3.0 * (fx - fp) / (stp - stx) + dx + dp;
+    const double sc = fmax(fabs(theta), fmax(fabs(dx), fabs(dp)));
+    double gamma = sc * sqrt((theta / sc) * (theta / sc) - (dx / sc) * (dp / sc));
+    if (stp > stx) gamma = -gamma;
+    const double p = (gamma - dp) + theta, q = ((gamma - dp) + gamma) + dx, r = p / q;
+    const double stpc = stp + r * (stx - stp);
+    const double stpq = stp + (dp / (dp - dx)) * (stx - stp);
+    if (fabs(stpc - stp) > fabs(stpq - stp)) stpf = stpc;
+    else stpf = stpq;
+    brackt = 1;
+  } else if (fabs(dp) < fabs(dx)) {  // lower value, same sign, derivative shrinks
+    const double theta = 3.0 * (fx - fp) / (stp - stx) + dx + dp;
+    const double sc = fmax(fabs(theta), fmax(fabs(dx), fabs(dp)));
+    double gamma = sc * sqrt(fmax(0.0, (theta / sc) * (theta / sc) - (dx / sc) * (dp / sc)));
+    if (stp > stx) gamma = -gamma;
+    const double p = (gamma - dp) + theta, q = (gamma + (dx - dp)) + gamma, r = p / q;
+    double stpc;
+    if (r < 0.0 && gamma != 0.0) stpc = stp + r * (stx - stp);
+    else if (stp > stx) stpc = stpmax;
+    else stpc = stpmin;
+    const double stpq = stp + (dp / (dp - dx)) * (stx - stp);
+    if (brackt) {
+      if (fabs(stpc - stp) < fabs(stpq - stp)) stpf = stpc;
+      else stpf = stpq;
+      if (stp > stx) stpf = fmin(stp + p66 * (sty - stp), stpf);
+      else stpf = fmax(stp + p66 * (sty - stp), stpf);
+    } else {
+      if (fabs(stpc - stp) > fabs(stpq - stp)) stpf = stpc;
+      else stpf = stpq;
+      stpf = fmin(stpmax, stpf);
+      stpf = fmax(stpmin, stpf);
+    }
+  } else {  // lower value, same sign, derivative does not shrink
+    if (brackt) {
+      const double theta = 3.0 * (fp - fy) / (sty - stp) + dy + dp;
+      const double sc = fmax(fabs(theta), fmax(fabs(dy), fabs(dp)));
+      double gamma = sc * sqrt((theta / sc) * (theta / sc) - (dy / sc) * (dp / sc));
+      if (stp > sty) gamma = -gamma;
+      const double p = (gamma - dp) + theta, q = ((gamma - dp) + gamma) + dy, r = p / q;
+      stpf = stp + r * (sty - stp);
+    } else if (stp > stx) {
+      stpf = stpmax;
+    } else {
+      stpf = stpmin;
+    }
+  }
+  if (fp > fx) {
+    sty = stp; fy = fp; dy = dp;
+  } else {
+    if (sgnd < 0.0) { sty = stx; fy = fx; dy = dx; }
+    stx = stp; fx = fp; dx = dp;
+  }
+  stp = stpf;
+}
+
+enum { LS_START = 0, LS_FG = 1, LS_CONV = 2, LS_WARN = 3, LS_ERROR = 4 };
+
+LB_HD void dcsrch(State &s, double f, double g, double &stp, double ftol, double gtol,
+                  double xtol, double stpmin, double stpmax) {
+  const double xtrapl = 1.1, xtrapu = 4.0, p5 = 0.5, p66 = 0.66;
+  if (s.ls_task == LS_START) {
+    if (stp < stpmin || stp > stpmax || g >= 0.0 || ftol < 0.0 || gtol < 0.0 || xtol < 0.0 ||
+        stpmin < 0.0 || stpmax < stpmin) {
+      s.ls_task = LS_ERROR;
+      return;
+    }
+    s.brackt = 0;
+    s.ls_stage = 1;
+    s.finit = f;
+    s.ginit = g;
+    s.gtest = ftol * s.ginit;
+    s.width = stpmax - stpmin;
+    s.width1 = s.width / p5;
+    s.stx = 0.0; s.fx = s.finit; s.gx = s.ginit;
+    s.sty = 0.0; s.fy = s.finit; s.gy = s.ginit;
+    s.stmin = 0.0;
+    s.stmax = stp + xtrapu * stp;
+    s.ls_task = LS_FG;
+    return;
+  }
+  const double ftest = s.finit + stp * s.gtest;
+  if (s.ls_stage == 1 && f <= ftest && g >= 0.0) s.ls_stage = 2;
+  int task = LS_FG;
+  if (s.brackt && (stp <= s.stmin || stp >= s.stmax)) task = LS_WARN;
+  if (s.brackt && s.stmax - s.stmin <= xtol * s.stmax) task = LS_WARN;
+  if (stp == stpmax && f <= ftest && g <= s.gtest) task = LS_WARN;
+  if (stp == stpmin && (f > ftest || g >= s.gtest)) task = LS_WARN;
+  if (f <= ftest && fabs(g) <= gtol * (-s.ginit)) task = LS_CONV;
+  if (task != LS_FG) {
+    s.ls_task = task;
+    return;
+  }
+  if (s.ls_stage == 1 && f <= s.fx && f > ftest) {
+    const double fm = f - stp * s.gtest;
+    double fxm = s.fx - s.stx * s.gtest, fym = s.fy - s.sty * s.gtest;
+    const double gm = g - s.gtest;
+    double gxm = s.gx - s.gtest, gym = s.gy - s.gtest;
+    dcstep(s.stx, fxm, gxm, s.sty, fym, gym, stp, fm, gm, s.brackt, s.stmin, s.stmax);
+    s.fx = fxm + s.stx * s.gtest;
+    s.fy = fym + s.sty * s.gtest;
+    s.gx = gxm + s.gtest;
+    s.gy = gym + s.gtest;
+  } else {
+    dcstep(s.stx, s.fx, s.gx, s.sty, s.fy, s.gy, stp, f, g, s.brackt, s.stmin, s.stmax);
+  }
+  if (s.brackt) {
+    if (fabs(s.sty - s.stx) >= p66 * s.width1) stp = s.stx + p5 * (s.sty - s.stx);
+    s.width1 = s.width;
+    s.width = fabs(s.sty - s.stx);
+  }
+  if (s.brackt) {
+    s.stmin = fmin(s.stx, s.sty);
+    s.stmax = fmax(s.stx, s.sty);
+  } else {
+    s.stmin = stp + xtrapl * (stp - s.stx);
+    s.stmax = stp + xtrapu * (stp - s.stx);
+  }
+  stp = fmax(stp, stpmin);
+  stp = fmin(stp, stpmax);
+  if ((s.brackt && (stp <= s.stmin || stp >= s.stmax)) ||
+      (s.brackt && s.stmax - s.stmin <= xtol * s.stmax))
+    stp = s.stx;
+  s.ls_task = LS_FG;
+}
+
+// One call of the line-search driver.  first != 0 starts a new search along w.d.
+// Returns 1 if f/g is needed at the new w.x, 0 if the search ended (s.info tells how).
+LB_HD int lnsrlb(State &s, const Work &w, const double *l, const double *u, const int *nbd,
+                 int first) {
+  const int n = s.n;
+  const double big = 1e10, ftol = 1e-3, gtol = 0.9, xtol = 0.1;
+  if (first) {
+    s.dtd = ddot(n, w.d, w.d);
+    s.dnorm = sqrt(s.dtd);
+    s.stpmx = big;
+    if (s.cnstnd) {
+      if (s.iter == 0) {
+        s.stpmx = 1.0;
+      } else {
+        for (int i = 0; i < n; ++i) {
+          const double a1 = w.d[i];
+          if (nbd[i] != 0) {
+            if (a1 < 0.0 && nbd[i] <= 2) {
+              const double a2 = l[i] - w.x[i];
+              if (a2 >= 0.0) s.stpmx = 0.0;
+              else if (a1 * s.stpmx < a2) s.stpmx = a2 / a1;
+            } else if (a1 > 0.0 && nbd[i] >= 2) {
+              const double a2 = u[i] - w.x[i];
+              if (a2 <= 0.0) s.stpmx = 0.0;
+              else if (a1 * s.stpmx > a2) s.stpmx = a2 / a1;
+            }
+          }
+        }
+      }
+    }
+    if (s.iter == 0 && !s.boxed) s.stp = fmin(1.0 / s.dnorm, s.stpmx);
+    else s.stp = 1.0;
+    for (int i = 0; i < n; ++i) {
+      w.t[i] = w.x[i];
+      w.r[i] = w.g[i];
+    }
+    s.fold = s.f;
+    s.ifun = 0;
+    s.iback = 0;
+    s.ls_task = LS_START;
+  }
+  s.gd = ddot(n, w.g, w.d);
+  if (s.ifun == 0) {
+    s.gdold = s.gd;
+    if (s.gd >= 0.0) {  // ascent direction in projection: line search impossible
+      s.info = -4;
+      return 0;
+    }
+  }
+  dcsrch(s, s.f, s.gd, s.stp, ftol, gtol, xtol, 0.0, s.stpmx);
+  s.xstep = s.stp * s.dnorm;
+  if (s.ls_task != LS_CONV && s.ls_task != LS_WARN) {
+    // (LS_ERROR cannot arise: stp in [0, stpmx], gd < 0, constants valid; treated as FG by the
+    // original as well, whose caller then trips on info/iback)
+    ++s.ifun;
+    ++s.nfgv;
+    s.iback = s.ifun - 1;
+    if (s.stp == 1.0) {
+      for (int i = 0; i < n; ++i) w.x[i] = w.z[i];
+    } else {
+      for (int i = 0; i < n; ++i) w.x[i] = s.stp * w.d[i] + w.t[i];
+    }
+    return 1;
+  }
+  return 0;
+}
+
+// ---- BFGS matrix update -----------------------------------------------------------------------
+LB_HD void matupd(State &s, const Work &w, double rr, double dr) {
+  const int n = s.n, m = s.m;
+  if (s.iupdat <= m) {
+    s.col = s.iupdat;
+    s.itail = (s.head + s.iupdat - 1) % m;
+  } else {
+    s.itail = (s.itail + 1) % m;
+    s.head = (s.head + 1) % m;
+  }
+  for (int i = 0; i < n; ++i) {
+    w.ws[s.itail * n + i] = w.d[i];
+    w.wy[s.itail * n + i] = w.r[i];
+  }
+  s.theta = rr / dr;
+  const int col = s.col;
+  if (s.iupdat > m) {  // move old information
+    for (int j = 0; j < col - 1; ++j) {
+      for (int i = 0; i <= j; ++i) w.ss[j * m + i] = w.ss[(j + 1) * m + (i + 1)];
+      for (int i = 0; i < col - 1 - j; ++i) w.sy[j * m + (j + i)] = w.sy[(j + 1) * m + (j + 1 + i)];
+    }
+  }
+  int pointr = s.head;
+  for (int j = 0; j < col - 1; ++j) {
+    w.sy[j * m + (col - 1)] = ddot(n, w.d, w.wy + pointr * n);
+    w.ss[(col - 1) * m + j] = ddot(n, w.ws + pointr * n, w.d);
+    pointr = (pointr + 1) % m;
+  }
+  if (s.stp == 1.0) w.ss[(col - 1) * m + (col - 1)] = s.dtd;
+  else w.ss[(col - 1) * m + (col - 1)] = s.stp * s.stp * s.dtd;
+  w.sy[(col - 1) * m + (col - 1)] = dr;
+}
+
+LB_HD void refresh_memory(State &s) {
+  s.info = 0;
+  s.col = 0;
+  s.head = 0;
+  s.theta = 1.0;
+  s.iupdat = 0;
+  s.updatd = 0;
+}
+
+LB_HD void finish(State &s, int task, int msg) {
+  s.task = task;
+  s.msg = msg;
+  s.stage = S_FINISHED;
+  // scipy's warnflag: 0 converged, 1 maxfun/maxiter, 2 anything else
+  if (task == T_CONVERGENCE) s.status = 0;
+  else if (msg == M_MAXFUN || msg == M_MAXITER) s.status = 1;
+  else s.status = 2;
+}
+
+// Initialise a problem.  x0 is clipped into the box (scipy does that before the solver
+// sees it).  nbd[i]: 0 unbounded, 1 lower, 2 both, 3 upper.
+LB_HD void lbfgsb_init(State &s, const Work &w, int n, int m, const double *x0, const double *l,
+                       const double *u, const int *nbd) {
+  s.n = n;
+  s.m = m;
+  for (int i = 0; i < n; ++i) {
+    double xi = x0[i];
+    if (nbd[i] == 1 || nbd[i] == 2) xi = fmax(xi, l[i]);
+    if (nbd[i] == 2 || nbd[i] == 3) xi = fmin(xi, u[i]);
+    w.x[i] = xi;
+    w.g[i] = 0.0;
+  }
+  s.f = 0.0;
+  s.stage = S_INIT;
+  s.task = T_START;
+  s.msg = M_NONE;
+  s.nit = 0;
+  s.nfev = 0;
+  s.status = 2;
+}
+
+// Advance the problem until it needs f and g at w.x (LB_NEED_FG: the caller stores them in
+// s.f / w.g and calls again) or terminates (LB_DONE: result in w.x, s.f, w.g, s.nit,
+// s.nfev, s.status, s.task, s.msg).
+LB_HDN int lbfgsb_advance(State &s, const Work &w, const double *l, const double *u,
+                          const int *nbd, const Options &opt) {
+  const int n = s.n, m = s.m;
+  bool first_ls = false;
+  bool resume_ls = (s.stage == S_FG_LNSRCH);
+
+  if (s.stage == S_FINISHED) return LB_DONE;
+
+  if (s.stage == S_FG_START || s.stage == S_FG_LNSRCH) {  // fresh f, g at w.x have arrived
+    for (int i = 0; i < n; ++i) { w.xlast[i] = w.x[i]; w.glast[i] = w.g[i]; }
+    s.flast = s.f;
+  }
+
+  if (s.stage == S_INIT) {
+    s.col = 0; s.head = 0; s.theta = 1.0; s.iupdat = 0; s.updatd = 0;
+    s.iback = 0; s.itail = 0; s.ifun = 0; s.iter = 0; s.nfgv = 0; s.nseg = 0;
+    s.nfree = n; s.info = 0; s.iword = 0; s.nact = 0; s.nenter = 0; s.ileave = 0;
+    s.fold = 0.0; s.dnorm = 0.0; s.sbgnrm = 0.0; s.stp = 0.0; s.xstep = 0.0; s.stpmx = 0.0;
+    s.gd = 0.0; s.gdold = 0.0; s.dtd = 0.0; s.wrk = 0;
+    // errclb
+    if (n <= 0) { finish(s, T_ERROR, M_N_LE_0); return LB_DONE; }
+    if (m <= 0) { finish(s, T_ERROR, M_M_LE_0); return LB_DONE; }
+    if (opt.factr < 0.0) { finish(s, T_ERROR, M_FACTR_NEG); return LB_DONE; }
+    for (int i = 0; i < n; ++i) {
+      if (nbd[i] < 0 || nbd[i] > 3) { finish(s, T_ERROR, M_INVALID_NBD); return LB_DONE; }
+      if (nbd[i] == 2 && l[i] > u[i]) { finish(s, T_ERROR, M_NO_FEASIBLE); return LB_DONE; }
+    }
+    // active: project x, classify the variables
+    s.prjctd = 0; s.cnstnd = 0; s.boxed = 1;
+    for (int i = 0; i < n; ++i) {
+      if (nbd[i] > 0) {
+        if (nbd[i] <= 2 && w.x[i] <= l[i]) {
+          if (w.x[i] < l[i]) { s.prjctd = 1; w.x[i] = l[i]; }
+        } else if (nbd[i] >= 2 && w.x[i] >= u[i]) {
+          if (w.x[i] > u[i]) { s.prjctd = 1; w.x[i] = u[i]; }
+        }
+      }
+    }
+    for (int i = 0; i < n; ++i) {
+      if (nbd[i] != 2) s.boxed = 0;
+      if (nbd[i] == 0) {
+        w.iwhere[i] = -1;
+      } else {
+        s.cnstnd = 1;
+        if (nbd[i] == 2 && u[i] - l[i] <= 0.0) w.iwhere[i] = 3;
+        else w.iwhere[i] = 0;
+      }
+    }
+    s.stage = S_FG_START;
+    s.task = T_FG;
+    ++s.nfev;
+    return LB_NEED_FG;
+  }
+
+  if (s.stage == S_FG_START) {
+    s.nfgv = 1;
+    s.sbgnrm = projgr(n, l, u, nbd, w.x, w.g);
+    if (s.sbgnrm <= opt.pgtol) { finish(s, T_CONVERGENCE, M_PGTOL); return LB_DONE; }
+    resume_ls = false;
+  }
+
+  // otherwise S_FG_LNSRCH: f and g at the trial point have arrived; resume the line search
+
+  for (;;) {
+    if (resume_ls) {
+      resume_ls = false;
+      first_ls = false;
+    } else {
+      s.iword = -1;
+      if (!s.cnstnd && s.col > 0) {
+        for (int i = 0; i < n; ++i) w.z[i] = w.x[i];
+        s.wrk = s.updatd;
+        s.nseg = 0;
+      } else {
+        if (cauchy(s, w, l, u, nbd)) {  // singular triangular system: refresh the memory
+          refresh_memory(s);
+          continue;
+        }
+        freev(s, w);
+        s.nact = n - s.nfree;
+      }
+      if (s.nfree != 0 && s.col != 0) {
+        if (s.wrk) {
+          if (formk(s, w)) { refresh_memory(s); continue; }
+        }
+        if (cmprlb(s, w)) { refresh_memory(s); continue; }
+        if (subsm(s, w, l, u, nbd)) { refresh_memory(s); continue; }
+      }
+      for (int i = 0; i < n; ++i) w.d[i] = w.z[i] - w.x[i];
+      first_ls = true;
+    }
+
+    s.info = 0;
+    if (lnsrlb(s, w, l, u, nbd, first_ls ? 1 : 0)) {
+      if (s.iback < opt.maxls) {
+        // SciPy's ScalarFunction serves a request at the point it evaluated last from its
+        // cache (no call, nfev unchanged); a collapsed bracket asks for such points.
+        bool cached = true;
+        for (int i = 0; i < n; ++i) cached = cached && (w.x[i] == w.xlast[i]);
+        if (cached) {
+          s.f = s.flast;
+          for (int i = 0; i < n; ++i) w.g[i] = w.glast[i];
+          resume_ls = true;
+          continue;
+        }
+        s.stage = S_FG_LNSRCH;
+        s.task = T_FG;
+        ++s.nfev;
+        return LB_NEED_FG;
+      }
+      // maxls trial points used up: handled like a failed search (the trial x is dropped)
+    }
+    if (s.info != 0 || s.iback >= opt.maxls) {
+      // restore the previous iterate
+      for (int i = 0; i < n; ++i) { w.x[i] = w.t[i]; w.g[i] = w.r[i]; }
+      s.f = s.fold;
+      if (s.col == 0) {
+        // abnormal termination
+        if (s.info == 0) { s.info = -9; --s.nfgv; --s.ifun; --s.iback; }
+        ++s.iter;
+        finish(s, T_ABNORMAL, M_NONE);
+        return LB_DONE;
+      }
+      refresh_memory(s);  // restart from the steepest-descent-like state
+      continue;
+    }
+    // new iterate accepted
+    ++s.iter;
+    s.sbgnrm = projgr(n, l, u, nbd, w.x, w.g);
+    // --- what the SciPy driver does on NEW_X ---
+    ++s.nit;
+    if (s.nit >= opt.maxiter) { finish(s, T_STOP, M_MAXITER); return LB_DONE; }
+    if (s.nfev > opt.maxfun) { finish(s, T_STOP, M_MAXFUN); return LB_DONE; }
+    // --- convergence tests ---
+    if (s.sbgnrm <= opt.pgtol) { finish(s, T_CONVERGENCE, M_PGTOL); return LB_DONE; }
+    {
+      const double ddum = fmax(fmax(fabs(s.fold), fabs(s.f)), 1.0);
+      if ((s.fold - s.f) <= LB_EPSMCH * opt.factr * ddum) {
+        if (s.iback >= 10) s.info = -5;
+        finish(s, T_CONVERGENCE, M_FACTR);
+        return LB_DONE;
+      }
+    }
+    // --- BFGS update: r = g - g_old (y), d = step (s) ---
+    for (int i = 0; i < n; ++i) w.r[i] = w.g[i] - w.r[i];
+    {
+      const double rr = ddot(n, w.r, w.r);
+      double dr, ddum;
+      if (s.stp == 1.0) {
+        dr = s.gd - s.gdold;
+        ddum = -s.gdold;
+      } else {
+        dr = (s.gd - s.gdold) * s.stp;
+        for (int i = 0; i < n; ++i) w.d[i] *= s.stp;
+        ddum = -s.gdold * s.stp;
+      }
+      if (dr <= LB_EPSMCH * ddum) {  // curvature too small: skip the update
+        s.updatd = 0;
+        continue;
+      }
+      s.updatd = 1;
+      ++s.iupdat;
+      matupd(s, w, rr, dr);
+      if (formt(m, w.wt, w.sy, w.ss, s.col, s.theta)) {
+        refresh_memory(s);
+        continue;
+      }
+    }
+  }
+}
+
+}  // namespace lbfgsb

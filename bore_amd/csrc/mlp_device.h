@@ -129,6 +129,41 @@ __device__ __forceinline__ void bwd_delta(const MlpLayout &L, const float *th, f
   }
 }
 
+// Objective + input gradient of one tile whose rows sit in A_0: forward, T(sign*f) into
+// val_out[0..nb) (LDS or global), dT/dx into D_0.  Ends with a barrier; D_0 and val_out
+// are then readable by every thread.
+__device__ __forceinline__ void fg_tile(const MlpLayout &L, const float *th, float *tile, int nb,
+                                        int transform, float sign, float *val_out) {
+  const int n = L.n_layers;
+  for (int l = 1; l <= n; ++l) {
+    fwd_layer(L, th, tile, l, nb, false);
+    __syncthreads();
+  }
+  if ((int)threadIdx.x < nb) {
+    const int b = threadIdx.x;
+    const float f = tile[L.aoff[n] + b * L.lda[n]];
+    const float u = sign * f;
+    float T, dT;
+    if (transform == BORE_T_SIGMOID) {
+      T = sigmoid_stable(u);
+      dT = T * (1.f - T);
+    } else if (transform == BORE_T_EXP) {
+      T = expf(u);
+      dT = T;
+    } else {
+      T = u;
+      dT = 1.f;
+    }
+    val_out[b] = T;
+    tile[L.doff[n] + b * L.lda[n]] = sign * dT * act_grad(L.act[n], f);
+  }
+  __syncthreads();
+  for (int l = n; l >= 1; --l) {
+    bwd_delta(L, th, tile, l, nb);
+    __syncthreads();
+  }
+}
+
 // ---- shuffle stream ---------------------------------------------------------
 // One permutation of range(N) per (seed, model, epoch): row i draws the 32-bit key
 // mix(base + (i+1)*C3) >> 32 and the permutation lists the rows by ascending

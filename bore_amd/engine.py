@@ -11,7 +11,8 @@ stage being ONE launch over the leading replica dimension:
     screen  predict on num_samples uniform candidates (bore/mixins.py:49-56) 1 launch
     argmax  L x num_starts L-BFGS-B restarts          (bore/mixins.py:57-89) 1 launch / round
 
-Across GPUs the loops are sharded (rank r owns loops l with l % world == r); no
+Across GPUs the loops are sharded in contiguous blocks (rank r owns loops
+[r*L, (r+1)*L): the device streams are keyed by first id + offset); no
 data-path collective exists -- results are gathered once at the end (``gather_results``).
 """
 from __future__ import annotations
@@ -37,10 +38,19 @@ class ReplicaEngine:
     def __init__(self, loop_ids, input_dim=2, units=(16, 16, 1), acts=("relu", "relu", "sigmoid"),
                  transform="identity", gamma=0.25, epochs=200, batch_size=64, num_starts=3,
                  num_samples=1024, n_init=10, objective=branin01, max_points=None,
-                 options=None, device=None):
+                 options=None, device=None, mode="device", seed=0):
+        """mode "device": label, fit, candidate draw, screening and all L-BFGS-B restarts run
+        as five launches per BO iteration with ONE host sync (candidates from the device
+        counter stream).  mode "lockstep": candidates from each loop's numpy RandomState and
+        SciPy's L-BFGS-B on the host around the batched f/g kernel (the reference's streams
+        and optimiser code; slow -- one launch + L*R host state machines per round)."""
+        assert mode in ("device", "lockstep")
+        self.mode, self.seed = mode, int(seed)
         self.device = device or _lib.require_gpu()
         self.loop_ids = np.asarray(loop_ids, dtype=np.int64)
         self.L = L = len(self.loop_ids)
+        assert L >= 1 and np.array_equal(self.loop_ids, self.loop_ids[0] + np.arange(L)), \
+            "loop ids must be consecutive (the device streams are keyed by first id + offset)"
         self.D = D = int(input_dim)
         self.units, self.acts = list(units), list(acts)
         self.desc = _lib.make_desc(D, self.units, self.acts)
@@ -69,6 +79,7 @@ class ReplicaEngine:
         self.adam_v = torch.zeros_like(self.theta)
         self.adam_t = torch.zeros(L, dtype=torch.int64, device=self.device)
         self.epochs_seen = 0
+        self.draws = 0
         # observations
         self.X = np.stack([rs.uniform(self.low, self.high, size=(n_init, D)) for rs in self.rs])
         self.y = self.objective(self.X)
@@ -91,8 +102,8 @@ class ReplicaEngine:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         ops.mlp_fit(self.desc, self.theta, self.adam_m, self.adam_v, self.adam_t, Xd, zd,
-                    self.epochs, self.batch_size, seed=0, model_index0=0,
-                    epoch0=self.epochs_seen, want_loss=False)
+                    self.epochs, self.batch_size, seed=self.seed,
+                    model_index0=int(self.loop_ids[0]), epoch0=self.epochs_seen, want_loss=False)
         e1.record()
         self._ev.append((e0, e1))
         steps = -(-N // self.batch_size)
@@ -141,12 +152,54 @@ class ReplicaEngine:
                 x_next[l] = best.x
         return x_next
 
+    def step_device(self):
+        """One BO iteration of every loop, device-resident: 5 launches, 1 sync."""
+        L, N, D, R = self.L, self.N, self.D, self.num_starts
+        dev = self.device
+        Xd = torch.from_numpy(self.X.astype(np.float32)).to(dev, non_blocking=True)
+        yd = torch.from_numpy(self.y).to(dev, non_blocking=True)
+        zd = ops.labels(yd, self.gamma)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        ops.mlp_fit(self.desc, self.theta, self.adam_m, self.adam_v, self.adam_t, Xd, zd,
+                    self.epochs, self.batch_size, seed=self.seed,
+                    model_index0=int(self.loop_ids[0]), epoch0=self.epochs_seen, want_loss=False)
+        e1.record()
+        self._ev.append((e0, e1))
+        steps = -(-N // self.batch_size)
+        self.stats["fit_bytes"].append(L * self.epochs * (4 * N * (D + 1) + steps * 24 * self.P))
+        self.epochs_seen += self.epochs
+        Xc = ops.uniform_candidates(self.seed, L, self.num_samples, self.low, self.high,
+                                    model_index0=int(self.loop_ids[0]), draw_index=self.draws,
+                                    device=dev)
+        self.draws += 1
+        x0, _ = ops.screen_topk(self.desc, self.theta, Xc, R)
+        tr = self.transform.negated()
+        x, fun, _, info = ops.lbfgsb_minimize(self.desc, self.theta, x0, self.low, self.high,
+                                              tr.name, tr.negate, **self.options)
+        x, fun, info = x.cpu().numpy(), fun.cpu().numpy(), info.cpu().numpy()   # the one sync
+        self.stats["n_fg_rows"] += int(info[:, :, 1].sum())
+        self.stats["n_rounds"] += int(info[:, :, 1].max())
+        ok = (info[:, :, 2] == 0) | (info[:, :, 2] == 1)          # success or status == 1
+        f = np.where(ok, fun, np.inf)
+        best = np.argmin(f, axis=1)                                # ties keep the earliest
+        x_next = x[np.arange(L), best]
+        none = ~ok.any(axis=1)
+        if none.any():                                             # reference: random fallback
+            self.stats["none_results"] += int(none.sum())
+            for l in np.nonzero(none)[0]:
+                x_next[l] = self.rs[l].uniform(self.low, self.high)
+        return x_next
+
     def step(self):
         """One BO iteration of every loop."""
-        z = self.label()
-        self.fit(z)
-        results = self.restarts(self.screen())
-        x_next = self.suggest(results)
+        if self.mode == "device":
+            x_next = self.step_device()
+        else:
+            z = self.label()
+            self.fit(z)
+            results = self.restarts(self.screen())
+            x_next = self.suggest(results)
         y_next = self.objective(x_next)
         self.X = np.concatenate([self.X, x_next[:, None, :]], axis=1)
         self.y = np.concatenate([self.y, y_next[:, None]], axis=1)

@@ -17,10 +17,34 @@ from .optimizers import lockstep
 from .optimizers.utils import from_bounds
 from .transforms import identity, resolve
 
-#: how ``maxima`` runs its restarts.  "lockstep": all restarts share one batched f/g
-#: launch per round (results identical to "sequential").  "sequential": the reference's
-#: loop (bore/mixins.py:57-60), also used for any method other than L-BFGS-B.
-RESTART_MODES = ("lockstep", "sequential")
+#: how ``maxima`` runs its restarts.
+#: "device": every restart's L-BFGS-B runs inside ONE kernel (bore_lbfgsb_minimize; same
+#:     algorithm and stopping rules as SciPy's, fp64; trajectories agree with SciPy to
+#:     rounding, see tests/test_lbfgsb_host.py).
+#: "lockstep": SciPy's own L-BFGS-B state machines on the host, all restarts sharing one
+#:     batched f/g launch per round (results bit-identical to "sequential").
+#: "sequential": the reference's loop (bore/mixins.py:57-60), one scipy.optimize.minimize
+#:     per start; also used for any method other than L-BFGS-B.
+RESTART_MODES = ("device", "lockstep", "sequential")
+
+_LBFGSB_MESSAGES = None
+
+
+def _message(task, msg):
+    global _LBFGSB_MESSAGES
+    if _LBFGSB_MESSAGES is None:
+        try:
+            from scipy.optimize._lbfgsb_py import status_messages, task_messages
+        except Exception:  # pragma: no cover
+            status_messages = {0: "START", 1: "NEW_X", 3: "FG", 4: "CONVERGENCE", 5: "STOP",
+                               7: "ERROR", 8: "ABNORMAL"}
+            task_messages = {0: "", 401: "NORM OF PROJECTED GRADIENT <= PGTOL",
+                             402: "RELATIVE REDUCTION OF F <= FACTR*EPSMCH",
+                             502: "TOTAL NO. OF F,G EVALUATIONS EXCEEDS LIMIT",
+                             504: "TOTAL NO. OF ITERATIONS REACHED LIMIT"}
+        _LBFGSB_MESSAGES = (status_messages, task_messages)
+    st, tk = _LBFGSB_MESSAGES
+    return st.get(task, str(task)) + ": " + tk.get(msg, str(msg))
 
 _DEFAULT_OPTIONS = dict(maxiter=1000, ftol=1e-9)   # bore/mixins.py:23
 
@@ -55,7 +79,30 @@ class MaximizableMixin:
         X_init = random_state.uniform(low=low, high=high, size=(num_samples, dim))
         return X_init, -self.predict(X_init).squeeze(axis=-1)
 
+    def _minimize_on_device(self, X0, bounds, options):
+        import torch
+        from . import ops
+        (low, high), dim = from_bounds(bounds)
+        low = [-np.inf if v is None else v for v in low]
+        high = [np.inf if v is None else v for v in high]
+        unknown = set(options) - {"maxcor", "ftol", "gtol", "maxfun", "maxiter", "maxls"}
+        if unknown:
+            raise TypeError(f"unknown L-BFGS-B options: {sorted(unknown)}")
+        self._ensure_built(X0)
+        x0 = torch.from_numpy(np.ascontiguousarray(X0, dtype=np.float64)[None]).to(self.theta.device)
+        tr = self._func_min.transform
+        x, fun, jac, info = ops.lbfgsb_minimize(self._desc, self.theta, x0, low, high, tr.name,
+                                                tr.negate, **options)
+        x, fun, jac, info = (t[0].cpu().numpy() for t in (x, fun, jac, info))
+        return [OptimizeResult(x=x[r], fun=float(fun[r]), jac=jac[r], nit=int(info[r, 0]),
+                               nfev=int(info[r, 1]), njev=int(info[r, 1]),
+                               status=int(info[r, 2]), success=bool(info[r, 2] == 0),
+                               message=_message(int(info[r, 3]), int(info[r, 4])))
+                for r in range(len(X0))]
+
     def _minimize_from(self, X0, bounds, method, options):
+        if method == "L-BFGS-B" and self.restart_mode == "device":
+            return self._minimize_on_device(X0, bounds, dict(options or {}))
         if method == "L-BFGS-B" and self.restart_mode == "lockstep" and lockstep.available():
             return lockstep.minimize_lockstep(self._func_min, X0, bounds=bounds,
                                               **dict(options or {}))

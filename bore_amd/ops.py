@@ -132,3 +132,93 @@ def shuffle_perm(seed, n_models, epochs, N, model_index0=0, epoch0=0, device=Non
                                             n_models, int(epoch0), epochs, N, _lib.ptr(perm),
                                             _lib.stream_ptr()))
     return perm
+
+
+def labels(y, gamma, want_tau=False):
+    """y [L,N] f64 -> z [L,N] f32 in {0,1} (z = y < np.quantile(y, gamma)); optionally tau [L]."""
+    if y.dim() != 2:
+        raise ValueError("y: expected [n_models, N]")
+    L, N = y.shape
+    _chk(y, torch.float64, (L, N), "y")
+    z = torch.empty((L, N), dtype=torch.float32, device=y.device)
+    tau = torch.empty(L, dtype=torch.float64, device=y.device) if want_tau else None
+    _lib.check(_lib.lib().bore_labels(L, _lib.ptr(y), N, float(gamma), _lib.ptr(z), _lib.ptr(tau),
+                                      _lib.stream_ptr()))
+    return (z, tau) if want_tau else z
+
+
+def _host_f64(a, D, name):
+    import numpy as np
+    a = np.ascontiguousarray(np.broadcast_to(np.asarray(a, dtype=np.float64), (D,)))
+    if a.shape != (D,):
+        raise ValueError(f"{name}: expected {D} values")
+    return a, a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def uniform_candidates(seed, n_models, n_samples, low, high, model_index0=0, draw_index=0,
+                       device=None):
+    """X ~ U(low, high): [n_models, n_samples, D] f64 from the counter-based device stream
+    (numpy statement: bore_amd.sampling.uniform_candidates)."""
+    import numpy as np
+    device = device or _lib.require_gpu()
+    D = len(np.atleast_1d(low))
+    lo, lo_p = _host_f64(low, D, "low")
+    hi, hi_p = _host_f64(high, D, "high")
+    X = torch.empty((n_models, n_samples, D), dtype=torch.float64, device=device)
+    _lib.check(_lib.lib().bore_uniform_candidates(C.c_uint64(seed & (2**64 - 1)), int(model_index0),
+                                                  n_models, int(draw_index), n_samples, D, lo_p,
+                                                  hi_p, _lib.ptr(X), _lib.stream_ptr()))
+    return X
+
+
+def screen_topk(desc, theta, X_init, num_starts, want_pred=False):
+    """Screening of ``maxima``: predict on X_init ([L,Ns,D] or shared [Ns,D], f64) and return
+    (x0 [L,R,D] f64, idx [L,R] int32[, pred [L,Ns] f32]) for the R = num_starts best rows."""
+    L, P = theta.shape
+    D = desc.input_dim
+    shared = X_init.dim() == 2
+    Ns = X_init.shape[-2]
+    _chk(theta, torch.float32, (L, param_count(desc)), "theta")
+    _chk(X_init, torch.float64, (Ns, D) if shared else (L, Ns, D), "X_init")
+    R = int(num_starts)
+    x0 = torch.empty((L, R, D), dtype=torch.float64, device=theta.device)
+    idx = torch.empty((L, R), dtype=torch.int32, device=theta.device)
+    pred = torch.empty((L, Ns), dtype=torch.float32, device=theta.device) if want_pred else None
+    _lib.check(_lib.lib().bore_screen_topk(C.byref(desc), L, _lib.ptr(theta), _lib.ptr(X_init), Ns,
+                                           int(shared), R, _lib.ptr(x0), _lib.ptr(idx),
+                                           _lib.ptr(pred), _lib.stream_ptr()))
+    return (x0, idx, pred) if want_pred else (x0, idx)
+
+
+def lbfgsb_minimize(desc, theta, x0, low, high, transform="identity", negate=True, maxcor=10,
+                    ftol=2.2204460492503131e-09, gtol=1e-5, maxfun=15000, maxiter=15000,
+                    maxls=20):
+    """R bound-constrained L-BFGS-B minimisations of T(+-f(x)) per model, on the device.
+
+    x0 [L,R,D] f64; low/high: length-D host sequences (+-inf for open sides).
+    Returns (x [L,R,D] f64, fun [L,R] f64, jac [L,R,D] f64, info [L,R,5] int32) with
+    info = (nit, nfev, status, task, message) as in scipy's OptimizeResult / task tables."""
+    L, P = theta.shape
+    D = desc.input_dim
+    _chk(theta, torch.float32, (L, param_count(desc)), "theta")
+    if x0.dim() != 3:
+        raise ValueError("x0: expected [n_models, num_starts, D]")
+    R = x0.shape[1]
+    _chk(x0, torch.float64, (L, R, D), "x0")
+    if transform not in _lib.TRANSFORM:
+        raise ValueError(f"unknown transform {transform!r}")
+    lo, lo_p = _host_f64(low, D, "low")
+    hi, hi_p = _host_f64(high, D, "high")
+    opts = _lib.LbfgsbOpts(int(maxcor), int(maxiter), int(maxfun), int(maxls), float(ftol),
+                           float(gtol))
+    x = torch.empty_like(x0)
+    jac = torch.empty_like(x0)
+    fun = torch.empty((L, R), dtype=torch.float64, device=theta.device)
+    info = torch.empty((L, R, 5), dtype=torch.int32, device=theta.device)
+    if R == 0:
+        return x, fun, jac, info
+    _lib.check(_lib.lib().bore_lbfgsb_minimize(
+        C.byref(desc), L, _lib.ptr(theta), _lib.TRANSFORM[transform], int(bool(negate)),
+        _lib.ptr(x0), R, lo_p, hi_p, C.byref(opts), _lib.ptr(x), _lib.ptr(fun), _lib.ptr(jac),
+        _lib.ptr(info), _lib.stream_ptr()))
+    return x, fun, jac, info

@@ -34,6 +34,7 @@ extern "C" {
 #define BORE_ABI_VERSION 1
 #define BORE_MAX_LAYERS 8
 #define BORE_BATCH_MAX 64 /* rows per tile == wavefront width */
+#define BORE_DIM_MAX 64   /* largest input dimension for the by-value bound arrays */
 
 enum bore_status {
   BORE_OK = 0,
@@ -138,6 +139,70 @@ int bore_mlp_fit(const bore_mlp_desc *desc, int n_models, float *theta,
 int bore_mlp_evaluate(const bore_mlp_desc *desc, int n_models, const float *theta,
                       const float *X, const float *z, int64_t N, float *loss,
                       float *acc, void *stream);
+
+/*
+ * Label step of the BO loop: tau = quantile(y, gamma) with numpy's default linear
+ * interpolation, z = (y < tau) (bore/data.py:31-35; README.rst:89-90).  fp64, bit-exact
+ * with numpy for finite y.
+ *   y    device fp64 [n_models][N];  z device fp32 [n_models][N] in {0,1};  tau device fp64 [n_models]
+ */
+int bore_labels(int n_models, const double *y, int64_t N, double gamma, float *z, double *tau,
+                void *stream);
+
+/*
+ * Candidate sampling of maxima(): X ~ U(low, high), shape [n_models][n_samples][D]
+ * (bore/mixins.py:49).  The reference draws from numpy's RandomState on the host; this
+ * entry point is the device-resident alternative for replica runs: a counter-based
+ * stream keyed by (seed, model_index0 + model, draw_index) -- bore_amd/sampling.py holds
+ * the identical numpy statement.  low/high are HOST arrays of length D (D <= 64).
+ */
+int bore_uniform_candidates(uint64_t seed, int64_t model_index0, int n_models, int64_t draw_index,
+                            int64_t n_samples, int D, const double *low, const double *high,
+                            double *X, void *stream);
+
+/*
+ * Screening of maxima(): predict on the candidates and keep the num_starts best
+ * (bore/mixins.py:50-56: z_init = predict(X_init); argpartition(-z_init, num_starts-1)).
+ * Selection is by descending prediction, ties to the lower index (numpy's argpartition
+ * returns the same SET in an unspecified order).
+ *   X_init  device fp64 [n_models][n_samples][D] (or [n_samples][D] when x_shared != 0)
+ *   x0      device fp64 [n_models][num_starts][D]   the chosen rows
+ *   idx     device int32 [n_models][num_starts]     their row numbers
+ *   pred    device fp32 [n_models][n_samples] or NULL
+ */
+int bore_screen_topk(const bore_mlp_desc *desc, int n_models, const float *theta,
+                     const double *X_init, int64_t n_samples, int x_shared, int num_starts,
+                     double *x0, int32_t *idx, float *pred, void *stream);
+
+/* scipy.optimize.minimize(method="L-BFGS-B") options as the reference passes them
+ * (bore/mixins.py:23: maxiter=1000, ftol=1e-9; SciPy defaults for the rest). */
+typedef struct bore_lbfgsb_opts {
+  int32_t maxcor;   /* 10 */
+  int32_t maxiter;  /* 15000 (reference: 1000) */
+  int32_t maxfun;   /* 15000 */
+  int32_t maxls;    /* 20 */
+  double ftol;      /* 2.22e-9 (reference: 1e-9) */
+  double gtol;      /* 1e-5 */
+} bore_lbfgsb_opts;
+
+/*
+ * The restart loop of maxima() (bore/mixins.py:57-66): num_starts independent
+ * bound-constrained L-BFGS-B minimisations of transform(+-f(x)) per model, all inside ONE
+ * launch -- the optimiser state machines run on the device (bore_amd/csrc/lbfgsb.h), the
+ * f/g requests of a workgroup's problems are evaluated together against weights held in
+ * LDS.  Same algorithm, constants, stopping rules and status codes as SciPy's L-BFGS-B.
+ *   x0       device fp64 [n_models][num_starts][D]  (clipped into the box like SciPy does)
+ *   lb, ub   HOST fp64 [D]; +-INFINITY for an open side (D <= 64)
+ *   x, jac   device fp64 [n_models][num_starts][D];  fun device fp64 [n_models][num_starts]
+ *            (the fp32 objective value, widened)
+ *   info     device int32 [n_models][num_starts][5] = {nit, nfev, status, task, message}
+ *            status 0 converged / 1 maxiter-or-maxfun / 2 abnormal (OptimizeResult.status);
+ *            (task, message) index scipy's status_messages / task_messages
+ */
+int bore_lbfgsb_minimize(const bore_mlp_desc *desc, int n_models, const float *theta,
+                         int transform, int negate, const double *x0, int num_starts,
+                         const double *lb, const double *ub, const bore_lbfgsb_opts *opts,
+                         double *x, double *fun, double *jac, int32_t *info, void *stream);
 
 /* The in-kernel shuffle stream of bore_mlp_fit, written out:
  * perm device int32 [n_models][epochs][N]. */

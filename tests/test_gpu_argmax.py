@@ -1,0 +1,207 @@
+"""Device-side acquisition: label step, candidate stream, screening + top-k and the
+in-kernel multi-start L-BFGS-B, through the C-ABI on an MI355X."""
+import numpy as np
+import pytest
+import torch
+from scipy.optimize import Bounds
+
+import lbfgsb_host as H
+from bore_amd import _lib, ops, sampling
+from bore_amd.layers import Dense
+from bore_amd.models import MaximizableSequential
+from bore_amd.optimizers import lockstep
+from oracle import bore_oracle as O
+from test_gpu_parity import dev, pack, rand_model
+
+pytestmark = pytest.mark.gpu
+
+
+def test_labels_bit_exact_with_reference_vectors(gpu, golden_labels, golden_misc):
+    g = golden_labels
+    for k, case in enumerate(golden_misc["label_cases"]):
+        y = g[f"y{k}"]
+        z, tau = ops.labels(dev(y[None]), case["gamma"], want_tau=True)
+        assert np.array_equal(z.cpu().numpy()[0] > 0.5, g[f"z{k}"]), case
+        assert float(tau[0]) == np.quantile(y, case["gamma"])          # bit-exact fp64
+    rs = np.random.RandomState(0)
+    for N in (1, 2, 3, 10, 64, 65, 110, 1000):
+        for gamma in (0.0, 0.1, 0.25, 1 / 3, 0.5, 0.9, 1.0):
+            Y = rs.normal(size=(5, N))
+            Y[1] = np.round(Y[1])                                      # ties
+            z, tau = ops.labels(dev(Y), gamma, want_tau=True)
+            want = np.quantile(Y, gamma, axis=1)
+            assert np.array_equal(tau.cpu().numpy(), want), (N, gamma)
+            assert np.array_equal(z.cpu().numpy() > 0.5, Y < want[:, None])
+
+
+def test_candidate_stream_bit_exact_with_host_statement(gpu):
+    for D, lo, hi in [(2, [0, 0], [1, 1]), (3, [-5, 0, 2], [10, 15, 2.5]), (1, [0], [1])]:
+        d = ops.uniform_candidates(77, 3, 257, lo, hi, model_index0=5, draw_index=9).cpu().numpy()
+        h = sampling.uniform_candidates(77, 3, 257, lo, hi, model_index0=5, draw_index=9)
+        assert np.array_equal(d, h)
+        assert (d >= np.array(lo)).all() and (d < np.array(hi) + 1e-12).all()
+    u = ops.uniform_candidates(1, 1, 20000, [0.0], [1.0]).cpu().numpy().ravel()
+    assert abs(u.mean() - 0.5) < 0.01 and abs(u.var() - 1 / 12) < 0.005
+    a = ops.uniform_candidates(1, 2, 64, [0, 0], [1, 1]).cpu().numpy()
+    b = ops.uniform_candidates(1, 1, 64, [0, 0], [1, 1], model_index0=1).cpu().numpy()
+    assert np.array_equal(a[1], b[0]) and not np.array_equal(a[0], a[1])
+
+
+@pytest.mark.parametrize("Ns,R", [(1024, 3), (1024, 5), (1000, 16), (1024, 256), (300, 300),
+                                  (4096, 1024), (64, 1), (7, 7)])
+def test_screen_topk_selects_the_best_rows(gpu, Ns, R):
+    rs = np.random.RandomState(Ns + R)
+    D, units, acts = 6, [32, 32, 1], ["relu", "relu", "linear"]
+    desc = _lib.make_desc(D, units, acts)
+    L = 3
+    params = [rand_model(rs, D, units) for _ in range(L)]
+    th = dev(np.stack([pack(p) for p in params]))
+    X = rs.uniform(size=(L, Ns, D))
+    x0, idx, pred = ops.screen_topk(desc, th, dev(X), R, want_pred=True)
+    x0, idx, pred = x0.cpu().numpy(), idx.cpu().numpy(), pred.cpu().numpy()
+    for l in range(L):
+        np.testing.assert_allclose(pred[l], O.predict(params[l], acts, X[l])[:, 0], rtol=2e-5, atol=2e-6)
+        order = np.lexsort((np.arange(Ns), -pred[l]))[:R]          # descending value, ties by row
+        assert np.array_equal(idx[l], order)
+        assert np.array_equal(x0[l], X[l][order])
+        # same SET as the reference's np.argpartition(-z_init, R-1)[:R] (up to exact ties)
+        part = np.argpartition(-pred[l], R - 1)[:R]
+        assert np.array_equal(np.sort(pred[l][part]), np.sort(pred[l][order]))
+    # shared candidates
+    x0s, idxs = ops.screen_topk(desc, th, dev(X[0]), R)
+    assert np.array_equal(idxs.cpu().numpy()[0], idx[0])
+
+
+CASES = [(2, [16, 16, 1], ["relu", "relu", "sigmoid"], "identity", 3),
+         (6, [32, 32, 1], ["relu", "relu", "linear"], "sigmoid", 40),
+         (3, [32, 32, 32, 1], ["elu"] * 3 + ["linear"], "exp", 9),
+         (16, [64, 64, 64, 1], ["relu"] * 3 + ["linear"], "sigmoid", 70)]
+
+
+@pytest.mark.parametrize("D,units,acts,tr,R", CASES)
+def test_device_lbfgsb_equals_host_build_and_tracks_scipy(gpu, D, units, acts, tr, R):
+    rs = np.random.RandomState(D)
+    desc = _lib.make_desc(D, units, acts)
+    L = 2
+    params = [rand_model(rs, D, units) for _ in range(L)]
+    th = dev(np.stack([pack(p) for p in params]))
+    X0 = rs.uniform(-0.1, 1.1, size=(L, R, D))              # some starts outside the box
+    lo, hi = np.zeros(D), np.ones(D)
+    opts = dict(maxiter=1000, ftol=1e-9)
+    x, fun, jac, info = (t.cpu().numpy() for t in
+                         ops.lbfgsb_minimize(desc, th, dev(X0), lo, hi, tr, True, **opts))
+    # like SciPy's, the line search's x = t + stp*d may leave the box by a rounding error
+    assert ((x >= -1e-12) & (x <= 1 + 1e-12)).all()
+    n_same_scipy, dfun = 0, []
+    for l in range(L):
+        def fg_gpu(Xb):
+            Xb = np.atleast_2d(Xb)
+            v, g = ops.mlp_value_and_input_grad(desc, th[l:l + 1], dev(Xb[None]), tr, True)
+            return v.cpu().numpy()[0], g.cpu().numpy()[0]
+
+        ref = lockstep.minimize_lockstep(fg_gpu, X0[l], bounds=Bounds(lo, hi), **opts)
+        for r in range(R):
+            # (1) bit-for-bit: the same header compiled for the host, fed the same f/g
+            h = H.minimize(lambda xx: tuple(a[0] for a in fg_gpu(xx)), X0[l, r], (lo, hi), **opts)
+            assert np.array_equal(h.x, x[l, r]) and h.fun == fun[l, r]
+            assert (h.nit, h.nfev, h.status) == tuple(info[l, r, :3])
+            assert np.array_equal(h.jac, jac[l, r]) and h.task == tuple(info[l, r, 3:])
+            # (2) against scipy's L-BFGS-B on the same f/g: same optimum; usually same counts
+            s = ref[r]
+            dfun.append(abs(s.fun - fun[l, r]))
+            n_same_scipy += ((s.nit, s.nfev, s.status) == tuple(info[l, r, :3])
+                             and np.allclose(s.x, x[l, r], atol=1e-7))
+            # the reported value/gradient are the kernel's f/g at the reported x
+            v, g = fg_gpu(x[l, r])
+            assert v[0] == fun[l, r] and np.array_equal(g[0], jac[l, r])
+    # fp32 noise + rounding can send a long search (hundreds of evaluations in 16-D) to a
+    # neighbouring stationary point; the bulk must coincide
+    assert n_same_scipy >= 0.7 * L * R
+    assert np.median(dfun) < 1e-6 and np.mean(np.array(dfun) < 2e-5) >= 0.9
+
+
+def test_device_lbfgsb_limits_and_open_bounds(gpu):
+    rs = np.random.RandomState(0)
+    D, units, acts = 4, [16, 1], ["tanh", "linear"]
+    desc = _lib.make_desc(D, units, acts)
+    th = dev(pack(rand_model(rs, D, units))).reshape(1, -1)
+    X0 = rs.uniform(size=(1, 6, D))
+    lo, hi = [0, -np.inf, 0, -np.inf], [1, 1, np.inf, np.inf]
+
+    def fg(xx):
+        v, g = ops.mlp_value_and_input_grad(desc, th, dev(np.atleast_2d(xx)[None]), "sigmoid", True)
+        return v.cpu().numpy()[0, 0], g.cpu().numpy()[0, 0]
+
+    for kw in (dict(maxiter=2), dict(maxfun=3), dict(maxls=2), dict(maxcor=2), dict()):
+        x, fun, jac, info = (t.cpu().numpy()[0] for t in
+                             ops.lbfgsb_minimize(desc, th, dev(X0), lo, hi, "sigmoid", True, **kw))
+        for r in range(6):
+            h = H.minimize(fg, X0[0, r], (np.array(lo, float), np.array(hi, float)), **kw)
+            assert np.array_equal(h.x, x[r]) and (h.nit, h.nfev, h.status) == tuple(info[r, :3]), kw
+        if "maxiter" in kw:
+            assert (info[:, 2] == 1).all() and (info[:, 0] == 2).all() and (info[:, 4] == 504).all()
+    with pytest.raises(RuntimeError, match="lower bounds"):
+        ops.lbfgsb_minimize(desc, th, dev(X0), [1, 0, 0, 0], [0, 1, 1, 1])
+
+
+@pytest.mark.parametrize("seed", [0, 42, 8888])
+def test_reference_property_test_with_device_restarts(gpu, seed):
+    """tests/test_models.py:12-50 of the reference, restarts on the device."""
+    from bore_amd.models import MaximizableDenseSequential
+    rs = np.random.RandomState(seed)
+    bounds = Bounds(lb=np.zeros(2), ub=np.ones(2))
+    model = MaximizableDenseSequential(input_dim=2, output_dim=1, num_layers=2, num_units=32, seed=seed)
+    model.restart_mode = "device"
+    X_test = rs.uniform(size=(1024, 2))
+    y_test = model.predict(X_test)
+    opt = model.argmax(bounds=bounds, num_starts=5, num_samples=1024, method="L-BFGS-B",
+                       options=dict(maxiter=1000, ftol=1e-9), print_fn=lambda x: None, random_state=rs)
+    assert opt.x.shape == (2,) and opt.success
+    assert np.greater_equal(model.predict(opt.x[None]), y_test).all()
+    w_eff = np.linalg.multi_dot([w.astype(np.float64) for w in model.get_weights()[0::2]])[:, 0]
+    np.testing.assert_allclose(opt.x, (w_eff > 0).astype(float), atol=1e-6)
+    assert "CONVERGENCE" in opt.message
+
+
+def test_device_restarts_agree_with_lockstep_on_a_trained_classifier(gpu):
+    rs = np.random.RandomState(3)
+    model = MaximizableSequential(seed=5)
+    model.add(Dense(16, activation="relu", input_dim=2))
+    model.add(Dense(16, activation="relu"))
+    model.add(Dense(1, activation="sigmoid"))
+    model.compile(optimizer="adam", loss="binary_crossentropy")
+    X = rs.uniform(size=(60, 2))
+    y = np.sum((X - 0.35) ** 2, 1)
+    model.fit(X, y < np.quantile(y, 0.25), epochs=200, batch_size=64)
+    b = Bounds(np.zeros(2), np.ones(2))
+    out = {}
+    for mode in ("device", "lockstep"):
+        model.restart_mode = mode
+        out[mode] = model.maxima(b, num_starts=16, num_samples=1024, print_fn=lambda s: None,
+                                 random_state=np.random.RandomState(7))
+    same = 0
+    for a, c in zip(out["device"], out["lockstep"]):
+        assert abs(a.fun - c.fun) < 2e-5
+        same += (a.nit, a.nfev, a.status) == (c.nit, c.nfev, c.status) and np.allclose(a.x, c.x, atol=1e-7)
+    assert same >= 11
+    best = {m: min((r for r in out[m] if r.success or r.status == 1), key=lambda r: r.fun) for m in out}
+    assert abs(best["device"].fun - best["lockstep"].fun) < 1e-6      # same suggested optimum value
+
+
+def test_replica_engine_device_mode_runs_bo(gpu):
+    from bore_amd.engine import ReplicaEngine
+    eng = ReplicaEngine(np.arange(4, 12), epochs=50, mode="device")
+    y0 = eng.y.min(axis=1).copy()
+    for _ in range(8):
+        x_next, y_next = eng.step()
+        assert x_next.shape == (8, 2) and ((x_next >= 0) & (x_next <= 1)).all()
+    eng.finish_timing()
+    assert eng.N == 18 and len(eng.stats["fit_ms"]) == 8
+    assert int(eng.adam_t[0]) == 8 * 50
+    xb, yb = eng.best()
+    assert (yb <= y0).all() and np.median(yb) < np.median(y0)
+    # loops are independent and reproducible: a sub-range of loops gives the same trajectory
+    eng2 = ReplicaEngine(np.arange(6, 9), epochs=50, mode="device")
+    for _ in range(8):
+        eng2.step()
+    assert np.array_equal(eng2.X, eng.X[2:5]) and np.array_equal(eng2.y, eng.y[2:5])

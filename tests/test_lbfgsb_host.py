@@ -1,0 +1,121 @@
+"""bore_amd/csrc/lbfgsb.h (the in-kernel L-BFGS-B state machine), compiled for the host
+with g++, against the third-party code the reference calls:
+scipy.optimize.minimize(method="L-BFGS-B") (bore/mixins.py:59-60)."""
+import numpy as np
+import pytest
+from scipy.optimize import Bounds, minimize, rosen, rosen_der
+
+import lbfgsb_host as H
+from oracle import bore_oracle as O
+
+OPTS = dict(maxiter=1000, ftol=1e-9)       # bore/mixins.py:23
+
+
+def both(fun, x0, lb, ub, **kw):
+    a = minimize(fun, x0, jac=True, method="L-BFGS-B", bounds=Bounds(lb, ub), options=kw)
+    b = H.minimize(fun, x0, (lb, ub), **kw)
+    return a, b
+
+
+@pytest.mark.parametrize("n", [2, 5, 10])
+@pytest.mark.parametrize("box", ["wide", "active", "free", "lower", "upper"])
+def test_same_trajectory_as_scipy_on_rosenbrock(n, box):
+    rs = np.random.RandomState(n)
+    for _ in range(4):
+        x0 = rs.uniform(-2, 2, size=n)
+        lb, ub = np.full(n, -1.5), np.full(n, 2.0)
+        if box == "active":
+            ub[:] = 0.8
+        elif box == "free":
+            lb[:], ub[:] = -np.inf, np.inf
+        elif box == "lower":
+            ub[:] = np.inf
+        elif box == "upper":
+            lb[:] = -np.inf
+        a, b = both(lambda x: (rosen(x), rosen_der(x)), x0, lb, ub, **OPTS)
+        assert (a.nit, a.nfev, a.status) == (b.nit, b.nfev, b.status)
+        np.testing.assert_allclose(b.x, a.x, rtol=0, atol=1e-6)    # rounding over <= 80 iterations
+        assert b.fun == pytest.approx(a.fun, abs=1e-10)
+        np.testing.assert_allclose(b.jac, a.jac, atol=1e-4)
+
+
+def test_limits_and_status_codes_match_scipy():
+    f = lambda x: (rosen(x), rosen_der(x))
+    x0 = np.array([-1.2, 1.0, -0.5, 0.7])
+    lb, ub = np.full(4, -2.0), np.full(4, 2.0)
+    for kw in (dict(maxiter=3), dict(maxiter=1), dict(maxfun=4), dict(maxfun=1), dict(maxls=1),
+               dict(maxls=2), dict(maxcor=3), dict(maxcor=1), dict(gtol=1e-1), dict(ftol=1e-2)):
+        a, b = both(f, x0, lb, ub, **kw)
+        assert (a.nit, a.nfev, a.status) == (b.nit, b.nfev, b.status), kw
+        np.testing.assert_allclose(b.x, a.x, atol=1e-4 if kw.get("maxcor") == 1 else 1e-9,
+                                   err_msg=str(kw))
+    # message codes
+    a, b = both(f, x0, lb, ub, maxiter=2)
+    assert b.task == (5, 504) and "ITERATIONS" in a.message
+    a, b = both(f, x0, lb, ub)
+    assert b.task[0] == 4 and a.status == 0
+
+
+def test_start_on_bounds_outside_box_and_stationary_points():
+    q = lambda x: (0.5 * np.sum((x - 0.3) ** 2), x - 0.3)
+    lb, ub = np.zeros(3), np.ones(3)
+    for x0 in (np.zeros(3), np.ones(3), np.array([-5.0, 0.5, 7.0]), np.full(3, 0.3)):
+        a, b = both(q, x0, lb, ub, **OPTS)
+        assert (a.nit, a.nfev, a.status) == (b.nit, b.nfev, b.status)
+        np.testing.assert_allclose(b.x, a.x, atol=1e-12)
+    # minimiser outside the box: every variable ends on a bound
+    q2 = lambda x: (0.5 * np.sum((x - 2.0) ** 2), x - 2.0)
+    a, b = both(q2, np.full(3, 0.5), lb, ub, **OPTS)
+    assert (a.nit, a.nfev, a.status) == (b.nit, b.nfev, b.status)
+    np.testing.assert_array_equal(b.x, np.ones(3))
+    # fixed variable (l == u)
+    lb2, ub2 = np.array([0.0, 0.4, 0.0]), np.array([1.0, 0.4, 1.0])
+    a, b = both(q, np.array([0.9, 0.4, 0.1]), lb2, ub2, **OPTS)
+    assert (a.nit, a.nfev, a.status) == (b.nit, b.nfev, b.status)
+    np.testing.assert_allclose(b.x, a.x, atol=1e-12)
+
+
+def test_ill_conditioned_quadratic_with_many_active_bounds():
+    rs = np.random.RandomState(0)
+    n = 30
+    A = rs.normal(size=(n, n))
+    A = A @ A.T + 1e-3 * np.eye(n)
+    c = rs.normal(size=n) * 3
+    f = lambda x: (0.5 * x @ A @ x - c @ x, A @ x - c)
+    a, b = both(f, rs.uniform(size=n), np.zeros(n), np.ones(n), maxiter=1000, ftol=1e-12)
+    assert a.status == b.status == 0
+    assert b.fun == pytest.approx(a.fun, rel=1e-9)
+    assert abs(a.nit - b.nit) <= max(3, a.nit // 5)
+    np.testing.assert_allclose(b.x, a.x, atol=1e-5)
+    assert ((b.x == 0) | (b.x == 1)).sum() >= 5
+
+
+@pytest.mark.parametrize("D,units,acts,tr", [(2, [16, 16, 1], ["relu", "relu", "sigmoid"], "identity"),
+                                             (6, [32, 32, 1], ["relu", "relu", "linear"], "sigmoid"),
+                                             (3, [32, 32, 32, 1], ["elu"] * 3 + ["linear"], "exp")])
+def test_fp32_classifier_objective_statistics_match_scipy(D, units, acts, tr):
+    """The real objective: fp32 network output, fp64 optimiser (bore/decorators.py:54-61).
+    The line search works at the fp32 noise floor here (ftol=1e-9 on values with 6e-8
+    resolution), yet almost every run reproduces scipy's iteration count, evaluation count
+    (including ScalarFunction's cache hits), status and iterate."""
+    rs = np.random.RandomState(1)
+    p = O.glorot_uniform_params(D, units, rs)
+    for i in range(1, len(p), 2):
+        p[i] = rs.normal(scale=.1, size=p[i].shape).astype(np.float32)
+    fg = lambda x: tuple(O.value_and_input_grad(p, acts, x, tr))
+    lb, ub = np.zeros(D), np.ones(D)
+    R = 40
+    res = [both(fg, rs.uniform(size=D), lb, ub, **OPTS) for _ in range(R)]
+    same = sum((a.nit, a.nfev, a.status) == (b.nit, b.nfev, b.status)
+               and np.allclose(a.x, b.x, atol=1e-7) for a, b in res)
+    assert same >= 0.8 * R
+    fa = np.array([a.fun for a, _ in res])
+    fb = np.array([b.fun for _, b in res])
+    assert np.median(np.abs(fa - fb)) <= 1e-6
+    assert np.mean(np.abs(fa - fb) < 1e-4) >= 0.9           # same local optimum, with few exceptions
+    ok_a = np.mean([a.success or a.status == 1 for a, _ in res])
+    ok_b = np.mean([b.success or b.status == 1 for _, b in res])
+    assert abs(ok_a - ok_b) <= 0.15                         # same share of accepted restarts
+    na = np.mean([a.nfev for a, _ in res])
+    nb = np.mean([b.nfev for _, b in res])
+    assert abs(na - nb) <= 0.25 * na
