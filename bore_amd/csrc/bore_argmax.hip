@@ -137,7 +137,7 @@ struct ScreenArgs {
   float *pred;
   long long n_samples;
   int x_shared, R, n_pad;
-  int o_tile, o_keys;  // float offsets (o_keys is 8-byte aligned)
+  int o_tile, o_keys, total;  // float offsets (o_keys is 8-byte aligned)
 };
 
 // float -> unsigned that sorts like the float
@@ -164,30 +164,31 @@ __global__ __launch_bounds__(BORE_THREADS) void screen_topk_kernel(const ScreenA
   const int Ns = (int)a.n_samples;
   float *th = smem, *tile = smem + a.o_tile;
   unsigned long long *keys = reinterpret_cast<unsigned long long *>(smem + a.o_keys);
+  const int wv = tid >> 6, lane = tid & 63, m16 = lane & 15, q4 = lane >> 4;
+  zero_lds(smem, a.total);
+  __syncthreads();
   load_theta(L, a.theta + model * L.P, th);
   const double *X = a.X + (a.x_shared ? 0 : model * a.n_samples * D);
   __syncthreads();
-  // predictions -> sort keys: ascending key == descending prediction, ties to the lower row
-  const int n_tiles = (Ns + L.tb - 1) / L.tb;
-  for (int t = 0; t < n_tiles; ++t) {
-    const int row0 = t * L.tb;
-    const int nb = min(L.tb, Ns - row0);
-    float *A0 = tile + L.aoff[0];
-    for (int i = tid; i < nb * D; i += nthr) {
-      const int b = i / D, d = i - b * D;
-      A0[b * L.lda[0] + d] = (float)X[(long long)row0 * D + i];
+  // predictions -> sort keys: ascending key == descending prediction, ties to the lower row.
+  // Every wave walks its own 16-row blocks of the candidates.
+  const int waves = L.tbp >> 4;
+  const int n_blocks = (Ns + 15) >> 4;
+  if (wv < waves)
+    for (int g = wv; g < n_blocks; g += waves) {
+      const int row = g * 16 + m16;
+      float *A0 = tile + L.aoff[0] + (wv * 16 + m16) * L.lda[0];
+      for (int d = q4; d < D; d += 4) A0[d] = row < Ns ? (float)X[(long long)row * D + d] : 0.f;
+      wave_lds_sync();
+      fwd_all(L, th, tile, wv, false);
+      if (lane < 16 && g * 16 + lane < Ns) {
+        const int r = g * 16 + lane;
+        const float p = tile[L.aoff[n] + (wv * 16 + lane) * L.lda[n]];
+        keys[r] = ((unsigned long long)(~orderable(p)) << 32) | (unsigned)r;
+        if (a.pred) a.pred[model * a.n_samples + r] = p;
+      }
+      wave_lds_sync();
     }
-    __syncthreads();
-    for (int l = 1; l <= n; ++l) {
-      fwd_layer(L, th, tile, l, nb, false);
-      __syncthreads();
-    }
-    if (tid < nb) {
-      const float p = tile[L.aoff[n] + tid * L.lda[n]];
-      keys[row0 + tid] = ((unsigned long long)(~orderable(p)) << 32) | (unsigned)(row0 + tid);
-      if (a.pred) a.pred[model * a.n_samples + row0 + tid] = p;
-    }
-  }
   for (int i = Ns + tid; i < a.n_pad; i += nthr) keys[i] = ~0ULL;
   __syncthreads();
 
@@ -267,6 +268,7 @@ extern "C" int bore_screen_topk(const bore_mlp_desc *desc, int n_models, const f
   a.o_tile = (int)off; off += a.L.tile_floats;
   off = (off + 1) & ~(size_t)1;
   a.o_keys = (int)off; off += 2 * ((size_t)n_pad + 32);
+  a.total = (int)off;
   rc = allow_lds(screen_topk_kernel, off * 4);
   if (rc) return rc;
   hipLaunchKernelGGL(screen_topk_kernel, dim3(n_models), dim3(BORE_THREADS), off * 4,
@@ -277,9 +279,15 @@ extern "C" int bore_screen_topk(const bore_mlp_desc *desc, int n_models, const f
 
 // ---------------------------------------------------------------------------
 // multi-start L-BFGS-B: grid = (models, problem blocks)
+//
+// A workgroup takes up to 64 restarts of one model.  Problem p runs on wave p & 3, lane
+// p >> 2, and its point lives in tile row 16 (p & 3) + (p >> 2) -- i.e. in the 16-row block
+// its OWN wave evaluates.  So a wave advances its (<= 16) state machines, evaluates their
+// pending points with one MFMA pass over weights held in LDS, feeds f/g back and repeats,
+// without ever waiting for another wave: no workgroup barrier inside the optimisation.
 // ---------------------------------------------------------------------------
 struct LbfgsbArgs {
-  MlpLayout L;  // L.tb = problems per workgroup
+  MlpLayout L;
   const float *theta;
   const double *x0;
   double *x, *fun, *jac;
@@ -287,35 +295,29 @@ struct LbfgsbArgs {
   BoxArgs box;
   int nbd[BORE_DIM_MAX];
   lbfgsb::Options opt;
-  int R, transform, max_rounds;
+  int R, PB, transform, max_rounds;  // PB = problems per workgroup
   float sign;
   // LDS carve (float offsets; the fp64 regions are 8-byte aligned)
-  int o_tile, o_vals, o_prob, prob_floats, o_state, o_dw, o_iw;
+  int o_tile, o_vals, o_prob, prob_floats, o_state, o_dw, o_iw, total;
 };
-
-// thread that runs the state machine of the workgroup's problem p: spread over the waves
-// first (each wave has its own program counter, so up to 4 problems advance concurrently
-// without divergence), then over lanes.
-__device__ __forceinline__ int problem_thread(int p) { return (p & 3) * 64 + (p >> 2); }
 
 __global__ __launch_bounds__(BORE_THREADS) void lbfgsb_kernel(const LbfgsbArgs a) {
   extern __shared__ float smem[];
   const MlpLayout &L = a.L;
-  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int tid = threadIdx.x;
+  const int wv = tid >> 6, lane = tid & 63;
   const long long model = blockIdx.x;
   const int D = L.w[0];
-  const int p0 = blockIdx.y * L.tb;               // first problem of this workgroup
-  const int np = min(L.tb, a.R - p0);             // problems here (>= 1 by grid construction)
+  const int p0 = blockIdx.y * a.PB;               // first problem of this workgroup
+  const int np = min(a.PB, a.R - p0);             // problems here (>= 1 by grid construction)
   float *th = smem, *tile = smem + a.o_tile, *vals = smem + a.o_vals;
+  zero_lds(smem, a.total);
+  __syncthreads();
   load_theta(L, a.theta + model * L.P, th);
 
-  // which problem (if any) this thread owns
-  int myp = -1;
-  {
-    const int wv = tid >> 6, ln = tid & 63;
-    const int p = ln * 4 + wv;
-    if (p < np && problem_thread(p) == tid) myp = p;
-  }
+  // the problem (if any) this thread owns, and its tile row
+  const int myp = (lane < 16 && lane * 4 + wv < np) ? lane * 4 + wv : -1;
+  const int myrow = wv * 16 + lane;
   lbfgsb::State *st = nullptr;
   lbfgsb::Work wk;
   if (myp >= 0) {
@@ -323,13 +325,11 @@ __global__ __launch_bounds__(BORE_THREADS) void lbfgsb_kernel(const LbfgsbArgs a
     st = reinterpret_cast<lbfgsb::State *>(base + a.o_state);
     wk = lbfgsb::make_work(reinterpret_cast<double *>(base + a.o_dw),
                            reinterpret_cast<int *>(base + a.o_iw), D, a.opt.m);
-    const int ndw = lbfgsb::dwork_size(D, a.opt.m);
-    double *dw = reinterpret_cast<double *>(base + a.o_dw);
-    for (int i = 0; i < ndw; ++i) dw[i] = 0.0;
     const double *x0 = a.x0 + (model * a.R + p0 + myp) * (long long)D;
     lbfgsb::lbfgsb_init(*st, wk, D, a.opt.m, x0, a.box.lo, a.box.hi, a.nbd);
   }
-  __syncthreads();
+  __syncthreads();  // weights staged; from here on the waves are independent
+  if (wv >= np) return;  // wave without problems (np < 4)
 
   bool done = (myp < 0);
   for (int round = 0; round < a.max_rounds; ++round) {
@@ -337,22 +337,22 @@ __global__ __launch_bounds__(BORE_THREADS) void lbfgsb_kernel(const LbfgsbArgs a
     if (!done) {
       const int rc = lbfgsb::lbfgsb_advance(*st, wk, a.box.lo, a.box.hi, a.nbd, a.opt);
       if (rc == lbfgsb::LB_NEED_FG) {
-        float *row = tile + L.aoff[0] + myp * L.lda[0];
+        float *row = tile + L.aoff[0] + myrow * L.lda[0];
         for (int d = 0; d < D; ++d) row[d] = (float)wk.x[d];  // Keras autocast fp64 -> fp32
         pending = 1;
       } else {
         done = true;
       }
     }
-    if (!__syncthreads_or(pending)) break;   // every problem of the workgroup has terminated
-    fg_tile(L, th, tile, np, a.transform, a.sign, vals);
+    if (!__any(pending)) break;  // every problem of this wave has terminated
+    wave_lds_sync();
+    fg_rowblock(L, th, tile, wv, a.transform, a.sign, vals);
     if (pending) {
-      st->f = (double)vals[myp];
-      const float *g = tile + L.doff[0] + myp * L.lda[0];
+      st->f = (double)vals[myrow];
+      const float *g = tile + L.doff[0] + myrow * L.lda[0];
       for (int d = 0; d < D; ++d) wk.g[d] = (double)g[d];
     }
-    // no barrier needed: the next writes to A_0 / reads of D_0 are by the same threads,
-    // and the cooperative pass starts behind the __syncthreads_or above
+    wave_lds_sync();
   }
 
   if (myp >= 0) {
@@ -380,6 +380,7 @@ extern "C" int bore_lbfgsb_minimize(const bore_mlp_desc *desc, int n_models, con
   LbfgsbArgs a;
   if (!desc || !theta || !x0 || !lb || !ub || !opts || !x || !fun || !jac || !info)
     return fail(BORE_E_INVALID, "lbfgsb_minimize: null pointer");
+  if (n_models < 1) return fail(BORE_E_INVALID, "n_models must be >= 1 (got %d)", n_models);
   const int D = desc->input_dim;
   if (D < 1 || D > BORE_DIM_MAX)
     return fail(BORE_E_UNSUPPORTED, "lbfgsb_minimize: input_dim must be 1..%d", BORE_DIM_MAX);
@@ -415,23 +416,32 @@ extern "C" int bore_lbfgsb_minimize(const bore_mlp_desc *desc, int n_models, con
   a.o_dw = (int)state_f;
   a.o_iw = (int)(state_f + dw_f);
   a.prob_floats = (int)(state_f + dw_f + iw_f);
-  const int max_rows = num_starts < BORE_BATCH_MAX ? num_starts : BORE_BATCH_MAX;
-  int rc = check_common(desc, n_models, 2, max_rows, true, 4, &a.L, a.prob_floats + 1);
-  if (rc) return rc;
+  // largest number of problems per workgroup whose state fits beside theta and the tile
+  // (tile rows: one 16-row block per wave that has a problem)
+  int PB = num_starts < BORE_BATCH_MAX ? num_starts : BORE_BATCH_MAX;
+  size_t off = 0;
+  for (;; --PB) {
+    if (PB < 1) return fail(BORE_E_UNSUPPORTED, "lbfgsb_minimize: one problem's state does not fit in LDS");
+    const int rows = 16 * (PB < 4 ? PB : 4);
+    if (bore_make_layout(desc, 2, rows, &a.L)) return fail(BORE_E_INVALID, "bad bore_mlp_desc");
+    off = a.L.P_lds;
+    a.o_tile = (int)off; off += a.L.tile_floats;
+    a.o_vals = (int)off; off += BORE_BATCH_MAX;
+    off = (off + 1) & ~(size_t)1;
+    a.o_prob = (int)off; off += (size_t)a.prob_floats * PB;
+    if (off * 4 <= BORE_LDS_BYTES) break;
+  }
+  a.total = (int)off;
+  a.PB = PB;
   if (a.L.w[a.L.n_layers] != 1)
     return fail(BORE_E_INVALID, "lbfgsb_minimize: the last Dense layer must have 1 unit");
   a.theta = theta; a.x0 = x0; a.x = x; a.fun = fun; a.jac = jac; a.info = info;
   a.R = num_starts; a.transform = transform; a.sign = negate ? -1.f : 1.f;
   long long cap = (long long)opts->maxfun + opts->maxls + 64;
   a.max_rounds = (int)(cap > (1 << 24) ? (1 << 24) : cap);
-  size_t off = a.L.P_lds;
-  a.o_tile = (int)off; off += a.L.tile_floats;
-  a.o_vals = (int)off; off += a.L.tb;
-  off = (off + 1) & ~(size_t)1;
-  a.o_prob = (int)off; off += (size_t)a.prob_floats * a.L.tb;
-  rc = allow_lds(lbfgsb_kernel, off * 4);
+  int rc = allow_lds(lbfgsb_kernel, off * 4);
   if (rc) return rc;
-  const int blocks = (num_starts + a.L.tb - 1) / a.L.tb;
+  const int blocks = (num_starts + PB - 1) / PB;
   if (blocks > 65535) return fail(BORE_E_UNSUPPORTED, "lbfgsb_minimize: too many restarts");
   hipLaunchKernelGGL(lbfgsb_kernel, dim3(n_models, blocks), dim3(BORE_THREADS), off * 4,
                      (hipStream_t)stream, a);

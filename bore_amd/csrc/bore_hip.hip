@@ -1,10 +1,9 @@
-// bore_hip.hip -- kernels + C-ABI of libbore_hip.so (include/bore_hip.h).
-// gfx950 (MI355X) only.  See DESIGN.md for the data layout and per-kernel rooflines.
+// bore_hip.hip -- fit / forward / value+input-gradient / evaluate / shuffle kernels and their
+// C-ABI entry points (include/bore_hip.h).  gfx950 (MI355X) only.
+// See DESIGN.md for the data layout and per-kernel rooflines.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
-#include <cstdarg>
-#include <cstdio>
 #include <cstring>
 
 #include "host_common.h"
@@ -37,20 +36,29 @@ struct FitArgs {
   float lr, beta1, beta2, eps;
   int state_in_lds, data_in_lds;
   // LDS carve (float offsets)
-  int o_tile, o_zt, o_misc, o_m, o_v, o_perm, o_keys, o_X, o_z;
+  int o_tile, o_zt, o_misc, o_m, o_v, o_perm, o_keys, o_X, o_z, total;
 };
+
+// Adam update of one parameter (ResourceApplyAdam, non-nesterov); returns the new weight.
+__device__ __forceinline__ float adam_update(float w, float g, float &m, float &v, float alpha,
+                                             float omb1, float omb2, float eps) {
+  m += (g - m) * omb1;
+  v += (g * g - v) * omb2;
+  return w - (m * alpha) / (sqrtf(v) + eps);
+}
 
 __global__ __launch_bounds__(BORE_THREADS) void fit_kernel(const FitArgs a) {
   extern __shared__ float smem[];
   const MlpLayout &L = a.L;
   const int tid = threadIdx.x, nthr = blockDim.x;
+  const int wv = tid >> 6, lane = tid & 63, m16 = lane & 15, q4 = lane >> 4;
   const long long model = blockIdx.x;
   const int P = L.P, n = L.n_layers, D = L.w[0], N = a.N;
 
   float *th = smem;
   float *tile = smem + a.o_tile;
   float *zt = smem + a.o_zt;
-  float *misc = smem + a.o_misc;  // [0] = l2 penalty accumulator
+  float *misc = smem + a.o_misc;  // [0] l2 penalty of the current weights, [1..4] per-wave loss
   int *perm_s = reinterpret_cast<int *>(smem + a.o_perm);
   unsigned *keys = reinterpret_cast<unsigned *>(smem + a.o_keys);
 
@@ -59,24 +67,21 @@ __global__ __launch_bounds__(BORE_THREADS) void fit_kernel(const FitArgs a) {
   float *v_g = a.av + model * P;
   const float *X_g = a.X + model * (long long)N * D;
   const float *z_g = a.z + model * (long long)N;
-
-  // state: m, v indexed by PACKED index p (adjacent threads, adjacent p)
-  float *sm = a.state_in_lds ? smem + a.o_m : m_g;
-  float *sv = a.state_in_lds ? smem + a.o_v : v_g;
+  float *sm = smem + a.o_m, *sv = smem + a.o_v;  // padded images (when state_in_lds)
   const float *Xs = a.data_in_lds ? smem + a.o_X : X_g;
   const float *zs = a.data_in_lds ? smem + a.o_z : z_g;
 
+  zero_lds(smem, a.total);
+  __syncthreads();
   load_theta(L, theta_g, th);
-  if (a.state_in_lds)
-    for (int p = tid; p < P; p += nthr) {
-      smem[a.o_m + p] = m_g[p];
-      smem[a.o_v + p] = v_g[p];
-    }
+  if (a.state_in_lds) {
+    load_theta(L, m_g, sm);
+    load_theta(L, v_g, sv);
+  }
   if (a.data_in_lds) {
     for (int i = tid; i < N * D; i += nthr) smem[a.o_X + i] = X_g[i];
     for (int i = tid; i < N; i += nthr) smem[a.o_z + i] = z_g[i];
   }
-  if (tid == 0) misc[0] = 0.f;
   __syncthreads();
   if (L.any_l2) {  // l2 penalty of the incoming weights (what the first step's loss sees)
     float reg = 0.f;
@@ -87,7 +92,7 @@ __global__ __launch_bounds__(BORE_THREADS) void fit_kernel(const FitArgs a) {
       reg = fmaf(l2 * w, w, reg);
     }
     reg = wave_sum(reg);
-    if ((tid & 63) == 0) atomicAdd(&misc[0], reg);
+    if (lane == 0) atomicAdd(&misc[0], reg);
   }
 
   // running beta powers in fp64 (rounded to fp32 at use; see DESIGN.md "Adam")
@@ -106,94 +111,154 @@ __global__ __launch_bounds__(BORE_THREADS) void fit_kernel(const FitArgs a) {
     } else {
       make_perm(shuffle_base(a.seed, a.model0 + model, a.epoch0 + e), N, keys, perm_s);
     }
-    float eloss = 0.f;  // thread 0: sum over the epoch of per-row losses (+ nb * penalty)
+    float eloss = 0.f;  // per wave: sum over the epoch of its rows' losses
 
     for (int s = 0; s < steps; ++s) {
       const int row0 = s * a.B;
       const int nb = min(a.B, N - row0);
-      // gather the mini-batch rows
-      {
-        float *A0 = tile + L.aoff[0];
-        const int lda0 = L.lda[0];
-        for (int idx = tid; idx < nb * D; idx += nthr) {
-          const int b = idx / D, d = idx - b * D;
-          A0[b * lda0 + d] = Xs[perm_s[row0 + b] * D + d];
+      // ---- forward / loss / backward: wave wv owns rows [16 wv, 16 wv + 16), no barriers ----
+      if (wv * 16 < nb) {
+        const int rb = wv;
+        {  // gather the mini-batch rows of this row-block (rows >= nb: zeros)
+          float *A0 = tile + L.aoff[0] + (rb * 16 + m16) * L.lda[0];
+          const int row = rb * 16 + m16;
+          const int src = row < nb ? perm_s[row0 + row] : 0;
+          for (int d = q4; d < D; d += 4) A0[d] = row < nb ? Xs[src * D + d] : 0.f;
+          if (q4 == 0) zt[row] = row < nb ? zs[src] : 0.f;
         }
-        if (tid < nb) zt[tid] = zs[perm_s[row0 + tid]];
-      }
-      __syncthreads();
-      for (int l = 1; l <= n; ++l) {
-        fwd_layer(L, th, tile, l, nb, /*keep_logits=*/l == n);
-        __syncthreads();
-      }
-      // loss + d loss / d logit  (the final layer has one unit)
-      if (tid < 64) {
+        wave_lds_sync();
+        fwd_all(L, th, tile, rb, /*keep_logits=*/true);
         float lossb = 0.f;
-        if (tid < nb) {
-          const float x = tile[L.aoff[n] + tid * L.lda[n]];
-          const float zz = zt[tid];
-          lossb = fmaxf(x, 0.f) - x * zz + log1pf(expf(-fabsf(x)));
-          tile[L.doff[n] + tid * L.lda[n]] = (sigmoid_stable(x) - zz) / (float)nb;
+        if (lane < 16) {  // loss + d loss / d logit (the final layer has one unit)
+          const int row = rb * 16 + lane;
+          float delta = 0.f;
+          if (row < nb) {
+            const float x = tile[L.aoff[n] + row * L.lda[n]];
+            const float zz = zt[row];
+            lossb = fmaxf(x, 0.f) - x * zz + log1pf(expf(-fabsf(x)));
+            delta = (sigmoid_stable(x) - zz) / (float)nb;
+          }
+          tile[L.doff[n] + row * L.lda[n]] = delta;
         }
         lossb = wave_sum(lossb);
-        if (tid == 0) eloss += lossb + (L.any_l2 ? misc[0] * (float)nb : 0.f);
+        if (wv == 0 && L.any_l2) {  // (every lane of wave 0: same value, uniform branch)
+          lossb += misc[0] * (float)nb;
+          wave_lds_sync();
+          if (lane == 0) misc[0] = 0.f;  // consumed; re-accumulated from the updated weights
+        }
+        eloss += lossb;
+        wave_lds_sync();
+        for (int l = n; l >= 2; --l) {
+          bwd_rowblock(L, th, tile, l, rb);
+          wave_lds_sync();
+        }
       }
       __syncthreads();
-      for (int l = n; l >= 2; --l) {
-        bwd_delta(L, th, tile, l, nb);
-        __syncthreads();
-      }
-      if (L.any_l2 && tid == 0) misc[0] = 0.f;  // consumed above; re-accumulated below
-      // weight gradients + Adam, one thread per parameter (packed order)
+
+      // ---- weight gradients (sums over all rows) + Adam, one 16x16 tile per wave at a time ----
       b1p *= (double)a.beta1;
       b2p *= (double)a.beta2;
       const float alpha = a.lr * sqrtf(1.f - (float)b2p) / (1.f - (float)b1p);
+      const int kch = (nb + 3) >> 2;
       float reg = 0.f;
-      for (int p = tid; p < P; p += nthr) {
-        const ParamRef r = param_ref(L, p);
-        const float *Dl = tile + L.doff[r.l] + r.j;
-        const int ldd = L.lda[r.l];
-        float g = 0.f;
-        if (r.k >= 0) {
-          const float *Ap = tile + L.aoff[r.l - 1] + r.k;
-          const int ldap = L.lda[r.l - 1];
-          for (int b = 0; b < nb; ++b) g = fmaf(Ap[b * ldap], Dl[b * ldd], g);
-        } else {
-          for (int b = 0; b < nb; ++b) g += Dl[b * ldd];
-        }
-        float w = th[r.lds];
-        const float l2 = r.k >= 0 ? L.l2_w[r.l] : L.l2_b[r.l];
-        if (l2 != 0.f) g = fmaf(2.f * l2, w, g);
-        float mm = sm[p], vv = sv[p];
-        mm += (g - mm) * omb1;
-        vv += (g * g - vv) * omb2;
-        w -= (mm * alpha) / (sqrtf(vv) + a.eps);
-        sm[p] = mm;
-        sv[p] = vv;
-        th[r.lds] = w;
-        if (l2 != 0.f) reg = fmaf(l2 * w, w, reg);
+      int t = 0;
+      for (int l = 1; l <= n; ++l) {
+        const int K = L.w[l - 1], Nw = L.w[l], ldw = L.ldw[l];
+        const int lda_p = L.lda[l - 1], ldd = L.lda[l];
+        for (int kb = 0; kb < (L.Np[l - 1] >> 4); ++kb)
+          for (int cb = 0; cb < (L.Np[l] >> 4); ++cb, ++t) {
+            if ((t & 3) != wv) continue;
+            // dW[k][j] = sum_rows A_{l-1}[row][k] * D_l[row][j]
+            const float *ap = tile + L.aoff[l - 1] + q4 * lda_p + kb * 16 + m16;
+            const float *bp = tile + L.doff[l] + q4 * ldd + cb * 16 + m16;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            float bsum = 0.f;
+#pragma unroll 4
+            for (int kc = 0; kc < kch; ++kc) {
+              const float av = ap[kc * 4 * lda_p], bv = bp[kc * 4 * ldd];
+              acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+              bsum += bv;
+            }
+            const int col = cb * 16 + m16;
+            const bool cvalid = col < Nw;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int row = kb * 16 + q4 * 4 + r;
+              if (cvalid && row < K) {
+                const int li = L.woff[l] + row * ldw + col;
+                float w = th[li];
+                float g = acc[r];
+                const float l2 = L.l2_w[l];
+                if (l2 != 0.f) g = fmaf(2.f * l2, w, g);
+                if (a.state_in_lds) {
+                  float mm = sm[li], vv = sv[li];
+                  w = adam_update(w, g, mm, vv, alpha, omb1, omb2, a.eps);
+                  sm[li] = mm;
+                  sv[li] = vv;
+                } else {
+                  const int gi = L.goff_w[l] + row * Nw + col;
+                  float mm = m_g[gi], vv = v_g[gi];
+                  w = adam_update(w, g, mm, vv, alpha, omb1, omb2, a.eps);
+                  m_g[gi] = mm;
+                  v_g[gi] = vv;
+                }
+                th[li] = w;
+                if (l2 != 0.f) reg = fmaf(l2 * w, w, reg);
+              }
+            }
+            if (kb == 0) {  // bias gradient: column sums of D_l (rows q4, q4+4, ... per lane)
+              bsum += __shfl_xor(bsum, 16, 64);
+              bsum += __shfl_xor(bsum, 32, 64);
+              if (q4 == 0 && cvalid) {
+                const int li = L.boff[l] + col;
+                float w = th[li];
+                float g = bsum;
+                const float l2 = L.l2_b[l];
+                if (l2 != 0.f) g = fmaf(2.f * l2, w, g);
+                if (a.state_in_lds) {
+                  float mm = sm[li], vv = sv[li];
+                  w = adam_update(w, g, mm, vv, alpha, omb1, omb2, a.eps);
+                  sm[li] = mm;
+                  sv[li] = vv;
+                } else {
+                  const int gi = L.goff_b[l] + col;
+                  float mm = m_g[gi], vv = v_g[gi];
+                  w = adam_update(w, g, mm, vv, alpha, omb1, omb2, a.eps);
+                  m_g[gi] = mm;
+                  v_g[gi] = vv;
+                }
+                th[li] = w;
+                if (l2 != 0.f) reg = fmaf(l2 * w, w, reg);
+              }
+            }
+          }
       }
-      __syncthreads();
       if (L.any_l2) {  // penalty of the UPDATED weights = the one the next step's loss sees
         reg = wave_sum(reg);
-        if ((tid & 63) == 0) atomicAdd(&misc[0], reg);
-        __syncthreads();
+        if (lane == 0) atomicAdd(&misc[0], reg);
       }
+      __syncthreads();
     }
-    if (tid == 0 && a.epoch_loss) a.epoch_loss[model * a.epochs + e] = eloss / (float)N;
+    if (a.epoch_loss) {
+      if (lane == 0) misc[1 + wv] = eloss;
+      __syncthreads();
+      if (tid == 0)
+        a.epoch_loss[model * a.epochs + e] = (misc[1] + misc[2] + misc[3] + misc[4]) / (float)N;
+    }
   }
 
+  __syncthreads();
   store_theta(L, th, theta_g);
-  if (a.state_in_lds)
-    for (int p = tid; p < P; p += nthr) {
-      m_g[p] = smem[a.o_m + p];
-      v_g[p] = smem[a.o_v + p];
-    }
+  if (a.state_in_lds) {
+    store_theta(L, sm, m_g);
+    store_theta(L, sv, v_g);
+  }
   if (tid == 0) a.at[model] = t0 + (long long)a.epochs * steps;
 }
 
 // ---------------------------------------------------------------------------
-// forward (predict) / value + input gradient: grid = (models, tile slots)
+// forward (predict) / value + input gradient: grid = (models, workgroups); every wave walks
+// its own 16-row blocks of the input -- no barrier after the weights are staged
 // ---------------------------------------------------------------------------
 struct RowArgs {
   MlpLayout L;
@@ -205,68 +270,52 @@ struct RowArgs {
   long long n_rows;
   int x_shared, transform;
   float sign;  // -1: T(-f) (minimisation form), +1: T(f)
-  int o_tile;
+  int o_tile, o_vals, total;
 };
 
-__global__ __launch_bounds__(BORE_THREADS) void forward_kernel(const RowArgs a) {
+template <bool WITH_GRAD>
+__global__ __launch_bounds__(BORE_THREADS) void rows_kernel(const RowArgs a) {
   extern __shared__ float smem[];
   const MlpLayout &L = a.L;
-  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int tid = threadIdx.x;
+  const int wv = tid >> 6, lane = tid & 63, m16 = lane & 15, q4 = lane >> 4;
   const long long model = blockIdx.x;
   const int n = L.n_layers, D = L.w[0];
-  float *th = smem, *tile = smem + a.o_tile;
+  float *th = smem, *tile = smem + a.o_tile, *vals = smem + a.o_vals;
+  zero_lds(smem, a.total);
+  __syncthreads();
   load_theta(L, a.theta + model * L.P, th);
-  const float *X = a.Xf + (a.x_shared ? 0 : model * a.n_rows * D);
+  __syncthreads();
+  const int waves = L.tbp >> 4;  // waves that own a 16-row slice of the tile buffers
+  if (wv >= waves) return;
+  const long long xoff = a.x_shared ? 0 : model * a.n_rows * D;
   float *out = a.out + model * a.n_rows;
-  const long long n_tiles = (a.n_rows + L.tb - 1) / L.tb;
-  __syncthreads();
-  for (long long t = blockIdx.y; t < n_tiles; t += gridDim.y) {
-    const long long row0 = t * L.tb;
-    const int nb = (int)min((long long)L.tb, a.n_rows - row0);
-    float *A0 = tile + L.aoff[0];
-    for (int idx = tid; idx < nb * D; idx += nthr) {
-      const int b = idx / D, d = idx - b * D;
-      A0[b * L.lda[0] + d] = X[row0 * D + idx];
+  const long long n_blocks = (a.n_rows + 15) >> 4;
+  for (long long g = (long long)blockIdx.y * waves + wv; g < n_blocks;
+       g += (long long)gridDim.y * waves) {
+    const long long row = g * 16 + m16;  // the global row of this lane's operand slot
+    float *A0 = tile + L.aoff[0] + (wv * 16 + m16) * L.lda[0];
+    for (int d = q4; d < D; d += 4) {
+      float x = 0.f;
+      if (row < a.n_rows)
+        x = WITH_GRAD ? (float)a.Xd[xoff + row * D + d]  // Keras autocast fp64 -> fp32
+                      : a.Xf[xoff + row * D + d];
+      A0[d] = x;
     }
-    __syncthreads();
-    for (int l = 1; l <= n; ++l) {
-      fwd_layer(L, th, tile, l, nb, false);
-      __syncthreads();
+    wave_lds_sync();
+    if (WITH_GRAD) {
+      fg_rowblock(L, th, tile, wv, a.transform, a.sign, vals);
+      if (lane < 16 && g * 16 + lane < a.n_rows) out[g * 16 + lane] = vals[wv * 16 + lane];
+      const float *D0 = tile + L.doff[0] + (wv * 16 + m16) * L.lda[0];
+      double *grad = a.grad + (model * a.n_rows) * D;
+      if (row < a.n_rows)
+        for (int d = q4; d < D; d += 4) grad[row * D + d] = (double)D0[d];
+    } else {
+      fwd_all(L, th, tile, wv, false);
+      if (lane < 16 && g * 16 + lane < a.n_rows)
+        out[g * 16 + lane] = tile[L.aoff[n] + (wv * 16 + lane) * L.lda[n]];
     }
-    if (tid < nb) out[row0 + tid] = tile[L.aoff[n] + tid * L.lda[n]];
-    // next tile's gather only touches A_0, whose readers passed a barrier already
-  }
-}
-
-__global__ __launch_bounds__(BORE_THREADS) void value_grad_kernel(const RowArgs a) {
-  extern __shared__ float smem[];
-  const MlpLayout &L = a.L;
-  const int tid = threadIdx.x, nthr = blockDim.x;
-  const long long model = blockIdx.x;
-  const int n = L.n_layers, D = L.w[0];
-  float *th = smem, *tile = smem + a.o_tile;
-  load_theta(L, a.theta + model * L.P, th);
-  const double *X = a.Xd + model * a.n_rows * D;
-  float *val = a.out + model * a.n_rows;
-  double *grad = a.grad + model * a.n_rows * D;
-  const long long n_tiles = (a.n_rows + L.tb - 1) / L.tb;
-  __syncthreads();
-  for (long long t = blockIdx.y; t < n_tiles; t += gridDim.y) {
-    const long long row0 = t * L.tb;
-    const int nb = (int)min((long long)L.tb, a.n_rows - row0);
-    float *A0 = tile + L.aoff[0];
-    for (int idx = tid; idx < nb * D; idx += nthr) {
-      const int b = idx / D, d = idx - b * D;
-      A0[b * L.lda[0] + d] = (float)X[row0 * D + idx];  // Keras autocast fp64 -> fp32
-    }
-    __syncthreads();
-    fg_tile(L, th, tile, nb, a.transform, a.sign, val + row0);
-    const float *D0 = tile + L.doff[0];
-    for (int idx = tid; idx < nb * D; idx += nthr) {
-      const int b = idx / D, d = idx - b * D;
-      grad[row0 * D + idx] = (double)D0[b * L.lda[0] + d];
-    }
-    __syncthreads();
+    wave_lds_sync();
   }
 }
 
@@ -278,44 +327,42 @@ struct EvalArgs {
   const float *theta, *X, *z;
   float *loss, *acc;
   long long N;
-  int o_tile, o_misc;
+  int o_tile, o_misc, total;
 };
 
 __global__ __launch_bounds__(BORE_THREADS) void evaluate_kernel(const EvalArgs a) {
   extern __shared__ float smem[];
   const MlpLayout &L = a.L;
   const int tid = threadIdx.x, nthr = blockDim.x;
+  const int wv = tid >> 6, lane = tid & 63, m16 = lane & 15, q4 = lane >> 4;
   const long long model = blockIdx.x;
   const int n = L.n_layers, D = L.w[0];
   float *th = smem, *tile = smem + a.o_tile, *misc = smem + a.o_misc;
+  zero_lds(smem, a.total);
+  __syncthreads();
   load_theta(L, a.theta + model * L.P, th);
-  if (tid == 0) misc[0] = 0.f;
+  __syncthreads();
   const float *X = a.X + model * a.N * D;
   const float *z = a.z + model * a.N;
-  const long long n_tiles = (a.N + L.tb - 1) / L.tb;
+  const int waves = L.tbp >> 4;
+  const long long n_blocks = (a.N + 15) >> 4;
   float lsum = 0.f, csum = 0.f;
-  __syncthreads();
-  for (long long t = 0; t < n_tiles; ++t) {
-    const long long row0 = t * L.tb;
-    const int nb = (int)min((long long)L.tb, a.N - row0);
-    float *A0 = tile + L.aoff[0];
-    for (int idx = tid; idx < nb * D; idx += nthr) {
-      const int b = idx / D, d = idx - b * D;
-      A0[b * L.lda[0] + d] = X[row0 * D + idx];
+  if (wv < waves)
+    for (long long g = wv; g < n_blocks; g += waves) {
+      const long long row = g * 16 + m16;
+      float *A0 = tile + L.aoff[0] + (wv * 16 + m16) * L.lda[0];
+      for (int d = q4; d < D; d += 4) A0[d] = row < a.N ? X[row * D + d] : 0.f;
+      wave_lds_sync();
+      fwd_all(L, th, tile, wv, true);
+      if (lane < 16 && g * 16 + lane < a.N) {
+        const float x = tile[L.aoff[n] + (wv * 16 + lane) * L.lda[n]];
+        const float zz = z[g * 16 + lane];
+        lsum += fmaxf(x, 0.f) - x * zz + log1pf(expf(-fabsf(x)));
+        const float o = L.act[n] == BORE_ACT_SIGMOID ? sigmoid_stable(x) : x;
+        csum += ((o > 0.5f) == (zz > 0.5f)) ? 1.f : 0.f;
+      }
+      wave_lds_sync();
     }
-    __syncthreads();
-    for (int l = 1; l <= n; ++l) {
-      fwd_layer(L, th, tile, l, nb, l == n);
-      __syncthreads();
-    }
-    if (tid < nb) {
-      const float x = tile[L.aoff[n] + tid * L.lda[n]];
-      const float zz = z[row0 + tid];
-      lsum += fmaxf(x, 0.f) - x * zz + log1pf(expf(-fabsf(x)));
-      const float o = L.act[n] == BORE_ACT_SIGMOID ? sigmoid_stable(x) : x;
-      csum += ((o > 0.5f) == (zz > 0.5f)) ? 1.f : 0.f;
-    }
-  }
   float reg = 0.f;
   if (L.any_l2)
     for (int p = tid; p < L.P; p += nthr) {
@@ -324,16 +371,18 @@ __global__ __launch_bounds__(BORE_THREADS) void evaluate_kernel(const EvalArgs a
       const float w = th[r.lds];
       reg = fmaf(l2 * w, w, reg);
     }
+  lsum = wave_sum(lsum);
+  csum = wave_sum(csum);
   reg = wave_sum(reg);
-  if (L.any_l2 && (tid & 63) == 0) atomicAdd(&misc[0], reg);
+  if (lane == 0) {
+    atomicAdd(&misc[0], lsum);
+    atomicAdd(&misc[1], csum);
+    atomicAdd(&misc[2], reg);
+  }
   __syncthreads();
-  if (tid < 64) {
-    lsum = wave_sum(lsum);
-    csum = wave_sum(csum);
-    if (tid == 0) {
-      a.loss[model] = lsum / (float)a.N + misc[0];
-      a.acc[model] = csum / (float)a.N;
-    }
+  if (tid == 0) {
+    a.loss[model] = misc[0] / (float)a.N + misc[2];
+    a.acc[model] = misc[1] / (float)a.N;
   }
 }
 
@@ -394,11 +443,11 @@ extern "C" int bore_mlp_fit(const bore_mlp_desc *desc, int n_models, float *thet
   if (off * 4 > BORE_LDS_BYTES)
     return fail(BORE_E_UNSUPPORTED, "fit: theta+tile+perm need %zu B of LDS (> %d)", off * 4,
                 BORE_LDS_BYTES);
-  a.state_in_lds = (off + 2 * (size_t)L.P) * 4 <= BORE_LDS_BYTES;
+  a.state_in_lds = (off + 2 * (size_t)L.P_lds) * 4 <= BORE_LDS_BYTES;
   a.o_m = a.o_v = 0;
   if (a.state_in_lds) {
-    a.o_m = (int)off; off += L.P;
-    a.o_v = (int)off; off += L.P;
+    a.o_m = (int)off; off += L.P_lds;
+    a.o_v = (int)off; off += L.P_lds;
   }
   const size_t data = (size_t)N * (L.w[0] + 1);
   a.data_in_lds = (off + data) * 4 <= BORE_LDS_BYTES;
@@ -407,6 +456,7 @@ extern "C" int bore_mlp_fit(const bore_mlp_desc *desc, int n_models, float *thet
     a.o_X = (int)off; off += (size_t)N * L.w[0];
     a.o_z = (int)off; off += N;
   }
+  a.total = (int)off;
   rc = allow_lds(fit_kernel, off * 4);
   if (rc) return rc;
   hipLaunchKernelGGL(fit_kernel, dim3(n_models), dim3(BORE_THREADS), off * 4,
@@ -415,32 +465,32 @@ extern "C" int bore_mlp_fit(const bore_mlp_desc *desc, int n_models, float *thet
   return 0;
 }
 
-static int row_launch(bool with_grad, const bore_mlp_desc *desc, int n_models, RowArgs &a,
-                      void *stream) {
+static int row_launch(bool with_grad, int n_models, RowArgs &a, void *stream) {
   const MlpLayout &L = a.L;
   size_t off = L.P_lds;
-  a.o_tile = (int)off;
-  off += L.tile_floats;
-  const long long n_tiles = (a.n_rows + L.tb - 1) / L.tb;
-  // enough workgroups to fill 256 CUs a few times over, never more than tiles
-  long long gy = n_tiles;
+  a.o_tile = (int)off; off += L.tile_floats;
+  a.o_vals = (int)off; off += BORE_BATCH_MAX;  // objective values of the tile rows
+  a.total = (int)off;
+  const int waves = L.tbp >> 4;
+  const long long n_blocks = (a.n_rows + 15) / 16;
+  // enough workgroups to fill 256 CUs a few times over, never more than there is work
+  long long gy = (n_blocks + waves - 1) / waves;
   const long long cap = (2048 + n_models - 1) / n_models;
   if (gy > cap) gy = cap < 1 ? 1 : cap;
   if (gy > 65535) gy = 65535;
   int rc;
   if (with_grad) {
-    rc = allow_lds(value_grad_kernel, off * 4);
+    rc = allow_lds(rows_kernel<true>, off * 4);
     if (rc) return rc;
-    hipLaunchKernelGGL(value_grad_kernel, dim3(n_models, (unsigned)gy), dim3(BORE_THREADS),
+    hipLaunchKernelGGL(rows_kernel<true>, dim3(n_models, (unsigned)gy), dim3(BORE_THREADS),
                        off * 4, (hipStream_t)stream, a);
   } else {
-    rc = allow_lds(forward_kernel, off * 4);
+    rc = allow_lds(rows_kernel<false>, off * 4);
     if (rc) return rc;
-    hipLaunchKernelGGL(forward_kernel, dim3(n_models, (unsigned)gy), dim3(BORE_THREADS), off * 4,
-                       (hipStream_t)stream, a);
+    hipLaunchKernelGGL(rows_kernel<false>, dim3(n_models, (unsigned)gy), dim3(BORE_THREADS),
+                       off * 4, (hipStream_t)stream, a);
   }
   HIP_TRY(hipGetLastError());
-  (void)desc;
   return 0;
 }
 
@@ -448,7 +498,7 @@ extern "C" int bore_mlp_forward(const bore_mlp_desc *desc, int n_models, const f
                                 const float *X, int64_t n_rows, int x_shared, float *out,
                                 void *stream) {
   RowArgs a;
-  int rc = check_common(desc, n_models, 0, BORE_BATCH_MAX, true, 0, &a.L);
+  int rc = check_common(desc, n_models, 0, BORE_BATCH_MAX, true, BORE_BATCH_MAX, &a.L);
   if (rc) return rc;
   if (a.L.w[a.L.n_layers] != 1)
     return fail(BORE_E_INVALID, "forward: the last Dense layer must have 1 unit");
@@ -457,7 +507,7 @@ extern "C" int bore_mlp_forward(const bore_mlp_desc *desc, int n_models, const f
   if (n_rows == 0) return 0;
   a.theta = theta; a.Xf = X; a.Xd = nullptr; a.out = out; a.grad = nullptr;
   a.n_rows = n_rows; a.x_shared = x_shared; a.transform = 0; a.sign = 1.f;
-  return row_launch(false, desc, n_models, a, stream);
+  return row_launch(false, n_models, a, stream);
 }
 
 extern "C" int bore_mlp_value_and_input_grad(const bore_mlp_desc *desc, int n_models,
@@ -465,7 +515,7 @@ extern "C" int bore_mlp_value_and_input_grad(const bore_mlp_desc *desc, int n_mo
                                              int transform, int negate, float *val,
                                              double *grad, void *stream) {
   RowArgs a;
-  int rc = check_common(desc, n_models, 2, BORE_BATCH_MAX, true, 0, &a.L);
+  int rc = check_common(desc, n_models, 2, BORE_BATCH_MAX, true, BORE_BATCH_MAX, &a.L);
   if (rc) return rc;
   if (a.L.w[a.L.n_layers] != 1)
     return fail(BORE_E_INVALID, "value_and_input_grad: the last Dense layer must have 1 unit");
@@ -476,7 +526,7 @@ extern "C" int bore_mlp_value_and_input_grad(const bore_mlp_desc *desc, int n_mo
   if (n_rows == 0) return 0;
   a.theta = theta; a.Xf = nullptr; a.Xd = X; a.out = val; a.grad = grad;
   a.n_rows = n_rows; a.x_shared = 0; a.transform = transform; a.sign = negate ? -1.f : 1.f;
-  return row_launch(true, desc, n_models, a, stream);
+  return row_launch(true, n_models, a, stream);
 }
 
 extern "C" int bore_mlp_evaluate(const bore_mlp_desc *desc, int n_models, const float *theta,
@@ -493,6 +543,7 @@ extern "C" int bore_mlp_evaluate(const bore_mlp_desc *desc, int n_models, const 
   size_t off = a.L.P_lds;
   a.o_tile = (int)off; off += a.L.tile_floats;
   a.o_misc = (int)off; off += 8;
+  a.total = (int)off;
   rc = allow_lds(evaluate_kernel, off * 4);
   if (rc) return rc;
   hipLaunchKernelGGL(evaluate_kernel, dim3(n_models), dim3(BORE_THREADS), off * 4,

@@ -34,20 +34,18 @@ inline int allow_lds(K kernel, size_t bytes) {
   return 0;
 }
 
-// Builds the layout with the largest tile (<= max_rows rows, halving) whose theta + tile +
-// `extra_floats` (+ `extra_floats_per_row` for every tile row) fit the CU's LDS; a tile may
-// shrink only when `may_shrink`.
+// Builds the layout with the largest tile (max_rows, then 16 rows fewer each try: a wave's
+// unit of work is a 16-row block) whose theta + tile + `extra_floats` fit the CU's LDS; the
+// tile may shrink only when `may_shrink`.
 inline int check_common(const bore_mlp_desc *desc, int n_models, int with_deltas, int max_rows,
-                        bool may_shrink, size_t extra_floats, MlpLayout *L,
-                        size_t extra_floats_per_row = 0) {
+                        bool may_shrink, size_t extra_floats, MlpLayout *L) {
   if (n_models < 1) return fail(BORE_E_INVALID, "n_models must be >= 1 (got %d)", n_models);
-  for (int tb = max_rows;; tb = (tb > 16 ? tb >> 1 : tb - 1)) {
+  for (int tb = max_rows;; tb -= 16) {
     if (tb < 1 || bore_make_layout(desc, with_deltas, tb, L))
       return fail(BORE_E_INVALID, "bad bore_mlp_desc");
-    const size_t need =
-        ((size_t)L->P_lds + L->tile_floats + extra_floats + extra_floats_per_row * tb) * 4;
+    const size_t need = ((size_t)L->P_lds + L->tile_floats + extra_floats) * 4;
     if (need <= BORE_LDS_BYTES) return 0;
-    if (!may_shrink || tb == 1)
+    if (!may_shrink || tb <= 16)
       return fail(BORE_E_UNSUPPORTED,
                   "model needs %zu B of LDS per workgroup (> %d) at %d rows per tile", need,
                   BORE_LDS_BYTES, tb);

@@ -1,18 +1,27 @@
-// mlp_device.h -- device building blocks shared by the fit / forward / input-gradient
-// kernels.  gfx950 only: 64-wide wavefronts, one 256-thread workgroup per model,
-// weights + activations of a 64-row tile resident in LDS.
+// mlp_device.h -- device building blocks shared by every kernel of the path.
+// gfx950 only: 64-wide wavefronts, v_mfma_f32_16x16x4_f32 tiles, operands in LDS.
 //
-// Tile convention: a tile is up to 64 rows (BORE_BATCH_MAX, one Keras mini-batch).
-// A_l is the OUTPUT of layer l (A_0 = the input rows), D_l = d objective / d
-// pre-activation of layer l (D_0 = d objective / d input).  Every activation
-// derivative is written in terms of the activation output, so pre-activations
-// are never stored.
+// Unit of work: a ROW-BLOCK = 16 rows of the tile.  One wave carries its row-block through
+// the whole network: layer l+1 of those rows needs only layer l of the same rows, which the
+// same wave produced, so forward and backward need no workgroup barrier -- only the weight
+// gradient (a sum over ALL rows) does.
+//
+// A_l is the OUTPUT of layer l (A_0 = the input rows), D_l = d objective / d pre-activation
+// of layer l (D_0 = d objective / d input).  Activation derivatives are written in terms of
+// the activation output, so pre-activations are never stored.
+//
+// MFMA operand maps (v_mfma_f32_16x16x4_f32, lane l, m = l & 15, q = l >> 4):
+//   A[16x4]: lane holds A[m][q]      B[4x16]: lane holds B[q][m]
+//   C/D[16x16]: lane holds C[4q + r][m], r = 0..3
+// The product is bit-for-bit a k-ordered fp32 fmaf chain (no wider accumulation).
 #pragma once
 #include <hip/hip_runtime.h>
 
 #include "mlp_layout.h"
 
 namespace bore {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float sigmoid_stable(float x) {
   float e = expf(-fabsf(x));  // expf: ocml, <=1 ulp
@@ -47,12 +56,19 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+// Lanes of ONE wave exchange data through LDS between two program points: all of the
+// wave's earlier LDS accesses complete and the compiler may not move memory operations
+// across (a wave runs in lock-step, so no s_barrier is involved).
+__device__ __forceinline__ void wave_lds_sync() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
 // packed (Keras order) parameter index -> which tensor element it is.
 struct ParamRef {
   int l;     // layer, 1-based
   int k;     // input index (row of W_l); -1 for a bias
   int j;     // output index
-  int lds;   // index in the padded LDS copy
+  int lds;   // index in the padded LDS image
 };
 
 __device__ __forceinline__ ParamRef param_ref(const MlpLayout &L, int p) {
@@ -74,7 +90,11 @@ __device__ __forceinline__ ParamRef param_ref(const MlpLayout &L, int p) {
   return r;
 }
 
-// HBM -> LDS: packed theta into the padded LDS image (coalesced reads).
+__device__ __forceinline__ void zero_lds(float *p, int n_floats) {
+  for (int i = threadIdx.x; i < n_floats; i += blockDim.x) p[i] = 0.f;
+}
+
+// HBM -> LDS: packed vector into the (already zeroed) padded image; coalesced reads.
 __device__ __forceinline__ void load_theta(const MlpLayout &L, const float *__restrict__ g,
                                            float *th) {
   for (int p = threadIdx.x; p < L.P; p += blockDim.x) th[param_ref(L, p).lds] = g[p];
@@ -85,63 +105,81 @@ __device__ __forceinline__ void store_theta(const MlpLayout &L, const float *th,
   for (int p = threadIdx.x; p < L.P; p += blockDim.x) g[p] = th[param_ref(L, p).lds];
 }
 
-// A_l = act_l(A_{l-1} W_l + b_l) for the nb rows of the tile.  Adjacent threads take
-// adjacent output units j: W_l[k][j..] is a contiguous LDS read, A_{l-1}[b][k] a
-// broadcast.  Accumulation order: bias, then k ascending, one fmaf each.
-__device__ __forceinline__ void fwd_layer(const MlpLayout &L, const float *th, float *tile,
-                                          int l, int nb, bool keep_logits) {
-  const int K = L.w[l - 1], N = L.w[l];
-  const float *Ain = tile + L.aoff[l - 1];
-  float *Aout = tile + L.aoff[l];
+// One 16x16 tile: sum over kchunks*4 of A[m][k] * B[k][n].  ap / bp are THIS LANE's operand
+// addresses for k-chunk 0; sa / sb the address step per k-chunk (4 values of k).
+__device__ __forceinline__ f32x4 tile_mma(const float *ap, int sa, const float *bp, int sb,
+                                          int kchunks) {
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+  for (int kc = 0; kc < kchunks; ++kc)
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[kc * sa], bp[kc * sb], acc, 0, 0, 0);
+  return acc;
+}
+
+// Rows [16 rb, 16 rb + 16) of A_l = act_l(A_{l-1} W_l + b_l), by the calling wave.
+__device__ __forceinline__ void fwd_rowblock(const MlpLayout &L, const float *th, float *tile,
+                                             int l, int rb, bool keep_logits) {
+  const int lane = threadIdx.x & 63, m = lane & 15, q = lane >> 4;
   const int lda_in = L.lda[l - 1], lda_out = L.lda[l], ldw = L.ldw[l];
+  const float *ap = tile + L.aoff[l - 1] + (rb * 16 + m) * lda_in + q;
   const float *W = th + L.woff[l];
   const float *bias = th + L.boff[l];
+  float *Aout = tile + L.aoff[l] + (rb * 16 + q * 4) * lda_out;
+  const int kch = (L.w[l - 1] + 3) >> 2;
   const int a = keep_logits ? BORE_ACT_LINEAR : L.act[l];
-  for (int idx = threadIdx.x; idx < nb * N; idx += blockDim.x) {
-    const int b = idx / N, j = idx - b * N;
-    const float *arow = Ain + b * lda_in;
-    const float *wcol = W + j;
-    float acc = bias[j];
-    for (int k = 0; k < K; ++k) acc = fmaf(arow[k], wcol[k * ldw], acc);
-    Aout[b * lda_out + j] = act_fwd(a, acc);
+  for (int cb = 0; cb < (L.Np[l] >> 4); ++cb) {
+    const int col = cb * 16 + m;
+    const f32x4 acc = tile_mma(ap, 4, W + q * ldw + col, 4 * ldw, kch);
+    const bool valid = col < L.w[l];
+    const float b = valid ? bias[col] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Aout[r * lda_out + col] = valid ? act_fwd(a, acc[r] + b) : 0.f;
   }
 }
 
-// D_{l-1} = (D_l W_l^T) .* act'_{l-1}(A_{l-1}).  Adjacent threads take adjacent k:
-// rows of W_l sit ldw (odd) floats apart, so the walk is bank-conflict free.
-__device__ __forceinline__ void bwd_delta(const MlpLayout &L, const float *th, float *tile,
-                                          int l, int nb) {
-  const int K = L.w[l - 1], N = L.w[l];
-  const float *Din = tile + L.doff[l];
-  float *Dout = tile + L.doff[l - 1];
-  const float *Aprev = tile + L.aoff[l - 1];
+// Rows [16 rb, 16 rb + 16) of D_{l-1} = (D_l W_l^T) .* act'_{l-1}(A_{l-1}).
+__device__ __forceinline__ void bwd_rowblock(const MlpLayout &L, const float *th, float *tile,
+                                             int l, int rb) {
+  const int lane = threadIdx.x & 63, m = lane & 15, q = lane >> 4;
   const int ld_in = L.lda[l], ld_out = L.lda[l - 1], ldw = L.ldw[l];
+  const float *ap = tile + L.doff[l] + (rb * 16 + m) * ld_in + q;
   const float *W = th + L.woff[l];
+  float *Dout = tile + L.doff[l - 1] + (rb * 16 + q * 4) * ld_out;
+  const float *Aprev = tile + L.aoff[l - 1] + (rb * 16 + q * 4) * ld_out;
+  const int kch = (L.w[l] + 3) >> 2;
   const int a = L.act[l - 1];
-  for (int idx = threadIdx.x; idx < nb * K; idx += blockDim.x) {
-    const int b = idx / K, k = idx - b * K;
-    const float *drow = Din + b * ld_in;
-    const float *wrow = W + k * ldw;
-    float acc = 0.f;
-    for (int j = 0; j < N; ++j) acc = fmaf(drow[j], wrow[j], acc);
-    if (l > 1) acc *= act_grad(a, Aprev[b * ld_out + k]);
-    Dout[b * ld_out + k] = acc;
+  for (int kb = 0; kb < (L.Np[l - 1] >> 4); ++kb) {
+    const int col = kb * 16 + m;  // input index of layer l == column of D_{l-1}
+    const f32x4 acc = tile_mma(ap, 4, W + col * ldw + q, 4, kch);
+    const bool valid = col < L.w[l - 1];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float v = valid ? acc[r] : 0.f;
+      if (l > 1 && valid) v *= act_grad(a, Aprev[r * ld_out + col]);
+      Dout[r * ld_out + col] = v;
+    }
   }
 }
 
-// Objective + input gradient of one tile whose rows sit in A_0: forward, T(sign*f) into
-// val_out[0..nb) (LDS or global), dT/dx into D_0.  Ends with a barrier; D_0 and val_out
-// are then readable by every thread.
-__device__ __forceinline__ void fg_tile(const MlpLayout &L, const float *th, float *tile, int nb,
-                                        int transform, float sign, float *val_out) {
-  const int n = L.n_layers;
-  for (int l = 1; l <= n; ++l) {
-    fwd_layer(L, th, tile, l, nb, false);
-    __syncthreads();
+// Forward through every layer for one row-block (calling wave).
+__device__ __forceinline__ void fwd_all(const MlpLayout &L, const float *th, float *tile, int rb,
+                                        bool keep_logits) {
+  for (int l = 1; l <= L.n_layers; ++l) {
+    fwd_rowblock(L, th, tile, l, rb, keep_logits && l == L.n_layers);
+    wave_lds_sync();
   }
-  if ((int)threadIdx.x < nb) {
-    const int b = threadIdx.x;
-    const float f = tile[L.aoff[n] + b * L.lda[n]];
+}
+
+// Objective + input gradient for one row-block whose rows sit in A_0: forward, T(sign*f)
+// into val_out[row] (LDS or global, indexed by tile row), d T / d x into D_0.
+__device__ __forceinline__ void fg_rowblock(const MlpLayout &L, const float *th, float *tile,
+                                            int rb, int transform, float sign, float *val_out) {
+  const int n = L.n_layers;
+  const int lane = threadIdx.x & 63;
+  fwd_all(L, th, tile, rb, false);
+  if (lane < 16) {
+    const int row = rb * 16 + lane;
+    const float f = tile[L.aoff[n] + row * L.lda[n]];
     const float u = sign * f;
     float T, dT;
     if (transform == BORE_T_SIGMOID) {
@@ -154,13 +192,13 @@ __device__ __forceinline__ void fg_tile(const MlpLayout &L, const float *th, flo
       T = u;
       dT = 1.f;
     }
-    val_out[b] = T;
-    tile[L.doff[n] + b * L.lda[n]] = sign * dT * act_grad(L.act[n], f);
+    val_out[row] = T;
+    tile[L.doff[n] + row * L.lda[n]] = sign * dT * act_grad(L.act[n], f);
   }
-  __syncthreads();
+  wave_lds_sync();
   for (int l = n; l >= 1; --l) {
-    bwd_delta(L, th, tile, l, nb);
-    __syncthreads();
+    bwd_rowblock(L, th, tile, l, rb);
+    wave_lds_sync();
   }
 }
 
