@@ -1,8 +1,8 @@
 #!/usr/bin/env python
 """bench.py -- BO-iterations/sec (fit + argmax) for the 16-16-1 classifier on MI355X.
 
-Workload (BASELINE.json config 4 per GPU = config 1 replicated): `--loops` independent
-Branin BO loops per GPU (default 64 = 512 loops / 8 GPUs), 16-16-1 MLP, gamma 0.25,
+Workload (BASELINE.json config 4 = config 1 replicated): `--loops` independent Branin BO
+loops per GPU (default 512, the whole of config 4 on one GPU), 16-16-1 MLP, gamma 0.25,
 fit(epochs=200, batch_size=64) warm-started every iteration, argmax with 3 L-BFGS-B
 restarts from 1024 uniform samples (maxiter 1000, ftol 1e-9), 10 initial points.  One
 "step" is one BO iteration of EVERY loop on the GPU; the data set grows by one point per
@@ -69,7 +69,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--loops", type=int, default=64, help="BO loops per GPU")
+    ap.add_argument("--loops", type=int, default=512, help="BO loops per GPU")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--mode", default="device", choices=["device", "lockstep"],
                     help="device: L-BFGS-B restarts inside one kernel; lockstep: scipy on the host")
@@ -129,7 +129,7 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "BASELINE config 4 shard = config 1 x loops: Branin-2D, "
+            "config": {"workload": "BASELINE config 4 (= config 1 x independent loops): Branin-2D, "
                                    "16-16-1 MLP, q=0.25, 200 epochs, batch 64, 3 L-BFGS-B "
                                    "restarts from 1024 samples",
                        "loops_per_gpu": args.loops, "restarts": args.mode, "N_start": int(n_start),

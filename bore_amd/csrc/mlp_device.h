@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 
 #include "mlp_layout.h"
+#include "mlp_shapes.h"
 
 namespace bore {
 
@@ -94,6 +95,37 @@ __device__ __forceinline__ void zero_lds(float *p, int n_floats) {
   for (int i = threadIdx.x; i < n_floats; i += blockDim.x) p[i] = 0.f;
 }
 
+// Zero the workgroup's LDS and park a copy of the layout at smem[o_layout].  The kernels
+// index the layout tables by a run-time layer number; from the kernarg segment that is a
+// ~1 us global load per lookup, from LDS a broadcast ds_read.  Ends with a barrier.
+__device__ __forceinline__ const MlpLayout &stage_layout(const MlpLayout &Lk, float *smem,
+                                                        int total_floats, int o_layout) {
+  zero_lds(smem, total_floats);
+  __syncthreads();
+  const int *src = reinterpret_cast<const int *>(&Lk);
+  int *dst = reinterpret_cast<int *>(smem + o_layout);
+  for (int i = threadIdx.x; i < (int)(sizeof(MlpLayout) / 4); i += blockDim.x) dst[i] = src[i];
+  __syncthreads();
+  return *reinterpret_cast<const MlpLayout *>(smem + o_layout);
+}
+
+#define BORE_LAYOUT_FLOATS ((int)((sizeof(MlpLayout) + 15) / 16 * 4))
+
+// Start of every kernel: zero the LDS, then hand out the layout -- the LDS copy (SHAPE 0) or
+// nothing at all (SHAPE > 0: the caller holds a constexpr layout).  Ends with a barrier.
+template <int SHAPE>
+__device__ __forceinline__ const MlpLayout &begin_kernel(const MlpLayout &Lstatic,
+                                                        const MlpLayout &Lk, float *smem,
+                                                        int total_floats, int o_layout) {
+  if constexpr (SHAPE == 0) {
+    return stage_layout(Lk, smem, total_floats, o_layout);
+  } else {
+    zero_lds(smem, total_floats);
+    __syncthreads();
+    return Lstatic;
+  }
+}
+
 // HBM -> LDS: packed vector into the (already zeroed) padded image; coalesced reads.
 __device__ __forceinline__ void load_theta(const MlpLayout &L, const float *__restrict__ g,
                                            float *th) {
@@ -107,11 +139,23 @@ __device__ __forceinline__ void store_theta(const MlpLayout &L, const float *th,
 
 // One 16x16 tile: sum over kchunks*4 of A[m][k] * B[k][n].  ap / bp are THIS LANE's operand
 // addresses for k-chunk 0; sa / sb the address step per k-chunk (4 values of k).
+// Operands are fetched four k-chunks at a time (8 independent ds_reads in flight) ahead of
+// the dependent MFMA chain.
 __device__ __forceinline__ f32x4 tile_mma(const float *ap, int sa, const float *bp, int sb,
                                           int kchunks) {
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-  for (int kc = 0; kc < kchunks; ++kc)
+  int kc = 0;
+  for (; kc + 4 <= kchunks; kc += 4) {
+    const float a0 = ap[kc * sa], a1 = ap[(kc + 1) * sa], a2 = ap[(kc + 2) * sa],
+                a3 = ap[(kc + 3) * sa];
+    const float b0 = bp[kc * sb], b1 = bp[(kc + 1) * sb], b2 = bp[(kc + 2) * sb],
+                b3 = bp[(kc + 3) * sb];
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, b2, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a3, b3, acc, 0, 0, 0);
+  }
+  for (; kc < kchunks; ++kc)
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[kc * sa], bp[kc * sb], acc, 0, 0, 0);
   return acc;
 }
@@ -127,10 +171,12 @@ __device__ __forceinline__ void fwd_rowblock(const MlpLayout &L, const float *th
   float *Aout = tile + L.aoff[l] + (rb * 16 + q * 4) * lda_out;
   const int kch = (L.w[l - 1] + 3) >> 2;
   const int a = keep_logits ? BORE_ACT_LINEAR : L.act[l];
-  for (int cb = 0; cb < (L.Np[l] >> 4); ++cb) {
+  const int ncb = L.Np[l] >> 4, wl = L.w[l];
+#pragma unroll
+  for (int cb = 0; cb < ncb; ++cb) {
     const int col = cb * 16 + m;
     const f32x4 acc = tile_mma(ap, 4, W + q * ldw + col, 4 * ldw, kch);
-    const bool valid = col < L.w[l];
+    const bool valid = col < wl;
     const float b = valid ? bias[col] : 0.f;
 #pragma unroll
     for (int r = 0; r < 4; ++r) Aout[r * lda_out + col] = valid ? act_fwd(a, acc[r] + b) : 0.f;
@@ -148,10 +194,12 @@ __device__ __forceinline__ void bwd_rowblock(const MlpLayout &L, const float *th
   const float *Aprev = tile + L.aoff[l - 1] + (rb * 16 + q * 4) * ld_out;
   const int kch = (L.w[l] + 3) >> 2;
   const int a = L.act[l - 1];
-  for (int kb = 0; kb < (L.Np[l - 1] >> 4); ++kb) {
+  const int nkb = L.Np[l - 1] >> 4, wp = L.w[l - 1];
+#pragma unroll
+  for (int kb = 0; kb < nkb; ++kb) {
     const int col = kb * 16 + m;  // input index of layer l == column of D_{l-1}
     const f32x4 acc = tile_mma(ap, 4, W + col * ldw + q, 4, kch);
-    const bool valid = col < L.w[l - 1];
+    const bool valid = col < wp;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       float v = valid ? acc[r] : 0.f;
@@ -164,6 +212,7 @@ __device__ __forceinline__ void bwd_rowblock(const MlpLayout &L, const float *th
 // Forward through every layer for one row-block (calling wave).
 __device__ __forceinline__ void fwd_all(const MlpLayout &L, const float *th, float *tile, int rb,
                                         bool keep_logits) {
+#pragma unroll
   for (int l = 1; l <= L.n_layers; ++l) {
     fwd_rowblock(L, th, tile, l, rb, keep_logits && l == L.n_layers);
     wave_lds_sync();
@@ -196,6 +245,7 @@ __device__ __forceinline__ void fg_rowblock(const MlpLayout &L, const float *th,
     tile[L.doff[n] + row * L.lda[n]] = sign * dT * act_grad(L.act[n], f);
   }
   wave_lds_sync();
+#pragma unroll
   for (int l = n; l >= 1; --l) {
     bwd_rowblock(L, th, tile, l, rb);
     wave_lds_sync();

@@ -41,12 +41,14 @@ struct MlpLayout {
   int any_l2;
 };
 
-static inline int bore_round_up(int x, int m) { return (x + m - 1) / m * m; }
+static constexpr int bore_round_up(int x, int m) { return (x + m - 1) / m * m; }
 
 // Returns 0 on success.  with_deltas: 0 = forward only, 1 = deltas D_1..D_n (fit),
 // 2 = deltas D_0..D_n (input gradient).  tile_rows: rows held per tile, 1..BORE_BATCH_MAX.
-static inline int bore_make_layout(const bore_mlp_desc *d, int with_deltas, int tile_rows,
-                                   MlpLayout *L) {
+// constexpr: the kernels specialised for a fixed network shape (mlp_shapes.h) evaluate it at
+// compile time, so every offset below becomes an immediate.
+static constexpr int bore_make_layout(const bore_mlp_desc *d, int with_deltas, int tile_rows,
+                                      MlpLayout *L) {
   if (!d || d->n_layers < 1 || d->n_layers > BORE_MAX_LAYERS || d->input_dim < 1) return -1;
   if (tile_rows < 1 || tile_rows > BORE_BATCH_MAX) return -1;
   L->tb = tile_rows;

@@ -1,0 +1,62 @@
+// mlp_shapes.h -- network shapes with a compile-time layout.
+//
+// The generic kernels read the layout tables (widths, strides, LDS offsets) at run time,
+// indexed by the layer number: every lookup is a dependent LDS read in the middle of a
+// latency-bound chain.  For the shapes listed here -- the configurations BASELINE.json
+// quotes -- the same kernel source is instantiated with the layout as a constant
+// expression: layer loops unroll, offsets fold into ds_read immediates, the k-loops of
+// the MFMA tiles have constant trip counts.  SHAPE 0 is the generic path.
+#pragma once
+#include "mlp_layout.h"
+
+#define BORE_N_SHAPES 2  // ids 1..BORE_N_SHAPES
+
+struct ShapeSpec {
+  int D, n_layers;
+  int units[4];
+  int act[4];
+};
+
+// 1: README.rst:60-63 / BASELINE config 1 and 4 (Branin-2D, 16-16-1, relu relu sigmoid)
+// 2: BASELINE config 2 (Hartmann-6D, 32-32-1, relu relu + logit output)
+static constexpr ShapeSpec kShapes[BORE_N_SHAPES + 1] = {
+    {0, 0, {0, 0, 0, 0}, {0, 0, 0, 0}},
+    {2, 3, {16, 16, 1, 0}, {BORE_ACT_RELU, BORE_ACT_RELU, BORE_ACT_SIGMOID, 0}},
+    {6, 3, {32, 32, 1, 0}, {BORE_ACT_RELU, BORE_ACT_RELU, BORE_ACT_LINEAR, 0}},
+};
+
+static constexpr bore_mlp_desc bore_shape_desc(int shape) {
+  bore_mlp_desc d{};
+  d.input_dim = kShapes[shape].D;
+  d.n_layers = kShapes[shape].n_layers;
+  for (int i = 0; i < 4; ++i) {
+    d.units[i] = kShapes[shape].units[i];
+    d.act[i] = kShapes[shape].act[i];
+  }
+  return d;
+}
+
+static constexpr MlpLayout bore_static_layout(int shape, int with_deltas, int tile_rows) {
+  MlpLayout L{};
+  bore_mlp_desc d = bore_shape_desc(shape);
+  bore_make_layout(&d, with_deltas, tile_rows, &L);
+  return L;
+}
+
+template <int SHAPE, int DELTAS, int ROWS>
+struct StaticLayout {
+  static constexpr MlpLayout value = bore_static_layout(SHAPE, DELTAS, ROWS);
+};
+
+// Which static shape (if any) a descriptor matches: same widths and activations, no l2.
+static inline int bore_match_shape(const bore_mlp_desc *d) {
+  for (int s = 1; s <= BORE_N_SHAPES; ++s) {
+    if (d->input_dim != kShapes[s].D || d->n_layers != kShapes[s].n_layers) continue;
+    bool ok = true;
+    for (int i = 0; i < d->n_layers; ++i)
+      ok = ok && d->units[i] == kShapes[s].units[i] && d->act[i] == kShapes[s].act[i] &&
+           d->l2_kernel[i] == 0.f && d->l2_bias[i] == 0.f;
+    if (ok) return s;
+  }
+  return 0;
+}

@@ -7,10 +7,13 @@
 #include <cstring>
 
 #include "host_common.h"
-#include "lbfgsb.h"
+#include "../../scratch/lbfgsb_stamp.h"
 #include "mlp_device.h"
 
 using namespace bore;
+__device__ long long g_lstamps[8];
+extern "C" int bore_debug_ls(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(lbfgsb::g_ls), sizeof(long long)*16); }
+extern "C" int bore_debug_lstamps(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lstamps), sizeof(long long)*8); }
 
 // ---------------------------------------------------------------------------
 // labels: tau = np.quantile(y, gamma) (linear interpolation), z = y < tau
@@ -356,8 +359,10 @@ __global__ __launch_bounds__(BORE_THREADS) void lbfgsb_kernel(const LbfgsbArgs a
   if (wv >= np) return;  // wave without problems (np < 4)
 
   bool done = (myp < 0);
+  long long t_adv = 0, t_fg = 0, n_rounds = 0, t_first = 0;
   for (int round = 0; round < a.max_rounds; ++round) {
     int pending = 0;
+    long long c0 = clock64();
     if (!done) {
       const int rc = lbfgsb::lbfgsb_advance(st, wk, blo, bhi, bnbd, a.opt);
       if (rc == lbfgsb::LB_NEED_FG) {
@@ -368,6 +373,7 @@ __global__ __launch_bounds__(BORE_THREADS) void lbfgsb_kernel(const LbfgsbArgs a
         done = true;
       }
     }
+    long long c1 = clock64(); t_adv += c1 - c0; if (round == 0) t_first = c1 - c0;
     if (!__any(pending)) break;  // every problem of this wave has terminated
     wave_lds_sync();
     fg_rowblock(L, th, tile, wv, a.transform, a.sign, vals);
@@ -377,7 +383,9 @@ __global__ __launch_bounds__(BORE_THREADS) void lbfgsb_kernel(const LbfgsbArgs a
       for (int d = 0; d < D; ++d) wk.g[d] = (double)g[d];
     }
     wave_lds_sync();
+    t_fg += clock64() - c1; ++n_rounds;
   }
+  if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) { g_lstamps[0] = t_adv; g_lstamps[1] = t_fg; g_lstamps[2] = n_rounds; g_lstamps[3] = st.nit; g_lstamps[4] = t_first; }
 
   if (myp >= 0) {
     const long long q = model * a.R + p0 + myp;

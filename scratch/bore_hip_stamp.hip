@@ -10,6 +10,9 @@
 #include "mlp_device.h"
 
 using namespace bore;
+__device__ long long g_stamps[64];
+#define STAMP(i) do { if (blockIdx.x == 0 && tid == 0 && e == 1 && s == 0) g_stamps[i] = clock64(); if (blockIdx.x==0 && tid==64 && e==1 && s==0) g_stamps[32+i] = clock64(); } while (0)
+extern "C" int bore_debug_stamps(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(long long)*64); }
 
 extern "C" int bore_abi_version(void) { return BORE_ABI_VERSION; }
 extern "C" const char *bore_last_error(void) { return g_bore_err; }
@@ -114,6 +117,7 @@ __global__ __launch_bounds__(BORE_THREADS) void fit_kernel(const FitArgs a) {
     float eloss = 0.f;  // per wave: sum over the epoch of its rows' losses
 
     for (int s = 0; s < steps; ++s) {
+      STAMP(0);
       const int row0 = s * a.B;
       const int nb = min(a.B, N - row0);
       // ---- forward / loss / backward: wave wv owns rows [16 wv, 16 wv + 16), no barriers ----
@@ -127,7 +131,9 @@ __global__ __launch_bounds__(BORE_THREADS) void fit_kernel(const FitArgs a) {
           if (q4 == 0) zt[row] = row < nb ? zs[src] : 0.f;
         }
         wave_lds_sync();
+        STAMP(1);
         fwd_all(L, th, tile, rb, /*keep_logits=*/true);
+        STAMP(2);
         float lossb = 0.f;
         if (lane < 16) {  // loss + d loss / d logit (the final layer has one unit)
           const int row = rb * 16 + lane;
@@ -148,13 +154,16 @@ __global__ __launch_bounds__(BORE_THREADS) void fit_kernel(const FitArgs a) {
         }
         eloss += lossb;
         wave_lds_sync();
+        STAMP(3);
 #pragma unroll
         for (int l = n; l >= 2; --l) {
           bwd_rowblock(L, th, tile, l, rb);
           wave_lds_sync();
         }
+        STAMP(4);
       }
       __syncthreads();
+      STAMP(5);
 
       // ---- weight gradients (sums over all rows) + Adam, one 16x16 tile per wave at a time ----
       b1p *= (double)a.beta1;
@@ -249,11 +258,13 @@ __global__ __launch_bounds__(BORE_THREADS) void fit_kernel(const FitArgs a) {
             }
           }
       }
+      STAMP(6);
       if (L.any_l2) {  // penalty of the UPDATED weights = the one the next step's loss sees
         reg = wave_sum(reg);
         if (lane == 0) atomicAdd(&misc[0], reg);
       }
       __syncthreads();
+      STAMP(7);
     }
     if (a.epoch_loss) {
       if (lane == 0) misc[1 + wv] = eloss;

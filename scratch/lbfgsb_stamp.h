@@ -39,6 +39,12 @@
 #endif
 
 namespace lbfgsb {
+__device__ long long g_ls[16];
+#if defined(__HIP_DEVICE_COMPILE__)
+#define LST(i) do { if (blockIdx.x==0 && blockIdx.y==0 && threadIdx.x==0) g_ls[i] = clock64(); } while(0)
+#else
+#define LST(i)
+#endif
 
 enum { LB_NEED_FG = 1, LB_DONE = 2 };
 
@@ -1045,6 +1051,7 @@ LB_HDN int lbfgsb_advance(State &s, const Work &w, const double *l, const double
   bool first_ls = false;
   bool resume_ls = (s.stage == S_FG_LNSRCH);
 
+  LST(0);
   if (s.stage == S_FINISHED) return LB_DONE;
 
   if (s.stage == S_FG_START || s.stage == S_FG_LNSRCH) {  // fresh f, g at w.x have arrived
@@ -1132,7 +1139,9 @@ LB_HDN int lbfgsb_advance(State &s, const Work &w, const double *l, const double
     }
 
     s.info = 0;
+    LST(1);
     if (lnsrlb(s, w, l, u, nbd, first_ls ? 1 : 0)) {
+      LST(2);
       if (s.iback < opt.maxls) {
         // SciPy's ScalarFunction serves a request at the point it evaluated last from its
         // cache (no call, nfev unchanged); a collapsed bracket asks for such points.
@@ -1147,6 +1156,7 @@ LB_HDN int lbfgsb_advance(State &s, const Work &w, const double *l, const double
         s.stage = S_FG_LNSRCH;
         s.task = T_FG;
         ++s.nfev;
+        LST(3);
         return LB_NEED_FG;
       }
       // maxls trial points used up: handled like a failed search (the trial x is dropped)
