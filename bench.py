@@ -77,7 +77,7 @@ def main():
 
     import torch
     import torch.distributed as dist
-    from bore_amd.engine import ReplicaEngine, gather_results
+    from bore_amd.engine import ReplicaEngine, gather_results, shard_loop_ids
 
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
@@ -87,7 +87,7 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
-    loop_ids = rank * args.loops + np.arange(args.loops)   # contiguous shard per rank
+    loop_ids = shard_loop_ids(rank, world, args.loops)     # contiguous shard per rank
     eng = ReplicaEngine(loop_ids, mode=args.mode)
 
     def barrier():
@@ -99,7 +99,7 @@ def main():
     for _ in range(args.warmup):
         eng.step()
     eng.finish_timing()
-    for k in ("fit_ms", "fit_bytes"):
+    for k in ("fit_ms", "fit_bytes", "argmax_ms", "argmax_bytes"):
         eng.stats[k] = []
     eng.stats["n_fg_rows"] = eng.stats["n_rounds"] = 0
     n_start = eng.N
@@ -122,7 +122,20 @@ def main():
         total_iters = args.loops * world * args.steps
         fit_ms = np.array(eng.stats["fit_ms"])
         fit_bytes = np.array(eng.stats["fit_bytes"], dtype=np.float64)
-        achieved = fit_bytes.sum() / (fit_ms.sum() * 1e-3) / 1e9
+
+        def roof(name, ms, nbytes):
+            ach = nbytes.sum() / (ms.sum() * 1e-3) / 1e9
+            return {"bound": "hbm", "kernel": name, "achieved": ach, "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                    "avg_launch_ms": float(ms.mean()),
+                    "algorithmic_bytes_per_launch": float(nbytes.mean()),
+                    "share_of_step": float(ms.sum() / (1e3 * dt))}
+
+        kernels = [roof("fit_kernel", fit_ms, fit_bytes)]
+        if eng.stats["argmax_ms"]:
+            kernels.append(roof("lbfgsb_kernel", np.array(eng.stats["argmax_ms"]),
+                                np.array(eng.stats["argmax_bytes"], dtype=np.float64)))
+        dominant = max(kernels, key=lambda k: k["share_of_step"])
         out = {
             "metric": "BO-iterations/sec (fit+argmax), 16-16-1 MLP",
             "value": total_iters / dt, "unit": "BO-iterations/s", "n_gpus": world,
@@ -134,11 +147,8 @@ def main():
                                    "restarts from 1024 samples",
                        "loops_per_gpu": args.loops, "restarts": args.mode, "N_start": int(n_start),
                        "N_end": int(eng.N), "parallelism": f"replica-shard x{world}"},
-            "roofline": {"bound": "hbm", "kernel": "fit_kernel", "achieved": achieved,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None,
-                         "avg_launch_ms": float(fit_ms.mean()),
-                         "algorithmic_bytes_per_launch": float(fit_bytes.mean())},
+            "roofline": dominant,
+            "kernels": kernels,
             "phases": {"fit_ms_per_step": float(fit_ms.mean()),
                        "fg_rows_per_step": eng.stats["n_fg_rows"] / args.steps,
                        "fg_rounds_per_step": eng.stats["n_rounds"] / args.steps,

@@ -83,8 +83,9 @@ class ReplicaEngine:
         # observations
         self.X = np.stack([rs.uniform(self.low, self.high, size=(n_init, D)) for rs in self.rs])
         self.y = self.objective(self.X)
-        self.stats = dict(fit_ms=[], fit_bytes=[], n_fg_rows=0, n_rounds=0, none_results=0)
-        self._ev = []
+        self.stats = dict(fit_ms=[], fit_bytes=[], argmax_ms=[], argmax_bytes=[], n_fg_rows=0,
+                          n_rounds=0, none_results=0)
+        self._ev, self._ev2 = [], []
 
     @property
     def N(self):
@@ -175,11 +176,20 @@ class ReplicaEngine:
         self.draws += 1
         x0, _ = ops.screen_topk(self.desc, self.theta, Xc, R)
         tr = self.transform.negated()
+        e2, e3 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e2.record()
         x, fun, _, info = ops.lbfgsb_minimize(self.desc, self.theta, x0, self.low, self.high,
                                               tr.name, tr.negate, **self.options)
+        e3.record()
+        self._ev2.append((e2, e3))
         x, fun, info = x.cpu().numpy(), fun.cpu().numpy(), info.cpu().numpy()   # the one sync
-        self.stats["n_fg_rows"] += int(info[:, :, 1].sum())
-        self.stats["n_rounds"] += int(info[:, :, 1].max())
+        nfev = info[:, :, 1]
+        self.stats["n_fg_rows"] += int(nfev.sum())
+        self.stats["n_rounds"] += int(nfev.max())
+        # every f/g row reads x and writes val+grad; every round of a loop
+        # re-reads its theta (streaming model)
+        self.stats["argmax_bytes"].append(int(nfev.sum()) * 4 * (2 * D + 1)
+                                          + int(nfev.max(axis=1).sum()) * 4 * self.P)
         ok = (info[:, :, 2] == 0) | (info[:, :, 2] == 1)          # success or status == 1
         f = np.where(ok, fun, np.inf)
         best = np.argmin(f, axis=1)                                # ties keep the earliest
@@ -209,11 +219,19 @@ class ReplicaEngine:
         torch.cuda.synchronize()
         for e0, e1 in self._ev:
             self.stats["fit_ms"].append(e0.elapsed_time(e1))
-        self._ev = []
+        for e0, e1 in self._ev2:
+            self.stats["argmax_ms"].append(e0.elapsed_time(e1))
+        self._ev, self._ev2 = [], []
 
     def best(self):
         i = np.argmin(self.y, axis=1)
         return self.X[np.arange(self.L), i], self.y[np.arange(self.L), i]
+
+
+def shard_loop_ids(rank, world_size, loops_per_gpu):
+    """Loop ids owned by `rank`: the contiguous block [rank*L, (rank+1)*L).  Weak scaling: the
+    job has world_size*L loops; no loop is shared, none is dropped."""
+    return rank * loops_per_gpu + np.arange(loops_per_gpu, dtype=np.int64)
 
 
 def gather_results(engine, world_size):

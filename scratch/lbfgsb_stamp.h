@@ -41,7 +41,7 @@
 namespace lbfgsb {
 __device__ long long g_ls[16];
 #if defined(__HIP_DEVICE_COMPILE__)
-#define LST(i) do { if (blockIdx.x==0 && blockIdx.y==0 && threadIdx.x==0) g_ls[i] = clock64(); } while(0)
+#define LST(i) do { if (blockIdx.x==0 && blockIdx.y==0 && threadIdx.x==0 && lsflag) g_ls[i] = clock64(); } while(0)
 #else
 #define LST(i)
 #endif
@@ -1051,6 +1051,7 @@ LB_HDN int lbfgsb_advance(State &s, const Work &w, const double *l, const double
   bool first_ls = false;
   bool resume_ls = (s.stage == S_FG_LNSRCH);
 
+  const bool lsflag = (s.stage == S_FG_LNSRCH && s.ifun >= 2);
   LST(0);
   if (s.stage == S_FINISHED) return LB_DONE;
 
@@ -1058,6 +1059,7 @@ LB_HDN int lbfgsb_advance(State &s, const Work &w, const double *l, const double
     for (int i = 0; i < n; ++i) { w.xlast[i] = w.x[i]; w.glast[i] = w.g[i]; }
     s.flast = s.f;
   }
+  LST(1);
 
   if (s.stage == S_INIT) {
     s.col = 0; s.head = 0; s.theta = 1.0; s.iupdat = 0; s.updatd = 0;
@@ -1139,14 +1141,15 @@ LB_HDN int lbfgsb_advance(State &s, const Work &w, const double *l, const double
     }
 
     s.info = 0;
-    LST(1);
+    LST(2);
     if (lnsrlb(s, w, l, u, nbd, first_ls ? 1 : 0)) {
-      LST(2);
+      LST(3);
       if (s.iback < opt.maxls) {
         // SciPy's ScalarFunction serves a request at the point it evaluated last from its
         // cache (no call, nfev unchanged); a collapsed bracket asks for such points.
         bool cached = true;
         for (int i = 0; i < n; ++i) cached = cached && (w.x[i] == w.xlast[i]);
+        LST(4);
         if (cached) {
           s.f = s.flast;
           for (int i = 0; i < n; ++i) w.g[i] = w.glast[i];
@@ -1156,7 +1159,7 @@ LB_HDN int lbfgsb_advance(State &s, const Work &w, const double *l, const double
         s.stage = S_FG_LNSRCH;
         s.task = T_FG;
         ++s.nfev;
-        LST(3);
+        LST(5);
         return LB_NEED_FG;
       }
       // maxls trial points used up: handled like a failed search (the trial x is dropped)
