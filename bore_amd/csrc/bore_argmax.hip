@@ -337,9 +337,13 @@ __global__ __launch_bounds__(BORE_THREADS) void lbfgsb_kernel(const LbfgsbArgs a
   load_theta(L, a.theta + model * L.P, th);
   __syncthreads();
 
-  // the problem (if any) this thread owns, and its tile row
-  const int myp = (lane < 16 && lane * 4 + wv < np) ? lane * 4 + wv : -1;
-  const int myrow = wv * 16 + lane;
+  // Which problem this thread works on.  With at most one problem per wave (np <= 4: the
+  // BASELINE config-1 shape, 3 restarts) ALL 64 lanes of wave wv run problem wv together
+  // (lbfgsb::Coop); otherwise lane s < 16 of wave wv runs problem 4 s + wv on its own.
+  const bool coop = np <= 4;
+  const int myp = coop ? (wv < np ? wv : -1) : ((lane < 16 && lane * 4 + wv < np) ? lane * 4 + wv : -1);
+  const int myrow = coop ? wv * 16 : wv * 16 + lane;
+  const lbfgsb::Coop cp = coop ? lbfgsb::Coop{lane, 64} : lbfgsb::Coop{0, 1};
   // The scalar state of the optimiser stays in this thread's REGISTERS for the whole launch
   // (its vectors and matrices are in LDS): kept in memory, every store to a workspace array
   // would force the compiler to reload the state fields it may alias.
@@ -359,7 +363,7 @@ __global__ __launch_bounds__(BORE_THREADS) void lbfgsb_kernel(const LbfgsbArgs a
   for (int round = 0; round < a.max_rounds; ++round) {
     int pending = 0;
     if (!done) {
-      const int rc = lbfgsb::lbfgsb_advance(st, wk, blo, bhi, bnbd, a.opt);
+      const int rc = lbfgsb::lbfgsb_advance(st, wk, blo, bhi, bnbd, a.opt, cp);
       if (rc == lbfgsb::LB_NEED_FG) {
         float *row = tile + L.aoff[0] + myrow * L.lda[0];
         for (int d = 0; d < D; ++d) row[d] = (float)wk.x[d];  // Keras autocast fp64 -> fp32
@@ -379,6 +383,7 @@ __global__ __launch_bounds__(BORE_THREADS) void lbfgsb_kernel(const LbfgsbArgs a
     wave_lds_sync();
   }
 
+  if (coop && lane != 0) return;  // one lane reports the shared problem
   if (myp >= 0) {
     const long long q = model * a.R + p0 + myp;
     if (st.stage != lbfgsb::S_FINISHED) {  // round cap hit (cannot happen with a sane cap)
@@ -436,7 +441,7 @@ extern "C" int bore_lbfgsb_minimize(const bore_mlp_desc *desc, int n_models, con
   // State lives in registers
   const size_t state_f = 0;
   const size_t dw_f = 2 * (size_t)lbfgsb::dwork_size(D, m);
-  const size_t iw_f = ((size_t)lbfgsb::iwork_size(D) + 1) & ~(size_t)1;
+  const size_t iw_f = ((size_t)lbfgsb::iwork_size(D) + 3) & ~(size_t)3;
   a.o_state = 0;
   a.o_dw = (int)state_f;
   a.o_iw = (int)(state_f + dw_f);
@@ -453,8 +458,9 @@ extern "C" int bore_lbfgsb_minimize(const bore_mlp_desc *desc, int n_models, con
     off = a.L.P_lds;
     a.o_tile = (int)off; off += a.L.tile_floats;
     a.o_vals = (int)off; off += BORE_BATCH_MAX;
-    off = (off + 1) & ~(size_t)1;
-    a.o_box = (int)off; off += 4 * (size_t)D + (((size_t)D + 1) & ~(size_t)1);
+    off = (off + 3) & ~(size_t)3;  // 16-byte boundary for the fp64 regions
+    a.o_box = (int)off; off += 4 * (size_t)D + (((size_t)D + 3) & ~(size_t)3) + (D & 1 ? 2 : 0);
+    off = (off + 3) & ~(size_t)3;
     a.o_prob = (int)off; off += (size_t)a.prob_floats * PB;
     a.total = (int)off;
     off = (off + 3) & ~(size_t)3;

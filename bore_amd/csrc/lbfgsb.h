@@ -32,7 +32,7 @@
 
 #if defined(__HIPCC__)
 #define LB_HD __host__ __device__ __forceinline__
-#define LB_HDN __host__ __device__ __forceinline__  // one call site each: no device call stack
+#define LB_HDN __host__ __device__ __forceinline__  // (real calls measured slower: +20 % kernel time)
 #else
 #define LB_HD inline
 #define LB_HDN
@@ -79,7 +79,14 @@ struct State {
   double flast;
 };
 
-LB_HD int dwork_size(int n, int m) { return 2 * m * n + 11 * m * m + 8 * m + 9 * n; }
+// Every sub-array starts on a 16-byte boundary (vectors are padded to an even length) and the
+// caller must hand in a 16-byte aligned base: the device compiler merges adjacent fp64 LDS
+// loads into ds_read_b128, which returns WRONG data at 8-byte alignment on gfx950 (found as a
+// host/device mismatch for odd n; see tests/test_gpu_argmax.py).
+LB_HD int dwork_size(int n, int m) {
+  const int ne = (n + 1) & ~1, mne = (m * n + 1) & ~1, mm = (m * m + 1) & ~1;
+  return 2 * mne + 3 * mm + 8 * m * m + 8 * m + 9 * ne;
+}
 LB_HD int iwork_size(int n) { return 3 * n; }
 
 // Views into the workspaces (all 0-based; matrices column-major like the original).
@@ -95,22 +102,23 @@ struct Work {
 
 LB_HD Work make_work(double *dw, int *iw, int n, int m) {
   Work w;
-  w.ws = dw; dw += m * n;
-  w.wy = dw; dw += m * n;
-  w.sy = dw; dw += m * m;
-  w.ss = dw; dw += m * m;
-  w.wt = dw; dw += m * m;
+  const int ne = (n + 1) & ~1, mne = (m * n + 1) & ~1, mm = (m * m + 1) & ~1;
+  w.ws = dw; dw += mne;
+  w.wy = dw; dw += mne;
+  w.sy = dw; dw += mm;
+  w.ss = dw; dw += mm;
+  w.wt = dw; dw += mm;
   w.wn = dw; dw += 4 * m * m;
   w.snd = dw; dw += 4 * m * m;
-  w.z = dw; dw += n;
-  w.r = dw; dw += n;
-  w.d = dw; dw += n;
-  w.t = dw; dw += n;
-  w.xp = dw; dw += n;
-  w.x = dw; dw += n;
-  w.g = dw; dw += n;
-  w.xlast = dw; dw += n;
-  w.glast = dw; dw += n;
+  w.z = dw; dw += ne;
+  w.r = dw; dw += ne;
+  w.d = dw; dw += ne;
+  w.t = dw; dw += ne;
+  w.xp = dw; dw += ne;
+  w.x = dw; dw += ne;
+  w.g = dw; dw += ne;
+  w.xlast = dw; dw += ne;
+  w.glast = dw; dw += ne;
   w.wa = dw;
   w.index = iw;
   w.iwhere = iw + n;
@@ -120,11 +128,71 @@ LB_HD Work make_work(double *dw, int *iw, int n, int m) {
 
 #define LB_EPSMCH 2.220446049250313e-16
 
+// ---- lanes cooperating on ONE problem ---------------------------------------------------
+// When a wave owns a single problem, all 64 lanes run the state machine in lock-step with
+// identical scalars (uniform control flow, redundant stores of identical values) and SHARE
+// the loops whose iterations produce independent outputs: lane `lane` of `nl` takes
+// iterations lane, lane+nl, ...  Every output is still computed by one lane with the
+// sequential operation order, so results do not depend on nl (host build: nl = 1).
+// LB_LANES_SYNC separates such a loop from readers of its outputs in other lanes.
+struct Coop {
+  int lane, nl;
+};
+#if defined(__HIP_DEVICE_COMPILE__)
+#define LB_LANES_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#else
+#define LB_LANES_SYNC() ((void)0)
+#endif
+
 // ---- small dense kernels ------------------------------------------------------
+// Sums strictly left to right (results do not depend on the unrolling); operands are fetched
+// eight at a time so that their LDS latencies overlap -- on the device a dependent
+// load-multiply-add per element costs a full LDS round trip (~130 cycles).
 LB_HD double ddot(int n, const double *a, const double *b) {
   double s = 0.0;
-  for (int i = 0; i < n; ++i) s += a[i] * b[i];
+  int i = 0;
+  for (; i + 4 <= n; i += 4) {
+    const double a0 = a[i], a1 = a[i + 1], a2 = a[i + 2], a3 = a[i + 3];
+    const double b0 = b[i], b1 = b[i + 1], b2 = b[i + 2], b3 = b[i + 3];
+    s += a0 * b0;
+    s += a1 * b1;
+    s += a2 * b2;
+    s += a3 * b3;
+  }
+  for (; i < n; ++i) s += a[i] * b[i];
   return s;
+}
+
+// sum_i a[i*sa] * b[i*sb] / d[i*sd], left to right, operands fetched four terms at a time
+LB_HD double dot_div(int n, const double *a, int sa, const double *b, int sb, const double *d,
+                     int sd) {
+  double s = 0.0;
+  int i = 0;
+  for (; i + 4 <= n; i += 4) {
+    const double a0 = a[i * sa], a1 = a[(i + 1) * sa], a2 = a[(i + 2) * sa], a3 = a[(i + 3) * sa];
+    const double b0 = b[i * sb], b1 = b[(i + 1) * sb], b2 = b[(i + 2) * sb], b3 = b[(i + 3) * sb];
+    const double d0 = d[i * sd], d1 = d[(i + 1) * sd], d2 = d[(i + 2) * sd], d3 = d[(i + 3) * sd];
+    s += a0 * b0 / d0;
+    s += a1 * b1 / d1;
+    s += a2 * b2 / d2;
+    s += a3 * b3 / d3;
+  }
+  for (; i < n; ++i) s += a[i * sa] * b[i * sb] / d[i * sd];
+  return s;
+}
+
+// y[i] += alpha * x[i], i < n  (x and y do not overlap)
+LB_HD void daxpy(int n, double alpha, const double *x, double *y) {
+  int i = 0;
+  for (; i + 4 <= n; i += 4) {
+    const double x0 = x[i], x1 = x[i + 1], x2 = x[i + 2], x3 = x[i + 3];
+    const double y0 = y[i], y1 = y[i + 1], y2 = y[i + 2], y3 = y[i + 3];
+    y[i] = y0 + alpha * x0;
+    y[i + 1] = y1 + alpha * x1;
+    y[i + 2] = y2 + alpha * x2;
+    y[i + 3] = y3 + alpha * x3;
+  }
+  for (; i < n; ++i) y[i] += alpha * x[i];
 }
 
 // Cholesky of the leading n x n block of a (leading dimension ld), upper triangle:
@@ -154,9 +222,7 @@ LB_HD int dtrsl_upper(const double *t, int ld, int n, double *b, int trans) {
   if (!trans) {
     b[n - 1] = b[n - 1] / t[(n - 1) * ld + (n - 1)];
     for (int j = n - 2; j >= 0; --j) {
-      const double temp = -b[j + 1];
-      const double *col = t + (j + 1) * ld;
-      for (int i = 0; i <= j; ++i) b[i] += temp * col[i];
+      daxpy(j + 1, -b[j + 1], t + (j + 1) * ld, b);
       b[j] = b[j] / t[j * ld + j];
     }
   } else {
@@ -171,42 +237,40 @@ LB_HD int dtrsl_upper(const double *t, int ld, int n, double *b, int trans) {
 
 // ---- limited-memory matrix products ---------------------------------------------
 // Product of the 2col x 2col middle matrix of the compact L-BFGS formula with v -> p.
-LB_HD int bmv(int m, const double *sy, const double *wt, int col, const double *v, double *p) {
+LB_HD int bmv(int m, const double *sy, const double *wt, int col, const double *v, double *p,
+              const Coop c) {
   if (col == 0) return 0;
   // solve [  D^(1/2)      O ] [ p1 ] = [ v1 ]
   //       [ -L*D^(-1/2)   J ] [ p2 ]   [ v2 ]
-  p[col] = v[col];
-  for (int i = 1; i < col; ++i) {
-    double sum = 0.0;
-    for (int k = 0; k < i; ++k) sum += sy[k * m + i] * v[k] / sy[k * m + k];
-    p[col + i] = v[col + i] + sum;
-  }
+  for (int i = c.lane; i < col; i += c.nl)
+    p[col + i] = i == 0 ? v[col] : v[col + i] + dot_div(i, sy + i, m, v, 1, sy, m + 1);
+  LB_LANES_SYNC();
   int info = dtrsl_upper(wt, m, col, p + col, 1);
   if (info) return info;
-  for (int i = 0; i < col; ++i) p[i] = v[i] / sqrt(sy[i * m + i]);
   // solve [ -D^(1/2)   D^(-1/2)*L' ] [ p1 ] = [ p1 ]
   //       [  0         J'          ] [ p2 ]   [ p2 ]
   info = dtrsl_upper(wt, m, col, p + col, 0);
   if (info) return info;
-  for (int i = 0; i < col; ++i) p[i] = -p[i] / sqrt(sy[i * m + i]);
-  for (int i = 0; i < col; ++i) {
-    double sum = 0.0;
-    for (int k = i + 1; k < col; ++k) sum += sy[i * m + k] * p[col + k] / sy[i * m + i];
-    p[i] += sum;
+  for (int i = c.lane; i < col; i += c.nl) {
+    const double sq = sqrt(sy[i * m + i]);
+    double pi = v[i] / sq;
+    pi = -pi / sq;
+    p[i] = pi + dot_div(col - i - 1, sy + i * m + i + 1, 1, p + col + i + 1, 1, sy + i * m + i, 0);
   }
+  LB_LANES_SYNC();
   return 0;
 }
 
 // T = theta*SS + L*D^(-1)*L' (upper triangle), then its Cholesky factor J' in wt.
-LB_HD int formt(int m, double *wt, const double *sy, const double *ss, int col, double theta) {
-  for (int j = 0; j < col; ++j) wt[j * m] = theta * ss[j * m];
-  for (int i = 1; i < col; ++i)
-    for (int j = i; j < col; ++j) {
-      const int k1 = (i < j ? i : j);
-      double ddum = 0.0;
-      for (int k = 0; k < k1; ++k) ddum += sy[k * m + i] * sy[k * m + j] / sy[k * m + k];
-      wt[j * m + i] = ddum + theta * ss[j * m + i];
-    }
+LB_HD int formt(int m, double *wt, const double *sy, const double *ss, int col, double theta,
+                const Coop c) {
+  for (int e = c.lane; e < col * col; e += c.nl) {  // the entries (i, j >= i) are independent
+    const int i = e / col, j = e - i * col;
+    if (j < i) continue;
+    if (i == 0) wt[j * m] = theta * ss[j * m];
+    else wt[j * m + i] = dot_div(i, sy + i, m, sy + j, m, sy, m + 1) + theta * ss[j * m + i];
+  }
+  LB_LANES_SYNC();
   return dpofa(wt, m, col) ? -3 : 0;
 }
 
@@ -277,11 +341,22 @@ LB_HD void hpsolb(int n, double *t, int *iorder, int iheap) {
   }
 }
 
+// The three once-per-iteration routines below are real (non-inlined) device functions, so that
+// the per-evaluation path (line search) stays a few KB of code.  They take the scalars they
+// need BY VALUE (the caller's State stays in registers) and return theirs packed in an int.
+struct IterArgs {
+  int n, m, col, head, nfree, nenter, ileave, updatd, iupdat;
+  double theta, sbgnrm;
+  Coop c;
+};
+
 // ---- generalized Cauchy point ----------------------------------------------------------
 // xcp = w.z, breakpoints in w.t, search direction in w.d, iorder = w.indx2,
-// p | c | wbp | v = w.wa.
-LB_HDN int cauchy(State &s, const Work &w, const double *l, const double *u, const int *nbd) {
+// p | c | wbp | v = w.wa.  Returns info (0 ok) in the low 8 bits and nseg above them.
+LB_HDN int cauchy(const IterArgs s, const Work w, const double *l, const double *u,
+                  const int *nbd) {
   const int n = s.n, m = s.m, col = s.col, col2 = 2 * s.col;
+  int nseg = 0;
   double *x = w.x, *g = w.g, *t = w.t, *d = w.d, *xcp = w.z;
   double *p = w.wa, *c = w.wa + 2 * m, *wbp = w.wa + 4 * m, *v = w.wa + 6 * m;
   int *iorder = w.indx2, *iwhere = w.iwhere;
@@ -291,6 +366,7 @@ LB_HDN int cauchy(State &s, const Work &w, const double *l, const double *u, con
     for (int i = 0; i < n; ++i) xcp[i] = x[i];
     return 0;
   }
+#define LB_CAUCHY_RET(info) (((info) & 0xff) | (nseg << 8))
   bool bnded = true;
   int nfree = n + 1, nbreak = 0, ibkmin = 0;
   double bkmin = 0.0, f1 = 0.0;
@@ -350,19 +426,19 @@ LB_HDN int cauchy(State &s, const Work &w, const double *l, const double *u, con
   if (theta != 1.0)
     for (int j = 0; j < col; ++j) p[col + j] *= theta;
   for (int i = 0; i < n; ++i) xcp[i] = x[i];
-  if (nbreak == 0 && nfree == n + 1) return 0;  // d is zero: GCP = x
+  if (nbreak == 0 && nfree == n + 1) return LB_CAUCHY_RET(0);  // d is zero: GCP = x
   for (int j = 0; j < col2; ++j) c[j] = 0.0;
 
   double f2 = -theta * f1;
   const double f2_org = f2;
   if (col > 0) {
-    const int info = bmv(m, w.sy, w.wt, col, p, v);
-    if (info) return info;
+    const int info = bmv(m, w.sy, w.wt, col, p, v, s.c);
+    if (info) return LB_CAUCHY_RET(info);
     f2 -= ddot(col2, v, p);
   }
   double dtm = -f1 / f2;
   double tsum = 0.0;
-  s.nseg = 1;
+  nseg = 1;
   bool skip_to_999 = false;
 
   if (nbreak > 0) {
@@ -406,7 +482,7 @@ LB_HDN int cauchy(State &s, const Work &w, const double *l, const double *u, con
         skip_to_999 = true;
         break;
       }
-      ++s.nseg;
+      ++nseg;
       const double dibp2 = dibp * dibp;
       f1 = f1 + dt * f2 + dibp2 - theta * dibp * zibp;
       f2 = f2 - theta * dibp2;
@@ -418,8 +494,8 @@ LB_HDN int cauchy(State &s, const Work &w, const double *l, const double *u, con
           wbp[col + j] = theta * w.ws[pointr * n + (ibp - 1)];
           pointr = (pointr + 1) % m;
         }
-        const int info = bmv(m, w.sy, w.wt, col, wbp, v);
-        if (info) return info;
+        const int info = bmv(m, w.sy, w.wt, col, wbp, v, s.c);
+        if (info) return LB_CAUCHY_RET(info);
         const double wmc = ddot(col2, c, v);
         const double wmp = ddot(col2, p, v);
         const double wmw = ddot(col2, wbp, v);
@@ -448,7 +524,8 @@ LB_HDN int cauchy(State &s, const Work &w, const double *l, const double *u, con
   }
   if (col > 0)
     for (int j = 0; j < col2; ++j) c[j] += dtm * p[j];
-  return 0;
+  return LB_CAUCHY_RET(0);
+#undef LB_CAUCHY_RET
 }
 
 // ---- free / active bookkeeping at the GCP ------------------------------------------------
@@ -487,8 +564,9 @@ LB_HD void freev(State &s, const Work &w) {
 }
 
 // ---- LEL^T factorisation of the reduced middle matrix (subspace minimisation) ---------------
-LB_HDN int formk(State &s, const Work &w) {
+LB_HDN int formk(const IterArgs s, const Work w) {
   const int n = s.n, m = s.m, col = s.col, nsub = s.nfree, m2 = 2 * s.m;
+  const Coop c = s.c;
   double *wn = w.wn, *wn1 = w.snd;
   const int *ind = w.index, *indx2 = w.indx2;
 #define WN(i, j) wn[(j) * m2 + (i)]
@@ -497,7 +575,7 @@ LB_HDN int formk(State &s, const Work &w) {
 #define WY(k, p) w.wy[(p) * n + (k)]
   int upcl;
   if (s.updatd) {
-    if (s.iupdat > m) {  // shift the old part of WN1
+    if (s.iupdat > m) {  // shift the old part of WN1 (overlapping moves: kept sequential)
       for (int jy = 0; jy < m - 1; ++jy) {
         const int js = m + jy;
         for (int i = 0; i < m - 1 - jy; ++i) {
@@ -506,99 +584,92 @@ LB_HDN int formk(State &s, const Work &w) {
         }
         for (int i = 0; i < m - 1; ++i) WN1(m + i, jy) = WN1(m + 1 + i, jy + 1);
       }
+      LB_LANES_SYNC();
     }
-    // new rows in blocks (1,1), (2,1), (2,2)
-    int ipntr = (s.head + col - 1) % m;
-    const int iy = col - 1, is = m + col - 1;
-    int jpntr = s.head;
-    for (int jy = 0; jy < col; ++jy) {
-      const int js = m + jy;
-      double temp1 = 0.0, temp2 = 0.0, temp3 = 0.0;
-      for (int k = 0; k < nsub; ++k) {
-        const int k1 = ind[k] - 1;
-        temp1 += WY(k1, ipntr) * WY(k1, jpntr);
+    // new rows in blocks (1,1), (2,1), (2,2) and the new column in block (2,1): one entry
+    // set per jy, independent of each other
+    {
+      const int ipntr = (s.head + col - 1) % m;
+      const int iy = col - 1, is = m + col - 1;
+      for (int jy = c.lane; jy < col; jy += c.nl) {
+        const int js = m + jy;
+        const int jpntr = (s.head + jy) % m;
+        double temp1 = 0.0, temp2 = 0.0, temp3 = 0.0;
+        for (int k = 0; k < nsub; ++k) {
+          const int k1 = ind[k] - 1;
+          temp1 += WY(k1, ipntr) * WY(k1, jpntr);
+        }
+        for (int k = nsub; k < n; ++k) {
+          const int k1 = ind[k] - 1;
+          temp2 += WS(k1, ipntr) * WS(k1, jpntr);
+          temp3 += WS(k1, ipntr) * WY(k1, jpntr);
+        }
+        WN1(iy, jy) = temp1;
+        WN1(is, js) = temp2;
+        WN1(is, jy) = temp3;
       }
-      for (int k = nsub; k < n; ++k) {
-        const int k1 = ind[k] - 1;
-        temp2 += WS(k1, ipntr) * WS(k1, jpntr);
-        temp3 += WS(k1, ipntr) * WY(k1, jpntr);
+      LB_LANES_SYNC();
+      const int jyc = col - 1;
+      const int jpntr = (s.head + col - 1) % m;
+      for (int i = c.lane; i < col; i += c.nl) {
+        const int is2 = m + i;
+        const int ip = (s.head + i) % m;
+        double temp3 = 0.0;
+        for (int k = 0; k < nsub; ++k) {
+          const int k1 = ind[k] - 1;
+          temp3 += WS(k1, ip) * WY(k1, jpntr);
+        }
+        WN1(is2, jyc) = temp3;
       }
-      WN1(iy, jy) = temp1;
-      WN1(is, js) = temp2;
-      WN1(is, jy) = temp3;
-      jpntr = (jpntr + 1) % m;
-    }
-    // new column in block (2,1)
-    const int jy = col - 1;
-    jpntr = (s.head + col - 1) % m;
-    ipntr = s.head;
-    for (int i = 0; i < col; ++i) {
-      const int is2 = m + i;
-      double temp3 = 0.0;
-      for (int k = 0; k < nsub; ++k) {
-        const int k1 = ind[k] - 1;
-        temp3 += WS(k1, ipntr) * WY(k1, jpntr);
-      }
-      ipntr = (ipntr + 1) % m;
-      WN1(is2, jy) = temp3;
+      LB_LANES_SYNC();
     }
     upcl = col - 1;
   } else {
     upcl = col;
   }
-  // old parts of blocks (1,1) and (2,2): variables that entered / left the free set
-  {
-    int ipntr = s.head;
-    for (int iy = 0; iy < upcl; ++iy) {
+  // old parts of blocks (1,1), (2,2) and (2,1): variables that entered / left the free set.
+  // Each (iy, jy) entry is independent.
+  for (int e = c.lane; e < upcl * upcl; e += c.nl) {
+    const int iy = e / upcl, jy = e - iy * upcl;
+    const int ipntr = (s.head + iy) % m, jpntr = (s.head + jy) % m;
+    if (jy <= iy) {
+      const int is = m + iy, js = m + jy;
+      double temp1 = 0.0, temp2 = 0.0, temp3 = 0.0, temp4 = 0.0;
+      for (int k = 0; k < s.nenter; ++k) {
+        const int k1 = indx2[k] - 1;
+        temp1 += WY(k1, ipntr) * WY(k1, jpntr);
+        temp2 += WS(k1, ipntr) * WS(k1, jpntr);
+      }
+      for (int k = s.ileave - 1; k < n; ++k) {
+        const int k1 = indx2[k] - 1;
+        temp3 += WY(k1, ipntr) * WY(k1, jpntr);
+        temp4 += WS(k1, ipntr) * WS(k1, jpntr);
+      }
+      WN1(iy, jy) += temp1 - temp3;
+      WN1(is, js) += -temp2 + temp4;
+    }
+    {  // block (2,1), entry (m + iy, jy)
       const int is = m + iy;
-      int jpntr = s.head;
-      for (int jy = 0; jy <= iy; ++jy) {
-        const int js = m + jy;
-        double temp1 = 0.0, temp2 = 0.0, temp3 = 0.0, temp4 = 0.0;
-        for (int k = 0; k < s.nenter; ++k) {
-          const int k1 = indx2[k] - 1;
-          temp1 += WY(k1, ipntr) * WY(k1, jpntr);
-          temp2 += WS(k1, ipntr) * WS(k1, jpntr);
-        }
-        for (int k = s.ileave - 1; k < n; ++k) {
-          const int k1 = indx2[k] - 1;
-          temp3 += WY(k1, ipntr) * WY(k1, jpntr);
-          temp4 += WS(k1, ipntr) * WS(k1, jpntr);
-        }
-        WN1(iy, jy) += temp1 - temp3;
-        WN1(is, js) += -temp2 + temp4;
-        jpntr = (jpntr + 1) % m;
+      double temp1 = 0.0, temp3 = 0.0;
+      for (int k = 0; k < s.nenter; ++k) {
+        const int k1 = indx2[k] - 1;
+        temp1 += WS(k1, ipntr) * WY(k1, jpntr);
       }
-      ipntr = (ipntr + 1) % m;
+      for (int k = s.ileave - 1; k < n; ++k) {
+        const int k1 = indx2[k] - 1;
+        temp3 += WS(k1, ipntr) * WY(k1, jpntr);
+      }
+      if (is <= jy + m)
+        WN1(is, jy) += temp1 - temp3;
+      else
+        WN1(is, jy) += -temp1 + temp3;
     }
   }
-  // old part of block (2,1)
-  {
-    int ipntr = s.head;
-    for (int is = m; is < m + upcl; ++is) {
-      int jpntr = s.head;
-      for (int jy = 0; jy < upcl; ++jy) {
-        double temp1 = 0.0, temp3 = 0.0;
-        for (int k = 0; k < s.nenter; ++k) {
-          const int k1 = indx2[k] - 1;
-          temp1 += WS(k1, ipntr) * WY(k1, jpntr);
-        }
-        for (int k = s.ileave - 1; k < n; ++k) {
-          const int k1 = indx2[k] - 1;
-          temp3 += WS(k1, ipntr) * WY(k1, jpntr);
-        }
-        if (is <= jy + m)
-          WN1(is, jy) += temp1 - temp3;
-        else
-          WN1(is, jy) += -temp1 + temp3;
-        jpntr = (jpntr + 1) % m;
-      }
-      ipntr = (ipntr + 1) % m;
-    }
-  }
+  LB_LANES_SYNC();
   // upper triangle of WN = [D+Y'ZZ'Y/theta   -L_a'+R_z'] [-L_a+R_z   S'AA'S*theta]
+  // (each iy writes its own columns iy and col+iy)
   const double theta = s.theta;
-  for (int iy = 0; iy < col; ++iy) {
+  for (int iy = c.lane; iy < col; iy += c.nl) {
     const int is = col + iy, is1 = m + iy;
     for (int jy = 0; jy <= iy; ++jy) {
       const int js = col + jy, js1 = m + jy;
@@ -609,14 +680,21 @@ LB_HDN int formk(State &s, const Work &w) {
     for (int jy = iy; jy < col; ++jy) WN(jy, is) = WN1(is1, jy);
     WN(iy, iy) += w.sy[iy * m + iy];
   }
-  // Cholesky of the (1,1) block, then L^-1(-L_a'+R_z') in the (1,2) block
+  LB_LANES_SYNC();
+  // Cholesky of the (1,1) block, then L^-1(-L_a'+R_z') in the (1,2) block (one right-hand
+  // side per lane)
   if (dpofa(wn, m2, col)) return -1;
   const int col2 = 2 * col;
-  for (int js = col; js < col2; ++js)
-    if (dtrsl_upper(wn, m2, col, wn + js * m2, 1)) return -1;
+  for (int j = 0; j < col; ++j)
+    if (wn[j * m2 + j] == 0.0) return -1;
+  for (int js = col + c.lane; js < col2; js += c.nl) dtrsl_upper(wn, m2, col, wn + js * m2, 1);
+  LB_LANES_SYNC();
   // (2,2) block: S'AA'S*theta + (L^-1(-L_a'+R_z'))'(L^-1(-L_a'+R_z')), then its Cholesky
-  for (int is = col; is < col2; ++is)
-    for (int js = is; js < col2; ++js) WN(is, js) += ddot(col, wn + is * m2, wn + js * m2);
+  for (int e = c.lane; e < col * col; e += c.nl) {
+    const int is = col + e / col, js = col + e % col;
+    if (js >= is) WN(is, js) += ddot(col, wn + is * m2, wn + js * m2);
+  }
+  LB_LANES_SYNC();
   if (dpofa(wn + col * m2 + col, m2, col)) return -2;
   return 0;
 #undef WN
@@ -626,7 +704,7 @@ LB_HDN int formk(State &s, const Work &w) {
 }
 
 // r = -Z'B(xcp - x) - Z'g   (uses c = wa[2m..4m) from cauchy; p = wa[0..2m) as scratch)
-LB_HD int cmprlb(State &s, const Work &w) {
+LB_HD int cmprlb(State &s, const Work &w, const Coop c) {
   const int n = s.n, m = s.m, col = s.col;
   if (!s.cnstnd && col > 0) {
     for (int i = 0; i < n; ++i) w.r[i] = -w.g[i];
@@ -636,7 +714,7 @@ LB_HD int cmprlb(State &s, const Work &w) {
     const int k = w.index[i] - 1;
     w.r[i] = -s.theta * (w.z[k] - w.x[k]) - w.g[k];
   }
-  if (bmv(m, w.sy, w.wt, col, w.wa + 2 * m, w.wa)) return -8;
+  if (bmv(m, w.sy, w.wt, col, w.wa + 2 * m, w.wa, c)) return -8;
   int pointr = s.head;
   for (int j = 0; j < col; ++j) {
     const double a1 = w.wa[j], a2 = s.theta * w.wa[col + j];
@@ -651,15 +729,19 @@ LB_HD int cmprlb(State &s, const Work &w) {
 
 // Subspace minimisation: on entry w.z = xcp and w.r = reduced gradient; on exit w.z is
 // the (projected) subspace minimiser.  wv = wa[0..2m).
-LB_HDN int subsm(State &s, const Work &w, const double *l, const double *u, const int *nbd) {
+// Returns info (0 ok) in the low 8 bits and iword (1: the step hit a bound) in bit 8.
+LB_HDN int subsm(const IterArgs s, const Work w, const double *l, const double *u,
+                 const int *nbd) {
   const int n = s.n, m = s.m, col = s.col, nsub = s.nfree, m2 = 2 * s.m, col2 = 2 * s.col;
+  int iword = 0;
   double *x = w.z, *d = w.r, *xp = w.xp, *wv = w.wa;
   const double *xx = w.x, *gg = w.g;
   const int *ind = w.index;
   const double theta = s.theta;
   if (nsub <= 0) return 0;
-  int pointr = s.head;
-  for (int i = 0; i < col; ++i) {
+  const Coop c = s.c;
+  for (int i = c.lane; i < col; i += c.nl) {  // wv = W'Zd, one entry pair per i
+    const int pointr = (s.head + i) % m;
     double temp1 = 0.0, temp2 = 0.0;
     for (int j = 0; j < nsub; ++j) {
       const int k = ind[j] - 1;
@@ -668,23 +750,23 @@ LB_HDN int subsm(State &s, const Work &w, const double *l, const double *u, cons
     }
     wv[i] = temp1;
     wv[col + i] = theta * temp2;
-    pointr = (pointr + 1) % m;
   }
+  LB_LANES_SYNC();
   if (dtrsl_upper(w.wn, m2, col2, wv, 1)) return 1;
   for (int i = 0; i < col; ++i) wv[i] = -wv[i];
   if (dtrsl_upper(w.wn, m2, col2, wv, 0)) return 1;
-  pointr = s.head;
-  for (int jy = 0; jy < col; ++jy) {
-    const int js = col + jy;
-    for (int i = 0; i < nsub; ++i) {
-      const int k = ind[i] - 1;
-      d[i] += w.wy[pointr * n + k] * wv[jy] / theta + w.ws[pointr * n + k] * wv[js];
+  for (int i = c.lane; i < nsub; i += c.nl) {  // d = (1/theta)d + (1/theta^2)Z'W wv, per entry
+    const int k = ind[i] - 1;
+    double di = d[i];
+    for (int jy = 0; jy < col; ++jy) {
+      const int pointr = (s.head + jy) % m;
+      di += w.wy[pointr * n + k] * wv[jy] / theta + w.ws[pointr * n + k] * wv[col + jy];
     }
-    pointr = (pointr + 1) % m;
+    d[i] = di * (1.0 / theta);
   }
-  for (int i = 0; i < nsub; ++i) d[i] *= 1.0 / theta;
+  LB_LANES_SYNC();
   // projected Newton step
-  s.iword = 0;
+  iword = 0;
   for (int i = 0; i < n; ++i) xp[i] = x[i];
   for (int i = 0; i < nsub; ++i) {
     const int k = ind[i] - 1;
@@ -692,20 +774,20 @@ LB_HDN int subsm(State &s, const Work &w, const double *l, const double *u, cons
     if (nbd[k] != 0) {
       if (nbd[k] == 1) {
         x[k] = fmax(l[k], xk + dk);
-        if (x[k] == l[k]) s.iword = 1;
+        if (x[k] == l[k]) iword = 1;
       } else if (nbd[k] == 2) {
         const double xk2 = fmax(l[k], xk + dk);
         x[k] = fmin(u[k], xk2);
-        if (x[k] == l[k] || x[k] == u[k]) s.iword = 1;
+        if (x[k] == l[k] || x[k] == u[k]) iword = 1;
       } else if (nbd[k] == 3) {
         x[k] = fmin(u[k], xk + dk);
-        if (x[k] == u[k]) s.iword = 1;
+        if (x[k] == u[k]) iword = 1;
       }
     } else {
       x[k] = xk + dk;
     }
   }
-  if (s.iword == 0) return 0;
+  if (iword == 0) return 0;
   // sign of the directional derivative along the projected step
   double dd_p = 0.0;
   for (int i = 0; i < n; ++i) dd_p += (x[i] - xx[i]) * gg[i];
@@ -748,7 +830,7 @@ LB_HDN int subsm(State &s, const Work &w, const double *l, const double *u, cons
       x[k] += alpha * d[i];
     }
   }
-  return 0;
+  return iword << 8;
 }
 
 // ---- More'-Thuente line search -------------------------------------------------------------
@@ -1039,8 +1121,10 @@ LB_HD void lbfgsb_init(State &s, const Work &w, int n, int m, const double *x0, 
 // Advance the problem until it needs f and g at w.x (LB_NEED_FG: the caller stores them in
 // s.f / w.g and calls again) or terminates (LB_DONE: result in w.x, s.f, w.g, s.nit,
 // s.nfev, s.status, s.task, s.msg).
-LB_HDN int lbfgsb_advance(State &s, const Work &w, const double *l, const double *u,
-                          const int *nbd, const Options &opt) {
+// `coop`: {0, 1} for a thread that owns its problem alone; {lane, 64} when the 64 lanes of a
+// wave run ONE problem together (every lane calls with identical State; see struct Coop).
+LB_HD int lbfgsb_advance(State &s, const Work &w, const double *l, const double *u,
+                         const int *nbd, const Options &opt, const Coop coop = Coop{0, 1}) {
   const int n = s.n, m = s.m;
   bool first_ls = false;
   bool resume_ls = (s.stage == S_FG_LNSRCH);
@@ -1113,7 +1197,11 @@ LB_HDN int lbfgsb_advance(State &s, const Work &w, const double *l, const double
         s.wrk = s.updatd;
         s.nseg = 0;
       } else {
-        if (cauchy(s, w, l, u, nbd)) {  // singular triangular system: refresh the memory
+        const IterArgs ia{n, m, s.col, s.head, s.nfree, s.nenter, s.ileave, s.updatd, s.iupdat,
+                          s.theta, s.sbgnrm, coop};
+        const int rc = cauchy(ia, w, l, u, nbd);
+        s.nseg = rc >> 8;
+        if (rc & 0xff) {  // singular triangular system: refresh the memory
           refresh_memory(s);
           continue;
         }
@@ -1121,11 +1209,15 @@ LB_HDN int lbfgsb_advance(State &s, const Work &w, const double *l, const double
         s.nact = n - s.nfree;
       }
       if (s.nfree != 0 && s.col != 0) {
+        const IterArgs ia{n, m, s.col, s.head, s.nfree, s.nenter, s.ileave, s.updatd, s.iupdat,
+                          s.theta, s.sbgnrm, coop};
         if (s.wrk) {
-          if (formk(s, w)) { refresh_memory(s); continue; }
+          if (formk(ia, w)) { refresh_memory(s); continue; }
         }
-        if (cmprlb(s, w)) { refresh_memory(s); continue; }
-        if (subsm(s, w, l, u, nbd)) { refresh_memory(s); continue; }
+        if (cmprlb(s, w, coop)) { refresh_memory(s); continue; }
+        const int rc = subsm(ia, w, l, u, nbd);
+        s.iword = rc >> 8;
+        if (rc & 0xff) { refresh_memory(s); continue; }
       }
       for (int i = 0; i < n; ++i) w.d[i] = w.z[i] - w.x[i];
       first_ls = true;
@@ -1202,7 +1294,7 @@ LB_HDN int lbfgsb_advance(State &s, const Work &w, const double *l, const double
       s.updatd = 1;
       ++s.iupdat;
       matupd(s, w, rr, dr);
-      if (formt(m, w.wt, w.sy, w.ss, s.col, s.theta)) {
+      if (formt(m, w.wt, w.sy, w.ss, s.col, s.theta, coop)) {
         refresh_memory(s);
         continue;
       }

@@ -11,9 +11,8 @@
 #include "mlp_device.h"
 
 using namespace bore;
-__device__ long long g_lstamps[8];
-extern "C" int bore_debug_ls(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(lbfgsb::g_ls), sizeof(long long)*16); }
-extern "C" int bore_debug_lstamps(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lstamps), sizeof(long long)*8); }
+extern "C" int bore_debug_acc(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(lbfgsb::g_acc), sizeof(unsigned long long)*16); }
+extern "C" int bore_debug_acc_reset() { unsigned long long z[16] = {0}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(lbfgsb::g_acc), z, sizeof(z)); }
 
 // ---------------------------------------------------------------------------
 // labels: tau = np.quantile(y, gamma) (linear interpolation), z = y < tau
@@ -359,10 +358,9 @@ __global__ __launch_bounds__(BORE_THREADS) void lbfgsb_kernel(const LbfgsbArgs a
   if (wv >= np) return;  // wave without problems (np < 4)
 
   bool done = (myp < 0);
-  long long t_adv = 0, t_fg = 0, n_rounds = 0, t_first = 0;
+  long long t_fg = 0, t_all0 = clock64();
   for (int round = 0; round < a.max_rounds; ++round) {
     int pending = 0;
-    long long c0 = clock64();
     if (!done) {
       const int rc = lbfgsb::lbfgsb_advance(st, wk, blo, bhi, bnbd, a.opt);
       if (rc == lbfgsb::LB_NEED_FG) {
@@ -373,8 +371,8 @@ __global__ __launch_bounds__(BORE_THREADS) void lbfgsb_kernel(const LbfgsbArgs a
         done = true;
       }
     }
-    long long c1 = clock64(); t_adv += c1 - c0; if (round == 0) t_first = c1 - c0;
     if (!__any(pending)) break;  // every problem of this wave has terminated
+    long long c1 = clock64();
     wave_lds_sync();
     fg_rowblock(L, th, tile, wv, a.transform, a.sign, vals);
     if (pending) {
@@ -383,9 +381,9 @@ __global__ __launch_bounds__(BORE_THREADS) void lbfgsb_kernel(const LbfgsbArgs a
       for (int d = 0; d < D; ++d) wk.g[d] = (double)g[d];
     }
     wave_lds_sync();
-    t_fg += clock64() - c1; ++n_rounds;
+    t_fg += clock64() - c1;
   }
-  if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) { g_lstamps[0] = t_adv; g_lstamps[1] = t_fg; g_lstamps[2] = n_rounds; g_lstamps[3] = st.nit; g_lstamps[4] = t_first; }
+  if (myp >= 0) { for (int i = 0; i < 11; ++i) atomicAdd(&lbfgsb::g_acc[i], (unsigned long long)st.acc[i]); atomicAdd(&lbfgsb::g_acc[11], (unsigned long long)t_fg); atomicAdd(&lbfgsb::g_acc[12], (unsigned long long)(clock64() - t_all0)); atomicAdd(&lbfgsb::g_acc[13], (unsigned long long)st.nit); atomicAdd(&lbfgsb::g_acc[14], (unsigned long long)st.nfev); atomicMax(&lbfgsb::g_acc[15], (unsigned long long)(clock64() - t_all0)); }
 
   if (myp >= 0) {
     const long long q = model * a.R + p0 + myp;
@@ -444,7 +442,7 @@ extern "C" int bore_lbfgsb_minimize(const bore_mlp_desc *desc, int n_models, con
   // State lives in registers
   const size_t state_f = 0;
   const size_t dw_f = 2 * (size_t)lbfgsb::dwork_size(D, m);
-  const size_t iw_f = ((size_t)lbfgsb::iwork_size(D) + 1) & ~(size_t)1;
+  const size_t iw_f = ((size_t)lbfgsb::iwork_size(D) + 3) & ~(size_t)3;
   a.o_state = 0;
   a.o_dw = (int)state_f;
   a.o_iw = (int)(state_f + dw_f);
@@ -461,8 +459,9 @@ extern "C" int bore_lbfgsb_minimize(const bore_mlp_desc *desc, int n_models, con
     off = a.L.P_lds;
     a.o_tile = (int)off; off += a.L.tile_floats;
     a.o_vals = (int)off; off += BORE_BATCH_MAX;
-    off = (off + 1) & ~(size_t)1;
-    a.o_box = (int)off; off += 4 * (size_t)D + (((size_t)D + 1) & ~(size_t)1);
+    off = (off + 3) & ~(size_t)3;  // 16-byte boundary for the fp64 regions
+    a.o_box = (int)off; off += 4 * (size_t)D + (((size_t)D + 3) & ~(size_t)3) + (D & 1 ? 2 : 0);
+    off = (off + 3) & ~(size_t)3;
     a.o_prob = (int)off; off += (size_t)a.prob_floats * PB;
     a.total = (int)off;
     off = (off + 3) & ~(size_t)3;

@@ -32,18 +32,20 @@
 
 #if defined(__HIPCC__)
 #define LB_HD __host__ __device__ __forceinline__
-#define LB_HDN __host__ __device__ __forceinline__  // one call site each: no device call stack
+#define LB_HDN __host__ __device__ __forceinline__  // (real calls measured slower: +20 % kernel time)
 #else
 #define LB_HD inline
 #define LB_HDN
 #endif
 
 namespace lbfgsb {
-__device__ long long g_ls[16];
+__device__ unsigned long long g_acc[16];
 #if defined(__HIP_DEVICE_COMPILE__)
-#define LST(i) do { if (blockIdx.x==0 && blockIdx.y==0 && threadIdx.x==0 && lsflag) g_ls[i] = clock64(); } while(0)
+#define TIC long long _t0 = clock64()
+#define TOC(i) do { long long _t1 = clock64(); acc[i] += _t1 - _t0; _t0 = _t1; } while(0)
 #else
-#define LST(i)
+#define TIC
+#define TOC(i)
 #endif
 
 enum { LB_NEED_FG = 1, LB_DONE = 2 };
@@ -83,9 +85,17 @@ struct State {
   // driver
   int stage, task, msg, nit, nfev, status;
   double flast;
+  long long acc[12];
 };
 
-LB_HD int dwork_size(int n, int m) { return 2 * m * n + 11 * m * m + 8 * m + 9 * n; }
+// Every sub-array starts on a 16-byte boundary (vectors are padded to an even length) and the
+// caller must hand in a 16-byte aligned base: the device compiler merges adjacent fp64 LDS
+// loads into ds_read_b128, which returns WRONG data at 8-byte alignment on gfx950 (found as a
+// host/device mismatch for odd n; see tests/test_gpu_argmax.py).
+LB_HD int dwork_size(int n, int m) {
+  const int ne = (n + 1) & ~1, mne = (m * n + 1) & ~1, mm = (m * m + 1) & ~1;
+  return 2 * mne + 3 * mm + 8 * m * m + 8 * m + 9 * ne;
+}
 LB_HD int iwork_size(int n) { return 3 * n; }
 
 // Views into the workspaces (all 0-based; matrices column-major like the original).
@@ -101,22 +111,23 @@ struct Work {
 
 LB_HD Work make_work(double *dw, int *iw, int n, int m) {
   Work w;
-  w.ws = dw; dw += m * n;
-  w.wy = dw; dw += m * n;
-  w.sy = dw; dw += m * m;
-  w.ss = dw; dw += m * m;
-  w.wt = dw; dw += m * m;
+  const int ne = (n + 1) & ~1, mne = (m * n + 1) & ~1, mm = (m * m + 1) & ~1;
+  w.ws = dw; dw += mne;
+  w.wy = dw; dw += mne;
+  w.sy = dw; dw += mm;
+  w.ss = dw; dw += mm;
+  w.wt = dw; dw += mm;
   w.wn = dw; dw += 4 * m * m;
   w.snd = dw; dw += 4 * m * m;
-  w.z = dw; dw += n;
-  w.r = dw; dw += n;
-  w.d = dw; dw += n;
-  w.t = dw; dw += n;
-  w.xp = dw; dw += n;
-  w.x = dw; dw += n;
-  w.g = dw; dw += n;
-  w.xlast = dw; dw += n;
-  w.glast = dw; dw += n;
+  w.z = dw; dw += ne;
+  w.r = dw; dw += ne;
+  w.d = dw; dw += ne;
+  w.t = dw; dw += ne;
+  w.xp = dw; dw += ne;
+  w.x = dw; dw += ne;
+  w.g = dw; dw += ne;
+  w.xlast = dw; dw += ne;
+  w.glast = dw; dw += ne;
   w.wa = dw;
   w.index = iw;
   w.iwhere = iw + n;
@@ -127,10 +138,54 @@ LB_HD Work make_work(double *dw, int *iw, int n, int m) {
 #define LB_EPSMCH 2.220446049250313e-16
 
 // ---- small dense kernels ------------------------------------------------------
+// Sums strictly left to right (results do not depend on the unrolling); operands are fetched
+// eight at a time so that their LDS latencies overlap -- on the device a dependent
+// load-multiply-add per element costs a full LDS round trip (~130 cycles).
 LB_HD double ddot(int n, const double *a, const double *b) {
   double s = 0.0;
-  for (int i = 0; i < n; ++i) s += a[i] * b[i];
+  int i = 0;
+  for (; i + 4 <= n; i += 4) {
+    const double a0 = a[i], a1 = a[i + 1], a2 = a[i + 2], a3 = a[i + 3];
+    const double b0 = b[i], b1 = b[i + 1], b2 = b[i + 2], b3 = b[i + 3];
+    s += a0 * b0;
+    s += a1 * b1;
+    s += a2 * b2;
+    s += a3 * b3;
+  }
+  for (; i < n; ++i) s += a[i] * b[i];
   return s;
+}
+
+// sum_i a[i*sa] * b[i*sb] / d[i*sd], left to right, operands fetched four terms at a time
+LB_HD double dot_div(int n, const double *a, int sa, const double *b, int sb, const double *d,
+                     int sd) {
+  double s = 0.0;
+  int i = 0;
+  for (; i + 4 <= n; i += 4) {
+    const double a0 = a[i * sa], a1 = a[(i + 1) * sa], a2 = a[(i + 2) * sa], a3 = a[(i + 3) * sa];
+    const double b0 = b[i * sb], b1 = b[(i + 1) * sb], b2 = b[(i + 2) * sb], b3 = b[(i + 3) * sb];
+    const double d0 = d[i * sd], d1 = d[(i + 1) * sd], d2 = d[(i + 2) * sd], d3 = d[(i + 3) * sd];
+    s += a0 * b0 / d0;
+    s += a1 * b1 / d1;
+    s += a2 * b2 / d2;
+    s += a3 * b3 / d3;
+  }
+  for (; i < n; ++i) s += a[i * sa] * b[i * sb] / d[i * sd];
+  return s;
+}
+
+// y[i] += alpha * x[i], i < n  (x and y do not overlap)
+LB_HD void daxpy(int n, double alpha, const double *x, double *y) {
+  int i = 0;
+  for (; i + 4 <= n; i += 4) {
+    const double x0 = x[i], x1 = x[i + 1], x2 = x[i + 2], x3 = x[i + 3];
+    const double y0 = y[i], y1 = y[i + 1], y2 = y[i + 2], y3 = y[i + 3];
+    y[i] = y0 + alpha * x0;
+    y[i + 1] = y1 + alpha * x1;
+    y[i + 2] = y2 + alpha * x2;
+    y[i + 3] = y3 + alpha * x3;
+  }
+  for (; i < n; ++i) y[i] += alpha * x[i];
 }
 
 // Cholesky of the leading n x n block of a (leading dimension ld), upper triangle:
@@ -160,9 +215,7 @@ LB_HD int dtrsl_upper(const double *t, int ld, int n, double *b, int trans) {
   if (!trans) {
     b[n - 1] = b[n - 1] / t[(n - 1) * ld + (n - 1)];
     for (int j = n - 2; j >= 0; --j) {
-      const double temp = -b[j + 1];
-      const double *col = t + (j + 1) * ld;
-      for (int i = 0; i <= j; ++i) b[i] += temp * col[i];
+      daxpy(j + 1, -b[j + 1], t + (j + 1) * ld, b);
       b[j] = b[j] / t[j * ld + j];
     }
   } else {
@@ -182,11 +235,8 @@ LB_HD int bmv(int m, const double *sy, const double *wt, int col, const double *
   // solve [  D^(1/2)      O ] [ p1 ] = [ v1 ]
   //       [ -L*D^(-1/2)   J ] [ p2 ]   [ v2 ]
   p[col] = v[col];
-  for (int i = 1; i < col; ++i) {
-    double sum = 0.0;
-    for (int k = 0; k < i; ++k) sum += sy[k * m + i] * v[k] / sy[k * m + k];
-    p[col + i] = v[col + i] + sum;
-  }
+  for (int i = 1; i < col; ++i)
+    p[col + i] = v[col + i] + dot_div(i, sy + i, m, v, 1, sy, m + 1);
   int info = dtrsl_upper(wt, m, col, p + col, 1);
   if (info) return info;
   for (int i = 0; i < col; ++i) p[i] = v[i] / sqrt(sy[i * m + i]);
@@ -195,11 +245,8 @@ LB_HD int bmv(int m, const double *sy, const double *wt, int col, const double *
   info = dtrsl_upper(wt, m, col, p + col, 0);
   if (info) return info;
   for (int i = 0; i < col; ++i) p[i] = -p[i] / sqrt(sy[i * m + i]);
-  for (int i = 0; i < col; ++i) {
-    double sum = 0.0;
-    for (int k = i + 1; k < col; ++k) sum += sy[i * m + k] * p[col + k] / sy[i * m + i];
-    p[i] += sum;
-  }
+  for (int i = 0; i < col; ++i)
+    p[i] += dot_div(col - i - 1, sy + i * m + i + 1, 1, p + col + i + 1, 1, sy + i * m + i, 0);
   return 0;
 }
 
@@ -209,9 +256,7 @@ LB_HD int formt(int m, double *wt, const double *sy, const double *ss, int col, 
   for (int i = 1; i < col; ++i)
     for (int j = i; j < col; ++j) {
       const int k1 = (i < j ? i : j);
-      double ddum = 0.0;
-      for (int k = 0; k < k1; ++k) ddum += sy[k * m + i] * sy[k * m + j] / sy[k * m + k];
-      wt[j * m + i] = ddum + theta * ss[j * m + i];
+      wt[j * m + i] = dot_div(k1, sy + i, m, sy + j, m, sy, m + 1) + theta * ss[j * m + i];
     }
   return dpofa(wt, m, col) ? -3 : 0;
 }
@@ -283,11 +328,21 @@ LB_HD void hpsolb(int n, double *t, int *iorder, int iheap) {
   }
 }
 
+// The three once-per-iteration routines below are real (non-inlined) device functions, so that
+// the per-evaluation path (line search) stays a few KB of code.  They take the scalars they
+// need BY VALUE (the caller's State stays in registers) and return theirs packed in an int.
+struct IterArgs {
+  int n, m, col, head, nfree, nenter, ileave, updatd, iupdat;
+  double theta, sbgnrm;
+};
+
 // ---- generalized Cauchy point ----------------------------------------------------------
 // xcp = w.z, breakpoints in w.t, search direction in w.d, iorder = w.indx2,
-// p | c | wbp | v = w.wa.
-LB_HDN int cauchy(State &s, const Work &w, const double *l, const double *u, const int *nbd) {
+// p | c | wbp | v = w.wa.  Returns info (0 ok) in the low 8 bits and nseg above them.
+LB_HDN int cauchy(const IterArgs s, const Work w, const double *l, const double *u,
+                  const int *nbd) {
   const int n = s.n, m = s.m, col = s.col, col2 = 2 * s.col;
+  int nseg = 0;
   double *x = w.x, *g = w.g, *t = w.t, *d = w.d, *xcp = w.z;
   double *p = w.wa, *c = w.wa + 2 * m, *wbp = w.wa + 4 * m, *v = w.wa + 6 * m;
   int *iorder = w.indx2, *iwhere = w.iwhere;
@@ -297,6 +352,7 @@ LB_HDN int cauchy(State &s, const Work &w, const double *l, const double *u, con
     for (int i = 0; i < n; ++i) xcp[i] = x[i];
     return 0;
   }
+#define LB_CAUCHY_RET(info) (((info) & 0xff) | (nseg << 8))
   bool bnded = true;
   int nfree = n + 1, nbreak = 0, ibkmin = 0;
   double bkmin = 0.0, f1 = 0.0;
@@ -356,19 +412,19 @@ LB_HDN int cauchy(State &s, const Work &w, const double *l, const double *u, con
   if (theta != 1.0)
     for (int j = 0; j < col; ++j) p[col + j] *= theta;
   for (int i = 0; i < n; ++i) xcp[i] = x[i];
-  if (nbreak == 0 && nfree == n + 1) return 0;  // d is zero: GCP = x
+  if (nbreak == 0 && nfree == n + 1) return LB_CAUCHY_RET(0);  // d is zero: GCP = x
   for (int j = 0; j < col2; ++j) c[j] = 0.0;
 
   double f2 = -theta * f1;
   const double f2_org = f2;
   if (col > 0) {
     const int info = bmv(m, w.sy, w.wt, col, p, v);
-    if (info) return info;
+    if (info) return LB_CAUCHY_RET(info);
     f2 -= ddot(col2, v, p);
   }
   double dtm = -f1 / f2;
   double tsum = 0.0;
-  s.nseg = 1;
+  nseg = 1;
   bool skip_to_999 = false;
 
   if (nbreak > 0) {
@@ -412,7 +468,7 @@ LB_HDN int cauchy(State &s, const Work &w, const double *l, const double *u, con
         skip_to_999 = true;
         break;
       }
-      ++s.nseg;
+      ++nseg;
       const double dibp2 = dibp * dibp;
       f1 = f1 + dt * f2 + dibp2 - theta * dibp * zibp;
       f2 = f2 - theta * dibp2;
@@ -425,7 +481,7 @@ LB_HDN int cauchy(State &s, const Work &w, const double *l, const double *u, con
           pointr = (pointr + 1) % m;
         }
         const int info = bmv(m, w.sy, w.wt, col, wbp, v);
-        if (info) return info;
+        if (info) return LB_CAUCHY_RET(info);
         const double wmc = ddot(col2, c, v);
         const double wmp = ddot(col2, p, v);
         const double wmw = ddot(col2, wbp, v);
@@ -454,7 +510,8 @@ LB_HDN int cauchy(State &s, const Work &w, const double *l, const double *u, con
   }
   if (col > 0)
     for (int j = 0; j < col2; ++j) c[j] += dtm * p[j];
-  return 0;
+  return LB_CAUCHY_RET(0);
+#undef LB_CAUCHY_RET
 }
 
 // ---- free / active bookkeeping at the GCP ------------------------------------------------
@@ -493,7 +550,7 @@ LB_HD void freev(State &s, const Work &w) {
 }
 
 // ---- LEL^T factorisation of the reduced middle matrix (subspace minimisation) ---------------
-LB_HDN int formk(State &s, const Work &w) {
+LB_HDN int formk(const IterArgs s, const Work w) {
   const int n = s.n, m = s.m, col = s.col, nsub = s.nfree, m2 = 2 * s.m;
   double *wn = w.wn, *wn1 = w.snd;
   const int *ind = w.index, *indx2 = w.indx2;
@@ -657,8 +714,11 @@ LB_HD int cmprlb(State &s, const Work &w) {
 
 // Subspace minimisation: on entry w.z = xcp and w.r = reduced gradient; on exit w.z is
 // the (projected) subspace minimiser.  wv = wa[0..2m).
-LB_HDN int subsm(State &s, const Work &w, const double *l, const double *u, const int *nbd) {
+// Returns info (0 ok) in the low 8 bits and iword (1: the step hit a bound) in bit 8.
+LB_HDN int subsm(const IterArgs s, const Work w, const double *l, const double *u,
+                 const int *nbd) {
   const int n = s.n, m = s.m, col = s.col, nsub = s.nfree, m2 = 2 * s.m, col2 = 2 * s.col;
+  int iword = 0;
   double *x = w.z, *d = w.r, *xp = w.xp, *wv = w.wa;
   const double *xx = w.x, *gg = w.g;
   const int *ind = w.index;
@@ -690,7 +750,7 @@ LB_HDN int subsm(State &s, const Work &w, const double *l, const double *u, cons
   }
   for (int i = 0; i < nsub; ++i) d[i] *= 1.0 / theta;
   // projected Newton step
-  s.iword = 0;
+  iword = 0;
   for (int i = 0; i < n; ++i) xp[i] = x[i];
   for (int i = 0; i < nsub; ++i) {
     const int k = ind[i] - 1;
@@ -698,20 +758,20 @@ LB_HDN int subsm(State &s, const Work &w, const double *l, const double *u, cons
     if (nbd[k] != 0) {
       if (nbd[k] == 1) {
         x[k] = fmax(l[k], xk + dk);
-        if (x[k] == l[k]) s.iword = 1;
+        if (x[k] == l[k]) iword = 1;
       } else if (nbd[k] == 2) {
         const double xk2 = fmax(l[k], xk + dk);
         x[k] = fmin(u[k], xk2);
-        if (x[k] == l[k] || x[k] == u[k]) s.iword = 1;
+        if (x[k] == l[k] || x[k] == u[k]) iword = 1;
       } else if (nbd[k] == 3) {
         x[k] = fmin(u[k], xk + dk);
-        if (x[k] == u[k]) s.iword = 1;
+        if (x[k] == u[k]) iword = 1;
       }
     } else {
       x[k] = xk + dk;
     }
   }
-  if (s.iword == 0) return 0;
+  if (iword == 0) return 0;
   // sign of the directional derivative along the projected step
   double dd_p = 0.0;
   for (int i = 0; i < n; ++i) dd_p += (x[i] - xx[i]) * gg[i];
@@ -754,7 +814,7 @@ LB_HDN int subsm(State &s, const Work &w, const double *l, const double *u, cons
       x[k] += alpha * d[i];
     }
   }
-  return 0;
+  return iword << 8;
 }
 
 // ---- More'-Thuente line search -------------------------------------------------------------
@@ -1045,21 +1105,20 @@ LB_HD void lbfgsb_init(State &s, const Work &w, int n, int m, const double *x0, 
 // Advance the problem until it needs f and g at w.x (LB_NEED_FG: the caller stores them in
 // s.f / w.g and calls again) or terminates (LB_DONE: result in w.x, s.f, w.g, s.nit,
 // s.nfev, s.status, s.task, s.msg).
-LB_HDN int lbfgsb_advance(State &s, const Work &w, const double *l, const double *u,
+LB_HD int lbfgsb_advance(State &s, const Work &w, const double *l, const double *u,
                           const int *nbd, const Options &opt) {
   const int n = s.n, m = s.m;
   bool first_ls = false;
   bool resume_ls = (s.stage == S_FG_LNSRCH);
+  long long *acc = s.acc;
+  TIC;
 
-  const bool lsflag = (s.stage == S_FG_LNSRCH && s.ifun >= 2);
-  LST(0);
   if (s.stage == S_FINISHED) return LB_DONE;
 
   if (s.stage == S_FG_START || s.stage == S_FG_LNSRCH) {  // fresh f, g at w.x have arrived
     for (int i = 0; i < n; ++i) { w.xlast[i] = w.x[i]; w.glast[i] = w.g[i]; }
     s.flast = s.f;
   }
-  LST(1);
 
   if (s.stage == S_INIT) {
     s.col = 0; s.head = 0; s.theta = 1.0; s.iupdat = 0; s.updatd = 0;
@@ -1112,6 +1171,7 @@ LB_HDN int lbfgsb_advance(State &s, const Work &w, const double *l, const double
   // otherwise S_FG_LNSRCH: f and g at the trial point have arrived; resume the line search
 
   for (;;) {
+    TOC(0);
     if (resume_ls) {
       resume_ls = false;
       first_ls = false;
@@ -1122,34 +1182,46 @@ LB_HDN int lbfgsb_advance(State &s, const Work &w, const double *l, const double
         s.wrk = s.updatd;
         s.nseg = 0;
       } else {
-        if (cauchy(s, w, l, u, nbd)) {  // singular triangular system: refresh the memory
+        const IterArgs ia{n, m, s.col, s.head, s.nfree, s.nenter, s.ileave, s.updatd, s.iupdat,
+                          s.theta, s.sbgnrm};
+        const int rc = cauchy(ia, w, l, u, nbd);
+        s.nseg = rc >> 8;
+        if (rc & 0xff) {  // singular triangular system: refresh the memory
           refresh_memory(s);
           continue;
         }
+        TOC(1);
         freev(s, w);
         s.nact = n - s.nfree;
+        TOC(2);
       }
       if (s.nfree != 0 && s.col != 0) {
+        const IterArgs ia{n, m, s.col, s.head, s.nfree, s.nenter, s.ileave, s.updatd, s.iupdat,
+                          s.theta, s.sbgnrm};
         if (s.wrk) {
-          if (formk(s, w)) { refresh_memory(s); continue; }
+          if (formk(ia, w)) { refresh_memory(s); continue; }
         }
+        TOC(3);
         if (cmprlb(s, w)) { refresh_memory(s); continue; }
-        if (subsm(s, w, l, u, nbd)) { refresh_memory(s); continue; }
+        const int rc = subsm(ia, w, l, u, nbd);
+        s.iword = rc >> 8;
+        if (rc & 0xff) { refresh_memory(s); continue; }
+        TOC(4);
       }
       for (int i = 0; i < n; ++i) w.d[i] = w.z[i] - w.x[i];
       first_ls = true;
     }
 
     s.info = 0;
-    LST(2);
-    if (lnsrlb(s, w, l, u, nbd, first_ls ? 1 : 0)) {
-      LST(3);
+    TOC(5);
+    const int lsr = lnsrlb(s, w, l, u, nbd, first_ls ? 1 : 0);
+    TOC(6);
+    if (lsr) {
       if (s.iback < opt.maxls) {
         // SciPy's ScalarFunction serves a request at the point it evaluated last from its
         // cache (no call, nfev unchanged); a collapsed bracket asks for such points.
         bool cached = true;
         for (int i = 0; i < n; ++i) cached = cached && (w.x[i] == w.xlast[i]);
-        LST(4);
         if (cached) {
           s.f = s.flast;
           for (int i = 0; i < n; ++i) w.g[i] = w.glast[i];
@@ -1159,7 +1231,7 @@ LB_HDN int lbfgsb_advance(State &s, const Work &w, const double *l, const double
         s.stage = S_FG_LNSRCH;
         s.task = T_FG;
         ++s.nfev;
-        LST(5);
+        TOC(7);
         return LB_NEED_FG;
       }
       // maxls trial points used up: handled like a failed search (the trial x is dropped)
@@ -1195,6 +1267,7 @@ LB_HDN int lbfgsb_advance(State &s, const Work &w, const double *l, const double
         return LB_DONE;
       }
     }
+    TOC(8);
     // --- BFGS update: r = g - g_old (y), d = step (s) ---
     for (int i = 0; i < n; ++i) w.r[i] = w.g[i] - w.r[i];
     {
@@ -1215,10 +1288,12 @@ LB_HDN int lbfgsb_advance(State &s, const Work &w, const double *l, const double
       s.updatd = 1;
       ++s.iupdat;
       matupd(s, w, rr, dr);
+      TOC(9);
       if (formt(m, w.wt, w.sy, w.ss, s.col, s.theta)) {
         refresh_memory(s);
         continue;
       }
+      TOC(10);
     }
   }
 }

@@ -16,7 +16,7 @@ def run(D,units,acts,tr,R,L=1):
     for _ in range(2):
         e0=torch.cuda.Event(enable_timing=True); e1=torch.cuda.Event(enable_timing=True)
         e0.record(); x,fun,jac,info=ops.lbfgsb_minimize(desc,th,dev(X0),np.zeros(D),np.ones(D),tr,True,maxiter=1000,ftol=1e-9); e1.record(); torch.cuda.synchronize()
-    o2=(C.c_longlong*16)(); lib.bore_debug_ls(o2); o2=list(o2); print('   LS round stamps: deltas', [o2[i+1]-o2[i] for i in range(5)])
+    o2=(C.c_longlong*16)(); lib.bore_debug_ls(o2); o2=list(o2); print('   LS round stamps: deltas [entry,copy->lnsrlb,ddot,dcsrch,xupd,cachechk,tail]', [o2[i+1]-o2[i] for i in range(7)])
     out=(C.c_longlong*8)(); lib.bore_debug_lstamps(out)
     o=list(out)
     info=info.cpu().numpy()
