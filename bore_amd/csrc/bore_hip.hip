@@ -70,8 +70,6 @@ __global__ __launch_bounds__(BORE_THREADS) void fit_kernel(const FitArgs a) {
   const float *X_g = a.X + model * (long long)N * D;
   const float *z_g = a.z + model * (long long)N;
   float *sm = smem + a.o_m, *sv = smem + a.o_v;  // padded images (when state_in_lds)
-  const float *Xs = a.data_in_lds ? smem + a.o_X : X_g;
-  const float *zs = a.data_in_lds ? smem + a.o_z : z_g;
 
   load_theta(L, theta_g, th);
   if (a.state_in_lds) {
@@ -111,7 +109,7 @@ __global__ __launch_bounds__(BORE_THREADS) void fit_kernel(const FitArgs a) {
     } else {
       make_perm(shuffle_base(a.seed, a.model0 + model, a.epoch0 + e), N, keys, perm_s);
     }
-    float eloss = 0.f;  // per wave: sum over the epoch of its rows' losses
+    float eloss = 0.f;  // per lane: sum over the epoch of the losses of its row slot
 
     for (int s = 0; s < steps; ++s) {
       const int row0 = s * a.B;
@@ -123,30 +121,34 @@ __global__ __launch_bounds__(BORE_THREADS) void fit_kernel(const FitArgs a) {
           float *A0 = tile + L.aoff[0] + (rb * 16 + m16) * L.lda[0];
           const int row = rb * 16 + m16;
           const int src = row < nb ? perm_s[row0 + row] : 0;
-          for (int d = q4; d < D; d += 4) A0[d] = row < nb ? Xs[src * D + d] : 0.f;
-          if (q4 == 0) zt[row] = row < nb ? zs[src] : 0.f;
+          if (a.data_in_lds) {  // (two branches: a selected pointer would make these flat loads)
+            for (int d = q4; d < D; d += 4) A0[d] = row < nb ? smem[a.o_X + src * D + d] : 0.f;
+            if (q4 == 0) zt[row] = row < nb ? smem[a.o_z + src] : 0.f;
+          } else {
+            for (int d = q4; d < D; d += 4) A0[d] = row < nb ? X_g[src * D + d] : 0.f;
+            if (q4 == 0) zt[row] = row < nb ? z_g[src] : 0.f;
+          }
         }
         wave_lds_sync();
         fwd_all(L, th, tile, rb, /*keep_logits=*/true);
-        float lossb = 0.f;
         if (lane < 16) {  // loss + d loss / d logit (the final layer has one unit)
           const int row = rb * 16 + lane;
           float delta = 0.f;
           if (row < nb) {
             const float x = tile[L.aoff[n] + row * L.lda[n]];
             const float zz = zt[row];
-            lossb = fmaxf(x, 0.f) - x * zz + log1pf(expf(-fabsf(x)));
-            delta = (sigmoid_stable(x) - zz) / (float)nb;
+            const float ex = expf(-fabsf(x));  // shared by the loss and the sigmoid
+            const float den = 1.f + ex;
+            const float sig = x >= 0.f ? 1.f / den : ex / den;
+            eloss += fmaxf(x, 0.f) - x * zz + log1pf(ex);  // per-lane; reduced once per epoch
+            delta = (sig - zz) / (float)nb;
           }
           tile[L.doff[n] + row * L.lda[n]] = delta;
         }
-        lossb = wave_sum(lossb);
-        if (wv == 0 && L.any_l2) {  // (every lane of wave 0: same value, uniform branch)
-          lossb += misc[0] * (float)nb;
-          wave_lds_sync();
-          if (lane == 0) misc[0] = 0.f;  // consumed; re-accumulated from the updated weights
+        if (tid == 0 && L.any_l2) {
+          eloss += misc[0] * (float)nb;
+          misc[0] = 0.f;  // consumed; re-accumulated from the updated weights below
         }
-        eloss += lossb;
         wave_lds_sync();
 #pragma unroll
         for (int l = n; l >= 2; --l) {
@@ -177,7 +179,8 @@ __global__ __launch_bounds__(BORE_THREADS) void fit_kernel(const FitArgs a) {
             const float *ap = tile + L.aoff[l - 1] + q4 * lda_p + kb * 16 + m16;
             const float *bp = tile + L.doff[l] + q4 * ldd + cb * 16 + m16;
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            float bsum = 0.f;
+            f32x4 ones = {0.f, 0.f, 0.f, 0.f};  // ones^T D_l: every row = the column sums of D_l
+            const bool want_bias = kb == 0;
             int kc = 0;
             for (; kc + 4 <= kch; kc += 4) {  // operands of four row-chunks in flight
               const float a0 = ap[kc * 4 * lda_p], a1 = ap[(kc + 1) * 4 * lda_p],
@@ -188,12 +191,17 @@ __global__ __launch_bounds__(BORE_THREADS) void fit_kernel(const FitArgs a) {
               acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc, 0, 0, 0);
               acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, b2, acc, 0, 0, 0);
               acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a3, b3, acc, 0, 0, 0);
-              bsum += (b0 + b1) + (b2 + b3);
+              if (want_bias) {  // independent of `acc`: fills its issue gaps
+                ones = __builtin_amdgcn_mfma_f32_16x16x4f32(1.f, b0, ones, 0, 0, 0);
+                ones = __builtin_amdgcn_mfma_f32_16x16x4f32(1.f, b1, ones, 0, 0, 0);
+                ones = __builtin_amdgcn_mfma_f32_16x16x4f32(1.f, b2, ones, 0, 0, 0);
+                ones = __builtin_amdgcn_mfma_f32_16x16x4f32(1.f, b3, ones, 0, 0, 0);
+              }
             }
             for (; kc < kch; ++kc) {
               const float av = ap[kc * 4 * lda_p], bv = bp[kc * 4 * ldd];
               acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
-              bsum += bv;
+              if (want_bias) ones = __builtin_amdgcn_mfma_f32_16x16x4f32(1.f, bv, ones, 0, 0, 0);
             }
             const int col = cb * 16 + m16;
             const bool cvalid = col < Nw;
@@ -222,13 +230,11 @@ __global__ __launch_bounds__(BORE_THREADS) void fit_kernel(const FitArgs a) {
                 if (l2 != 0.f) reg = fmaf(l2 * w, w, reg);
               }
             }
-            if (kb == 0) {  // bias gradient: column sums of D_l (rows q4, q4+4, ... per lane)
-              bsum += __shfl_xor(bsum, 16, 64);
-              bsum += __shfl_xor(bsum, 32, 64);
+            if (want_bias) {  // bias gradient: row 0 of ones^T D_l (lanes 0..15, register 0)
               if (q4 == 0 && cvalid) {
                 const int li = L.boff[l] + col;
                 float w = th[li];
-                float g = bsum;
+                float g = ones[0];
                 const float l2 = L.l2_b[l];
                 if (l2 != 0.f) g = fmaf(2.f * l2, w, g);
                 if (a.state_in_lds) {
@@ -256,6 +262,7 @@ __global__ __launch_bounds__(BORE_THREADS) void fit_kernel(const FitArgs a) {
       __syncthreads();
     }
     if (a.epoch_loss) {
+      eloss = wave_sum(eloss);
       if (lane == 0) misc[1 + wv] = eloss;
       __syncthreads();
       if (tid == 0)
@@ -427,7 +434,7 @@ extern "C" int bore_mlp_fit(const bore_mlp_desc *desc, int n_models, float *thet
   if (N < 1 || N > (1 << 20)) return fail(BORE_E_INVALID, "fit: N=%lld out of range", (long long)N);
   // the whole mini-batch is one tile; perm (+ keys) and the batch targets ride along
   int rc = check_common(desc, n_models, 1, batch_size, false,
-                        BORE_BATCH_MAX + 8 + BORE_LAYOUT_FLOATS + 4 + (size_t)N * (perm ? 1 : 2),
+                        BORE_BATCH_MAX + 8 + BORE_LAYOUT_FLOATS + 12 + (size_t)N * (perm ? 1 : 3),
                         &a.L);
   if (rc) return rc;
   const MlpLayout &L = a.L;
@@ -453,7 +460,8 @@ extern "C" int bore_mlp_fit(const bore_mlp_desc *desc, int n_models, float *thet
   a.o_zt = (int)off; off += BORE_BATCH_MAX;
   a.o_misc = (int)off; off += 8;
   a.o_perm = (int)off; off += N;
-  a.o_keys = (int)off; off += perm ? 0 : N;
+  off = (off + 3) & ~(size_t)3;  // keys: 64-bit words fetched two at a time
+  a.o_keys = (int)off; off += perm ? 0 : 2 * ((N + 1) & ~1);
   if ((off + BORE_LAYOUT_FLOATS + 4) * 4 > BORE_LDS_BYTES)
     return fail(BORE_E_UNSUPPORTED, "fit: theta+tile+perm need %zu B of LDS (> %d)", off * 4,
                 BORE_LDS_BYTES);
@@ -603,7 +611,7 @@ extern "C" int bore_shuffle_perm(uint64_t seed, int64_t model_index0, int n_mode
     return fail(BORE_E_INVALID, "shuffle_perm: bad argument");
   if (epochs == 0) return 0;
   if (epochs > 65535) return fail(BORE_E_UNSUPPORTED, "shuffle_perm: epochs > 65535");
-  const size_t bytes = (size_t)N * 4;
+  const size_t bytes = (((size_t)N + 1) & ~(size_t)1) * 8;
   int rc = allow_lds(shuffle_kernel, bytes);
   if (rc) return rc;
   hipLaunchKernelGGL(shuffle_kernel, dim3(n_models, epochs), dim3(BORE_THREADS), bytes,

@@ -274,17 +274,25 @@ __host__ __device__ __forceinline__ unsigned shuffle_key(unsigned long long base
   return (unsigned)(mix64(base + 0x8CB92BA72F3D8DD7ULL * (unsigned long long)(i + 1)) >> 32);
 }
 
-// keys: LDS scratch [N]; perm_out: [N] (LDS or global).  Ends with a barrier.
+// keys: LDS scratch of round_up(N, 2) 64-bit words, 16-byte aligned; perm_out: [N] (LDS or
+// global).  Ends with a barrier.  Row i's rank is the number of 64-bit words
+// (key_j << 32 | j) below its own -- one compare per row pair, the words fetched two at a time
+// (a broadcast ds_read_b128).
 __device__ __forceinline__ void make_perm(unsigned long long base, int N, unsigned *keys,
                                           int *perm_out) {
-  for (int i = threadIdx.x; i < N; i += blockDim.x) keys[i] = shuffle_key(base, i);
+  unsigned long long *k64 = reinterpret_cast<unsigned long long *>(keys);
+  const int N2 = (N + 1) & ~1;
+  for (int i = threadIdx.x; i < N2; i += blockDim.x)
+    k64[i] = i < N ? ((unsigned long long)shuffle_key(base, i) << 32) | (unsigned)i : ~0ULL;
   __syncthreads();
+  const ulonglong2 *kk = reinterpret_cast<const ulonglong2 *>(keys);
   for (int i = threadIdx.x; i < N; i += blockDim.x) {
-    const unsigned ki = keys[i];
+    const unsigned long long ki = k64[i];
     int r = 0;
-    for (int j = 0; j < N; ++j) {
-      const unsigned kj = keys[j];
-      r += (kj < ki) || (kj == ki && j < i);
+    for (int j = 0; j < (N2 >> 1); ++j) {  // the padding word (all ones) is never below ki
+      const ulonglong2 k = kk[j];
+      r += k.x < ki;
+      r += k.y < ki;
     }
     perm_out[r] = i;
   }

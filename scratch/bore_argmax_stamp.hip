@@ -339,9 +339,13 @@ __global__ __launch_bounds__(BORE_THREADS) void lbfgsb_kernel(const LbfgsbArgs a
   load_theta(L, a.theta + model * L.P, th);
   __syncthreads();
 
-  // the problem (if any) this thread owns, and its tile row
-  const int myp = (lane < 16 && lane * 4 + wv < np) ? lane * 4 + wv : -1;
-  const int myrow = wv * 16 + lane;
+  // Which problem this thread works on.  With at most one problem per wave (np <= 4: the
+  // BASELINE config-1 shape, 3 restarts) ALL 64 lanes of wave wv run problem wv together
+  // (lbfgsb::Coop); otherwise lane s < 16 of wave wv runs problem 4 s + wv on its own.
+  const bool coop = np <= 4;
+  const int myp = coop ? (wv < np ? wv : -1) : ((lane < 16 && lane * 4 + wv < np) ? lane * 4 + wv : -1);
+  const int myrow = coop ? wv * 16 : wv * 16 + lane;
+  const lbfgsb::Coop cp = coop ? lbfgsb::Coop{lane, 64} : lbfgsb::Coop{0, 1};
   // The scalar state of the optimiser stays in this thread's REGISTERS for the whole launch
   // (its vectors and matrices are in LDS): kept in memory, every store to a workspace array
   // would force the compiler to reload the state fields it may alias.
@@ -362,7 +366,7 @@ __global__ __launch_bounds__(BORE_THREADS) void lbfgsb_kernel(const LbfgsbArgs a
   for (int round = 0; round < a.max_rounds; ++round) {
     int pending = 0;
     if (!done) {
-      const int rc = lbfgsb::lbfgsb_advance(st, wk, blo, bhi, bnbd, a.opt);
+      const int rc = lbfgsb::lbfgsb_advance(st, wk, blo, bhi, bnbd, a.opt, cp);
       if (rc == lbfgsb::LB_NEED_FG) {
         float *row = tile + L.aoff[0] + myrow * L.lda[0];
         for (int d = 0; d < D; ++d) row[d] = (float)wk.x[d];  // Keras autocast fp64 -> fp32
@@ -383,8 +387,9 @@ __global__ __launch_bounds__(BORE_THREADS) void lbfgsb_kernel(const LbfgsbArgs a
     wave_lds_sync();
     t_fg += clock64() - c1;
   }
-  if (myp >= 0) { for (int i = 0; i < 11; ++i) atomicAdd(&lbfgsb::g_acc[i], (unsigned long long)st.acc[i]); atomicAdd(&lbfgsb::g_acc[11], (unsigned long long)t_fg); atomicAdd(&lbfgsb::g_acc[12], (unsigned long long)(clock64() - t_all0)); atomicAdd(&lbfgsb::g_acc[13], (unsigned long long)st.nit); atomicAdd(&lbfgsb::g_acc[14], (unsigned long long)st.nfev); atomicMax(&lbfgsb::g_acc[15], (unsigned long long)(clock64() - t_all0)); }
 
+  if (coop && lane != 0) return;
+  if (myp >= 0) { for (int i = 0; i < 11; ++i) atomicAdd(&lbfgsb::g_acc[i], (unsigned long long)st.acc[i]); atomicAdd(&lbfgsb::g_acc[11], (unsigned long long)t_fg); atomicAdd(&lbfgsb::g_acc[12], (unsigned long long)(clock64() - t_all0)); atomicAdd(&lbfgsb::g_acc[13], (unsigned long long)st.nit); atomicAdd(&lbfgsb::g_acc[14], (unsigned long long)st.nfev); atomicMax(&lbfgsb::g_acc[15], (unsigned long long)(clock64() - t_all0)); }  // one lane reports the shared problem
   if (myp >= 0) {
     const long long q = model * a.R + p0 + myp;
     if (st.stage != lbfgsb::S_FINISHED) {  // round cap hit (cannot happen with a sane cap)

@@ -12,6 +12,7 @@
 using namespace bore;
 __device__ long long g_stamps[64];
 #define STAMP(i) do { if (blockIdx.x == 0 && tid == 0 && e == 1 && s == 0) g_stamps[i] = clock64(); if (blockIdx.x==0 && tid==64 && e==1 && s==0) g_stamps[32+i] = clock64(); } while (0)
+#define STAMPE(i) do { if (blockIdx.x == 0 && tid == 0 && e == 1) g_stamps[i] = clock64(); } while (0)
 extern "C" int bore_debug_stamps(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(long long)*64); }
 
 extern "C" int bore_abi_version(void) { return BORE_ABI_VERSION; }
@@ -73,8 +74,6 @@ __global__ __launch_bounds__(BORE_THREADS) void fit_kernel(const FitArgs a) {
   const float *X_g = a.X + model * (long long)N * D;
   const float *z_g = a.z + model * (long long)N;
   float *sm = smem + a.o_m, *sv = smem + a.o_v;  // padded images (when state_in_lds)
-  const float *Xs = a.data_in_lds ? smem + a.o_X : X_g;
-  const float *zs = a.data_in_lds ? smem + a.o_z : z_g;
 
   load_theta(L, theta_g, th);
   if (a.state_in_lds) {
@@ -107,6 +106,7 @@ __global__ __launch_bounds__(BORE_THREADS) void fit_kernel(const FitArgs a) {
   __syncthreads();
 
   for (int e = 0; e < a.epochs; ++e) {
+    STAMPE(10);
     if (a.perm) {
       const int *pg = a.perm + (model * a.epochs + e) * (long long)N;
       for (int i = tid; i < N; i += nthr) perm_s[i] = pg[i];
@@ -114,7 +114,8 @@ __global__ __launch_bounds__(BORE_THREADS) void fit_kernel(const FitArgs a) {
     } else {
       make_perm(shuffle_base(a.seed, a.model0 + model, a.epoch0 + e), N, keys, perm_s);
     }
-    float eloss = 0.f;  // per wave: sum over the epoch of its rows' losses
+    STAMPE(11);
+    float eloss = 0.f;  // per lane: sum over the epoch of the losses of its row slot
 
     for (int s = 0; s < steps; ++s) {
       STAMP(0);
@@ -127,32 +128,36 @@ __global__ __launch_bounds__(BORE_THREADS) void fit_kernel(const FitArgs a) {
           float *A0 = tile + L.aoff[0] + (rb * 16 + m16) * L.lda[0];
           const int row = rb * 16 + m16;
           const int src = row < nb ? perm_s[row0 + row] : 0;
-          for (int d = q4; d < D; d += 4) A0[d] = row < nb ? Xs[src * D + d] : 0.f;
-          if (q4 == 0) zt[row] = row < nb ? zs[src] : 0.f;
+          if (a.data_in_lds) {  // (two branches: a selected pointer would make these flat loads)
+            for (int d = q4; d < D; d += 4) A0[d] = row < nb ? smem[a.o_X + src * D + d] : 0.f;
+            if (q4 == 0) zt[row] = row < nb ? smem[a.o_z + src] : 0.f;
+          } else {
+            for (int d = q4; d < D; d += 4) A0[d] = row < nb ? X_g[src * D + d] : 0.f;
+            if (q4 == 0) zt[row] = row < nb ? z_g[src] : 0.f;
+          }
         }
         wave_lds_sync();
         STAMP(1);
         fwd_all(L, th, tile, rb, /*keep_logits=*/true);
         STAMP(2);
-        float lossb = 0.f;
         if (lane < 16) {  // loss + d loss / d logit (the final layer has one unit)
           const int row = rb * 16 + lane;
           float delta = 0.f;
           if (row < nb) {
             const float x = tile[L.aoff[n] + row * L.lda[n]];
             const float zz = zt[row];
-            lossb = fmaxf(x, 0.f) - x * zz + log1pf(expf(-fabsf(x)));
-            delta = (sigmoid_stable(x) - zz) / (float)nb;
+            const float ex = expf(-fabsf(x));  // shared by the loss and the sigmoid
+            const float den = 1.f + ex;
+            const float sig = x >= 0.f ? 1.f / den : ex / den;
+            eloss += fmaxf(x, 0.f) - x * zz + log1pf(ex);  // per-lane; reduced once per epoch
+            delta = (sig - zz) / (float)nb;
           }
           tile[L.doff[n] + row * L.lda[n]] = delta;
         }
-        lossb = wave_sum(lossb);
-        if (wv == 0 && L.any_l2) {  // (every lane of wave 0: same value, uniform branch)
-          lossb += misc[0] * (float)nb;
-          wave_lds_sync();
-          if (lane == 0) misc[0] = 0.f;  // consumed; re-accumulated from the updated weights
+        if (tid == 0 && L.any_l2) {
+          eloss += misc[0] * (float)nb;
+          misc[0] = 0.f;  // consumed; re-accumulated from the updated weights below
         }
-        eloss += lossb;
         wave_lds_sync();
         STAMP(3);
 #pragma unroll
@@ -186,7 +191,8 @@ __global__ __launch_bounds__(BORE_THREADS) void fit_kernel(const FitArgs a) {
             const float *ap = tile + L.aoff[l - 1] + q4 * lda_p + kb * 16 + m16;
             const float *bp = tile + L.doff[l] + q4 * ldd + cb * 16 + m16;
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            float bsum = 0.f;
+            f32x4 ones = {0.f, 0.f, 0.f, 0.f};  // ones^T D_l: every row = the column sums of D_l
+            const bool want_bias = kb == 0;
             int kc = 0;
             for (; kc + 4 <= kch; kc += 4) {  // operands of four row-chunks in flight
               const float a0 = ap[kc * 4 * lda_p], a1 = ap[(kc + 1) * 4 * lda_p],
@@ -197,12 +203,17 @@ __global__ __launch_bounds__(BORE_THREADS) void fit_kernel(const FitArgs a) {
               acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc, 0, 0, 0);
               acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, b2, acc, 0, 0, 0);
               acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a3, b3, acc, 0, 0, 0);
-              bsum += (b0 + b1) + (b2 + b3);
+              if (want_bias) {  // independent of `acc`: fills its issue gaps
+                ones = __builtin_amdgcn_mfma_f32_16x16x4f32(1.f, b0, ones, 0, 0, 0);
+                ones = __builtin_amdgcn_mfma_f32_16x16x4f32(1.f, b1, ones, 0, 0, 0);
+                ones = __builtin_amdgcn_mfma_f32_16x16x4f32(1.f, b2, ones, 0, 0, 0);
+                ones = __builtin_amdgcn_mfma_f32_16x16x4f32(1.f, b3, ones, 0, 0, 0);
+              }
             }
             for (; kc < kch; ++kc) {
               const float av = ap[kc * 4 * lda_p], bv = bp[kc * 4 * ldd];
               acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
-              bsum += bv;
+              if (want_bias) ones = __builtin_amdgcn_mfma_f32_16x16x4f32(1.f, bv, ones, 0, 0, 0);
             }
             const int col = cb * 16 + m16;
             const bool cvalid = col < Nw;
@@ -231,13 +242,11 @@ __global__ __launch_bounds__(BORE_THREADS) void fit_kernel(const FitArgs a) {
                 if (l2 != 0.f) reg = fmaf(l2 * w, w, reg);
               }
             }
-            if (kb == 0) {  // bias gradient: column sums of D_l (rows q4, q4+4, ... per lane)
-              bsum += __shfl_xor(bsum, 16, 64);
-              bsum += __shfl_xor(bsum, 32, 64);
+            if (want_bias) {  // bias gradient: row 0 of ones^T D_l (lanes 0..15, register 0)
               if (q4 == 0 && cvalid) {
                 const int li = L.boff[l] + col;
                 float w = th[li];
-                float g = bsum;
+                float g = ones[0];
                 const float l2 = L.l2_b[l];
                 if (l2 != 0.f) g = fmaf(2.f * l2, w, g);
                 if (a.state_in_lds) {
@@ -267,6 +276,7 @@ __global__ __launch_bounds__(BORE_THREADS) void fit_kernel(const FitArgs a) {
       STAMP(7);
     }
     if (a.epoch_loss) {
+      eloss = wave_sum(eloss);
       if (lane == 0) misc[1 + wv] = eloss;
       __syncthreads();
       if (tid == 0)

@@ -137,6 +137,22 @@ LB_HD Work make_work(double *dw, int *iw, int n, int m) {
 
 #define LB_EPSMCH 2.220446049250313e-16
 
+// ---- lanes cooperating on ONE problem ---------------------------------------------------
+// When a wave owns a single problem, all 64 lanes run the state machine in lock-step with
+// identical scalars (uniform control flow, redundant stores of identical values) and SHARE
+// the loops whose iterations produce independent outputs: lane `lane` of `nl` takes
+// iterations lane, lane+nl, ...  Every output is still computed by one lane with the
+// sequential operation order, so results do not depend on nl (host build: nl = 1).
+// LB_LANES_SYNC separates such a loop from readers of its outputs in other lanes.
+struct Coop {
+  int lane, nl;
+};
+#if defined(__HIP_DEVICE_COMPILE__)
+#define LB_LANES_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#else
+#define LB_LANES_SYNC() ((void)0)
+#endif
+
 // ---- small dense kernels ------------------------------------------------------
 // Sums strictly left to right (results do not depend on the unrolling); operands are fetched
 // eight at a time so that their LDS latencies overlap -- on the device a dependent
@@ -230,34 +246,40 @@ LB_HD int dtrsl_upper(const double *t, int ld, int n, double *b, int trans) {
 
 // ---- limited-memory matrix products ---------------------------------------------
 // Product of the 2col x 2col middle matrix of the compact L-BFGS formula with v -> p.
-LB_HD int bmv(int m, const double *sy, const double *wt, int col, const double *v, double *p) {
+LB_HD int bmv(int m, const double *sy, const double *wt, int col, const double *v, double *p,
+              const Coop c) {
   if (col == 0) return 0;
   // solve [  D^(1/2)      O ] [ p1 ] = [ v1 ]
   //       [ -L*D^(-1/2)   J ] [ p2 ]   [ v2 ]
-  p[col] = v[col];
-  for (int i = 1; i < col; ++i)
-    p[col + i] = v[col + i] + dot_div(i, sy + i, m, v, 1, sy, m + 1);
+  for (int i = c.lane; i < col; i += c.nl)
+    p[col + i] = i == 0 ? v[col] : v[col + i] + dot_div(i, sy + i, m, v, 1, sy, m + 1);
+  LB_LANES_SYNC();
   int info = dtrsl_upper(wt, m, col, p + col, 1);
   if (info) return info;
-  for (int i = 0; i < col; ++i) p[i] = v[i] / sqrt(sy[i * m + i]);
   // solve [ -D^(1/2)   D^(-1/2)*L' ] [ p1 ] = [ p1 ]
   //       [  0         J'          ] [ p2 ]   [ p2 ]
   info = dtrsl_upper(wt, m, col, p + col, 0);
   if (info) return info;
-  for (int i = 0; i < col; ++i) p[i] = -p[i] / sqrt(sy[i * m + i]);
-  for (int i = 0; i < col; ++i)
-    p[i] += dot_div(col - i - 1, sy + i * m + i + 1, 1, p + col + i + 1, 1, sy + i * m + i, 0);
+  for (int i = c.lane; i < col; i += c.nl) {
+    const double sq = sqrt(sy[i * m + i]);
+    double pi = v[i] / sq;
+    pi = -pi / sq;
+    p[i] = pi + dot_div(col - i - 1, sy + i * m + i + 1, 1, p + col + i + 1, 1, sy + i * m + i, 0);
+  }
+  LB_LANES_SYNC();
   return 0;
 }
 
 // T = theta*SS + L*D^(-1)*L' (upper triangle), then its Cholesky factor J' in wt.
-LB_HD int formt(int m, double *wt, const double *sy, const double *ss, int col, double theta) {
-  for (int j = 0; j < col; ++j) wt[j * m] = theta * ss[j * m];
-  for (int i = 1; i < col; ++i)
-    for (int j = i; j < col; ++j) {
-      const int k1 = (i < j ? i : j);
-      wt[j * m + i] = dot_div(k1, sy + i, m, sy + j, m, sy, m + 1) + theta * ss[j * m + i];
-    }
+LB_HD int formt(int m, double *wt, const double *sy, const double *ss, int col, double theta,
+                const Coop c) {
+  for (int e = c.lane; e < col * col; e += c.nl) {  // the entries (i, j >= i) are independent
+    const int i = e / col, j = e - i * col;
+    if (j < i) continue;
+    if (i == 0) wt[j * m] = theta * ss[j * m];
+    else wt[j * m + i] = dot_div(i, sy + i, m, sy + j, m, sy, m + 1) + theta * ss[j * m + i];
+  }
+  LB_LANES_SYNC();
   return dpofa(wt, m, col) ? -3 : 0;
 }
 
@@ -334,6 +356,7 @@ LB_HD void hpsolb(int n, double *t, int *iorder, int iheap) {
 struct IterArgs {
   int n, m, col, head, nfree, nenter, ileave, updatd, iupdat;
   double theta, sbgnrm;
+  Coop c;
 };
 
 // ---- generalized Cauchy point ----------------------------------------------------------
@@ -418,7 +441,7 @@ LB_HDN int cauchy(const IterArgs s, const Work w, const double *l, const double 
   double f2 = -theta * f1;
   const double f2_org = f2;
   if (col > 0) {
-    const int info = bmv(m, w.sy, w.wt, col, p, v);
+    const int info = bmv(m, w.sy, w.wt, col, p, v, s.c);
     if (info) return LB_CAUCHY_RET(info);
     f2 -= ddot(col2, v, p);
   }
@@ -480,7 +503,7 @@ LB_HDN int cauchy(const IterArgs s, const Work w, const double *l, const double 
           wbp[col + j] = theta * w.ws[pointr * n + (ibp - 1)];
           pointr = (pointr + 1) % m;
         }
-        const int info = bmv(m, w.sy, w.wt, col, wbp, v);
+        const int info = bmv(m, w.sy, w.wt, col, wbp, v, s.c);
         if (info) return LB_CAUCHY_RET(info);
         const double wmc = ddot(col2, c, v);
         const double wmp = ddot(col2, p, v);
@@ -552,6 +575,7 @@ LB_HD void freev(State &s, const Work &w) {
 // ---- LEL^T factorisation of the reduced middle matrix (subspace minimisation) ---------------
 LB_HDN int formk(const IterArgs s, const Work w) {
   const int n = s.n, m = s.m, col = s.col, nsub = s.nfree, m2 = 2 * s.m;
+  const Coop c = s.c;
   double *wn = w.wn, *wn1 = w.snd;
   const int *ind = w.index, *indx2 = w.indx2;
 #define WN(i, j) wn[(j) * m2 + (i)]
@@ -560,7 +584,7 @@ LB_HDN int formk(const IterArgs s, const Work w) {
 #define WY(k, p) w.wy[(p) * n + (k)]
   int upcl;
   if (s.updatd) {
-    if (s.iupdat > m) {  // shift the old part of WN1
+    if (s.iupdat > m) {  // shift the old part of WN1 (overlapping moves: kept sequential)
       for (int jy = 0; jy < m - 1; ++jy) {
         const int js = m + jy;
         for (int i = 0; i < m - 1 - jy; ++i) {
@@ -569,99 +593,92 @@ LB_HDN int formk(const IterArgs s, const Work w) {
         }
         for (int i = 0; i < m - 1; ++i) WN1(m + i, jy) = WN1(m + 1 + i, jy + 1);
       }
+      LB_LANES_SYNC();
     }
-    // new rows in blocks (1,1), (2,1), (2,2)
-    int ipntr = (s.head + col - 1) % m;
-    const int iy = col - 1, is = m + col - 1;
-    int jpntr = s.head;
-    for (int jy = 0; jy < col; ++jy) {
-      const int js = m + jy;
-      double temp1 = 0.0, temp2 = 0.0, temp3 = 0.0;
-      for (int k = 0; k < nsub; ++k) {
-        const int k1 = ind[k] - 1;
-        temp1 += WY(k1, ipntr) * WY(k1, jpntr);
+    // new rows in blocks (1,1), (2,1), (2,2) and the new column in block (2,1): one entry
+    // set per jy, independent of each other
+    {
+      const int ipntr = (s.head + col - 1) % m;
+      const int iy = col - 1, is = m + col - 1;
+      for (int jy = c.lane; jy < col; jy += c.nl) {
+        const int js = m + jy;
+        const int jpntr = (s.head + jy) % m;
+        double temp1 = 0.0, temp2 = 0.0, temp3 = 0.0;
+        for (int k = 0; k < nsub; ++k) {
+          const int k1 = ind[k] - 1;
+          temp1 += WY(k1, ipntr) * WY(k1, jpntr);
+        }
+        for (int k = nsub; k < n; ++k) {
+          const int k1 = ind[k] - 1;
+          temp2 += WS(k1, ipntr) * WS(k1, jpntr);
+          temp3 += WS(k1, ipntr) * WY(k1, jpntr);
+        }
+        WN1(iy, jy) = temp1;
+        WN1(is, js) = temp2;
+        WN1(is, jy) = temp3;
       }
-      for (int k = nsub; k < n; ++k) {
-        const int k1 = ind[k] - 1;
-        temp2 += WS(k1, ipntr) * WS(k1, jpntr);
-        temp3 += WS(k1, ipntr) * WY(k1, jpntr);
+      LB_LANES_SYNC();
+      const int jyc = col - 1;
+      const int jpntr = (s.head + col - 1) % m;
+      for (int i = c.lane; i < col; i += c.nl) {
+        const int is2 = m + i;
+        const int ip = (s.head + i) % m;
+        double temp3 = 0.0;
+        for (int k = 0; k < nsub; ++k) {
+          const int k1 = ind[k] - 1;
+          temp3 += WS(k1, ip) * WY(k1, jpntr);
+        }
+        WN1(is2, jyc) = temp3;
       }
-      WN1(iy, jy) = temp1;
-      WN1(is, js) = temp2;
-      WN1(is, jy) = temp3;
-      jpntr = (jpntr + 1) % m;
-    }
-    // new column in block (2,1)
-    const int jy = col - 1;
-    jpntr = (s.head + col - 1) % m;
-    ipntr = s.head;
-    for (int i = 0; i < col; ++i) {
-      const int is2 = m + i;
-      double temp3 = 0.0;
-      for (int k = 0; k < nsub; ++k) {
-        const int k1 = ind[k] - 1;
-        temp3 += WS(k1, ipntr) * WY(k1, jpntr);
-      }
-      ipntr = (ipntr + 1) % m;
-      WN1(is2, jy) = temp3;
+      LB_LANES_SYNC();
     }
     upcl = col - 1;
   } else {
     upcl = col;
   }
-  // old parts of blocks (1,1) and (2,2): variables that entered / left the free set
-  {
-    int ipntr = s.head;
-    for (int iy = 0; iy < upcl; ++iy) {
+  // old parts of blocks (1,1), (2,2) and (2,1): variables that entered / left the free set.
+  // Each (iy, jy) entry is independent.
+  for (int e = c.lane; e < upcl * upcl; e += c.nl) {
+    const int iy = e / upcl, jy = e - iy * upcl;
+    const int ipntr = (s.head + iy) % m, jpntr = (s.head + jy) % m;
+    if (jy <= iy) {
+      const int is = m + iy, js = m + jy;
+      double temp1 = 0.0, temp2 = 0.0, temp3 = 0.0, temp4 = 0.0;
+      for (int k = 0; k < s.nenter; ++k) {
+        const int k1 = indx2[k] - 1;
+        temp1 += WY(k1, ipntr) * WY(k1, jpntr);
+        temp2 += WS(k1, ipntr) * WS(k1, jpntr);
+      }
+      for (int k = s.ileave - 1; k < n; ++k) {
+        const int k1 = indx2[k] - 1;
+        temp3 += WY(k1, ipntr) * WY(k1, jpntr);
+        temp4 += WS(k1, ipntr) * WS(k1, jpntr);
+      }
+      WN1(iy, jy) += temp1 - temp3;
+      WN1(is, js) += -temp2 + temp4;
+    }
+    {  // block (2,1), entry (m + iy, jy)
       const int is = m + iy;
-      int jpntr = s.head;
-      for (int jy = 0; jy <= iy; ++jy) {
-        const int js = m + jy;
-        double temp1 = 0.0, temp2 = 0.0, temp3 = 0.0, temp4 = 0.0;
-        for (int k = 0; k < s.nenter; ++k) {
-          const int k1 = indx2[k] - 1;
-          temp1 += WY(k1, ipntr) * WY(k1, jpntr);
-          temp2 += WS(k1, ipntr) * WS(k1, jpntr);
-        }
-        for (int k = s.ileave - 1; k < n; ++k) {
-          const int k1 = indx2[k] - 1;
-          temp3 += WY(k1, ipntr) * WY(k1, jpntr);
-          temp4 += WS(k1, ipntr) * WS(k1, jpntr);
-        }
-        WN1(iy, jy) += temp1 - temp3;
-        WN1(is, js) += -temp2 + temp4;
-        jpntr = (jpntr + 1) % m;
+      double temp1 = 0.0, temp3 = 0.0;
+      for (int k = 0; k < s.nenter; ++k) {
+        const int k1 = indx2[k] - 1;
+        temp1 += WS(k1, ipntr) * WY(k1, jpntr);
       }
-      ipntr = (ipntr + 1) % m;
+      for (int k = s.ileave - 1; k < n; ++k) {
+        const int k1 = indx2[k] - 1;
+        temp3 += WS(k1, ipntr) * WY(k1, jpntr);
+      }
+      if (is <= jy + m)
+        WN1(is, jy) += temp1 - temp3;
+      else
+        WN1(is, jy) += -temp1 + temp3;
     }
   }
-  // old part of block (2,1)
-  {
-    int ipntr = s.head;
-    for (int is = m; is < m + upcl; ++is) {
-      int jpntr = s.head;
-      for (int jy = 0; jy < upcl; ++jy) {
-        double temp1 = 0.0, temp3 = 0.0;
-        for (int k = 0; k < s.nenter; ++k) {
-          const int k1 = indx2[k] - 1;
-          temp1 += WS(k1, ipntr) * WY(k1, jpntr);
-        }
-        for (int k = s.ileave - 1; k < n; ++k) {
-          const int k1 = indx2[k] - 1;
-          temp3 += WS(k1, ipntr) * WY(k1, jpntr);
-        }
-        if (is <= jy + m)
-          WN1(is, jy) += temp1 - temp3;
-        else
-          WN1(is, jy) += -temp1 + temp3;
-        jpntr = (jpntr + 1) % m;
-      }
-      ipntr = (ipntr + 1) % m;
-    }
-  }
+  LB_LANES_SYNC();
   // upper triangle of WN = [D+Y'ZZ'Y/theta   -L_a'+R_z'] [-L_a+R_z   S'AA'S*theta]
+  // (each iy writes its own columns iy and col+iy)
   const double theta = s.theta;
-  for (int iy = 0; iy < col; ++iy) {
+  for (int iy = c.lane; iy < col; iy += c.nl) {
     const int is = col + iy, is1 = m + iy;
     for (int jy = 0; jy <= iy; ++jy) {
       const int js = col + jy, js1 = m + jy;
@@ -672,14 +689,21 @@ LB_HDN int formk(const IterArgs s, const Work w) {
     for (int jy = iy; jy < col; ++jy) WN(jy, is) = WN1(is1, jy);
     WN(iy, iy) += w.sy[iy * m + iy];
   }
-  // Cholesky of the (1,1) block, then L^-1(-L_a'+R_z') in the (1,2) block
+  LB_LANES_SYNC();
+  // Cholesky of the (1,1) block, then L^-1(-L_a'+R_z') in the (1,2) block (one right-hand
+  // side per lane)
   if (dpofa(wn, m2, col)) return -1;
   const int col2 = 2 * col;
-  for (int js = col; js < col2; ++js)
-    if (dtrsl_upper(wn, m2, col, wn + js * m2, 1)) return -1;
+  for (int j = 0; j < col; ++j)
+    if (wn[j * m2 + j] == 0.0) return -1;
+  for (int js = col + c.lane; js < col2; js += c.nl) dtrsl_upper(wn, m2, col, wn + js * m2, 1);
+  LB_LANES_SYNC();
   // (2,2) block: S'AA'S*theta + (L^-1(-L_a'+R_z'))'(L^-1(-L_a'+R_z')), then its Cholesky
-  for (int is = col; is < col2; ++is)
-    for (int js = is; js < col2; ++js) WN(is, js) += ddot(col, wn + is * m2, wn + js * m2);
+  for (int e = c.lane; e < col * col; e += c.nl) {
+    const int is = col + e / col, js = col + e % col;
+    if (js >= is) WN(is, js) += ddot(col, wn + is * m2, wn + js * m2);
+  }
+  LB_LANES_SYNC();
   if (dpofa(wn + col * m2 + col, m2, col)) return -2;
   return 0;
 #undef WN
@@ -689,7 +713,7 @@ LB_HDN int formk(const IterArgs s, const Work w) {
 }
 
 // r = -Z'B(xcp - x) - Z'g   (uses c = wa[2m..4m) from cauchy; p = wa[0..2m) as scratch)
-LB_HD int cmprlb(State &s, const Work &w) {
+LB_HD int cmprlb(State &s, const Work &w, const Coop c) {
   const int n = s.n, m = s.m, col = s.col;
   if (!s.cnstnd && col > 0) {
     for (int i = 0; i < n; ++i) w.r[i] = -w.g[i];
@@ -699,7 +723,7 @@ LB_HD int cmprlb(State &s, const Work &w) {
     const int k = w.index[i] - 1;
     w.r[i] = -s.theta * (w.z[k] - w.x[k]) - w.g[k];
   }
-  if (bmv(m, w.sy, w.wt, col, w.wa + 2 * m, w.wa)) return -8;
+  if (bmv(m, w.sy, w.wt, col, w.wa + 2 * m, w.wa, c)) return -8;
   int pointr = s.head;
   for (int j = 0; j < col; ++j) {
     const double a1 = w.wa[j], a2 = s.theta * w.wa[col + j];
@@ -724,8 +748,9 @@ LB_HDN int subsm(const IterArgs s, const Work w, const double *l, const double *
   const int *ind = w.index;
   const double theta = s.theta;
   if (nsub <= 0) return 0;
-  int pointr = s.head;
-  for (int i = 0; i < col; ++i) {
+  const Coop c = s.c;
+  for (int i = c.lane; i < col; i += c.nl) {  // wv = W'Zd, one entry pair per i
+    const int pointr = (s.head + i) % m;
     double temp1 = 0.0, temp2 = 0.0;
     for (int j = 0; j < nsub; ++j) {
       const int k = ind[j] - 1;
@@ -734,21 +759,21 @@ LB_HDN int subsm(const IterArgs s, const Work w, const double *l, const double *
     }
     wv[i] = temp1;
     wv[col + i] = theta * temp2;
-    pointr = (pointr + 1) % m;
   }
+  LB_LANES_SYNC();
   if (dtrsl_upper(w.wn, m2, col2, wv, 1)) return 1;
   for (int i = 0; i < col; ++i) wv[i] = -wv[i];
   if (dtrsl_upper(w.wn, m2, col2, wv, 0)) return 1;
-  pointr = s.head;
-  for (int jy = 0; jy < col; ++jy) {
-    const int js = col + jy;
-    for (int i = 0; i < nsub; ++i) {
-      const int k = ind[i] - 1;
-      d[i] += w.wy[pointr * n + k] * wv[jy] / theta + w.ws[pointr * n + k] * wv[js];
+  for (int i = c.lane; i < nsub; i += c.nl) {  // d = (1/theta)d + (1/theta^2)Z'W wv, per entry
+    const int k = ind[i] - 1;
+    double di = d[i];
+    for (int jy = 0; jy < col; ++jy) {
+      const int pointr = (s.head + jy) % m;
+      di += w.wy[pointr * n + k] * wv[jy] / theta + w.ws[pointr * n + k] * wv[col + jy];
     }
-    pointr = (pointr + 1) % m;
+    d[i] = di * (1.0 / theta);
   }
-  for (int i = 0; i < nsub; ++i) d[i] *= 1.0 / theta;
+  LB_LANES_SYNC();
   // projected Newton step
   iword = 0;
   for (int i = 0; i < n; ++i) xp[i] = x[i];
@@ -1105,8 +1130,10 @@ LB_HD void lbfgsb_init(State &s, const Work &w, int n, int m, const double *x0, 
 // Advance the problem until it needs f and g at w.x (LB_NEED_FG: the caller stores them in
 // s.f / w.g and calls again) or terminates (LB_DONE: result in w.x, s.f, w.g, s.nit,
 // s.nfev, s.status, s.task, s.msg).
+// `coop`: {0, 1} for a thread that owns its problem alone; {lane, 64} when the 64 lanes of a
+// wave run ONE problem together (every lane calls with identical State; see struct Coop).
 LB_HD int lbfgsb_advance(State &s, const Work &w, const double *l, const double *u,
-                          const int *nbd, const Options &opt) {
+                         const int *nbd, const Options &opt, const Coop coop = Coop{0, 1}) {
   const int n = s.n, m = s.m;
   bool first_ls = false;
   bool resume_ls = (s.stage == S_FG_LNSRCH);
@@ -1183,7 +1210,7 @@ LB_HD int lbfgsb_advance(State &s, const Work &w, const double *l, const double 
         s.nseg = 0;
       } else {
         const IterArgs ia{n, m, s.col, s.head, s.nfree, s.nenter, s.ileave, s.updatd, s.iupdat,
-                          s.theta, s.sbgnrm};
+                          s.theta, s.sbgnrm, coop};
         const int rc = cauchy(ia, w, l, u, nbd);
         s.nseg = rc >> 8;
         if (rc & 0xff) {  // singular triangular system: refresh the memory
@@ -1197,12 +1224,12 @@ LB_HD int lbfgsb_advance(State &s, const Work &w, const double *l, const double 
       }
       if (s.nfree != 0 && s.col != 0) {
         const IterArgs ia{n, m, s.col, s.head, s.nfree, s.nenter, s.ileave, s.updatd, s.iupdat,
-                          s.theta, s.sbgnrm};
+                          s.theta, s.sbgnrm, coop};
         if (s.wrk) {
           if (formk(ia, w)) { refresh_memory(s); continue; }
         }
         TOC(3);
-        if (cmprlb(s, w)) { refresh_memory(s); continue; }
+        if (cmprlb(s, w, coop)) { refresh_memory(s); continue; }
         const int rc = subsm(ia, w, l, u, nbd);
         s.iword = rc >> 8;
         if (rc & 0xff) { refresh_memory(s); continue; }
@@ -1289,7 +1316,7 @@ LB_HD int lbfgsb_advance(State &s, const Work &w, const double *l, const double 
       ++s.iupdat;
       matupd(s, w, rr, dr);
       TOC(9);
-      if (formt(m, w.wt, w.sy, w.ss, s.col, s.theta)) {
+      if (formt(m, w.wt, w.sy, w.ss, s.col, s.theta, coop)) {
         refresh_memory(s);
         continue;
       }

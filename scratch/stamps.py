@@ -18,5 +18,5 @@ def run(N,units=(16,16,1),D=2,acts=("relu","relu","sigmoid")):
     torch.cuda.synchronize()
     out=(C.c_longlong*64)(); lib.bore_debug_stamps(out)
     a=np.array(out[:8]); b=np.array(out[32:40])
-    print(N,units,'wave0 deltas',np.diff(a),'total',a[7]-a[0]); print('   wave1 deltas',np.diff(b))
+    print(N,units,'wave0 deltas',np.diff(a),'total',a[7]-a[0], 'perm', out[11]-out[10]); print('   wave1 deltas',np.diff(b))
 run(16); run(64); run(64,(64,64,64,1),16,("relu",)*3+("linear",))
