@@ -24,13 +24,26 @@ inline int fail(int code, const char *fmt, ...) {
   } while (0)
 
 // Raise the kernel's dynamic-LDS limit to `bytes` (default cap is 64 KiB).
+// The attribute only ever needs to grow: one runtime call per kernel per new high-water mark
+// (hipFuncSetAttribute is a driver round trip -- not something for every launch).
 template <typename K>
 inline int allow_lds(K kernel, size_t bytes) {
   if (bytes > BORE_LDS_BYTES)
     return fail(BORE_E_UNSUPPORTED, "model needs %zu B of LDS per workgroup (> %d)", bytes,
                 BORE_LDS_BYTES);
-  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  struct Seen { const void *k; size_t bytes; };
+  static Seen seen[64];
+  static int n_seen = 0;
+  const void *kp = reinterpret_cast<const void *>(kernel);
+  for (int i = 0; i < n_seen; ++i)
+    if (seen[i].k == kp) {
+      if (bytes <= seen[i].bytes) return 0;
+      HIP_TRY(hipFuncSetAttribute(kp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+      seen[i].bytes = bytes;
+      return 0;
+    }
+  HIP_TRY(hipFuncSetAttribute(kp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  if (n_seen < 64) seen[n_seen++] = Seen{kp, bytes};
   return 0;
 }
 

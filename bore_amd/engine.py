@@ -19,6 +19,8 @@ from __future__ import annotations
 
 import time
 
+import ctypes as _lib_ctypes
+
 import numpy as np
 import torch
 
@@ -38,12 +40,17 @@ class ReplicaEngine:
     def __init__(self, loop_ids, input_dim=2, units=(16, 16, 1), acts=("relu", "relu", "sigmoid"),
                  transform="identity", gamma=0.25, epochs=200, batch_size=64, num_starts=3,
                  num_samples=1024, n_init=10, objective=branin01, max_points=None,
-                 options=None, device=None, mode="device", seed=0):
+                 options=None, device=None, mode="device", seed=0, groups=1):
         """mode "device": label, fit, candidate draw, screening and all L-BFGS-B restarts run
         as five launches per BO iteration with ONE host sync (candidates from the device
         counter stream).  mode "lockstep": candidates from each loop's numpy RandomState and
         SciPy's L-BFGS-B on the host around the batched f/g kernel (the reference's streams
         and optimiser code; slow -- one launch + L*R host state machines per round)."""
+        """groups > 1 (device mode): the loops are split into that many contiguous groups, each
+        stepping on its own HIP stream.  A BO iteration of a group ends when its SLOWEST
+        L-BFGS-B restart does; with several groups in flight one group's tail overlaps the
+        others' fit/argmax instead of idling the GPU (loops never interact, so grouping only
+        changes scheduling -- every loop's trajectory is the same; tested)."""
         assert mode in ("device", "lockstep")
         self.mode, self.seed = mode, int(seed)
         self.device = device or _lib.require_gpu()
@@ -78,38 +85,62 @@ class ReplicaEngine:
         self.adam_m = torch.zeros_like(self.theta)
         self.adam_v = torch.zeros_like(self.theta)
         self.adam_t = torch.zeros(L, dtype=torch.int64, device=self.device)
-        self.epochs_seen = 0
-        self.draws = 0
         # observations
-        self.X = np.stack([rs.uniform(self.low, self.high, size=(n_init, D)) for rs in self.rs])
-        self.y = self.objective(self.X)
+        X0 = np.stack([rs.uniform(self.low, self.high, size=(n_init, D)) for rs in self.rs])
+        y0 = self.objective(X0)
+        self._lo, self._lo_p = ops._host_f64(self.low, D, "low")
+        self._hi, self._hi_p = ops._host_f64(self.high, D, "high")
+        self._adam = _lib.AdamCfg(1e-3, 0.9, 0.999, 1e-7)
+        o = dict(maxcor=10, ftol=2.2204460492503131e-09, gtol=1e-5, maxfun=15000, maxiter=15000,
+                 maxls=20)
+        unknown = set(self.options) - set(o)
+        if unknown:
+            raise TypeError(f"unknown L-BFGS-B options: {sorted(unknown)}")
+        o.update(self.options)
+        self._lopts = _lib.LbfgsbOpts(int(o["maxcor"]), int(o["maxiter"]), int(o["maxfun"]),
+                                      int(o["maxls"]), float(o["ftol"]), float(o["gtol"]))
+        G = max(1, min(int(groups), L)) if mode == "device" else 1
+        bounds = np.linspace(0, L, G + 1).astype(int)
+        self.groups = [_Group(int(a), int(b), X0[a:b], y0[a:b], self)
+                       for a, b in zip(bounds[:-1], bounds[1:])]
         self.stats = dict(fit_ms=[], fit_bytes=[], argmax_ms=[], argmax_bytes=[], n_fg_rows=0,
                           n_rounds=0, none_results=0)
         self._ev, self._ev2 = [], []
 
     @property
     def N(self):
-        return self.X.shape[1]
+        return self.groups[0].X.shape[1]
+
+    @property
+    def X(self):
+        """[L, N, D] observations (all groups are at the same iteration between run() calls)."""
+        return np.concatenate([g.X for g in self.groups], axis=0)
+
+    @property
+    def y(self):
+        return np.concatenate([g.y for g in self.groups], axis=0)
 
     # -- stages ------------------------------------------------------------
     def label(self):
-        tau = np.quantile(self.y, q=self.gamma, axis=1)
-        return np.less(self.y, tau[:, None])
+        y = self.groups[0].y
+        tau = np.quantile(y, q=self.gamma, axis=1)
+        return np.less(y, tau[:, None])
 
     def fit(self, z):
         L, N, D = self.L, self.N, self.D
-        Xd = torch.from_numpy(self.X.astype(np.float32)).to(self.device)
+        g0 = self.groups[0]
+        Xd = torch.from_numpy(g0.X.astype(np.float32)).to(self.device)
         zd = torch.from_numpy(z.astype(np.float32)).to(self.device)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         ops.mlp_fit(self.desc, self.theta, self.adam_m, self.adam_v, self.adam_t, Xd, zd,
                     self.epochs, self.batch_size, seed=self.seed,
-                    model_index0=int(self.loop_ids[0]), epoch0=self.epochs_seen, want_loss=False)
+                    model_index0=int(self.loop_ids[0]), epoch0=g0.epochs_seen, want_loss=False)
         e1.record()
         self._ev.append((e0, e1))
         steps = -(-N // self.batch_size)
         self.stats["fit_bytes"].append(L * self.epochs * (4 * N * (D + 1) + steps * 24 * self.P))
-        self.epochs_seen += self.epochs
+        g0.epochs_seen += self.epochs
 
     def screen(self):
         Xs = np.stack([rs.uniform(self.low, self.high, size=(self.num_samples, self.D))
@@ -153,36 +184,69 @@ class ReplicaEngine:
                 x_next[l] = best.x
         return x_next
 
-    def step_device(self):
-        """One BO iteration of every loop, device-resident: 5 launches, 1 sync."""
-        L, N, D, R = self.L, self.N, self.D, self.num_starts
-        dev = self.device
-        Xd = torch.from_numpy(self.X.astype(np.float32)).to(dev, non_blocking=True)
-        yd = torch.from_numpy(self.y).to(dev, non_blocking=True)
-        zd = ops.labels(yd, self.gamma)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        ops.mlp_fit(self.desc, self.theta, self.adam_m, self.adam_v, self.adam_t, Xd, zd,
-                    self.epochs, self.batch_size, seed=self.seed,
-                    model_index0=int(self.loop_ids[0]), epoch0=self.epochs_seen, want_loss=False)
-        e1.record()
-        self._ev.append((e0, e1))
-        steps = -(-N // self.batch_size)
-        self.stats["fit_bytes"].append(L * self.epochs * (4 * N * (D + 1) + steps * 24 * self.P))
-        self.epochs_seen += self.epochs
-        Xc = ops.uniform_candidates(self.seed, L, self.num_samples, self.low, self.high,
-                                    model_index0=int(self.loop_ids[0]), draw_index=self.draws,
-                                    device=dev)
-        self.draws += 1
-        x0, _ = ops.screen_topk(self.desc, self.theta, Xc, R)
+    def _enqueue(self, g):
+        """Queue one BO iteration of group g on its stream: 5 launches + async copies.  Every
+        buffer is preallocated (an allocation or a pageable copy here would serialise the
+        streams) and the C-ABI is called directly (shapes were validated when the group's
+        buffers were made)."""
+        t_host0 = time.perf_counter()
+        Lg, N, D, R = g.b - g.a, g.X.shape[1], self.D, self.num_starts
+        if N > g.cap:
+            g.alloc_inputs(self, max(2 * g.cap, N))
+        lib, C, ptr = _lib.lib(), _lib_ctypes, _lib.ptr
+        # stage the observations in pinned memory, contiguous [Lg, N, D] / [Lg, N]
+        np.copyto(g.X_pin_np[:Lg * N * D].reshape(Lg, N, D), g.X, casting="same_kind")
+        np.copyto(g.y_pin_np[:Lg * N].reshape(Lg, N), g.y)
+        th, m, v, t = (x[g.a:g.b] for x in (self.theta, self.adam_m, self.adam_v, self.adam_t))
         tr = self.transform.negated()
-        e2, e3 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e2.record()
-        x, fun, _, info = ops.lbfgsb_minimize(self.desc, self.theta, x0, self.low, self.high,
-                                              tr.name, tr.negate, **self.options)
-        e3.record()
-        self._ev2.append((e2, e3))
-        x, fun, info = x.cpu().numpy(), fun.cpu().numpy(), info.cpu().numpy()   # the one sync
+        with torch.cuda.stream(g.stream):
+            sp = _lib.stream_ptr()
+            g.X_dev[:Lg * N * D].copy_(g.X_pin[:Lg * N * D], non_blocking=True)
+            g.y_dev[:Lg * N].copy_(g.y_pin[:Lg * N], non_blocking=True)
+            _lib.check(lib.bore_labels(Lg, ptr(g.y_dev), N, float(self.gamma), ptr(g.z_dev),
+                                       None, sp))
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            _lib.check(lib.bore_mlp_fit(C.byref(self.desc), Lg, ptr(th), ptr(m), ptr(v), ptr(t),
+                                        ptr(g.X_dev), ptr(g.z_dev), N, self.epochs,
+                                        self.batch_size, None, C.c_uint64(self.seed),
+                                        int(self.loop_ids[g.a]), g.epochs_seen,
+                                        C.byref(self._adam), None, sp))
+            e1.record()
+            self._ev.append((e0, e1))
+            steps = -(-N // self.batch_size)
+            self.stats["fit_bytes"].append(Lg * self.epochs * (4 * N * (D + 1)
+                                                               + steps * 24 * self.P))
+            g.epochs_seen += self.epochs
+            _lib.check(lib.bore_uniform_candidates(C.c_uint64(self.seed), int(self.loop_ids[g.a]),
+                                                   Lg, g.draws, self.num_samples, D, self._lo_p,
+                                                   self._hi_p, ptr(g.Xc), sp))
+            g.draws += 1
+            _lib.check(lib.bore_screen_topk(C.byref(self.desc), Lg, ptr(th), ptr(g.Xc),
+                                            self.num_samples, 0, R, ptr(g.x0), ptr(g.idx), None,
+                                            sp))
+            e2, e3 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e2.record()
+            _lib.check(lib.bore_lbfgsb_minimize(C.byref(self.desc), Lg, ptr(th),
+                                                _lib.TRANSFORM[tr.name], int(tr.negate),
+                                                ptr(g.x0), R, self._lo_p, self._hi_p,
+                                                C.byref(self._lopts), ptr(g.x), ptr(g.fun),
+                                                ptr(g.jac), ptr(g.info), sp))
+            e3.record()
+            self._ev2.append((e2, e3))
+            g.x_pin.copy_(g.x, non_blocking=True)
+            g.fun_pin.copy_(g.fun, non_blocking=True)
+            g.info_pin.copy_(g.info, non_blocking=True)
+            g.done.record()
+        g.inflight = True
+        self.stats["host_enqueue_s"] = self.stats.get("host_enqueue_s", 0.0) + time.perf_counter() - t_host0
+
+    def _finalize(self, g):
+        """Host side of a finished iteration of group g: pick each loop's suggestion, evaluate
+        the objective, append."""
+        t_host0 = time.perf_counter()
+        D = self.D
+        x, fun, info = g.x_pin.numpy(), g.fun_pin.numpy(), g.info_pin.numpy()
         nfev = info[:, :, 1]
         self.stats["n_fg_rows"] += int(nfev.sum())
         self.stats["n_rounds"] += int(nfev.max())
@@ -193,26 +257,58 @@ class ReplicaEngine:
         ok = (info[:, :, 2] == 0) | (info[:, :, 2] == 1)          # success or status == 1
         f = np.where(ok, fun, np.inf)
         best = np.argmin(f, axis=1)                                # ties keep the earliest
-        x_next = x[np.arange(L), best]
+        x_next = x[np.arange(g.b - g.a), best].copy()
         none = ~ok.any(axis=1)
         if none.any():                                             # reference: random fallback
             self.stats["none_results"] += int(none.sum())
             for l in np.nonzero(none)[0]:
-                x_next[l] = self.rs[l].uniform(self.low, self.high)
-        return x_next
+                x_next[l] = self.rs[g.a + l].uniform(self.low, self.high)
+        y_next = self.objective(x_next)
+        g.X = np.concatenate([g.X, x_next[:, None, :]], axis=1)
+        g.y = np.concatenate([g.y, y_next[:, None]], axis=1)
+        g.inflight = False
+        g.steps += 1
+        self.stats["host_finalize_s"] = self.stats.get("host_finalize_s", 0.0) + time.perf_counter() - t_host0
+        return x_next, y_next
+
+    def run(self, n_steps):
+        """Advance every loop by n_steps BO iterations.  Groups proceed independently; the
+        host only reacts to completion events."""
+        if self.mode != "device":
+            for _ in range(n_steps):
+                self.step()
+            return
+        target = [g.steps + n_steps for g in self.groups]
+        for g in self.groups:
+            self._enqueue(g)
+        remaining = len(self.groups)
+        while remaining:
+            for i, g in enumerate(self.groups):
+                if g.inflight and g.done.query():
+                    self._finalize(g)
+                    if g.steps < target[i]:
+                        self._enqueue(g)
+                    else:
+                        remaining -= 1
 
     def step(self):
-        """One BO iteration of every loop."""
+        """One BO iteration of every loop; returns (x_next [L, D], y_next [L])."""
         if self.mode == "device":
-            x_next = self.step_device()
-        else:
-            z = self.label()
-            self.fit(z)
-            results = self.restarts(self.screen())
-            x_next = self.suggest(results)
+            for g in self.groups:
+                self._enqueue(g)
+            outs = []
+            for g in self.groups:
+                g.done.synchronize()
+                outs.append(self._finalize(g))
+            return (np.concatenate([o[0] for o in outs]), np.concatenate([o[1] for o in outs]))
+        z = self.label()
+        self.fit(z)
+        results = self.restarts(self.screen())
+        x_next = self.suggest(results)
         y_next = self.objective(x_next)
-        self.X = np.concatenate([self.X, x_next[:, None, :]], axis=1)
-        self.y = np.concatenate([self.y, y_next[:, None]], axis=1)
+        g0 = self.groups[0]
+        g0.X = np.concatenate([g0.X, x_next[:, None, :]], axis=1)
+        g0.y = np.concatenate([g0.y, y_next[:, None]], axis=1)
         return x_next, y_next
 
     def finish_timing(self):
@@ -224,8 +320,48 @@ class ReplicaEngine:
         self._ev, self._ev2 = [], []
 
     def best(self):
-        i = np.argmin(self.y, axis=1)
-        return self.X[np.arange(self.L), i], self.y[np.arange(self.L), i]
+        X, y = self.X, self.y
+        i = np.argmin(y, axis=1)
+        return X[np.arange(self.L), i], y[np.arange(self.L), i]
+
+
+class _Group:
+    """A contiguous block of loops that steps together on its own stream."""
+
+    def __init__(self, a, b, X, y, eng):
+        self.a, self.b = a, b
+        self.X, self.y = np.array(X), np.array(y)
+        self.epochs_seen = self.draws = self.steps = 0
+        self.inflight = False
+        if eng.mode == "device":
+            R, D = eng.num_starts, eng.D
+            self.stream = torch.cuda.Stream(device=eng.device)
+            self.done = torch.cuda.Event()
+            Lg, dev = b - a, eng.device
+            self.x_pin = torch.empty((Lg, R, D), dtype=torch.float64).pin_memory()
+            self.fun_pin = torch.empty((Lg, R), dtype=torch.float64).pin_memory()
+            self.info_pin = torch.empty((Lg, R, 5), dtype=torch.int32).pin_memory()
+            self.Xc = torch.empty((Lg, eng.num_samples, D), dtype=torch.float64, device=dev)
+            self.x0 = torch.empty((Lg, R, D), dtype=torch.float64, device=dev)
+            self.idx = torch.empty((Lg, R), dtype=torch.int32, device=dev)
+            self.x = torch.empty((Lg, R, D), dtype=torch.float64, device=dev)
+            self.jac = torch.empty((Lg, R, D), dtype=torch.float64, device=dev)
+            self.fun = torch.empty((Lg, R), dtype=torch.float64, device=dev)
+            self.info = torch.empty((Lg, R, 5), dtype=torch.int32, device=dev)
+            self.cap = 0
+            self.alloc_inputs(eng, max(256, 2 * self.X.shape[1]))
+
+    def alloc_inputs(self, eng, cap):
+        """(Re)allocate the observation buffers for up to `cap` points per loop."""
+        Lg, D, dev = self.b - self.a, eng.D, eng.device
+        torch.cuda.synchronize()
+        self.cap = int(cap)
+        self.X_pin = torch.empty(Lg * self.cap * D, dtype=torch.float32).pin_memory()
+        self.y_pin = torch.empty(Lg * self.cap, dtype=torch.float64).pin_memory()
+        self.X_pin_np, self.y_pin_np = self.X_pin.numpy(), self.y_pin.numpy()
+        self.X_dev = torch.empty(Lg * self.cap * D, dtype=torch.float32, device=dev)
+        self.y_dev = torch.empty(Lg * self.cap, dtype=torch.float64, device=dev)
+        self.z_dev = torch.empty(Lg * self.cap, dtype=torch.float32, device=dev)
 
 
 def shard_loop_ids(rank, world_size, loops_per_gpu):

@@ -205,3 +205,12 @@ def test_replica_engine_device_mode_runs_bo(gpu):
     for _ in range(8):
         eng2.step()
     assert np.array_equal(eng2.X, eng.X[2:5]) and np.array_equal(eng2.y, eng.y[2:5])
+    # stream groups only change scheduling: same trajectories, stepping or free-running
+    eng3 = ReplicaEngine(np.arange(4, 12), epochs=50, mode="device", groups=3)
+    eng3.run(5)
+    for _ in range(3):
+        eng3.step()
+    eng3.finish_timing()
+    assert [g.b - g.a for g in eng3.groups] == [2, 3, 3] and len(eng3.stats["fit_ms"]) == 24
+    assert np.array_equal(eng3.X, eng.X) and np.array_equal(eng3.y, eng.y)
+    assert torch.equal(eng3.theta, eng.theta) and torch.equal(eng3.adam_t, eng.adam_t)
