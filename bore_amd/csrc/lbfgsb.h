@@ -422,7 +422,8 @@ LB_HDN int cauchy(const IterArgs s, const Work w, const double *l, const double 
   bool bnded = true;
   int nfree = n + 1, nbreak = 0, ibkmin = 0;
   double bkmin = 0.0, f1 = 0.0;
-  for (int i = 0; i < col2; ++i) p[i] = 0.0;
+  const Coop cp = s.c;
+  for (int i = cp.lane; i < col2; i += cp.nl) p[i] = 0.0;  // lane j owns p[j] throughout
 
   for (int i = 1; i <= n; ++i) {
     const double neggi = -g[i - 1];
@@ -447,10 +448,10 @@ LB_HDN int cauchy(const IterArgs s, const Work w, const double *l, const double 
     } else {
       d[i - 1] = neggi;
       f1 -= neggi * neggi;
-      for (int j = 0; j < col; ++j) {
-        p[j] += w.wy[pointr * n + (i - 1)] * neggi;
-        p[col + j] += w.ws[pointr * n + (i - 1)] * neggi;
-        pointr = (pointr + 1) % m;
+      for (int j = cp.lane; j < col; j += cp.nl) {
+        const int pj = (pointr + j) % m;
+        p[j] += w.wy[pj * n + (i - 1)] * neggi;
+        p[col + j] += w.ws[pj * n + (i - 1)] * neggi;
       }
       if (nbd[i - 1] <= 2 && nbd[i - 1] != 0 && neggi < 0.0) {
         ++nbreak;
@@ -476,10 +477,11 @@ LB_HDN int cauchy(const IterArgs s, const Work w, const double *l, const double 
     }
   }
   if (theta != 1.0)
-    for (int j = 0; j < col; ++j) p[col + j] *= theta;
+    for (int j = cp.lane; j < col; j += cp.nl) p[col + j] *= theta;
   for (int i = 0; i < n; ++i) xcp[i] = x[i];
   if (nbreak == 0 && nfree == n + 1) return LB_CAUCHY_RET(0);  // d is zero: GCP = x
-  for (int j = 0; j < col2; ++j) c[j] = 0.0;
+  for (int j = cp.lane; j < col2; j += cp.nl) c[j] = 0.0;
+  LB_LANES_SYNC();
 
   double f2 = -theta * f1;
   const double f2_org = f2;
@@ -539,19 +541,20 @@ LB_HDN int cauchy(const IterArgs s, const Work w, const double *l, const double 
       f1 = f1 + dt * f2 + dibp2 - theta * dibp * zibp;
       f2 = f2 - theta * dibp2;
       if (col > 0) {
-        for (int j = 0; j < col2; ++j) c[j] += dt * p[j];
-        int pointr = s.head;
-        for (int j = 0; j < col; ++j) {
-          wbp[j] = w.wy[pointr * n + (ibp - 1)];
-          wbp[col + j] = theta * w.ws[pointr * n + (ibp - 1)];
-          pointr = (pointr + 1) % m;
+        for (int j = cp.lane; j < col2; j += cp.nl) c[j] += dt * p[j];
+        for (int j = cp.lane; j < col; j += cp.nl) {
+          const int pj = (s.head + j) % m;
+          wbp[j] = w.wy[pj * n + (ibp - 1)];
+          wbp[col + j] = theta * w.ws[pj * n + (ibp - 1)];
         }
+        LB_LANES_SYNC();
         const int info = bmv(m, w.sy, w.wt, col, wbp, v, s.c);
         if (info) return LB_CAUCHY_RET(info);
         const double wmc = ddot(col2, c, v);
         const double wmp = ddot(col2, p, v);
         const double wmw = ddot(col2, wbp, v);
-        for (int j = 0; j < col2; ++j) p[j] -= dibp * wbp[j];
+        for (int j = cp.lane; j < col2; j += cp.nl) p[j] -= dibp * wbp[j];
+        LB_LANES_SYNC();
         f1 += dibp * wmc;
         f2 += 2.0 * dibp * wmp - dibp2 * wmw;
       }
@@ -575,7 +578,8 @@ LB_HDN int cauchy(const IterArgs s, const Work w, const double *l, const double 
     for (int i = 0; i < n; ++i) xcp[i] += tsum * d[i];
   }
   if (col > 0)
-    for (int j = 0; j < col2; ++j) c[j] += dtm * p[j];
+    for (int j = cp.lane; j < col2; j += cp.nl) c[j] += dtm * p[j];
+  LB_LANES_SYNC();
   return LB_CAUCHY_RET(0);
 #undef LB_CAUCHY_RET
 }
@@ -767,15 +771,17 @@ LB_HD int cmprlb(State &s, const Work &w, const Coop c) {
     w.r[i] = -s.theta * (w.z[k] - w.x[k]) - w.g[k];
   }
   if (bmv(m, w.sy, w.wt, col, w.wa + 2 * m, w.wa, c)) return -8;
-  int pointr = s.head;
-  for (int j = 0; j < col; ++j) {
-    const double a1 = w.wa[j], a2 = s.theta * w.wa[col + j];
-    for (int i = 0; i < s.nfree; ++i) {
-      const int k = w.index[i] - 1;
-      w.r[i] += w.wy[pointr * n + k] * a1 + w.ws[pointr * n + k] * a2;
+  for (int i = c.lane; i < s.nfree; i += c.nl) {  // each r[i]: its terms in the order j = 0, 1, ...
+    const int k = w.index[i] - 1;
+    double ri = w.r[i];
+    for (int j = 0; j < col; ++j) {
+      const int pointr = (s.head + j) % m;
+      const double a1 = w.wa[j], a2 = s.theta * w.wa[col + j];
+      ri += w.wy[pointr * n + k] * a1 + w.ws[pointr * n + k] * a2;
     }
-    pointr = (pointr + 1) % m;
+    w.r[i] = ri;
   }
+  LB_LANES_SYNC();
   return 0;
 }
 

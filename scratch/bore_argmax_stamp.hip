@@ -389,7 +389,7 @@ __global__ __launch_bounds__(BORE_THREADS) void lbfgsb_kernel(const LbfgsbArgs a
   }
 
   if (coop && lane != 0) return;
-  if (myp >= 0) { for (int i = 0; i < 11; ++i) atomicAdd(&lbfgsb::g_acc[i], (unsigned long long)st.acc[i]); atomicAdd(&lbfgsb::g_acc[11], (unsigned long long)t_fg); atomicAdd(&lbfgsb::g_acc[12], (unsigned long long)(clock64() - t_all0)); atomicAdd(&lbfgsb::g_acc[13], (unsigned long long)st.nit); atomicAdd(&lbfgsb::g_acc[14], (unsigned long long)st.nfev); atomicMax(&lbfgsb::g_acc[15], (unsigned long long)(clock64() - t_all0)); }  // one lane reports the shared problem
+  if (myp >= 0) { for (int i = 0; i < 12; ++i) if (i != 11) atomicAdd(&lbfgsb::g_acc[i], (unsigned long long)st.acc[i]); atomicAdd(&lbfgsb::g_acc[4], (unsigned long long)st.acc[11]*0); atomicAdd(&lbfgsb::g_acc[11], (unsigned long long)t_fg); atomicAdd(&lbfgsb::g_acc[12], (unsigned long long)(clock64() - t_all0)); atomicAdd(&lbfgsb::g_acc[13], (unsigned long long)st.nit); atomicAdd(&lbfgsb::g_acc[14], (unsigned long long)st.nfev); atomicAdd(&lbfgsb::g_acc[15], (unsigned long long)st.acc[11]); }  // one lane reports the shared problem
   if (myp >= 0) {
     const long long q = model * a.R + p0 + myp;
     if (st.stage != lbfgsb::S_FINISHED) {  // round cap hit (cannot happen with a sane cap)

@@ -207,7 +207,34 @@ LB_HD void daxpy(int n, double alpha, const double *x, double *y) {
 // Cholesky of the leading n x n block of a (leading dimension ld), upper triangle:
 // A = R'R with R stored in the upper triangle.  Returns 0, or k>0 if the leading minor
 // of order k is not positive definite.
-LB_HD int dpofa(double *a, int ld, int n) {
+//
+// With one lane per column (c.nl >= n) the factorisation runs as a wavefront: at step k lane
+// k finishes the diagonal R_kk, then every lane j > k computes its entry R_kj.  Each entry is
+// produced by the same operations in the same order as in the sequential loop nest (its
+// dot product runs over i ascending, the column's sum of squares over k ascending), so the
+// two forms give identical bits; the chain is n steps long instead of n^2/2.
+LB_HD int dpofa(double *a, int ld, int n, const Coop c = Coop{0, 1}) {
+  if (c.nl >= n && c.nl > 1) {
+    const int j = c.lane;
+    double s = 0.0;
+    for (int k = 0; k < n; ++k) {
+      if (j == k) {
+        const double dkk = a[k * ld + k] - s;
+        a[k * ld + k] = dkk <= 0.0 ? dkk : sqrt(dkk);  // <= 0 marks "not positive definite"
+      }
+      LB_LANES_SYNC();
+      const double rkk = a[k * ld + k];
+      if (rkk <= 0.0) return k + 1;
+      if (j > k && j < n) {
+        double t = a[j * ld + k] - ddot(k, a + k * ld, a + j * ld);
+        t = t / rkk;
+        a[j * ld + k] = t;
+        s += t * t;
+      }
+      LB_LANES_SYNC();
+    }
+    return 0;
+  }
   for (int j = 0; j < n; ++j) {
     double s = 0.0;
     for (int k = 0; k < j; ++k) {
@@ -225,9 +252,34 @@ LB_HD int dpofa(double *a, int ld, int n) {
 
 // Triangular solves with the UPPER triangle of t (leading dimension ld):
 // trans == 0:  T x = b;   trans != 0:  T' x = b.   Returns 0, or k>0 for a zero diagonal.
-LB_HD int dtrsl_upper(const double *t, int ld, int n, double *b, int trans) {
+// c.nl >= n: lane i owns x_i.  As soon as an unknown is final it is broadcast and every lane
+// still waiting folds it into its own running sum -- the same products, added in the same
+// order, as the sequential substitution (identical bits), n steps instead of n^2/2.
+LB_HD int dtrsl_upper(const double *t, int ld, int n, double *b, int trans,
+                      const Coop c = Coop{0, 1}) {
   for (int j = 0; j < n; ++j)
     if (t[j * ld + j] == 0.0) return j + 1;
+  if (c.nl >= n && c.nl > 1) {
+    const int me = c.lane;
+    const bool mine = me < n;
+    if (!trans) {  // T x = b, backward; the sequential form applies b[i] += (-x_j) T_ij, j descending
+      double bi = mine ? b[me] : 0.0;
+      for (int j = n - 1; j >= 0; --j) {
+        if (me == j) b[j] = bi / t[j * ld + j];
+        LB_LANES_SYNC();
+        if (mine && me < j) bi = bi + (-b[j]) * t[j * ld + me];
+      }
+    } else {  // T' x = b, forward; the sequential form is x_j = (b_j - sum_{i<j} T_ij x_i) / T_jj
+      double bj = mine ? b[me] : 0.0, acc = 0.0;
+      for (int i = 0; i < n; ++i) {
+        if (me == i) b[i] = i == 0 ? bj / t[0] : (bj - acc) / t[i * ld + i];
+        LB_LANES_SYNC();
+        if (mine && me > i) acc += t[me * ld + i] * b[i];
+      }
+    }
+    LB_LANES_SYNC();
+    return 0;
+  }
   if (!trans) {
     b[n - 1] = b[n - 1] / t[(n - 1) * ld + (n - 1)];
     for (int j = n - 2; j >= 0; --j) {
@@ -254,11 +306,11 @@ LB_HD int bmv(int m, const double *sy, const double *wt, int col, const double *
   for (int i = c.lane; i < col; i += c.nl)
     p[col + i] = i == 0 ? v[col] : v[col + i] + dot_div(i, sy + i, m, v, 1, sy, m + 1);
   LB_LANES_SYNC();
-  int info = dtrsl_upper(wt, m, col, p + col, 1);
+  int info = dtrsl_upper(wt, m, col, p + col, 1, c);
   if (info) return info;
   // solve [ -D^(1/2)   D^(-1/2)*L' ] [ p1 ] = [ p1 ]
   //       [  0         J'          ] [ p2 ]   [ p2 ]
-  info = dtrsl_upper(wt, m, col, p + col, 0);
+  info = dtrsl_upper(wt, m, col, p + col, 0, c);
   if (info) return info;
   for (int i = c.lane; i < col; i += c.nl) {
     const double sq = sqrt(sy[i * m + i]);
@@ -280,7 +332,7 @@ LB_HD int formt(int m, double *wt, const double *sy, const double *ss, int col, 
     else wt[j * m + i] = dot_div(i, sy + i, m, sy + j, m, sy, m + 1) + theta * ss[j * m + i];
   }
   LB_LANES_SYNC();
-  return dpofa(wt, m, col) ? -3 : 0;
+  return dpofa(wt, m, col, c) ? -3 : 0;
 }
 
 // ---- projected gradient norm -------------------------------------------------------
@@ -692,7 +744,7 @@ LB_HDN int formk(const IterArgs s, const Work w) {
   LB_LANES_SYNC();
   // Cholesky of the (1,1) block, then L^-1(-L_a'+R_z') in the (1,2) block (one right-hand
   // side per lane)
-  if (dpofa(wn, m2, col)) return -1;
+  if (dpofa(wn, m2, col, c)) return -1;
   const int col2 = 2 * col;
   for (int j = 0; j < col; ++j)
     if (wn[j * m2 + j] == 0.0) return -1;
@@ -704,7 +756,7 @@ LB_HDN int formk(const IterArgs s, const Work w) {
     if (js >= is) WN(is, js) += ddot(col, wn + is * m2, wn + js * m2);
   }
   LB_LANES_SYNC();
-  if (dpofa(wn + col * m2 + col, m2, col)) return -2;
+  if (dpofa(wn + col * m2 + col, m2, col, c)) return -2;
   return 0;
 #undef WN
 #undef WN1
@@ -761,9 +813,9 @@ LB_HDN int subsm(const IterArgs s, const Work w, const double *l, const double *
     wv[col + i] = theta * temp2;
   }
   LB_LANES_SYNC();
-  if (dtrsl_upper(w.wn, m2, col2, wv, 1)) return 1;
+  if (dtrsl_upper(w.wn, m2, col2, wv, 1, c)) return 1;
   for (int i = 0; i < col; ++i) wv[i] = -wv[i];
-  if (dtrsl_upper(w.wn, m2, col2, wv, 0)) return 1;
+  if (dtrsl_upper(w.wn, m2, col2, wv, 0, c)) return 1;
   for (int i = c.lane; i < nsub; i += c.nl) {  // d = (1/theta)d + (1/theta^2)Z'W wv, per entry
     const int k = ind[i] - 1;
     double di = d[i];
@@ -1230,6 +1282,7 @@ LB_HD int lbfgsb_advance(State &s, const Work &w, const double *l, const double 
         }
         TOC(3);
         if (cmprlb(s, w, coop)) { refresh_memory(s); continue; }
+        TOC(11);
         const int rc = subsm(ia, w, l, u, nbd);
         s.iword = rc >> 8;
         if (rc & 0xff) { refresh_memory(s); continue; }
