@@ -132,10 +132,21 @@ def main():
         fit_ms = np.array(eng.stats["fit_ms"])
         fit_bytes = np.array(eng.stats["fit_bytes"], dtype=np.float64)
 
+        # HBM traffic per launch from the committed PMC pass (FETCH_SIZE / WRITE_SIZE, gfx950
+        # correction applied): it is per model, launches here carry loops/groups models
+        try:
+            with open(os.path.join(ROOT, "profiles", "r1", "pmc_traffic.json")) as f:
+                pmc = json.load(f)
+        except Exception:
+            pmc = {}
+        models_per_launch = args.loops / len(eng.groups)
+
         def roof(name, ms, nbytes):
             ach = nbytes.sum() / (ms.sum() * 1e-3) / 1e9
+            per_model = pmc.get(name, {}).get("hbm_bytes_per_model")
             return {"bound": "hbm", "kernel": name, "achieved": ach, "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                    "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                    "traffic": None if per_model is None else per_model * models_per_launch,
                     "avg_launch_ms": float(ms.mean()),
                     "algorithmic_bytes_per_launch": float(nbytes.mean()),
                     "launches": int(len(ms)),
