@@ -148,9 +148,10 @@ class MaximizableMixin:
 
 
 class BatchMaximizableMixin(MaximizableMixin):
-    """bore/mixins.py:92-116.  ``_func_max`` (the SVGD objective: value + input gradient of
-    ``transform(f(x))``) runs on the same kernel; the SVGD driver itself is SURVEY.md §8
-    row f-2 ("next") and is not part of this build yet."""
+    """bore/mixins.py:92-116: batch acquisition by Stein variational gradient descent.
+    ``_func_max`` (value + input gradient of ``transform(f(x))`` for all particles) is one
+    HIP launch per SVGD iteration; the particle interaction is the reference's float64 numpy
+    arithmetic (bore_amd/optimizers/svgd.py)."""
 
     def __init__(self, transform=identity, *args, **kwargs):
         super(BatchMaximizableMixin, self).__init__(transform, *args, **kwargs)
@@ -159,5 +160,8 @@ class BatchMaximizableMixin(MaximizableMixin):
     def argmax_batch(self, batch_size, bounds, length_scale=None, n_iter=1000,
                      step_size=1e-3, alpha=.9, eps=1e-6, tau=1.0, lambd=None,
                      random_state=None):
-        raise NotImplementedError("argmax_batch (SVGD batch acquisition) is outside the hot "
-                                  "path built so far (SURVEY.md §8 row f-2)")
+        from .optimizers.svgd import SVGD, DistortionConstant, DistortionExpDecay, RadialBasis
+        distortion = DistortionConstant() if lambd is None else DistortionExpDecay(lambd=lambd)
+        svgd = SVGD(kernel=RadialBasis(length_scale=length_scale), n_iter=n_iter,
+                    step_size=step_size, alpha=alpha, eps=eps, tau=tau, distortion=distortion)
+        return svgd.optimize(self._func_max, batch_size, bounds=bounds, random_state=random_state)

@@ -146,7 +146,42 @@ def mlp_vectors():
         json.dump(meta, f, indent=1)
 
 
+def svgd_vectors():
+    """Trajectories of the REFERENCE's SVGD (bore.optimizers.svgd imports without TensorFlow)
+    on a fixed float64 objective: the oracle MLP's T(f) value/gradient."""
+    from bore.optimizers.svgd.base import SVGD, DistortionConstant, DistortionExpDecay, rank
+    from bore.optimizers.svgd.kernels import RadialBasis
+    from oracle import bore_oracle as O
+    out = {}
+    rs = np.random.RandomState(7)
+    D, units, acts = 3, [16, 16, 1], ["tanh", "relu", "linear"]
+    params = O.glorot_uniform_params(D, units, rs, dtype=np.float64)
+
+    def func(X):      # T(f) with T = sigmoid: negate the oracle's T(-f) convention
+        q = [p.copy() for p in params]
+        q[-2] = -q[-2]; q[-1] = -q[-1]                 # f -> -f on a linear output layer
+        v, g = O.value_and_input_grad(q, acts, X, "sigmoid", dtype=np.float64)
+        return v, g
+
+    for k, (n, ls, lambd, n_iter) in enumerate([(4, 0.5, None, 50), (16, None, None, 50),
+                                                 (16, 1.0, 1.0, 30), (64, None, 0.5, 20)]):
+        x0 = rs.uniform(size=(n, D))
+        dist = DistortionConstant() if lambd is None else DistortionExpDecay(lambd=lambd)
+        svgd = SVGD(kernel=RadialBasis(length_scale=ls), n_iter=n_iter, step_size=1e-2,
+                    distortion=dist)
+        out[f"x0_{k}"] = x0
+        out[f"x_{k}"] = svgd.optimize_from_init(func, x0, bounds=[(0.0, 1.0)] * D)
+        K, Kg = RadialBasis(length_scale=ls).value_and_grad(x0)
+        out[f"K_{k}"], out[f"Kg_{k}"] = K, Kg
+        out[f"rank_{k}"] = rank(func(x0)[0])
+        out[f"cfg_{k}"] = np.array([n, -1 if ls is None else ls, -1 if lambd is None else lambd, n_iter])
+    for i, p in enumerate(params):
+        out[f"p_{i}"] = p
+    np.savez_compressed(os.path.join(HERE, "ref_svgd.npz"), **out)
+
+
 if __name__ == "__main__":
     ref_vectors()
     mlp_vectors()
+    svgd_vectors()
     print("golden vectors written to", HERE)
