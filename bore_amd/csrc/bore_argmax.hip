@@ -158,16 +158,16 @@ __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
 template <int SHAPE>
 __global__ __launch_bounds__(BORE_THREADS) void screen_topk_kernel(const ScreenArgs a) {
   extern __shared__ float smem[];
-  constexpr MlpLayout Lc = bore_static_layout(SHAPE, 0, BORE_BATCH_MAX);
+  constexpr MlpLayout Lc = bore_static_layout(SHAPE > 0 ? SHAPE : 0, 0, BORE_BATCH_MAX);
   const MlpLayout &L = begin_kernel<SHAPE>(Lc, a.L, smem, a.total, a.o_layout);
   const int tid = threadIdx.x, nthr = blockDim.x;
   const long long model = blockIdx.x;
-  const int n = L.n_layers, D = L.w[0];
+  const int n = layer_count<SHAPE>(L), D = L.w[0];
   const int Ns = (int)a.n_samples;
   float *th = smem, *tile = smem + a.o_tile;
   unsigned long long *keys = reinterpret_cast<unsigned long long *>(smem + a.o_keys);
   const int wv = tid >> 6, lane = tid & 63, m16 = lane & 15, q4 = lane >> 4;
-  load_theta(L, a.theta + model * L.P, th);
+  load_theta(L, n, a.theta + model * L.P, th);
   const double *X = a.X + (a.x_shared ? 0 : model * a.n_samples * D);
   __syncthreads();
   // predictions -> sort keys: ascending key == descending prediction, ties to the lower row.
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(BORE_THREADS) void screen_topk_kernel(const ScreenA
       float *A0 = tile + L.aoff[0] + (wv * 16 + m16) * L.lda[0];
       for (int d = q4; d < D; d += 4) A0[d] = row < Ns ? (float)X[(long long)row * D + d] : 0.f;
       wave_lds_sync();
-      fwd_all(L, th, tile, wv, false);
+      fwd_all(L, n, th, tile, wv, false);
       if (lane < 16 && g * 16 + lane < Ns) {
         const int r = g * 16 + lane;
         const float p = tile[L.aoff[n] + (wv * 16 + lane) * L.lda[n]];
@@ -271,7 +271,7 @@ extern "C" int bore_screen_topk(const bore_mlp_desc *desc, int n_models, const f
   a.total = (int)off;
   off = (off + 3) & ~(size_t)3;
   a.o_layout = (int)off; off += BORE_LAYOUT_FLOATS;
-  const int shape = a.L.tb == BORE_BATCH_MAX ? bore_match_shape(desc) : 0;
+  const int shape = bore_kernel_flavour(desc, a.L.tb == BORE_BATCH_MAX);
 #define BORE_LAUNCH_SCREEN(S)                                                                 \
   case S:                                                                                     \
     rc = allow_lds(screen_topk_kernel<S>, off * 4);                                           \
@@ -282,6 +282,10 @@ extern "C" int bore_screen_topk(const bore_mlp_desc *desc, int n_models, const f
   switch (shape) {
     BORE_LAUNCH_SCREEN(1)
     BORE_LAUNCH_SCREEN(2)
+    BORE_LAUNCH_SCREEN(-1)
+    BORE_LAUNCH_SCREEN(-2)
+    BORE_LAUNCH_SCREEN(-3)
+    BORE_LAUNCH_SCREEN(-4)
     default:
     BORE_LAUNCH_SCREEN(0)
   }
@@ -317,12 +321,12 @@ struct LbfgsbArgs {
 template <int SHAPE>
 __global__ __launch_bounds__(BORE_THREADS) void lbfgsb_kernel(const LbfgsbArgs a) {
   extern __shared__ float smem[];
-  constexpr MlpLayout Lc = bore_static_layout(SHAPE, 2, BORE_BATCH_MAX);
+  constexpr MlpLayout Lc = bore_static_layout(SHAPE > 0 ? SHAPE : 0, 2, BORE_BATCH_MAX);
   const MlpLayout &L = begin_kernel<SHAPE>(Lc, a.L, smem, a.total, a.o_layout);
   const int tid = threadIdx.x;
   const int wv = tid >> 6, lane = tid & 63;
   const long long model = blockIdx.x;
-  const int D = L.w[0];
+  const int n_lay = layer_count<SHAPE>(L), D = L.w[0];
   const int p0 = blockIdx.y * a.PB;               // first problem of this workgroup
   const int np = min(a.PB, a.R - p0);             // problems here (>= 1 by grid construction)
   float *th = smem, *tile = smem + a.o_tile, *vals = smem + a.o_vals;
@@ -334,7 +338,7 @@ __global__ __launch_bounds__(BORE_THREADS) void lbfgsb_kernel(const LbfgsbArgs a
     bhi[tid] = a.box.hi[tid];
     bnbd[tid] = a.nbd[tid];
   }
-  load_theta(L, a.theta + model * L.P, th);
+  load_theta(L, n_lay, a.theta + model * L.P, th);
   __syncthreads();
 
   // Which problem this thread works on.  With at most one problem per wave (np <= 4: the
@@ -374,7 +378,7 @@ __global__ __launch_bounds__(BORE_THREADS) void lbfgsb_kernel(const LbfgsbArgs a
     }
     if (!__any(pending)) break;  // every problem of this wave has terminated
     wave_lds_sync();
-    fg_rowblock(L, th, tile, wv, a.transform, a.sign, vals);
+    fg_rowblock(L, n_lay, th, tile, wv, a.transform, a.sign, vals);
     if (pending) {
       st.f = (double)vals[myrow];
       const float *g = tile + L.doff[0] + myrow * L.lda[0];
@@ -449,7 +453,8 @@ extern "C" int bore_lbfgsb_minimize(const bore_mlp_desc *desc, int n_models, con
   // largest number of problems per workgroup whose state fits beside theta and the tile
   // (tile rows: one 16-row block per wave that has a problem)
   int PB = num_starts < BORE_BATCH_MAX ? num_starts : BORE_BATCH_MAX;
-  const int shape = bore_match_shape(desc);  // constexpr-layout kernels assume a 64-row tile
+  const int flavour = bore_kernel_flavour(desc, true);
+  const int shape = flavour > 0 ? flavour : 0;  // constexpr-layout kernels assume a 64-row tile
   size_t off = 0;
   for (;; --PB) {
     if (PB < 1) return fail(BORE_E_UNSUPPORTED, "lbfgsb_minimize: one problem's state does not fit in LDS");
@@ -484,9 +489,13 @@ extern "C" int bore_lbfgsb_minimize(const bore_mlp_desc *desc, int n_models, con
     hipLaunchKernelGGL(lbfgsb_kernel<S>, dim3(n_models, blocks), dim3(BORE_THREADS), off * 4,  \
                        (hipStream_t)stream, a);                                                \
     break;
-  switch (shape) {
+  switch (flavour) {
     BORE_LAUNCH_LBFGSB(1)
     BORE_LAUNCH_LBFGSB(2)
+    BORE_LAUNCH_LBFGSB(-1)
+    BORE_LAUNCH_LBFGSB(-2)
+    BORE_LAUNCH_LBFGSB(-3)
+    BORE_LAUNCH_LBFGSB(-4)
     default:
     BORE_LAUNCH_LBFGSB(0)
   }

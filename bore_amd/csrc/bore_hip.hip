@@ -50,12 +50,12 @@ __device__ __forceinline__ float adam_update(float w, float g, float &m, float &
 template <int SHAPE>
 __global__ __launch_bounds__(BORE_THREADS) void fit_kernel(const FitArgs a) {
   extern __shared__ float smem[];
-  constexpr MlpLayout Lc = bore_static_layout(SHAPE, 1, BORE_BATCH_MAX);
+  constexpr MlpLayout Lc = bore_static_layout(SHAPE > 0 ? SHAPE : 0, 1, BORE_BATCH_MAX);
   const MlpLayout &L = begin_kernel<SHAPE>(Lc, a.L, smem, a.total, a.o_layout);
   const int tid = threadIdx.x, nthr = blockDim.x;
   const int wv = tid >> 6, lane = tid & 63, m16 = lane & 15, q4 = lane >> 4;
   const long long model = blockIdx.x;
-  const int P = L.P, n = L.n_layers, D = L.w[0], N = a.N;
+  const int P = L.P, n = layer_count<SHAPE>(L), D = L.w[0], N = a.N;
 
   float *th = smem;
   float *tile = smem + a.o_tile;
@@ -71,10 +71,10 @@ __global__ __launch_bounds__(BORE_THREADS) void fit_kernel(const FitArgs a) {
   const float *z_g = a.z + model * (long long)N;
   float *sm = smem + a.o_m, *sv = smem + a.o_v;  // padded images (when state_in_lds)
 
-  load_theta(L, theta_g, th);
+  load_theta(L, n, theta_g, th);
   if (a.state_in_lds) {
-    load_theta(L, m_g, sm);
-    load_theta(L, v_g, sv);
+    load_theta(L, n, m_g, sm);
+    load_theta(L, n, v_g, sv);
   }
   if (a.data_in_lds) {
     for (int i = tid; i < N * D; i += nthr) smem[a.o_X + i] = X_g[i];
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(BORE_THREADS) void fit_kernel(const FitArgs a) {
   if (L.any_l2) {  // l2 penalty of the incoming weights (what the first step's loss sees)
     float reg = 0.f;
     for (int p = tid; p < P; p += nthr) {
-      const ParamRef r = param_ref(L, p);
+      const ParamRef r = param_ref(L, p, n);
       const float l2 = r.k >= 0 ? L.l2_w[r.l] : L.l2_b[r.l];
       const float w = th[r.lds];
       reg = fmaf(l2 * w, w, reg);
@@ -130,7 +130,7 @@ __global__ __launch_bounds__(BORE_THREADS) void fit_kernel(const FitArgs a) {
           }
         }
         wave_lds_sync();
-        fwd_all(L, th, tile, rb, /*keep_logits=*/true);
+        fwd_all(L, n, th, tile, rb, /*keep_logits=*/true);
         if (lane < 16) {  // loss + d loss / d logit (the final layer has one unit)
           const int row = rb * 16 + lane;
           float delta = 0.f;
@@ -271,10 +271,10 @@ __global__ __launch_bounds__(BORE_THREADS) void fit_kernel(const FitArgs a) {
   }
 
   __syncthreads();
-  store_theta(L, th, theta_g);
+  store_theta(L, n, th, theta_g);
   if (a.state_in_lds) {
-    store_theta(L, sm, m_g);
-    store_theta(L, sv, v_g);
+    store_theta(L, n, sm, m_g);
+    store_theta(L, n, sv, v_g);
   }
   if (tid == 0) a.at[model] = t0 + (long long)a.epochs * steps;
 }
@@ -299,14 +299,14 @@ struct RowArgs {
 template <bool WITH_GRAD, int SHAPE>
 __global__ __launch_bounds__(BORE_THREADS) void rows_kernel(const RowArgs a) {
   extern __shared__ float smem[];
-  constexpr MlpLayout Lc = bore_static_layout(SHAPE, WITH_GRAD ? 2 : 0, BORE_BATCH_MAX);
+  constexpr MlpLayout Lc = bore_static_layout(SHAPE > 0 ? SHAPE : 0, WITH_GRAD ? 2 : 0, BORE_BATCH_MAX);
   const MlpLayout &L = begin_kernel<SHAPE>(Lc, a.L, smem, a.total, a.o_layout);
   const int tid = threadIdx.x;
   const int wv = tid >> 6, lane = tid & 63, m16 = lane & 15, q4 = lane >> 4;
   const long long model = blockIdx.x;
-  const int n = L.n_layers, D = L.w[0];
+  const int n = layer_count<SHAPE>(L), D = L.w[0];
   float *th = smem, *tile = smem + a.o_tile, *vals = smem + a.o_vals;
-  load_theta(L, a.theta + model * L.P, th);
+  load_theta(L, n, a.theta + model * L.P, th);
   __syncthreads();
   const int waves = L.tbp >> 4;  // waves that own a 16-row slice of the tile buffers
   if (wv >= waves) return;
@@ -326,14 +326,14 @@ __global__ __launch_bounds__(BORE_THREADS) void rows_kernel(const RowArgs a) {
     }
     wave_lds_sync();
     if (WITH_GRAD) {
-      fg_rowblock(L, th, tile, wv, a.transform, a.sign, vals);
+      fg_rowblock(L, n, th, tile, wv, a.transform, a.sign, vals);
       if (lane < 16 && g * 16 + lane < a.n_rows) out[g * 16 + lane] = vals[wv * 16 + lane];
       const float *D0 = tile + L.doff[0] + (wv * 16 + m16) * L.lda[0];
       double *grad = a.grad + (model * a.n_rows) * D;
       if (row < a.n_rows)
         for (int d = q4; d < D; d += 4) grad[row * D + d] = (double)D0[d];
     } else {
-      fwd_all(L, th, tile, wv, false);
+      fwd_all(L, n, th, tile, wv, false);
       if (lane < 16 && g * 16 + lane < a.n_rows)
         out[g * 16 + lane] = tile[L.aoff[n] + (wv * 16 + lane) * L.lda[n]];
     }
@@ -360,7 +360,7 @@ __global__ __launch_bounds__(BORE_THREADS) void evaluate_kernel(const EvalArgs a
   const long long model = blockIdx.x;
   const int n = L.n_layers, D = L.w[0];
   float *th = smem, *tile = smem + a.o_tile, *misc = smem + a.o_misc;
-  load_theta(L, a.theta + model * L.P, th);
+  load_theta(L, n, a.theta + model * L.P, th);
   __syncthreads();
   const float *X = a.X + model * a.N * D;
   const float *z = a.z + model * a.N;
@@ -373,7 +373,7 @@ __global__ __launch_bounds__(BORE_THREADS) void evaluate_kernel(const EvalArgs a
       float *A0 = tile + L.aoff[0] + (wv * 16 + m16) * L.lda[0];
       for (int d = q4; d < D; d += 4) A0[d] = row < a.N ? X[row * D + d] : 0.f;
       wave_lds_sync();
-      fwd_all(L, th, tile, wv, true);
+      fwd_all(L, n, th, tile, wv, true);
       if (lane < 16 && g * 16 + lane < a.N) {
         const float x = tile[L.aoff[n] + (wv * 16 + lane) * L.lda[n]];
         const float zz = z[g * 16 + lane];
@@ -386,7 +386,7 @@ __global__ __launch_bounds__(BORE_THREADS) void evaluate_kernel(const EvalArgs a
   float reg = 0.f;
   if (L.any_l2)
     for (int p = tid; p < L.P; p += nthr) {
-      const ParamRef r = param_ref(L, p);
+      const ParamRef r = param_ref(L, p, n);
       const float l2 = r.k >= 0 ? L.l2_w[r.l] : L.l2_b[r.l];
       const float w = th[r.lds];
       reg = fmaf(l2 * w, w, reg);
@@ -483,7 +483,7 @@ extern "C" int bore_mlp_fit(const bore_mlp_desc *desc, int n_models, float *thet
   off = (off + 3) & ~(size_t)3;
   a.o_layout = (int)off; off += BORE_LAYOUT_FLOATS;
   // the constexpr-layout instantiation needs the layout it was compiled for (64-row tile)
-  const int shape = batch_size == BORE_BATCH_MAX ? bore_match_shape(desc) : 0;
+  const int shape = bore_kernel_flavour(desc, batch_size == BORE_BATCH_MAX);
 #define BORE_LAUNCH_FIT(S)                                                              \
   case S:                                                                               \
     rc = allow_lds(fit_kernel<S>, off * 4);                                             \
@@ -494,6 +494,10 @@ extern "C" int bore_mlp_fit(const bore_mlp_desc *desc, int n_models, float *thet
   switch (shape) {
     BORE_LAUNCH_FIT(1)
     BORE_LAUNCH_FIT(2)
+    BORE_LAUNCH_FIT(-1)
+    BORE_LAUNCH_FIT(-2)
+    BORE_LAUNCH_FIT(-3)
+    BORE_LAUNCH_FIT(-4)
     default:
     BORE_LAUNCH_FIT(0)
   }
@@ -518,7 +522,7 @@ static int row_launch(bool with_grad, int n_models, RowArgs &a, void *stream) {
   if (gy > cap) gy = cap < 1 ? 1 : cap;
   if (gy > 65535) gy = 65535;
   int rc = 0;
-  const int shape = L.tb == BORE_BATCH_MAX ? a.shape : 0;
+  const int shape = a.shape > 0 && L.tb != BORE_BATCH_MAX ? -L.n_layers : a.shape;
 #define BORE_LAUNCH_ROWS(G, S)                                                              \
   {                                                                                         \
     rc = allow_lds(rows_kernel<G, S>, off * 4);                                             \
@@ -529,10 +533,18 @@ static int row_launch(bool with_grad, int n_models, RowArgs &a, void *stream) {
   if (with_grad) {
     if (shape == 1) BORE_LAUNCH_ROWS(true, 1)
     else if (shape == 2) BORE_LAUNCH_ROWS(true, 2)
+    else if (shape == -1) BORE_LAUNCH_ROWS(true, -1)
+    else if (shape == -2) BORE_LAUNCH_ROWS(true, -2)
+    else if (shape == -3) BORE_LAUNCH_ROWS(true, -3)
+    else if (shape == -4) BORE_LAUNCH_ROWS(true, -4)
     else BORE_LAUNCH_ROWS(true, 0)
   } else {
     if (shape == 1) BORE_LAUNCH_ROWS(false, 1)
     else if (shape == 2) BORE_LAUNCH_ROWS(false, 2)
+    else if (shape == -1) BORE_LAUNCH_ROWS(false, -1)
+    else if (shape == -2) BORE_LAUNCH_ROWS(false, -2)
+    else if (shape == -3) BORE_LAUNCH_ROWS(false, -3)
+    else if (shape == -4) BORE_LAUNCH_ROWS(false, -4)
     else BORE_LAUNCH_ROWS(false, 0)
   }
 #undef BORE_LAUNCH_ROWS
@@ -554,7 +566,7 @@ extern "C" int bore_mlp_forward(const bore_mlp_desc *desc, int n_models, const f
   if (n_rows == 0) return 0;
   a.theta = theta; a.Xf = X; a.Xd = nullptr; a.out = out; a.grad = nullptr;
   a.n_rows = n_rows; a.x_shared = x_shared; a.transform = 0; a.sign = 1.f;
-  a.shape = bore_match_shape(desc);
+  a.shape = bore_kernel_flavour(desc, true);
   return row_launch(false, n_models, a, stream);
 }
 
@@ -575,7 +587,7 @@ extern "C" int bore_mlp_value_and_input_grad(const bore_mlp_desc *desc, int n_mo
   if (n_rows == 0) return 0;
   a.theta = theta; a.Xf = nullptr; a.Xd = X; a.out = val; a.grad = grad;
   a.n_rows = n_rows; a.x_shared = 0; a.transform = transform; a.sign = negate ? -1.f : 1.f;
-  a.shape = bore_match_shape(desc);
+  a.shape = bore_kernel_flavour(desc, true);
   return row_launch(true, n_models, a, stream);
 }
 

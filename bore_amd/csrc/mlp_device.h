@@ -72,21 +72,27 @@ struct ParamRef {
   int lds;   // index in the padded LDS image
 };
 
-__device__ __forceinline__ ParamRef param_ref(const MlpLayout &L, int p) {
+// (the layer loop is unrolled so that every table lookup has a constant index)
+__device__ __forceinline__ ParamRef param_ref(const MlpLayout &L, int p, int n) {
   ParamRef r;
   r.l = 1;
-  for (int l = 1; l <= L.n_layers; ++l)
-    if (p >= L.goff_w[l]) r.l = l;
-  const int l = r.l;
-  if (p < L.goff_b[l]) {
-    int q = p - L.goff_w[l];
-    r.k = q / L.w[l];
-    r.j = q - r.k * L.w[l];
-    r.lds = L.woff[l] + r.k * L.ldw[l] + r.j;
-  } else {
-    r.k = -1;
-    r.j = p - L.goff_b[l];
-    r.lds = L.boff[l] + r.j;
+  r.k = -1;
+  r.j = 0;
+  r.lds = 0;
+#pragma unroll
+  for (int l = 1; l <= n; ++l) {
+    if (p >= L.goff_w[l] && p < L.goff_b[l]) {
+      const int q = p - L.goff_w[l];
+      r.l = l;
+      r.k = q / L.w[l];
+      r.j = q - r.k * L.w[l];
+      r.lds = L.woff[l] + r.k * L.ldw[l] + r.j;
+    } else if (p >= L.goff_b[l] && p < L.goff_b[l] + L.w[l]) {
+      r.l = l;
+      r.k = -1;
+      r.j = p - L.goff_b[l];
+      r.lds = L.boff[l] + r.j;
+    }
   }
   return r;
 }
@@ -111,8 +117,12 @@ __device__ __forceinline__ const MlpLayout &stage_layout(const MlpLayout &Lk, fl
 
 #define BORE_LAYOUT_FLOATS ((int)((sizeof(MlpLayout) + 15) / 16 * 4))
 
-// Start of every kernel: zero the LDS, then hand out the layout -- the LDS copy (SHAPE 0) or
-// nothing at all (SHAPE > 0: the caller holds a constexpr layout).  Ends with a barrier.
+// Start of every kernel: zero the LDS, then hand out the layout.  Three kernel flavours:
+//   SHAPE > 0   a shape of mlp_shapes.h: the caller holds a constexpr layout (everything folds)
+//   SHAPE < 0   any widths, -SHAPE layers: the layer loops are unrolled, so the layout tables
+//               are read from the kernarg segment at CONSTANT offsets (scalar loads)
+//   SHAPE == 0  any widths, any depth: tables indexed at run time -> LDS copy
+// Ends with a barrier.
 template <int SHAPE>
 __device__ __forceinline__ const MlpLayout &begin_kernel(const MlpLayout &Lstatic,
                                                         const MlpLayout &Lk, float *smem,
@@ -122,19 +132,27 @@ __device__ __forceinline__ const MlpLayout &begin_kernel(const MlpLayout &Lstati
   } else {
     zero_lds(smem, total_floats);
     __syncthreads();
-    return Lstatic;
+    if constexpr (SHAPE > 0) return Lstatic;
+    else return Lk;
   }
 }
 
-// HBM -> LDS: packed vector into the (already zeroed) padded image; coalesced reads.
-__device__ __forceinline__ void load_theta(const MlpLayout &L, const float *__restrict__ g,
-                                           float *th) {
-  for (int p = threadIdx.x; p < L.P; p += blockDim.x) th[param_ref(L, p).lds] = g[p];
+// layer count as a compile-time constant where the kernel flavour fixes it
+template <int SHAPE>
+__device__ __forceinline__ int layer_count(const MlpLayout &L) {
+  if constexpr (SHAPE < 0) return -SHAPE;
+  else return L.n_layers;
 }
 
-__device__ __forceinline__ void store_theta(const MlpLayout &L, const float *th,
+// HBM -> LDS: packed vector into the (already zeroed) padded image; coalesced reads.
+__device__ __forceinline__ void load_theta(const MlpLayout &L, int n, const float *__restrict__ g,
+                                           float *th) {
+  for (int p = threadIdx.x; p < L.P; p += blockDim.x) th[param_ref(L, p, n).lds] = g[p];
+}
+
+__device__ __forceinline__ void store_theta(const MlpLayout &L, int n, const float *th,
                                             float *__restrict__ g) {
-  for (int p = threadIdx.x; p < L.P; p += blockDim.x) g[p] = th[param_ref(L, p).lds];
+  for (int p = threadIdx.x; p < L.P; p += blockDim.x) g[p] = th[param_ref(L, p, n).lds];
 }
 
 // One 16x16 tile: sum over kchunks*4 of A[m][k] * B[k][n].  ap / bp are THIS LANE's operand
@@ -210,22 +228,22 @@ __device__ __forceinline__ void bwd_rowblock(const MlpLayout &L, const float *th
 }
 
 // Forward through every layer for one row-block (calling wave).
-__device__ __forceinline__ void fwd_all(const MlpLayout &L, const float *th, float *tile, int rb,
-                                        bool keep_logits) {
+__device__ __forceinline__ void fwd_all(const MlpLayout &L, int n, const float *th, float *tile,
+                                        int rb, bool keep_logits) {
 #pragma unroll
-  for (int l = 1; l <= L.n_layers; ++l) {
-    fwd_rowblock(L, th, tile, l, rb, keep_logits && l == L.n_layers);
+  for (int l = 1; l <= n; ++l) {
+    fwd_rowblock(L, th, tile, l, rb, keep_logits && l == n);
     wave_lds_sync();
   }
 }
 
 // Objective + input gradient for one row-block whose rows sit in A_0: forward, T(sign*f)
 // into val_out[row] (LDS or global, indexed by tile row), d T / d x into D_0.
-__device__ __forceinline__ void fg_rowblock(const MlpLayout &L, const float *th, float *tile,
-                                            int rb, int transform, float sign, float *val_out) {
-  const int n = L.n_layers;
+__device__ __forceinline__ void fg_rowblock(const MlpLayout &L, int n, const float *th,
+                                            float *tile, int rb, int transform, float sign,
+                                            float *val_out) {
   const int lane = threadIdx.x & 63;
-  fwd_all(L, th, tile, rb, false);
+  fwd_all(L, n, th, tile, rb, false);
   if (lane < 16) {
     const int row = rb * 16 + lane;
     const float f = tile[L.aoff[n] + row * L.lda[n]];

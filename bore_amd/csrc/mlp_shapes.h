@@ -60,3 +60,12 @@ static inline int bore_match_shape(const bore_mlp_desc *d) {
   }
   return 0;
 }
+
+// Kernel flavour for a descriptor (template argument SHAPE of the kernels): a static shape id
+// when it matches one (and the launch uses the 64-row tile that layout was built for),
+// -n_layers for up to 4 layers of any width, 0 otherwise.
+static inline int bore_kernel_flavour(const bore_mlp_desc *d, bool full_tile) {
+  const int s = full_tile ? bore_match_shape(d) : 0;
+  if (s) return s;
+  return d->n_layers <= 4 ? -d->n_layers : 0;
+}
