@@ -181,6 +181,25 @@ __global__ __launch_bounds__(BORE_THREADS) void fit_kernel(const FitArgs a) {
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
             f32x4 ones = {0.f, 0.f, 0.f, 0.f};  // ones^T D_l: every row = the column sums of D_l
             const bool want_bias = kb == 0;
+            const int col = cb * 16 + m16;
+            const bool cvalid = col < Nw;
+            // Adam slots that live in HBM (wide nets): fetch this tile's m, v now, so that the
+            // loads are in flight under the MFMA chain instead of in front of every update
+            float pm[4] = {0.f, 0.f, 0.f, 0.f}, pv[4] = {0.f, 0.f, 0.f, 0.f}, pmb = 0.f, pvb = 0.f;
+            if (!a.state_in_lds) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const int row = kb * 16 + q4 * 4 + r;
+                if (cvalid && row < K) {
+                  pm[r] = m_g[L.goff_w[l] + row * Nw + col];
+                  pv[r] = v_g[L.goff_w[l] + row * Nw + col];
+                }
+              }
+              if (want_bias && q4 == 0 && cvalid) {
+                pmb = m_g[L.goff_b[l] + col];
+                pvb = v_g[L.goff_b[l] + col];
+              }
+            }
             int kc = 0;
             for (; kc + 4 <= kch; kc += 4) {  // operands of four row-chunks in flight
               const float a0 = ap[kc * 4 * lda_p], a1 = ap[(kc + 1) * 4 * lda_p],
@@ -203,8 +222,6 @@ __global__ __launch_bounds__(BORE_THREADS) void fit_kernel(const FitArgs a) {
               acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
               if (want_bias) ones = __builtin_amdgcn_mfma_f32_16x16x4f32(1.f, bv, ones, 0, 0, 0);
             }
-            const int col = cb * 16 + m16;
-            const bool cvalid = col < Nw;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const int row = kb * 16 + q4 * 4 + r;
@@ -221,7 +238,7 @@ __global__ __launch_bounds__(BORE_THREADS) void fit_kernel(const FitArgs a) {
                   sv[li] = vv;
                 } else {
                   const int gi = L.goff_w[l] + row * Nw + col;
-                  float mm = m_g[gi], vv = v_g[gi];
+                  float mm = pm[r], vv = pv[r];
                   w = adam_update(w, g, mm, vv, alpha, omb1, omb2, a.eps);
                   m_g[gi] = mm;
                   v_g[gi] = vv;
@@ -244,7 +261,7 @@ __global__ __launch_bounds__(BORE_THREADS) void fit_kernel(const FitArgs a) {
                   sv[li] = vv;
                 } else {
                   const int gi = L.goff_b[l] + col;
-                  float mm = m_g[gi], vv = v_g[gi];
+                  float mm = pmb, vv = pvb;
                   w = adam_update(w, g, mm, vv, alpha, omb1, omb2, a.eps);
                   m_g[gi] = mm;
                   v_g[gi] = vv;
