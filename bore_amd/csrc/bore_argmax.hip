@@ -9,6 +9,7 @@
 #include "host_common.h"
 #include "lbfgsb.h"
 #include "mlp_device.h"
+#include "mlp_regs.h"
 
 using namespace bore;
 
@@ -174,20 +175,35 @@ __global__ __launch_bounds__(BORE_THREADS) void screen_topk_kernel(const ScreenA
   // Every wave walks its own 16-row blocks of the candidates.
   const int waves = L.tbp >> 4;
   const int n_blocks = (Ns + 15) >> 4;
+  using Net = RegNet<(SHAPE > 0 ? SHAPE : 1), 0>;
+  Net net;  // static shapes: the weights stay in this lane's registers for every row-block
+  if constexpr (SHAPE > 0) net.load_fwd(th);
   if (wv < waves)
     for (int g = wv; g < n_blocks; g += waves) {
       const int row = g * 16 + m16;
-      float *A0 = tile + L.aoff[0] + (wv * 16 + m16) * L.lda[0];
-      for (int d = q4; d < D; d += 4) A0[d] = row < Ns ? (float)X[(long long)row * D + d] : 0.f;
-      wave_lds_sync();
-      fwd_all(L, n, th, tile, wv, false);
+      float p;  // prediction of row g*16 + lane, in the lanes < 16
+      if constexpr (SHAPE > 0) {  // activations in registers (mlp_regs.h)
+        float xin[Net::KC0];
+#pragma unroll
+        for (int kc = 0; kc < Net::KC0; ++kc) {
+          const int d = 4 * kc + q4;
+          xin[kc] = (d < D && row < Ns) ? (float)X[(long long)row * D + d] : 0.f;
+        }
+        net.forward(xin, false);
+        p = net.h[Net::n][0][0];
+      } else {
+        float *A0 = tile + L.aoff[0] + (wv * 16 + m16) * L.lda[0];
+        for (int d = q4; d < D; d += 4) A0[d] = row < Ns ? (float)X[(long long)row * D + d] : 0.f;
+        wave_lds_sync();
+        fwd_all(L, n, th, tile, wv, false);
+        p = tile[L.aoff[n] + (wv * 16 + (lane & 15)) * L.lda[n]];
+        wave_lds_sync();
+      }
       if (lane < 16 && g * 16 + lane < Ns) {
         const int r = g * 16 + lane;
-        const float p = tile[L.aoff[n] + (wv * 16 + lane) * L.lda[n]];
         keys[r] = ((unsigned long long)(~orderable(p)) << 32) | (unsigned)r;
         if (a.pred) a.pred[model * a.n_samples + r] = p;
       }
-      wave_lds_sync();
     }
   for (int i = Ns + tid; i < a.n_pad; i += nthr) keys[i] = ~0ULL;
   __syncthreads();
@@ -369,8 +385,10 @@ __global__ __launch_bounds__(BORE_THREADS) void lbfgsb_kernel(const LbfgsbArgs a
     if (!done) {
       const int rc = lbfgsb::lbfgsb_advance(st, wk, blo, bhi, bnbd, a.opt, cp);
       if (rc == lbfgsb::LB_NEED_FG) {
-        float *row = tile + L.aoff[0] + myrow * L.lda[0];
-        for (int d = 0; d < D; ++d) row[d] = (float)wk.x[d];  // Keras autocast fp64 -> fp32
+        if (!(SHAPE > 0 && coop)) {
+          float *row = tile + L.aoff[0] + myrow * L.lda[0];
+          for (int d = 0; d < D; ++d) row[d] = (float)wk.x[d];  // Keras autocast fp64 -> fp32
+        }
         pending = 1;
       } else {
         done = true;
@@ -378,11 +396,55 @@ __global__ __launch_bounds__(BORE_THREADS) void lbfgsb_kernel(const LbfgsbArgs a
     }
     if (!__any(pending)) break;  // every problem of this wave has terminated
     wave_lds_sync();
-    fg_rowblock(L, n_lay, th, tile, wv, a.transform, a.sign, vals);
-    if (pending) {
-      st.f = (double)vals[myrow];
-      const float *g = tile + L.doff[0] + myrow * L.lda[0];
-      for (int d = 0; d < D; ++d) wk.g[d] = (double)g[d];
+    if constexpr (SHAPE > 0) {
+      // static shape: the 16-row block goes through the network in registers (mlp_regs.h)
+      using Net = RegNet<SHAPE, 2>;
+      Net net;
+      const int m16 = lane & 15, q4 = lane >> 4;
+      float xin[Net::KC0];
+      net.load_fwd(th);  // (per evaluation: the optimiser's own state fills the register file)
+      net.template load_bwd<Net::n, 1>(th);
+      if (coop) {
+        // one point per wave: every row of the block evaluates it, read straight from the
+        // optimiser's fp64 x (Keras autocast fp64 -> fp32)
+#pragma unroll
+        for (int kc = 0; kc < Net::KC0; ++kc) {
+          const int d = 4 * kc + q4;
+          xin[kc] = d < D ? (float)wk.x[d] : 0.f;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const float Tv = net.fg(xin, a.transform, a.sign);
+        st.f = (double)__uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(Tv)));
+        if (m16 == 0) {
+#pragma unroll
+          for (int t = 0; t < Net::L.Np[0] / 16; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int d = 16 * t + 4 * q4 + r;
+              if (d < D) wk.g[d] = (double)net.d[0][t][r];
+            }
+        }
+      } else {
+        const float *A0 = tile + L.aoff[0] + (wv * 16 + m16) * L.lda[0];
+#pragma unroll
+        for (int kc = 0; kc < Net::KC0; ++kc) xin[kc] = A0[4 * kc + q4];
+        __builtin_amdgcn_sched_barrier(0);
+        const float Tv = net.fg(xin, a.transform, a.sign);
+        Net::template store_rows<0>(net.d[0], tile + L.doff[0], wv);
+        wave_lds_sync();
+        if (pending) {  // lane s < 16 owns row s: its value is already in this lane
+          st.f = (double)Tv;
+          const float *g = tile + L.doff[0] + myrow * L.lda[0];
+          for (int d = 0; d < D; ++d) wk.g[d] = (double)g[d];
+        }
+      }
+    } else {
+      fg_rowblock(L, n_lay, th, tile, wv, a.transform, a.sign, vals);
+      if (pending) {
+        st.f = (double)vals[myrow];
+        const float *g = tile + L.doff[0] + myrow * L.lda[0];
+        for (int d = 0; d < D; ++d) wk.g[d] = (double)g[d];
+      }
     }
     wave_lds_sync();
   }

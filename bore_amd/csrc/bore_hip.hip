@@ -8,8 +8,29 @@
 
 #include "host_common.h"
 #include "mlp_device.h"
+#include "mlp_regs.h"
 
 using namespace bore;
+
+// -DBORE_STAMPS: cycle stamps of one Adam step's phases (diagnostic builds only; scratch/stamps.py)
+#ifdef BORE_STAMPS
+__device__ long long g_stamps[64];
+#define BORE_STAMP(i)                                                                  \
+  do {                                                                                 \
+    if (blockIdx.x == 0 && (tid & 63) == 0 && e == 1 && s == 0) g_stamps[16 * (tid >> 6) + (i)] = clock64(); \
+  } while (0)
+extern "C" int bore_debug_stamps(long long *out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(long long) * 64);
+}
+__device__ int g_stamp_on;
+#define BORE_TSTAMP(i)                                                                         \
+  do {                                                                                         \
+    if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && g_stamp_on) g_stamps[16 * (threadIdx.x >> 6) + (i)] = clock64(); \
+  } while (0)
+#else
+#define BORE_STAMP(i)
+#define BORE_TSTAMP(i)
+#endif
 
 extern "C" int bore_abi_version(void) { return BORE_ABI_VERSION; }
 extern "C" const char *bore_last_error(void) { return g_bore_err; }
@@ -45,6 +66,137 @@ __device__ __forceinline__ float adam_update(float w, float g, float &m, float &
   m += (g - m) * omb1;
   v += (g * g - v) * omb2;
   return w - (m * alpha) / (sqrtf(v) + eps);
+}
+
+// Weight gradients + Adam for a static shape, NBLK = row-blocks of the batch that hold live
+// rows (the other blocks' rows are never read).  Same sums as the generic loop in fit_kernel
+// (k-ordered over the batch rows), but with every trip count a constant: the 2 x 4 NBLK MFMA
+// operands and the task's theta / m / v slots are all requested up front, so one LDS latency
+// is paid per task instead of one per group of k-chunks.  The Adam slots are in LDS (the host
+// only picks a static flavour when they fit).
+//
+// One TASK = one 16x16 tile of some dW_l, or half of its registers; tasks go round-robin over
+// the four waves.  What bounds a task is the serial sqrt/divide chain per register it updates,
+// not its MFMAs, so:
+//   * a layer with ONE unit is formed transposed (dW_l^T = D_l^T A_{l-1}): its 16 gradients land
+//     in one register of lanes 0..15 and the bias rides along in lane 16 -- 1 chain, not 5;
+//   * when the net has fewer tiles than the workgroup has waves, a full tile becomes two tasks
+//     (registers {0,1} + bias | {2,3}); both redo the tile's MFMAs, on different SIMDs.
+__device__ __forceinline__ void dw_task(const MlpLayout &L, float *smem, int o_tile, int o_m,
+                                        int o_v, int l, int kb, int cb, int r_lo, int r_hi,
+                                        bool want_bias, bool transposed, int kch, float alpha,
+                                        float omb1, float omb2, float eps) {
+  const int lane = threadIdx.x & 63, m16 = lane & 15, q4 = lane >> 4;
+  float *th = smem, *tile = smem + o_tile, *sm = smem + o_m, *sv = smem + o_v;
+  const int K = L.w[l - 1], Nw = L.w[l], ldw = L.ldw[l];
+  const int lda_p = L.lda[l - 1], ldd = L.lda[l];
+  const float *ap = tile + L.aoff[l - 1] + q4 * lda_p + kb * 16 + m16;
+  const float *bp = tile + L.doff[l] + q4 * ldd + cb * 16 + m16;
+  float av[4 * (BORE_BATCH_MAX / 16)], bv[4 * (BORE_BATCH_MAX / 16)];
+  BORE_TSTAMP(8);
+#pragma unroll
+  for (int kc = 0; kc < kch; ++kc) {
+    av[kc] = ap[kc * 4 * lda_p];
+    bv[kc] = bp[kc * 4 * ldd];
+  }
+  // the slots this lane updates: index 0..3 = registers of the tile, 4 = the bias
+  int li[5];
+  bool ok[5];
+  const int col = cb * 16 + m16;
+  if (transposed) {  // register 0 of lanes 0..15 = dW_l[kb*16 + m16][0]; lane 16 = the bias
+    const bool is_b = want_bias && lane == 16;
+    li[0] = is_b ? L.boff[l] : L.woff[l] + (kb * 16 + m16) * ldw;
+    ok[0] = is_b || (q4 == 0 && kb * 16 + m16 < K);
+  } else {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      li[r] = L.woff[l] + (kb * 16 + q4 * 4 + r) * ldw + col;
+      ok[r] = col < Nw && kb * 16 + q4 * 4 + r < K;
+    }
+    li[4] = L.boff[l] + col;
+    ok[4] = q4 == 0 && col < Nw;
+  }
+  float w[5], mm[5], vv[5];
+#pragma unroll
+  for (int r = 0; r < 5; ++r) {
+    const bool used = transposed ? r == 0 : (r == 4 ? want_bias : (r >= r_lo && r < r_hi));
+    if (!used) continue;
+    w[r] = th[li[r]];
+    mm[r] = sm[li[r]];
+    vv[r] = sv[li[r]];
+  }
+  // (the scheduler would otherwise re-interleave loads and MFMAs pair by pair, paying the LDS
+  // latency kch / 2 times)
+  __builtin_amdgcn_sched_barrier(0);
+  BORE_TSTAMP(9);
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  float bsum = 0.f;
+#pragma unroll
+  for (int kc = 0; kc < kch; ++kc) {
+    acc = transposed ? __builtin_amdgcn_mfma_f32_16x16x4f32(bv[kc], av[kc], acc, 0, 0, 0)
+                     : __builtin_amdgcn_mfma_f32_16x16x4f32(av[kc], bv[kc], acc, 0, 0, 0);
+    bsum += bv[kc];
+  }
+  float g[5] = {acc[0], acc[1], acc[2], acc[3], 0.f};
+  BORE_TSTAMP(10);
+  if (want_bias) {
+    const float gb = rows_sum4(bsum);  // column sums of D_l (every lane of the column)
+    if (transposed) g[0] = lane == 16 ? gb : g[0];
+    else g[4] = gb;
+  }
+  // branch-free: a lane updates all of the task's slots (padding slots work on zeros and are
+  // not stored), so the dependent sqrt/divide chains interleave
+  float wn[5];
+#pragma unroll
+  for (int r = 0; r < 5; ++r) {
+    const bool used = transposed ? r == 0 : (r == 4 ? want_bias : (r >= r_lo && r < r_hi));
+    if (!used) continue;
+    wn[r] = adam_update(w[r], g[r], mm[r], vv[r], alpha, omb1, omb2, eps);
+  }
+#pragma unroll
+  for (int r = 0; r < 5; ++r) {
+    const bool used = transposed ? r == 0 : (r == 4 ? want_bias : (r >= r_lo && r < r_hi));
+    if (!used) continue;
+    if (!ok[r]) continue;
+    th[li[r]] = wn[r];
+    sm[li[r]] = mm[r];
+    sv[li[r]] = vv[r];
+  }
+  BORE_TSTAMP(11);
+}
+
+template <int SHAPE, int NBLK>
+__device__ __forceinline__ void dw_adam_static(const FitArgs &a, float *smem, float alpha,
+                                               float omb1, float omb2) {
+  constexpr MlpLayout L = bore_static_layout(SHAPE, 1, BORE_BATCH_MAX);
+  constexpr int KCH = 4 * NBLK;
+  int n_tiles = 0;
+#pragma unroll
+  for (int l = 1; l <= L.n_layers; ++l) n_tiles += (L.Np[l - 1] >> 4) * (L.Np[l] >> 4);
+  const bool split = n_tiles < BORE_THREADS / 64;
+  const int wv = threadIdx.x >> 6;
+  int t = 0;
+#pragma unroll
+  for (int l = 1; l <= L.n_layers; ++l) {
+    const int nkb = L.Np[l - 1] >> 4, ncb = L.Np[l] >> 4;
+#pragma unroll
+    for (int kb = 0; kb < nkb; ++kb)
+#pragma unroll
+      for (int cb = 0; cb < ncb; ++cb) {
+        const bool transposed = L.w[l] == 1;
+        const bool two = !transposed && split && L.w[l - 1] - kb * 16 > 2;
+        if ((t & 3) == wv)
+          dw_task(L, smem, a.o_tile, a.o_m, a.o_v, l, kb, cb, 0, two ? 2 : 4, kb == 0, transposed,
+                  KCH, alpha, omb1, omb2, a.eps);
+        ++t;
+        if (two) {
+          if ((t & 3) == wv)
+            dw_task(L, smem, a.o_tile, a.o_m, a.o_v, l, kb, cb, 2, 4, false, false, KCH, alpha,
+                    omb1, omb2, a.eps);
+          ++t;
+        }
+      }
+  }
 }
 
 template <int SHAPE>
@@ -115,8 +267,67 @@ __global__ __launch_bounds__(BORE_THREADS) void fit_kernel(const FitArgs a) {
       const int row0 = s * a.B;
       const int nb = min(a.B, N - row0);
       // ---- forward / loss / backward: wave wv owns rows [16 wv, 16 wv + 16), no barriers ----
+      BORE_STAMP(0);
+      int src = 0;  // static path: this lane's mini-batch row, requested ahead of the arithmetic below
+      if constexpr (SHAPE > 0) {
+        if (wv * 16 + m16 < nb) src = perm_s[row0 + wv * 16 + m16];
+      }
+      // this step's size (depends on the step count only: fills the wait for `src`)
+      b1p *= (double)a.beta1;
+      b2p *= (double)a.beta2;
+      float alpha = a.lr * sqrtf(1.f - (float)b2p) / (1.f - (float)b1p);
+      asm volatile("" : "+v"(alpha));  // keep it HERE (the compiler would sink it behind the barrier)
       if (wv * 16 < nb) {
         const int rb = wv;
+        if constexpr (SHAPE > 0) {
+          // static shape: the row-block's activations and deltas stay in registers
+          // (mlp_regs.h); LDS only receives the copies the weight-gradient phase sums over
+          using Net = RegNet<SHAPE, 1>;
+          Net net;
+          const int row = rb * 16 + m16;
+          const bool live = row < nb;
+          float xin[Net::KC0];
+          float *A0 = tile + L.aoff[0] + row * L.lda[0];
+#pragma unroll
+          for (int kc = 0; kc < Net::KC0; ++kc) xin[kc] = 0.f;
+          float zz = 0.f;
+          if (a.data_in_lds) {  // (two branches: a selected pointer would make these flat loads)
+#pragma unroll
+            for (int kc = 0; kc < Net::KC0; ++kc)
+              if (4 * kc + q4 < D && live) xin[kc] = smem[a.o_X + src * D + 4 * kc + q4];
+            if (q4 == 0 && live) zz = smem[a.o_z + src];
+          } else {
+#pragma unroll
+            for (int kc = 0; kc < Net::KC0; ++kc)
+              if (4 * kc + q4 < D && live) xin[kc] = X_g[src * D + 4 * kc + q4];
+            if (q4 == 0 && live) zz = z_g[src];
+          }
+#pragma unroll
+          for (int kc = 0; kc < Net::KC0; ++kc)
+            if (4 * kc + q4 < D) A0[4 * kc + q4] = xin[kc];
+          net.load_fwd(th);
+          net.template load_bwd<Net::n, 2>(th);
+          __builtin_amdgcn_sched_barrier(0);  // every operand load is in flight before the chain
+          BORE_STAMP(1);
+          net.forward(xin, /*keep_logits=*/true);
+          BORE_STAMP(2);
+          net.template store_A<1, Net::n - 1>(tile, rb);
+          float delta = 0.f;
+          if (lane < 16 && live) {
+            const float x = net.h[Net::n][0][0];
+            const float ex = expf(-fabsf(x));
+            const float den = 1.f + ex;
+            const float sig = x >= 0.f ? 1.f / den : ex / den;
+            if (a.epoch_loss) eloss += fmaxf(x, 0.f) - x * zz + log1pf(ex);
+            delta = (sig - zz) / (float)nb;
+          }
+          if (lane < 16) tile[L.doff[Net::n] + row * L.lda[Net::n]] = delta;
+          net.set_output_delta(delta);
+          BORE_STAMP(3);
+          net.template backward<Net::n, 2>();
+          net.template store_D<1, Net::n - 1>(tile, rb);
+          BORE_STAMP(4);
+        } else {
         {  // gather the mini-batch rows of this row-block (rows >= nb: zeros)
           float *A0 = tile + L.aoff[0] + (rb * 16 + m16) * L.lda[0];
           const int row = rb * 16 + m16;
@@ -140,14 +351,11 @@ __global__ __launch_bounds__(BORE_THREADS) void fit_kernel(const FitArgs a) {
             const float ex = expf(-fabsf(x));  // shared by the loss and the sigmoid
             const float den = 1.f + ex;
             const float sig = x >= 0.f ? 1.f / den : ex / den;
-            eloss += fmaxf(x, 0.f) - x * zz + log1pf(ex);  // per-lane; reduced once per epoch
+            if (a.epoch_loss)  // per-lane; reduced once per epoch
+              eloss += fmaxf(x, 0.f) - x * zz + log1pf(ex);
             delta = (sig - zz) / (float)nb;
           }
           tile[L.doff[n] + row * L.lda[n]] = delta;
-        }
-        if (tid == 0 && L.any_l2) {
-          eloss += misc[0] * (float)nb;
-          misc[0] = 0.f;  // consumed; re-accumulated from the updated weights below
         }
         wave_lds_sync();
 #pragma unroll
@@ -155,16 +363,31 @@ __global__ __launch_bounds__(BORE_THREADS) void fit_kernel(const FitArgs a) {
           bwd_rowblock(L, th, tile, l, rb);
           wave_lds_sync();
         }
+        }
+        if (tid == 0 && L.any_l2) {
+          eloss += misc[0] * (float)nb;
+          misc[0] = 0.f;  // consumed; re-accumulated from the updated weights below
+        }
       }
       __syncthreads();
+#ifdef BORE_STAMPS
+      if (tid == 0) g_stamp_on = (e == 1 && s == 0);
+      __syncthreads();
+#endif
+      BORE_STAMP(5);
 
       // ---- weight gradients (sums over all rows) + Adam, one 16x16 tile per wave at a time ----
-      b1p *= (double)a.beta1;
-      b2p *= (double)a.beta2;
-      const float alpha = a.lr * sqrtf(1.f - (float)b2p) / (1.f - (float)b1p);
       const int kch = (nb + 3) >> 2;
       float reg = 0.f;
       int t = 0;
+      if constexpr (SHAPE > 0) {
+        switch ((nb + 15) >> 4) {
+          case 1: dw_adam_static<SHAPE, 1>(a, smem, alpha, omb1, omb2); break;
+          case 2: dw_adam_static<SHAPE, 2>(a, smem, alpha, omb1, omb2); break;
+          case 3: dw_adam_static<SHAPE, 3>(a, smem, alpha, omb1, omb2); break;
+          default: dw_adam_static<SHAPE, 4>(a, smem, alpha, omb1, omb2); break;
+        }
+      } else
 #pragma unroll
       for (int l = 1; l <= n; ++l) {
         const int K = L.w[l - 1], Nw = L.w[l], ldw = L.ldw[l];
@@ -179,7 +402,7 @@ __global__ __launch_bounds__(BORE_THREADS) void fit_kernel(const FitArgs a) {
             const float *ap = tile + L.aoff[l - 1] + q4 * lda_p + kb * 16 + m16;
             const float *bp = tile + L.doff[l] + q4 * ldd + cb * 16 + m16;
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            f32x4 ones = {0.f, 0.f, 0.f, 0.f};  // ones^T D_l: every row = the column sums of D_l
+            float bsum = 0.f;  // this lane's share of the column sums of D_l (rows q4, q4 + 4, ..)
             const bool want_bias = kb == 0;
             const int col = cb * 16 + m16;
             const bool cvalid = col < Nw;
@@ -210,17 +433,12 @@ __global__ __launch_bounds__(BORE_THREADS) void fit_kernel(const FitArgs a) {
               acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc, 0, 0, 0);
               acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, b2, acc, 0, 0, 0);
               acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a3, b3, acc, 0, 0, 0);
-              if (want_bias) {  // independent of `acc`: fills its issue gaps
-                ones = __builtin_amdgcn_mfma_f32_16x16x4f32(1.f, b0, ones, 0, 0, 0);
-                ones = __builtin_amdgcn_mfma_f32_16x16x4f32(1.f, b1, ones, 0, 0, 0);
-                ones = __builtin_amdgcn_mfma_f32_16x16x4f32(1.f, b2, ones, 0, 0, 0);
-                ones = __builtin_amdgcn_mfma_f32_16x16x4f32(1.f, b3, ones, 0, 0, 0);
-              }
+              bsum = (((bsum + b0) + b1) + b2) + b3;
             }
             for (; kc < kch; ++kc) {
               const float av = ap[kc * 4 * lda_p], bv = bp[kc * 4 * ldd];
               acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
-              if (want_bias) ones = __builtin_amdgcn_mfma_f32_16x16x4f32(1.f, bv, ones, 0, 0, 0);
+              bsum += bv;
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -247,11 +465,12 @@ __global__ __launch_bounds__(BORE_THREADS) void fit_kernel(const FitArgs a) {
                 if (l2 != 0.f) reg = fmaf(l2 * w, w, reg);
               }
             }
-            if (want_bias) {  // bias gradient: row 0 of ones^T D_l (lanes 0..15, register 0)
+            if (want_bias) {  // bias gradient: the column sums of D_l
+              const float gb = rows_sum4(bsum);
               if (q4 == 0 && cvalid) {
                 const int li = L.boff[l] + col;
                 float w = th[li];
-                float g = ones[0];
+                float g = gb;
                 const float l2 = L.l2_b[l];
                 if (l2 != 0.f) g = fmaf(2.f * l2, w, g);
                 if (a.state_in_lds) {
@@ -276,7 +495,9 @@ __global__ __launch_bounds__(BORE_THREADS) void fit_kernel(const FitArgs a) {
         reg = wave_sum(reg);
         if (lane == 0) atomicAdd(&misc[0], reg);
       }
+      BORE_STAMP(6);
       __syncthreads();
+      BORE_STAMP(7);
     }
     if (a.epoch_loss) {
       eloss = wave_sum(eloss);
@@ -330,9 +551,44 @@ __global__ __launch_bounds__(BORE_THREADS) void rows_kernel(const RowArgs a) {
   const long long xoff = a.x_shared ? 0 : model * a.n_rows * D;
   float *out = a.out + model * a.n_rows;
   const long long n_blocks = (a.n_rows + 15) >> 4;
+  using Net = RegNet<(SHAPE > 0 ? SHAPE : 1), WITH_GRAD ? 2 : 0>;
+  Net net;  // static shapes: the weights stay in this lane's registers for every row-block
+  if constexpr (SHAPE > 0) {
+    net.load_fwd(th);
+    if (WITH_GRAD) net.template load_bwd<Net::n, 1>(th);
+  }
   for (long long g = (long long)blockIdx.y * waves + wv; g < n_blocks;
        g += (long long)gridDim.y * waves) {
     const long long row = g * 16 + m16;  // the global row of this lane's operand slot
+    if constexpr (SHAPE > 0) {  // activations in registers (mlp_regs.h): no LDS tile at all
+      float xin[Net::KC0];
+#pragma unroll
+      for (int kc = 0; kc < Net::KC0; ++kc) {
+        const int d = 4 * kc + q4;
+        float x = 0.f;
+        if (d < D && row < a.n_rows)
+          x = WITH_GRAD ? (float)a.Xd[xoff + row * D + d] : a.Xf[xoff + row * D + d];
+        xin[kc] = x;
+      }
+      if (WITH_GRAD) {
+        const float Tv = net.fg(xin, a.transform, a.sign);
+        if (lane < 16 && row < a.n_rows) out[row] = Tv;
+        double *grad = a.grad + (model * a.n_rows) * D;
+        if (row < a.n_rows) {
+#pragma unroll
+          for (int t = 0; t < Net::L.Np[0] / 16; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int d = 16 * t + 4 * q4 + r;
+              if (d < D) grad[row * D + d] = (double)net.d[0][t][r];
+            }
+        }
+      } else {
+        net.forward(xin, false);
+        if (lane < 16 && row < a.n_rows) out[row] = net.h[Net::n][0][0];
+      }
+      continue;
+    }
     float *A0 = tile + L.aoff[0] + (wv * 16 + m16) * L.lda[0];
     for (int d = q4; d < D; d += 4) {
       float x = 0.f;
@@ -478,7 +734,7 @@ extern "C" int bore_mlp_fit(const bore_mlp_desc *desc, int n_models, float *thet
   a.o_misc = (int)off; off += 8;
   a.o_perm = (int)off; off += N;
   off = (off + 3) & ~(size_t)3;  // keys: 64-bit words fetched two at a time
-  a.o_keys = (int)off; off += perm ? 0 : 2 * ((N + 1) & ~1);
+  a.o_keys = (int)off; off += perm ? 0 : (size_t)perm_scratch_floats(N);
   if ((off + BORE_LAYOUT_FLOATS + 4) * 4 > BORE_LDS_BYTES)
     return fail(BORE_E_UNSUPPORTED, "fit: theta+tile+perm need %zu B of LDS (> %d)", off * 4,
                 BORE_LDS_BYTES);
@@ -500,7 +756,9 @@ extern "C" int bore_mlp_fit(const bore_mlp_desc *desc, int n_models, float *thet
   off = (off + 3) & ~(size_t)3;
   a.o_layout = (int)off; off += BORE_LAYOUT_FLOATS;
   // the constexpr-layout instantiation needs the layout it was compiled for (64-row tile)
-  const int shape = bore_kernel_flavour(desc, batch_size == BORE_BATCH_MAX);
+  // (and keeps the Adam slots in LDS unconditionally)
+  int shape = bore_kernel_flavour(desc, batch_size == BORE_BATCH_MAX);
+  if (shape > 0 && !a.state_in_lds) shape = -desc->n_layers;
 #define BORE_LAUNCH_FIT(S)                                                              \
   case S:                                                                               \
     rc = allow_lds(fit_kernel<S>, off * 4);                                             \
@@ -640,7 +898,7 @@ extern "C" int bore_shuffle_perm(uint64_t seed, int64_t model_index0, int n_mode
     return fail(BORE_E_INVALID, "shuffle_perm: bad argument");
   if (epochs == 0) return 0;
   if (epochs > 65535) return fail(BORE_E_UNSUPPORTED, "shuffle_perm: epochs > 65535");
-  const size_t bytes = (((size_t)N + 1) & ~(size_t)1) * 8;
+  const size_t bytes = (size_t)perm_scratch_floats(N) * 4;
   int rc = allow_lds(shuffle_kernel, bytes);
   if (rc) return rc;
   hipLaunchKernelGGL(shuffle_kernel, dim3(n_models, epochs), dim3(BORE_THREADS), bytes,

@@ -57,6 +57,16 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+// Sum over the four 16-lane rows of a wave, the same bits in every lane: (s0 + s1) + (s2 + s3).
+// permlane16_swap(x, y): x.row1 <-> y.row0, x.row3 <-> y.row2;  permlane32_swap(x, y):
+// x.rows{2,3} <-> y.rows{0,1}  (gfx950 VALU, no LDS).
+__device__ __forceinline__ float rows_sum4(float s) {
+  const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(s), __float_as_uint(s), false, false);
+  const float x = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+
 // Lanes of ONE wave exchange data through LDS between two program points: all of the
 // wave's earlier LDS accesses complete and the compiler may not move memory operations
 // across (a wave runs in lock-step, so no s_barrier is involved).
@@ -292,29 +302,54 @@ __host__ __device__ __forceinline__ unsigned shuffle_key(unsigned long long base
   return (unsigned)(mix64(base + 0x8CB92BA72F3D8DD7ULL * (unsigned long long)(i + 1)) >> 32);
 }
 
-// keys: LDS scratch of round_up(N, 2) 64-bit words, 16-byte aligned; perm_out: [N] (LDS or
+// floats of LDS scratch make_perm needs: round_up(N, 16) 64-bit words + N rank counters
+__host__ __device__ __forceinline__ long long perm_scratch_floats(long long N) {
+  return 2 * ((N + 15) & ~15LL) + ((N + 3) & ~3LL);
+}
+
+// keys: LDS scratch of perm_scratch_floats(N) floats, 16-byte aligned; perm_out: [N] (LDS or
 // global).  Ends with a barrier.  Row i's rank is the number of 64-bit words
-// (key_j << 32 | j) below its own -- one compare per row pair, the words fetched two at a time
-// (a broadcast ds_read_b128).
+// (key_j << 32 | j) below its own.  The words are fetched 16 at a time (8 broadcast
+// ds_read_b128 in flight); for small N the word range is split over up to 4 threads per row
+// (partial counts meet in an LDS counter), so that a 64-row shuffle keeps all 256 threads busy.
 __device__ __forceinline__ void make_perm(unsigned long long base, int N, unsigned *keys,
                                           int *perm_out) {
   unsigned long long *k64 = reinterpret_cast<unsigned long long *>(keys);
-  const int N2 = (N + 1) & ~1;
-  for (int i = threadIdx.x; i < N2; i += blockDim.x)
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int N16 = (N + 15) & ~15;
+  int *rank = reinterpret_cast<int *>(k64 + N16);
+  int parts = 1;
+  while (parts < 4 && N * parts * 2 <= nthr) parts *= 2;
+  for (int i = tid; i < N16; i += nthr)  // the padding words (all ones) are never below a key
     k64[i] = i < N ? ((unsigned long long)shuffle_key(base, i) << 32) | (unsigned)i : ~0ULL;
+  if (parts > 1)
+    for (int i = tid; i < N; i += nthr) rank[i] = 0;
   __syncthreads();
   const ulonglong2 *kk = reinterpret_cast<const ulonglong2 *>(keys);
-  for (int i = threadIdx.x; i < N; i += blockDim.x) {
+  const int nbat = N16 >> 4;
+  for (int u = tid; u < N * parts; u += nthr) {
+    const int p = u / N, i = u - p * N;
     const unsigned long long ki = k64[i];
+    const int b0 = p * nbat / parts, b1 = (p + 1) * nbat / parts;
     int r = 0;
-    for (int j = 0; j < (N2 >> 1); ++j) {  // the padding word (all ones) is never below ki
-      const ulonglong2 k = kk[j];
-      r += k.x < ki;
-      r += k.y < ki;
+    for (int b = b0; b < b1; ++b) {
+      ulonglong2 k[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) k[j] = kk[b * 8 + j];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        r += k[j].x < ki;
+        r += k[j].y < ki;
+      }
     }
-    perm_out[r] = i;
+    if (parts == 1) perm_out[r] = i;
+    else atomicAdd(&rank[i], r);
   }
   __syncthreads();
+  if (parts > 1) {
+    for (int i = tid; i < N; i += nthr) perm_out[rank[i]] = i;
+    __syncthreads();
+  }
 }
 
 }  // namespace bore

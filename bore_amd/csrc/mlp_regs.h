@@ -1,0 +1,264 @@
+// mlp_regs.h -- a row-block's trip through the network with the activations in REGISTERS.
+// gfx950 only; used by the kernels instantiated for a static shape (mlp_shapes.h).
+//
+// mlp_device.h's fwd_rowblock/bwd_rowblock pass a layer's output to the next layer through
+// LDS (write, s_waitcnt, read): ~250 cycles of pure latency per layer on a chain that one wave
+// walks alone.  Here the products are formed TRANSPOSED,
+//     H_l^T [units x 16 rows] = W_l^T [units x in] * H_{l-1}^T [in x 16 rows]
+// so the weights are the MFMA A operand (LDS, no dependence on the chain: the loads of every
+// layer can be in flight from the start) and the activations the B operand.  The output of
+// v_mfma_f32_16x16x4_f32 leaves lane (q, m) = (lane >> 4, lane & 15) holding
+//     C[4q + r][m] = H_l[row m][unit 16t + 4q + r],   r = 0..3
+// and the B operand of the next layer's k-chunk kc wants H_l[row m][unit 4 kc + q] in that
+// lane: a 4x4 transpose between the register index r and the 16-lane row index q, which
+// gfx950 does in four VALU instructions (v_permlane32_swap + v_permlane16_swap) -- no LDS.
+// The same holds backwards (D_{l-1}^T = W_l * D_l^T, A operand = W_l), and act' needs
+// H_{l-1} in exactly the C layout the forward pass left in this lane's registers.
+//
+// Arithmetic: identical to the LDS path, bit for bit -- the same k-ordered fmaf chain per
+// output (a*b commutes), the same bias add and activation expressions.
+#pragma once
+#include "mlp_device.h"
+
+namespace bore {
+
+// v[r] in lane-row q holds M[r][q]  ->  v[r] in lane-row q holds M[q][r]  (per column m)
+__device__ __forceinline__ void rows_transpose4(float (&v)[4]) {
+  // permlane32_swap(x, y): x.rows{2,3} <-> y.rows{0,1};  permlane16_swap(x, y): x.row1 <-> y.row0,
+  // x.row3 <-> y.row2  (rows of 16 lanes)
+  const auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[0]), __float_as_uint(v[2]),
+                                                  false, false);
+  const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[1]), __float_as_uint(v[3]),
+                                                  false, false);
+  const auto c = __builtin_amdgcn_permlane16_swap(a[0], b[0], false, false);
+  const auto d = __builtin_amdgcn_permlane16_swap(a[1], b[1], false, false);
+  v[0] = __uint_as_float(c[0]);
+  v[1] = __uint_as_float(c[1]);
+  v[2] = __uint_as_float(d[0]);
+  v[3] = __uint_as_float(d[1]);
+}
+
+template <int SHAPE, int DELTAS>
+struct RegNet {
+  static constexpr MlpLayout L = bore_static_layout(SHAPE, DELTAS, BORE_BATCH_MAX);
+  static constexpr int n = L.n_layers;
+  static constexpr int max_tiles() {
+    int t = 1;
+    for (int l = 0; l <= L.n_layers; ++l)
+      if (L.Np[l] / 16 > t) t = L.Np[l] / 16;
+    return t;
+  }
+  static constexpr int T = max_tiles();
+  static constexpr int KC0 = (L.w[0] + 3) / 4;  // k-chunks of the input layer
+
+  // ---- operand bookkeeping (all compile-time) ----
+  static constexpr int fkch(int l) { return (L.w[l - 1] + 3) / 4; }   // k-chunks, forward
+  static constexpr int ftiles(int l) { return L.Np[l] / 16; }          // output tiles, forward
+  static constexpr int fofs(int l) {
+    int o = 0;
+    for (int i = 1; i < l; ++i) o += fkch(i) * ftiles(i);
+    return o;
+  }
+  static constexpr int biasofs(int l) {
+    int o = 0;
+    for (int i = 1; i < l; ++i) o += 4 * ftiles(i);
+    return o;
+  }
+  static constexpr int bkch(int l) { return (L.w[l] + 3) / 4; }        // k-chunks, backward
+  static constexpr int btiles(int l) { return L.Np[l - 1] / 16; }      // output tiles, backward
+  static constexpr int bofs(int l) {  // layers are visited n, n-1, ..
+    int o = 0;
+    for (int i = L.n_layers; i > l; --i) o += bkch(i) * btiles(i);
+    return o;
+  }
+
+  // h[l][t][r] = A_l[row m][unit 16t + 4q + r] (l >= 1);  d[l][t][r] = D_l, same map
+  float h[n + 1][T][4];
+  float d[n + 1][T][4];
+  // this lane's MFMA A operands (weights) and biases, fetched ahead of the chain that uses them
+  float wf[fofs(n + 1)], bf[biasofs(n + 1)], wb[bofs(0)];
+
+  // Request every forward operand: W_l[4kc + q][16t + m] and b_l[16t + 4q + r].
+  template <int l = 1>
+  __device__ __forceinline__ void load_fwd(const float *th) {
+    if constexpr (l <= n) {
+      const int lane = threadIdx.x & 63, m = lane & 15, q = lane >> 4;
+      constexpr int kch = fkch(l), ldw = L.ldw[l];
+#pragma unroll
+      for (int t = 0; t < ftiles(l); ++t) {
+        const float *wp = th + L.woff[l] + q * ldw + 16 * t + m;
+#pragma unroll
+        for (int kc = 0; kc < kch; ++kc) wf[fofs(l) + t * kch + kc] = wp[kc * 4 * ldw];
+        const float *bp = th + L.boff[l] + 16 * t + 4 * q;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bf[biasofs(l) + 4 * t + r] = bp[r];
+      }
+      load_fwd<l + 1>(th);
+    }
+  }
+
+  // Request the backward operands of layers from, from-1, .., to: W_l[16t + m][4kc + q].
+  template <int from, int to>
+  __device__ __forceinline__ void load_bwd(const float *th) {
+    if constexpr (from >= to) {
+      const int lane = threadIdx.x & 63, m = lane & 15, q = lane >> 4;
+      constexpr int kch = bkch(from), ldw = L.ldw[from];
+#pragma unroll
+      for (int t = 0; t < btiles(from); ++t) {
+        const float *wp = th + L.woff[from] + (16 * t + m) * ldw + q;
+#pragma unroll
+        for (int kc = 0; kc < kch; ++kc) wb[bofs(from) + t * kch + kc] = wp[kc * 4];
+      }
+      load_bwd<from - 1, to>(th);
+    }
+  }
+
+  // B operands of a product whose inner dimension is a layer of width w held in C layout
+  template <int w>
+  static __device__ __forceinline__ void make_bop(const float (&src)[T][4], float (&bop)[4 * T]) {
+    const int q = (threadIdx.x & 63) >> 4;
+    if constexpr (w == 1) {
+      bop[0] = q == 0 ? src[0][0] : 0.f;
+    } else {
+      constexpr int kch = (w + 3) / 4;
+#pragma unroll
+      for (int t = 0; t < (kch + 3) / 4; ++t) {
+        float v[4] = {src[t][0], src[t][1], src[t][2], src[t][3]};
+        rows_transpose4(v);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (4 * t + j < kch) bop[4 * t + j] = v[j];
+      }
+    }
+  }
+
+  // A_l = act_l(A_{l-1} W_l + b_l); xin = the input rows' B operands (layer 1 only)
+  template <int l>
+  __device__ __forceinline__ void fwd_layer(const float (&xin)[KC0], bool keep_logits) {
+    const int q = (threadIdx.x & 63) >> 4;
+    constexpr int kch = fkch(l);
+    float bop[4 * T];
+    if constexpr (l == 1) {
+#pragma unroll
+      for (int kc = 0; kc < KC0; ++kc) bop[kc] = xin[kc];
+    } else {
+      make_bop<L.w[l - 1]>(h[l - 1], bop);
+    }
+    const int a = (keep_logits && l == n) ? BORE_ACT_LINEAR : L.act[l];
+#pragma unroll
+    for (int t = 0; t < ftiles(l); ++t) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kc = 0; kc < kch; ++kc)
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[fofs(l) + t * kch + kc], bop[kc], acc, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const bool valid = 16 * t + 4 * q + r < L.w[l];
+        h[l][t][r] = valid ? act_fwd(a, acc[r] + bf[biasofs(l) + 4 * t + r]) : 0.f;
+      }
+    }
+  }
+
+  // D_{l-1} = (D_l W_l^T) .* act'_{l-1}(A_{l-1})
+  template <int l>
+  __device__ __forceinline__ void bwd_layer() {
+    const int q = (threadIdx.x & 63) >> 4;
+    constexpr int kch = bkch(l);
+    float bop[4 * T];
+    make_bop<L.w[l]>(d[l], bop);
+#pragma unroll
+    for (int t = 0; t < btiles(l); ++t) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kc = 0; kc < kch; ++kc)
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[bofs(l) + t * kch + kc], bop[kc], acc, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const bool valid = 16 * t + 4 * q + r < L.w[l - 1];
+        float v = valid ? acc[r] : 0.f;
+        if (l > 1 && valid) v *= act_grad(L.act[l - 1], h[l - 1][t][r]);
+        d[l - 1][t][r] = v;
+      }
+    }
+  }
+
+  // (operands requested by load_fwd)
+  template <int l = 1>
+  __device__ __forceinline__ void forward(const float (&xin)[KC0], bool keep_logits) {
+    if constexpr (l <= n) {
+      fwd_layer<l>(xin, keep_logits);
+      forward<l + 1>(xin, keep_logits);
+    }
+  }
+
+  // bwd_layer for l = from, from-1, ..., to  (leaves D_{to-1}; operands requested by load_bwd)
+  template <int from, int to>
+  __device__ __forceinline__ void backward() {
+    if constexpr (from >= to) {
+      bwd_layer<from>();
+      backward<from - 1, to>();
+    }
+  }
+
+  // d loss / d logit (or d objective / d pre-activation of the output unit) of row m, given by
+  // the lanes < 16; every other slot of D_n is zero.
+  __device__ __forceinline__ void set_output_delta(float delta) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) d[n][t][r] = 0.f;
+    d[n][0][0] = lane < 16 ? delta : 0.f;
+  }
+
+  // Objective + input gradient (the register form of fg_rowblock): returns T(sign*f) of row
+  // m in the lanes < 16; D_0 (= d T / d x) is left in d[0].  Operands: load_fwd + load_bwd<n, 1>.
+  __device__ __forceinline__ float fg(const float (&xin)[KC0], int transform, float sign) {
+    forward(xin, false);
+    const float f = h[n][0][0];
+    const float u = sign * f;
+    float Tv, dT;
+    if (transform == BORE_T_SIGMOID) {
+      Tv = sigmoid_stable(u);
+      dT = Tv * (1.f - Tv);
+    } else if (transform == BORE_T_EXP) {
+      Tv = expf(u);
+      dT = Tv;
+    } else {
+      Tv = u;
+      dT = 1.f;
+    }
+    set_output_delta(sign * dT * act_grad(L.act[n], f));
+    backward<n, 1>();
+    return Tv;
+  }
+
+  template <int l, int hi>
+  __device__ __forceinline__ void store_A(float *tile, int rb) const {
+    if constexpr (l <= hi) {
+      store_rows<l>(h[l], tile + L.aoff[l], rb);
+      store_A<l + 1, hi>(tile, rb);
+    }
+  }
+  template <int l, int hi>
+  __device__ __forceinline__ void store_D(float *tile, int rb) const {
+    if constexpr (l <= hi) {
+      store_rows<l>(d[l], tile + L.doff[l], rb);
+      store_D<l + 1, hi>(tile, rb);
+    }
+  }
+
+  // Store layer l's C-layout registers into the padded LDS image rows [16 rb, 16 rb + 16)
+  // (the weight-gradient phase reads A_l / D_l of ALL rows from there).
+  template <int l>
+  static __device__ __forceinline__ void store_rows(const float (&src)[T][4], float *img, int rb) {
+    const int lane = threadIdx.x & 63, m = lane & 15, q = lane >> 4;
+    float *p = img + (rb * 16 + m) * L.lda[l] + 4 * q;
+#pragma unroll
+    for (int t = 0; t < L.Np[l] / 16; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) p[16 * t + r] = src[t][r];
+  }
+};
+
+}  // namespace bore

@@ -1,10 +1,9 @@
 import sys, os, subprocess, ctypes as C; sys.path.insert(0,'.')
 import numpy as np, torch
 from bore_amd import _lib
-# build the stamped variant into a separate .so and point the binding at it
 so = os.path.abspath('scratch/libbore_stamp.so')
-subprocess.run(['hipcc','-O3','--offload-arch=gfx950','-std=c++17','-shared','-fPIC','-ffp-contract=off','-Ibore_amd/csrc',
-                'scratch/bore_hip_stamp.hip','bore_amd/csrc/bore_argmax.hip','-o',so],check=True)
+subprocess.run(['hipcc','-O3','--offload-arch=gfx950','-std=c++17','-shared','-fPIC','-ffp-contract=off','-DBORE_STAMPS',
+                'bore_amd/csrc/bore_hip.hip','bore_amd/csrc/bore_argmax.hip','-o',so],check=True)
 _lib.LIB_PATH = so
 from bore_amd import ops
 lib=_lib.lib()
@@ -17,6 +16,6 @@ def run(N,units=(16,16,1),D=2,acts=("relu","relu","sigmoid")):
     for _ in range(3): ops.mlp_fit(desc,th,m,v,t,X,z,5,64,want_loss=False)
     torch.cuda.synchronize()
     out=(C.c_longlong*64)(); lib.bore_debug_stamps(out)
-    a=np.array(out[:8]); b=np.array(out[32:40])
-    print(N,units,'wave0 deltas',np.diff(a),'total',a[7]-a[0], 'perm', out[11]-out[10]); print('   wave1 deltas',np.diff(b))
-run(16); run(64); run(64,(64,64,64,1),16,("relu",)*3+("linear",))
+    for w in range(4):
+        a=np.array(out[16*w:16*w+12]); print(N,units,'wave',w,'deltas',np.diff(a[:8]),'task: pre',a[8]-a[5],'loads',a[9]-a[8],'mfma',a[10]-a[9],'adam',a[11]-a[10],'post',a[6]-a[11])
+run(16); run(64); run(64,(32,32,1),6,("relu","relu","linear"))
