@@ -12,6 +12,7 @@ from __future__ import annotations
 
 import numpy as np
 import torch
+from scipy.stats import truncnorm
 
 from . import ops
 from .transforms import resolve
@@ -41,3 +42,24 @@ def convert(model, transform=None):
 
     fn.transform = tr
     return fn
+
+
+def truncated_normal(loc, scale, lower, upper):
+    """Frozen normal(loc, scale) truncated to [lower, upper] (bore/base.py:45-48: scipy's
+    truncnorm takes its limits in standard-deviation units)."""
+    a = (lower - loc) / scale
+    b = (upper - loc) / scale
+    return truncnorm(a=a, b=b, loc=loc, scale=scale)
+
+
+def maybe_distort(loc, distortion=None, bounds=None, random_state=None, print_fn=print):
+    """Candidate post-processing of the plugin (bore/base.py:51-64): with ``distortion`` set,
+    replace the maximiser by one draw of a normal centred on it (scale = distortion) truncated
+    to the box; otherwise return it untouched.  ``bounds`` is a ``scipy.optimize.Bounds``."""
+    if distortion is None:
+        return loc
+    assert bounds is not None, "must specify bounds!"
+    ret = truncated_normal(loc=loc, scale=distortion, lower=bounds.lb,
+                           upper=bounds.ub).rvs(random_state=random_state)
+    print_fn(f"Suggesting x={ret} (after applying distortion={distortion:.3E})")
+    return ret

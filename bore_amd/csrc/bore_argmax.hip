@@ -334,6 +334,24 @@ struct LbfgsbArgs {
   int o_tile, o_vals, o_box, o_prob, prob_floats, o_state, o_dw, o_iw, o_layout, total;
 };
 
+// -DBORE_STAMPS: cycles spent in the optimiser / in f-g evaluation by wave 0 of workgroup 0
+#ifdef BORE_STAMPS
+__device__ long long g_lstamps[8];
+extern "C" int bore_debug_lstamps(long long *out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lstamps), sizeof(long long) * 8);
+}
+extern "C" int bore_debug_lphases(long long *out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(lbfgsb::g_lb_phase), sizeof(long long) * 16);
+}
+extern "C" int bore_debug_lphases_reset(void) {
+  long long z[16] = {0};
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(lbfgsb::g_lb_phase), z, sizeof(z));
+}
+#define BORE_LCLOCK() clock64()
+#else
+#define BORE_LCLOCK() 0LL
+#endif
+
 template <int SHAPE>
 __global__ __launch_bounds__(BORE_THREADS) void lbfgsb_kernel(const LbfgsbArgs a) {
   extern __shared__ float smem[];
@@ -380,8 +398,10 @@ __global__ __launch_bounds__(BORE_THREADS) void lbfgsb_kernel(const LbfgsbArgs a
   if (wv >= np) return;  // wave without problems (np < 4)
 
   bool done = (myp < 0);
+  long long t_adv = 0, t_fg = 0, n_rounds = 0;
   for (int round = 0; round < a.max_rounds; ++round) {
     int pending = 0;
+    const long long c0 = BORE_LCLOCK();
     if (!done) {
       const int rc = lbfgsb::lbfgsb_advance(st, wk, blo, bhi, bnbd, a.opt, cp);
       if (rc == lbfgsb::LB_NEED_FG) {
@@ -396,6 +416,7 @@ __global__ __launch_bounds__(BORE_THREADS) void lbfgsb_kernel(const LbfgsbArgs a
     }
     if (!__any(pending)) break;  // every problem of this wave has terminated
     wave_lds_sync();
+    const long long c1 = BORE_LCLOCK();
     if constexpr (SHAPE > 0) {
       // static shape: the 16-row block goes through the network in registers (mlp_regs.h)
       using Net = RegNet<SHAPE, 2>;
@@ -447,7 +468,15 @@ __global__ __launch_bounds__(BORE_THREADS) void lbfgsb_kernel(const LbfgsbArgs a
       }
     }
     wave_lds_sync();
+    t_adv += c1 - c0;
+    t_fg += BORE_LCLOCK() - c1;
+    ++n_rounds;
   }
+#ifdef BORE_STAMPS
+  if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) {
+    g_lstamps[0] = t_adv; g_lstamps[1] = t_fg; g_lstamps[2] = n_rounds; g_lstamps[3] = st.nit;
+  }
+#endif
 
   if (coop && lane != 0) return;  // one lane reports the shared problem
   if (myp >= 0) {

@@ -144,6 +144,41 @@ struct Coop {
 #define LB_LANES_SYNC() ((void)0)
 #endif
 
+// -DBORE_STAMPS: per-phase cycle accumulators (workgroup 0, thread 0); diagnostics only
+#if defined(BORE_STAMPS) && defined(__HIPCC__)
+__device__ long long g_lb_phase[16];
+#endif
+#if defined(BORE_STAMPS) && defined(__HIP_DEVICE_COMPILE__)
+#define LB_PHASE_BEGIN() const long long lb_t0_ = clock64()
+#define LB_PHASE_END(i)                                                                   \
+  do {                                                                                    \
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {                         \
+      g_lb_phase[i] += clock64() - lb_t0_;                                                \
+      g_lb_phase[8 + (i)] += 1;                                                           \
+    }                                                                                     \
+  } while (0)
+#else
+#define LB_PHASE_BEGIN() ((void)0)
+#define LB_PHASE_END(i) ((void)0)
+#endif
+
+// The value `v` holds in lane `src` (wave-uniform), in every lane of the wave.
+#if defined(__HIP_DEVICE_COMPILE__)
+LB_HD double lane_bcast(double v, int src) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+  return __hiloint2double(hi, lo);
+}
+LB_HD bool lanes_any(bool p) { return __any(p) != 0; }
+
+#else
+LB_HD double lane_bcast(double v, int) { return v; }
+LB_HD bool lanes_any(bool p) { return p; }
+#endif
+
+// p mod m for 0 <= p < 2m (circular indices into the m correction pairs; no integer divide)
+LB_HD int wrap(int p, int m) { return p >= m ? p - m : p; }
+
 // ---- small dense kernels ------------------------------------------------------
 // Sums strictly left to right (results do not depend on the unrolling); operands are fetched
 // eight at a time so that their LDS latencies overlap -- on the device a dependent
@@ -209,13 +244,14 @@ LB_HD int dpofa(double *a, int ld, int n, const Coop c = Coop{0, 1}) {
     const int j = c.lane;
     double s = 0.0;
     for (int k = 0; k < n; ++k) {
-      if (j == k) {
-        const double dkk = a[k * ld + k] - s;
-        a[k * ld + k] = dkk <= 0.0 ? dkk : sqrt(dkk);  // <= 0 marks "not positive definite"
+      // every lane forms "its" diagonal; lane k's is the real one (v_readlane broadcast)
+      const double dkk = a[k * ld + k] - s;
+      const double rkk = lane_bcast(dkk <= 0.0 ? dkk : sqrt(dkk), k);  // <= 0: not positive definite
+      if (j == k) a[k * ld + k] = rkk;
+      if (rkk <= 0.0) {
+        LB_LANES_SYNC();
+        return k + 1;
       }
-      LB_LANES_SYNC();
-      const double rkk = a[k * ld + k];
-      if (rkk <= 0.0) return k + 1;
       if (j > k && j < n) {
         double t = a[j * ld + k] - ddot(k, a + k * ld, a + j * ld);
         t = t / rkk;
@@ -248,26 +284,51 @@ LB_HD int dpofa(double *a, int ld, int n, const Coop c = Coop{0, 1}) {
 // order, as the sequential substitution (identical bits), n steps instead of n^2/2.
 LB_HD int dtrsl_upper(const double *t, int ld, int n, double *b, int trans,
                       const Coop c = Coop{0, 1}) {
-  for (int j = 0; j < n; ++j)
-    if (t[j * ld + j] == 0.0) return j + 1;
   if (c.nl >= n && c.nl > 1) {
+    if (lanes_any(c.lane < n && t[(c.lane < n ? c.lane : 0) * (ld + 1)] == 0.0)) {
+      for (int j = 0; j < n; ++j)
+        if (t[j * ld + j] == 0.0) return j + 1;
+    }
+  } else {
+    for (int j = 0; j < n; ++j)
+      if (t[j * ld + j] == 0.0) return j + 1;
+  }
+  if (c.nl >= n && c.nl > 1) {
+    // Every lane runs the divide on its own running value; the owner's quotient is broadcast
+    // with v_readlane (no LDS round trip in the chain) and T's entries for the next step are
+    // requested before the divide of this one.
     const int me = c.lane;
     const bool mine = me < n;
+    const int mc = mine ? me : 0;  // (lanes without an unknown read a valid address)
+    double xme = 0.0;
     if (!trans) {  // T x = b, backward; the sequential form applies b[i] += (-x_j) T_ij, j descending
       double bi = mine ? b[me] : 0.0;
+      double tjj = t[(n - 1) * ld + (n - 1)], tji = t[(n - 1) * ld + mc];
       for (int j = n - 1; j >= 0; --j) {
-        if (me == j) b[j] = bi / t[j * ld + j];
-        LB_LANES_SYNC();
-        if (mine && me < j) bi = bi + (-b[j]) * t[j * ld + me];
+        const int jn = j > 0 ? j - 1 : 0;
+        const double tjj_n = t[jn * ld + jn], tji_n = t[jn * ld + mc];
+        const double xj = lane_bcast(bi / tjj, j);
+        if (me == j) xme = xj;
+        if (mine && me < j) bi = bi + (-xj) * tji;
+        tjj = tjj_n;
+        tji = tji_n;
       }
     } else {  // T' x = b, forward; the sequential form is x_j = (b_j - sum_{i<j} T_ij x_i) / T_jj
-      double bj = mine ? b[me] : 0.0, acc = 0.0;
+      const double bj = mine ? b[me] : 0.0;
+      double acc = 0.0;
+      double tii = t[0], tmi = t[mc * ld];
       for (int i = 0; i < n; ++i) {
-        if (me == i) b[i] = i == 0 ? bj / t[0] : (bj - acc) / t[i * ld + i];
-        LB_LANES_SYNC();
-        if (mine && me > i) acc += t[me * ld + i] * b[i];
+        const int in = i + 1 < n ? i + 1 : i;
+        const double tii_n = t[in * ld + in], tmi_n = t[mc * ld + in];
+        const double xi = lane_bcast(i == 0 ? bj / tii : (bj - acc) / tii, i);
+        if (me == i) xme = xi;
+        if (mine && me > i) acc += tmi * xi;
+        tii = tii_n;
+        tmi = tmi_n;
       }
     }
+    LB_LANES_SYNC();  // (earlier reads of b by other lanes are complete)
+    if (mine) b[me] = xme;
     LB_LANES_SYNC();
     return 0;
   }
@@ -285,6 +346,42 @@ LB_HD int dtrsl_upper(const double *t, int ld, int n, double *b, int trans,
     }
   }
   return 0;
+}
+
+// T' x = b for one right-hand side by the calling thread alone; the caller has checked the
+// diagonal (same operations as dtrsl_upper(.., trans = 1) past its check).
+LB_HD void dtrsl_lower_rhs(const double *t, int ld, int n, double *b) {
+  b[0] = b[0] / t[0];
+  for (int j = 1; j < n; ++j) {
+    b[j] = b[j] - ddot(j, t + j * ld, b);
+    b[j] = b[j] / t[j * ld + j];
+  }
+}
+
+// Three dot products against the same vector, each summed left to right; the operands of all
+// three are fetched together (one LDS latency per four terms instead of three).
+LB_HD void ddot3(int n, const double *a, const double *b, const double *c, const double *v,
+                 double &av, double &bv, double &cv) {
+  double sa = 0.0, sb = 0.0, sc = 0.0;
+  int i = 0;
+  for (; i + 2 <= n; i += 2) {
+    const double a0 = a[i], a1 = a[i + 1], b0 = b[i], b1 = b[i + 1], c0 = c[i], c1 = c[i + 1];
+    const double v0 = v[i], v1 = v[i + 1];
+    sa += a0 * v0;
+    sb += b0 * v0;
+    sc += c0 * v0;
+    sa += a1 * v1;
+    sb += b1 * v1;
+    sc += c1 * v1;
+  }
+  for (; i < n; ++i) {
+    sa += a[i] * v[i];
+    sb += b[i] * v[i];
+    sc += c[i] * v[i];
+  }
+  av = sa;
+  bv = sb;
+  cv = sc;
 }
 
 // ---- limited-memory matrix products ---------------------------------------------
@@ -328,8 +425,25 @@ LB_HD int formt(int m, double *wt, const double *sy, const double *ss, int col, 
 
 // ---- projected gradient norm -------------------------------------------------------
 LB_HD double projgr(int n, const double *l, const double *u, const int *nbd, const double *x,
-                    const double *g) {
+                    const double *g, const Coop c = Coop{0, 1}) {
   double sb = 0.0;
+  if (c.nl > 1 && n <= c.nl) {  // lane i forms term i; the max runs over them in the same order
+    double v = 0.0;
+    if (c.lane < n) {
+      const int i = c.lane;
+      double gi = g[i];
+      if (nbd[i] != 0) {
+        if (gi < 0.0) {
+          if (nbd[i] >= 2) gi = fmax(x[i] - u[i], gi);
+        } else {
+          if (nbd[i] <= 2) gi = fmin(x[i] - l[i], gi);
+        }
+      }
+      v = fabs(gi);
+    }
+    for (int i = 0; i < n; ++i) sb = fmax(sb, lane_bcast(v, i));
+    return sb;
+  }
   for (int i = 0; i < n; ++i) {
     double gi = g[i];
     if (nbd[i] != 0) {
@@ -449,7 +563,7 @@ LB_HDN int cauchy(const IterArgs s, const Work w, const double *l, const double 
       d[i - 1] = neggi;
       f1 -= neggi * neggi;
       for (int j = cp.lane; j < col; j += cp.nl) {
-        const int pj = (pointr + j) % m;
+        const int pj = wrap(pointr + j, m);
         p[j] += w.wy[pj * n + (i - 1)] * neggi;
         p[col + j] += w.ws[pj * n + (i - 1)] * neggi;
       }
@@ -543,16 +657,15 @@ LB_HDN int cauchy(const IterArgs s, const Work w, const double *l, const double 
       if (col > 0) {
         for (int j = cp.lane; j < col2; j += cp.nl) c[j] += dt * p[j];
         for (int j = cp.lane; j < col; j += cp.nl) {
-          const int pj = (s.head + j) % m;
+          const int pj = wrap(s.head + j, m);
           wbp[j] = w.wy[pj * n + (ibp - 1)];
           wbp[col + j] = theta * w.ws[pj * n + (ibp - 1)];
         }
         LB_LANES_SYNC();
         const int info = bmv(m, w.sy, w.wt, col, wbp, v, s.c);
         if (info) return LB_CAUCHY_RET(info);
-        const double wmc = ddot(col2, c, v);
-        const double wmp = ddot(col2, p, v);
-        const double wmw = ddot(col2, wbp, v);
+        double wmc, wmp, wmw;
+        ddot3(col2, c, p, wbp, v, wmc, wmp, wmw);
         for (int j = cp.lane; j < col2; j += cp.nl) p[j] -= dibp * wbp[j];
         LB_LANES_SYNC();
         f1 += dibp * wmc;
@@ -645,11 +758,11 @@ LB_HDN int formk(const IterArgs s, const Work w) {
     // new rows in blocks (1,1), (2,1), (2,2) and the new column in block (2,1): one entry
     // set per jy, independent of each other
     {
-      const int ipntr = (s.head + col - 1) % m;
+      const int ipntr = wrap(s.head + col - 1, m);
       const int iy = col - 1, is = m + col - 1;
       for (int jy = c.lane; jy < col; jy += c.nl) {
         const int js = m + jy;
-        const int jpntr = (s.head + jy) % m;
+        const int jpntr = wrap(s.head + jy, m);
         double temp1 = 0.0, temp2 = 0.0, temp3 = 0.0;
         for (int k = 0; k < nsub; ++k) {
           const int k1 = ind[k] - 1;
@@ -666,10 +779,10 @@ LB_HDN int formk(const IterArgs s, const Work w) {
       }
       LB_LANES_SYNC();
       const int jyc = col - 1;
-      const int jpntr = (s.head + col - 1) % m;
+      const int jpntr = wrap(s.head + col - 1, m);
       for (int i = c.lane; i < col; i += c.nl) {
         const int is2 = m + i;
-        const int ip = (s.head + i) % m;
+        const int ip = wrap(s.head + i, m);
         double temp3 = 0.0;
         for (int k = 0; k < nsub; ++k) {
           const int k1 = ind[k] - 1;
@@ -687,7 +800,7 @@ LB_HDN int formk(const IterArgs s, const Work w) {
   // Each (iy, jy) entry is independent.
   for (int e = c.lane; e < upcl * upcl; e += c.nl) {
     const int iy = e / upcl, jy = e - iy * upcl;
-    const int ipntr = (s.head + iy) % m, jpntr = (s.head + jy) % m;
+    const int ipntr = wrap(s.head + iy, m), jpntr = wrap(s.head + jy, m);
     if (jy <= iy) {
       const int is = m + iy, js = m + jy;
       double temp1 = 0.0, temp2 = 0.0, temp3 = 0.0, temp4 = 0.0;
@@ -741,9 +854,13 @@ LB_HDN int formk(const IterArgs s, const Work w) {
   // side per lane)
   if (dpofa(wn, m2, col, c)) return -1;
   const int col2 = 2 * col;
-  for (int j = 0; j < col; ++j)
-    if (wn[j * m2 + j] == 0.0) return -1;
-  for (int js = col + c.lane; js < col2; js += c.nl) dtrsl_upper(wn, m2, col, wn + js * m2, 1);
+  if (c.nl > 1 && c.nl >= col) {
+    if (lanes_any(c.lane < col && wn[(c.lane < col ? c.lane : 0) * (m2 + 1)] == 0.0)) return -1;
+  } else {
+    for (int j = 0; j < col; ++j)
+      if (wn[j * m2 + j] == 0.0) return -1;
+  }
+  for (int js = col + c.lane; js < col2; js += c.nl) dtrsl_lower_rhs(wn, m2, col, wn + js * m2);
   LB_LANES_SYNC();
   // (2,2) block: S'AA'S*theta + (L^-1(-L_a'+R_z'))'(L^-1(-L_a'+R_z')), then its Cholesky
   for (int e = c.lane; e < col * col; e += c.nl) {
@@ -763,22 +880,27 @@ LB_HDN int formk(const IterArgs s, const Work w) {
 LB_HD int cmprlb(State &s, const Work &w, const Coop c) {
   const int n = s.n, m = s.m, col = s.col;
   if (!s.cnstnd && col > 0) {
-    for (int i = 0; i < n; ++i) w.r[i] = -w.g[i];
+    for (int i = c.lane; i < n; i += c.nl) w.r[i] = -w.g[i];
+    LB_LANES_SYNC();
     return 0;
-  }
-  for (int i = 0; i < s.nfree; ++i) {
-    const int k = w.index[i] - 1;
-    w.r[i] = -s.theta * (w.z[k] - w.x[k]) - w.g[k];
   }
   if (bmv(m, w.sy, w.wt, col, w.wa + 2 * m, w.wa, c)) return -8;
   for (int i = c.lane; i < s.nfree; i += c.nl) {  // each r[i]: its terms in the order j = 0, 1, ...
     const int k = w.index[i] - 1;
-    double ri = w.r[i];
-    for (int j = 0; j < col; ++j) {
-      const int pointr = (s.head + j) % m;
-      const double a1 = w.wa[j], a2 = s.theta * w.wa[col + j];
-      ri += w.wy[pointr * n + k] * a1 + w.ws[pointr * n + k] * a2;
+    double ri = -s.theta * (w.z[k] - w.x[k]) - w.g[k];
+    int p0 = s.head;
+    int j = 0;
+    for (; j + 2 <= col; j += 2) {  // operands of two terms in flight
+      const int p1 = p0 + 1 == m ? 0 : p0 + 1;
+      const double a10 = w.wa[j], a11 = w.wa[j + 1];
+      const double b20 = w.wa[col + j], b21 = w.wa[col + j + 1];
+      const double y0 = w.wy[p0 * n + k], s0 = w.ws[p0 * n + k];
+      const double y1 = w.wy[p1 * n + k], s1 = w.ws[p1 * n + k];
+      ri += y0 * a10 + s0 * (s.theta * b20);
+      ri += y1 * a11 + s1 * (s.theta * b21);
+      p0 = p1 + 1 == m ? 0 : p1 + 1;
     }
+    if (j < col) ri += w.wy[p0 * n + k] * w.wa[j] + w.ws[p0 * n + k] * (s.theta * w.wa[col + j]);
     w.r[i] = ri;
   }
   LB_LANES_SYNC();
@@ -799,7 +921,7 @@ LB_HDN int subsm(const IterArgs s, const Work w, const double *l, const double *
   if (nsub <= 0) return 0;
   const Coop c = s.c;
   for (int i = c.lane; i < col; i += c.nl) {  // wv = W'Zd, one entry pair per i
-    const int pointr = (s.head + i) % m;
+    const int pointr = wrap(s.head + i, m);
     double temp1 = 0.0, temp2 = 0.0;
     for (int j = 0; j < nsub; ++j) {
       const int k = ind[j] - 1;
@@ -811,40 +933,47 @@ LB_HDN int subsm(const IterArgs s, const Work w, const double *l, const double *
   }
   LB_LANES_SYNC();
   if (dtrsl_upper(w.wn, m2, col2, wv, 1, c)) return 1;
-  for (int i = 0; i < col; ++i) wv[i] = -wv[i];
+  for (int i = c.lane; i < col; i += c.nl) wv[i] = -wv[i];
+  LB_LANES_SYNC();
   if (dtrsl_upper(w.wn, m2, col2, wv, 0, c)) return 1;
+  for (int i = c.lane; i < n; i += c.nl) xp[i] = x[i];  // (the free variables are saved below too)
   for (int i = c.lane; i < nsub; i += c.nl) {  // d = (1/theta)d + (1/theta^2)Z'W wv, per entry
     const int k = ind[i] - 1;
     double di = d[i];
-    for (int jy = 0; jy < col; ++jy) {
-      const int pointr = (s.head + jy) % m;
-      di += w.wy[pointr * n + k] * wv[jy] / theta + w.ws[pointr * n + k] * wv[col + jy];
+    int p0 = s.head;
+    int jy = 0;
+    for (; jy + 2 <= col; jy += 2) {  // operands (and the two divides) of two terms in flight
+      const int p1 = p0 + 1 == m ? 0 : p0 + 1;
+      const double v0 = wv[jy], v1 = wv[jy + 1], u0 = wv[col + jy], u1 = wv[col + jy + 1];
+      const double y0 = w.wy[p0 * n + k], s0 = w.ws[p0 * n + k];
+      const double y1 = w.wy[p1 * n + k], s1 = w.ws[p1 * n + k];
+      di += y0 * v0 / theta + s0 * u0;
+      di += y1 * v1 / theta + s1 * u1;
+      p0 = p1 + 1 == m ? 0 : p1 + 1;
     }
-    d[i] = di * (1.0 / theta);
+    if (jy < col) di += w.wy[p0 * n + k] * wv[jy] / theta + w.ws[p0 * n + k] * wv[col + jy];
+    di = di * (1.0 / theta);
+    d[i] = di;
+    // projected Newton step of this free variable (distinct k per i)
+    const double xk = x[k];
+    const int nb = nbd[k];
+    double xn = xk + di;
+    bool hit = false;
+    if (nb == 1) {
+      xn = fmax(l[k], xn);
+      hit = xn == l[k];
+    } else if (nb == 2) {
+      xn = fmin(u[k], fmax(l[k], xn));
+      hit = xn == l[k] || xn == u[k];
+    } else if (nb == 3) {
+      xn = fmin(u[k], xn);
+      hit = xn == u[k];
+    }
+    x[k] = xn;
+    if (hit) iword = 1;
   }
   LB_LANES_SYNC();
-  // projected Newton step
-  iword = 0;
-  for (int i = 0; i < n; ++i) xp[i] = x[i];
-  for (int i = 0; i < nsub; ++i) {
-    const int k = ind[i] - 1;
-    const double dk = d[i], xk = x[k];
-    if (nbd[k] != 0) {
-      if (nbd[k] == 1) {
-        x[k] = fmax(l[k], xk + dk);
-        if (x[k] == l[k]) iword = 1;
-      } else if (nbd[k] == 2) {
-        const double xk2 = fmax(l[k], xk + dk);
-        x[k] = fmin(u[k], xk2);
-        if (x[k] == l[k] || x[k] == u[k]) iword = 1;
-      } else if (nbd[k] == 3) {
-        x[k] = fmin(u[k], xk + dk);
-        if (x[k] == u[k]) iword = 1;
-      }
-    } else {
-      x[k] = xk + dk;
-    }
-  }
+  if (c.nl > 1) iword = lanes_any(iword != 0) ? 1 : 0;
   if (iword == 0) return 0;
   // sign of the directional derivative along the projected step
   double dd_p = 0.0;
@@ -1036,8 +1165,10 @@ LB_HD void dcsrch(State &s, double f, double g, double &stp, double ftol, double
 
 // One call of the line-search driver.  first != 0 starts a new search along w.d.
 // Returns 1 if f/g is needed at the new w.x, 0 if the search ended (s.info tells how).
+// (the element-wise loops over the n variables are dealt to the lanes of a cooperating wave;
+// the dot products stay sequential -- their summation order is part of the result)
 LB_HD int lnsrlb(State &s, const Work &w, const double *l, const double *u, const int *nbd,
-                 int first) {
+                 int first, const Coop c = Coop{0, 1}) {
   const int n = s.n;
   const double big = 1e10, ftol = 1e-3, gtol = 0.9, xtol = 0.1;
   if (first) {
@@ -1066,10 +1197,11 @@ LB_HD int lnsrlb(State &s, const Work &w, const double *l, const double *u, cons
     }
     if (s.iter == 0 && !s.boxed) s.stp = fmin(1.0 / s.dnorm, s.stpmx);
     else s.stp = 1.0;
-    for (int i = 0; i < n; ++i) {
+    for (int i = c.lane; i < n; i += c.nl) {
       w.t[i] = w.x[i];
       w.r[i] = w.g[i];
     }
+    LB_LANES_SYNC();
     s.fold = s.f;
     s.ifun = 0;
     s.iback = 0;
@@ -1092,10 +1224,11 @@ LB_HD int lnsrlb(State &s, const Work &w, const double *l, const double *u, cons
     ++s.nfgv;
     s.iback = s.ifun - 1;
     if (s.stp == 1.0) {
-      for (int i = 0; i < n; ++i) w.x[i] = w.z[i];
+      for (int i = c.lane; i < n; i += c.nl) w.x[i] = w.z[i];
     } else {
-      for (int i = 0; i < n; ++i) w.x[i] = s.stp * w.d[i] + w.t[i];
+      for (int i = c.lane; i < n; i += c.nl) w.x[i] = s.stp * w.d[i] + w.t[i];
     }
+    LB_LANES_SYNC();
     return 1;
   }
   return 0;
@@ -1106,10 +1239,10 @@ LB_HD void matupd(State &s, const Work &w, double rr, double dr) {
   const int n = s.n, m = s.m;
   if (s.iupdat <= m) {
     s.col = s.iupdat;
-    s.itail = (s.head + s.iupdat - 1) % m;
+    s.itail = wrap(s.head + s.iupdat - 1, m);
   } else {
-    s.itail = (s.itail + 1) % m;
-    s.head = (s.head + 1) % m;
+    s.itail = wrap(s.itail + 1, m);
+    s.head = wrap(s.head + 1, m);
   }
   for (int i = 0; i < n; ++i) {
     w.ws[s.itail * n + i] = w.d[i];
@@ -1127,7 +1260,7 @@ LB_HD void matupd(State &s, const Work &w, double rr, double dr) {
   for (int j = 0; j < col - 1; ++j) {
     w.sy[j * m + (col - 1)] = ddot(n, w.d, w.wy + pointr * n);
     w.ss[(col - 1) * m + j] = ddot(n, w.ws + pointr * n, w.d);
-    pointr = (pointr + 1) % m;
+    pointr = wrap(pointr + 1, m);
   }
   if (s.stp == 1.0) w.ss[(col - 1) * m + (col - 1)] = s.dtd;
   else w.ss[(col - 1) * m + (col - 1)] = s.stp * s.stp * s.dtd;
@@ -1190,7 +1323,8 @@ LB_HD int lbfgsb_advance(State &s, const Work &w, const double *l, const double 
   if (s.stage == S_FINISHED) return LB_DONE;
 
   if (s.stage == S_FG_START || s.stage == S_FG_LNSRCH) {  // fresh f, g at w.x have arrived
-    for (int i = 0; i < n; ++i) { w.xlast[i] = w.x[i]; w.glast[i] = w.g[i]; }
+    for (int i = coop.lane; i < n; i += coop.nl) { w.xlast[i] = w.x[i]; w.glast[i] = w.g[i]; }
+    LB_LANES_SYNC();
     s.flast = s.f;
   }
 
@@ -1237,7 +1371,7 @@ LB_HD int lbfgsb_advance(State &s, const Work &w, const double *l, const double 
 
   if (s.stage == S_FG_START) {
     s.nfgv = 1;
-    s.sbgnrm = projgr(n, l, u, nbd, w.x, w.g);
+    s.sbgnrm = projgr(n, l, u, nbd, w.x, w.g, coop);
     if (s.sbgnrm <= opt.pgtol) { finish(s, T_CONVERGENCE, M_PGTOL); return LB_DONE; }
     resume_ls = false;
   }
@@ -1251,13 +1385,16 @@ LB_HD int lbfgsb_advance(State &s, const Work &w, const double *l, const double 
     } else {
       s.iword = -1;
       if (!s.cnstnd && s.col > 0) {
-        for (int i = 0; i < n; ++i) w.z[i] = w.x[i];
+        for (int i = coop.lane; i < n; i += coop.nl) w.z[i] = w.x[i];
+        LB_LANES_SYNC();
         s.wrk = s.updatd;
         s.nseg = 0;
       } else {
         const IterArgs ia{n, m, s.col, s.head, s.nfree, s.nenter, s.ileave, s.updatd, s.iupdat,
                           s.theta, s.sbgnrm, coop};
+        LB_PHASE_BEGIN();
         const int rc = cauchy(ia, w, l, u, nbd);
+        LB_PHASE_END(0);
         s.nseg = rc >> 8;
         if (rc & 0xff) {  // singular triangular system: refresh the memory
           refresh_memory(s);
@@ -1270,27 +1407,49 @@ LB_HD int lbfgsb_advance(State &s, const Work &w, const double *l, const double 
         const IterArgs ia{n, m, s.col, s.head, s.nfree, s.nenter, s.ileave, s.updatd, s.iupdat,
                           s.theta, s.sbgnrm, coop};
         if (s.wrk) {
-          if (formk(ia, w)) { refresh_memory(s); continue; }
+          LB_PHASE_BEGIN();
+          const int fk = formk(ia, w);
+          LB_PHASE_END(1);
+          if (fk) { refresh_memory(s); continue; }
         }
-        if (cmprlb(s, w, coop)) { refresh_memory(s); continue; }
-        const int rc = subsm(ia, w, l, u, nbd);
+        int rc;
+        {
+          LB_PHASE_BEGIN();
+          const int cm = cmprlb(s, w, coop);
+          LB_PHASE_END(2);
+          if (cm) { refresh_memory(s); continue; }
+        }
+        {
+          LB_PHASE_BEGIN();
+          rc = subsm(ia, w, l, u, nbd);
+          LB_PHASE_END(3);
+        }
         s.iword = rc >> 8;
         if (rc & 0xff) { refresh_memory(s); continue; }
       }
-      for (int i = 0; i < n; ++i) w.d[i] = w.z[i] - w.x[i];
+      for (int i = coop.lane; i < n; i += coop.nl) w.d[i] = w.z[i] - w.x[i];
+      LB_LANES_SYNC();
       first_ls = true;
     }
 
     s.info = 0;
-    if (lnsrlb(s, w, l, u, nbd, first_ls ? 1 : 0)) {
+    int ls_rc;
+    {
+      LB_PHASE_BEGIN();
+      ls_rc = lnsrlb(s, w, l, u, nbd, first_ls ? 1 : 0, coop);
+      LB_PHASE_END(4);
+    }
+    if (ls_rc) {
       if (s.iback < opt.maxls) {
         // SciPy's ScalarFunction serves a request at the point it evaluated last from its
         // cache (no call, nfev unchanged); a collapsed bracket asks for such points.
-        bool cached = true;
-        for (int i = 0; i < n; ++i) cached = cached && (w.x[i] == w.xlast[i]);
+        bool differs = false;
+        for (int i = coop.lane; i < n; i += coop.nl) differs = differs || (w.x[i] != w.xlast[i]);
+        const bool cached = coop.nl > 1 ? !lanes_any(differs) : !differs;
         if (cached) {
           s.f = s.flast;
-          for (int i = 0; i < n; ++i) w.g[i] = w.glast[i];
+          for (int i = coop.lane; i < n; i += coop.nl) w.g[i] = w.glast[i];
+          LB_LANES_SYNC();
           resume_ls = true;
           continue;
         }
@@ -1303,7 +1462,8 @@ LB_HD int lbfgsb_advance(State &s, const Work &w, const double *l, const double 
     }
     if (s.info != 0 || s.iback >= opt.maxls) {
       // restore the previous iterate
-      for (int i = 0; i < n; ++i) { w.x[i] = w.t[i]; w.g[i] = w.r[i]; }
+      for (int i = coop.lane; i < n; i += coop.nl) { w.x[i] = w.t[i]; w.g[i] = w.r[i]; }
+      LB_LANES_SYNC();
       s.f = s.fold;
       if (s.col == 0) {
         // abnormal termination
@@ -1317,7 +1477,7 @@ LB_HD int lbfgsb_advance(State &s, const Work &w, const double *l, const double 
     }
     // new iterate accepted
     ++s.iter;
-    s.sbgnrm = projgr(n, l, u, nbd, w.x, w.g);
+    s.sbgnrm = projgr(n, l, u, nbd, w.x, w.g, coop);
     // --- what the SciPy driver does on NEW_X ---
     ++s.nit;
     if (s.nit >= opt.maxiter) { finish(s, T_STOP, M_MAXITER); return LB_DONE; }
@@ -1333,7 +1493,8 @@ LB_HD int lbfgsb_advance(State &s, const Work &w, const double *l, const double 
       }
     }
     // --- BFGS update: r = g - g_old (y), d = step (s) ---
-    for (int i = 0; i < n; ++i) w.r[i] = w.g[i] - w.r[i];
+    for (int i = coop.lane; i < n; i += coop.nl) w.r[i] = w.g[i] - w.r[i];
+    LB_LANES_SYNC();
     {
       const double rr = ddot(n, w.r, w.r);
       double dr, ddum;
@@ -1342,7 +1503,8 @@ LB_HD int lbfgsb_advance(State &s, const Work &w, const double *l, const double 
         ddum = -s.gdold;
       } else {
         dr = (s.gd - s.gdold) * s.stp;
-        for (int i = 0; i < n; ++i) w.d[i] *= s.stp;
+        for (int i = coop.lane; i < n; i += coop.nl) w.d[i] *= s.stp;
+        LB_LANES_SYNC();
         ddum = -s.gdold * s.stp;
       }
       if (dr <= LB_EPSMCH * ddum) {  // curvature too small: skip the update
@@ -1351,8 +1513,18 @@ LB_HD int lbfgsb_advance(State &s, const Work &w, const double *l, const double 
       }
       s.updatd = 1;
       ++s.iupdat;
-      matupd(s, w, rr, dr);
-      if (formt(m, w.wt, w.sy, w.ss, s.col, s.theta, coop)) {
+      {
+        LB_PHASE_BEGIN();
+        matupd(s, w, rr, dr);
+        LB_PHASE_END(5);
+      }
+      int ft;
+      {
+        LB_PHASE_BEGIN();
+        ft = formt(m, w.wt, w.sy, w.ss, s.col, s.theta, coop);
+        LB_PHASE_END(6);
+      }
+      if (ft) {
         refresh_memory(s);
         continue;
       }
