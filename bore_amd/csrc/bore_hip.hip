@@ -251,6 +251,14 @@ __global__ __launch_bounds__(BORE_THREADS) void fit_kernel(const FitArgs a) {
   double b2p = pow((double)a.beta2, (double)t0);
   const float omb1 = 1.f - a.beta1, omb2 = 1.f - a.beta2;
   const int steps = (N + a.B - 1) / a.B;
+  // Step size of Adam step t: lr * sqrt(1 - beta2^t) / (1 - beta1^t).  Every wave forms the
+  // first one; after that the last wave computes the NEXT step's while it waits at the end of
+  // the weight-gradient phase and leaves it in misc[5] (one sqrt + divide per step per
+  // workgroup instead of per wave, and off the step's critical path).
+  b1p *= (double)a.beta1;
+  b2p *= (double)a.beta2;
+  const float alpha_first = a.lr * sqrtf(1.f - (float)b2p) / (1.f - (float)b1p);
+  bool first_step = true;
   __syncthreads();
 
   for (int e = 0; e < a.epochs; ++e) {
@@ -272,11 +280,8 @@ __global__ __launch_bounds__(BORE_THREADS) void fit_kernel(const FitArgs a) {
       if constexpr (SHAPE > 0) {
         if (wv * 16 + m16 < nb) src = perm_s[row0 + wv * 16 + m16];
       }
-      // this step's size (depends on the step count only: fills the wait for `src`)
-      b1p *= (double)a.beta1;
-      b2p *= (double)a.beta2;
-      float alpha = a.lr * sqrtf(1.f - (float)b2p) / (1.f - (float)b1p);
-      asm volatile("" : "+v"(alpha));  // keep it HERE (the compiler would sink it behind the barrier)
+      const float alpha = first_step ? alpha_first : misc[5];
+      first_step = false;
       if (wv * 16 < nb) {
         const int rb = wv;
         if constexpr (SHAPE > 0) {
@@ -494,6 +499,12 @@ __global__ __launch_bounds__(BORE_THREADS) void fit_kernel(const FitArgs a) {
       if (L.any_l2) {  // penalty of the UPDATED weights = the one the next step's loss sees
         reg = wave_sum(reg);
         if (lane == 0) atomicAdd(&misc[0], reg);
+      }
+      if (wv == (BORE_THREADS / 64) - 1) {  // the next step's size (read after the barrier below)
+        b1p *= (double)a.beta1;
+        b2p *= (double)a.beta2;
+        const float an = a.lr * sqrtf(1.f - (float)b2p) / (1.f - (float)b1p);
+        if (lane == 0) misc[5] = an;
       }
       BORE_STAMP(6);
       __syncthreads();
