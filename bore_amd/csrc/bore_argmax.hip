@@ -177,7 +177,10 @@ __global__ __launch_bounds__(BORE_THREADS) void screen_topk_kernel(const ScreenA
   const int n_blocks = (Ns + 15) >> 4;
   using Net = RegNet<(SHAPE > 0 ? SHAPE : 1), 0>;
   Net net;  // static shapes: the weights stay in this lane's registers for every row-block
-  if constexpr (SHAPE > 0) net.load_fwd(th);
+  if constexpr (SHAPE > 0) {
+    if constexpr (Net::RT_ACT) net.set_acts(a.L);
+    net.load_fwd(th);
+  }
   if (wv < waves)
     for (int g = wv; g < n_blocks; g += waves) {
       const int row = g * 16 + m16;
@@ -189,7 +192,7 @@ __global__ __launch_bounds__(BORE_THREADS) void screen_topk_kernel(const ScreenA
           const int d = 4 * kc + q4;
           xin[kc] = (d < D && row < Ns) ? (float)X[(long long)row * D + d] : 0.f;
         }
-        net.forward(xin, false);
+        net.forward(th, xin, false);
         p = net.h[Net::n][0][0];
       } else {
         float *A0 = tile + L.aoff[0] + (wv * 16 + m16) * L.lda[0];
@@ -287,7 +290,7 @@ extern "C" int bore_screen_topk(const bore_mlp_desc *desc, int n_models, const f
   a.total = (int)off;
   off = (off + 3) & ~(size_t)3;
   a.o_layout = (int)off; off += BORE_LAYOUT_FLOATS;
-  const int shape = bore_kernel_flavour(desc, a.L.tb == BORE_BATCH_MAX);
+  const int shape = bore_kernel_flavour(desc, true);  // (static flavours do not use the tile)
 #define BORE_LAUNCH_SCREEN(S)                                                                 \
   case S:                                                                                     \
     rc = allow_lds(screen_topk_kernel<S>, off * 4);                                           \
@@ -298,6 +301,8 @@ extern "C" int bore_screen_topk(const bore_mlp_desc *desc, int n_models, const f
   switch (shape) {
     BORE_LAUNCH_SCREEN(1)
     BORE_LAUNCH_SCREEN(2)
+    BORE_LAUNCH_SCREEN(3)
+    BORE_LAUNCH_SCREEN(4)
     BORE_LAUNCH_SCREEN(-1)
     BORE_LAUNCH_SCREEN(-2)
     BORE_LAUNCH_SCREEN(-3)
@@ -421,6 +426,7 @@ __global__ __launch_bounds__(BORE_THREADS) void lbfgsb_kernel(const LbfgsbArgs a
       // static shape: the 16-row block goes through the network in registers (mlp_regs.h)
       using Net = RegNet<SHAPE, 2>;
       Net net;
+      if constexpr (Net::RT_ACT) net.set_acts(a.L);
       const int m16 = lane & 15, q4 = lane >> 4;
       float xin[Net::KC0];
       net.load_fwd(th);  // (per evaluation: the optimiser's own state fills the register file)
@@ -434,7 +440,7 @@ __global__ __launch_bounds__(BORE_THREADS) void lbfgsb_kernel(const LbfgsbArgs a
           xin[kc] = d < D ? (float)wk.x[d] : 0.f;
         }
         __builtin_amdgcn_sched_barrier(0);
-        const float Tv = net.fg(xin, a.transform, a.sign);
+        const float Tv = net.fg(th, xin, a.transform, a.sign);
         st.f = (double)__uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(Tv)));
         if (m16 == 0) {
 #pragma unroll
@@ -450,12 +456,12 @@ __global__ __launch_bounds__(BORE_THREADS) void lbfgsb_kernel(const LbfgsbArgs a
 #pragma unroll
         for (int kc = 0; kc < Net::KC0; ++kc) xin[kc] = A0[4 * kc + q4];
         __builtin_amdgcn_sched_barrier(0);
-        const float Tv = net.fg(xin, a.transform, a.sign);
-        Net::template store_rows<0>(net.d[0], tile + L.doff[0], wv);
+        const float Tv = net.fg(th, xin, a.transform, a.sign);
+        Net::template store_rows<0>(net.d[0], tile + BORE_BATCH_MAX * L.lda[0], wv);
         wave_lds_sync();
         if (pending) {  // lane s < 16 owns row s: its value is already in this lane
           st.f = (double)Tv;
-          const float *g = tile + L.doff[0] + myrow * L.lda[0];
+          const float *g = tile + BORE_BATCH_MAX * L.lda[0] + myrow * L.lda[0];
           for (int d = 0; d < D; ++d) wk.g[d] = (double)g[d];
         }
       }
@@ -472,6 +478,7 @@ __global__ __launch_bounds__(BORE_THREADS) void lbfgsb_kernel(const LbfgsbArgs a
     t_fg += BORE_LCLOCK() - c1;
     ++n_rounds;
   }
+  (void)t_adv; (void)t_fg; (void)n_rounds;
 #ifdef BORE_STAMPS
   if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) {
     g_lstamps[0] = t_adv; g_lstamps[1] = t_fg; g_lstamps[2] = n_rounds; g_lstamps[3] = st.nit;
@@ -544,15 +551,22 @@ extern "C" int bore_lbfgsb_minimize(const bore_mlp_desc *desc, int n_models, con
   // largest number of problems per workgroup whose state fits beside theta and the tile
   // (tile rows: one 16-row block per wave that has a problem)
   int PB = num_starts < BORE_BATCH_MAX ? num_starts : BORE_BATCH_MAX;
+  // One problem per WAVE (all 64 lanes on it, lbfgsb::Coop) finishes a problem ~1.6x sooner than one
+  // problem per lane and uses every lane; prefer it while the launch still fits the GPU a few
+  // times over (256 CUs): 4 problems per workgroup, grid = models x ceil(R / 4).
+  if (PB > 4 && (long long)n_models * ((num_starts + 3) / 4) <= 8192) PB = 4;
   const int flavour = bore_kernel_flavour(desc, true);
   const int shape = flavour > 0 ? flavour : 0;  // constexpr-layout kernels assume a 64-row tile
   size_t off = 0;
   for (;; --PB) {
     if (PB < 1) return fail(BORE_E_UNSUPPORTED, "lbfgsb_minimize: one problem's state does not fit in LDS");
-    const int rows = shape ? BORE_BATCH_MAX : 16 * (PB < 4 ? PB : 4);
+    // static flavours keep the row-blocks in registers; their tile region only stages the
+    // points (A_0) and gradients (D_0) of waves that run several problems: 2 x 64 rows
+    const int rows = shape ? 16 : 16 * (PB < 4 ? PB : 4);
     if (bore_make_layout(desc, 2, rows, &a.L)) return fail(BORE_E_INVALID, "bad bore_mlp_desc");
     off = a.L.P_lds;
-    a.o_tile = (int)off; off += a.L.tile_floats;
+    a.o_tile = (int)off;
+    off += shape ? 2 * (size_t)BORE_BATCH_MAX * a.L.lda[0] : (size_t)a.L.tile_floats;
     a.o_vals = (int)off; off += BORE_BATCH_MAX;
     off = (off + 3) & ~(size_t)3;  // 16-byte boundary for the fp64 regions
     a.o_box = (int)off; off += 4 * (size_t)D + (((size_t)D + 3) & ~(size_t)3) + (D & 1 ? 2 : 0);
@@ -583,6 +597,8 @@ extern "C" int bore_lbfgsb_minimize(const bore_mlp_desc *desc, int n_models, con
   switch (flavour) {
     BORE_LAUNCH_LBFGSB(1)
     BORE_LAUNCH_LBFGSB(2)
+    BORE_LAUNCH_LBFGSB(3)
+    BORE_LAUNCH_LBFGSB(4)
     BORE_LAUNCH_LBFGSB(-1)
     BORE_LAUNCH_LBFGSB(-2)
     BORE_LAUNCH_LBFGSB(-3)

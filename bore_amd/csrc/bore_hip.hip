@@ -199,6 +199,155 @@ __device__ __forceinline__ void dw_adam_static(const FitArgs &a, float *smem, fl
   }
 }
 
+// Weight gradients + Adam for a WIDE static shape (mlp_shapes.h: 64-wide hidden layers): too
+// many tiles to unroll (40 for 16->64-64-64-1), so the wave walks its tiles t = wv, wv + 4, ...
+// in a run-time loop; per tile the same plan as dw_task -- all 2 x 16 MFMA operands and the
+// tile's theta / m / v slots requested up front (m, v from HBM when they do not fit in LDS: the
+// loads then fly under the MFMA chain), k-ordered MFMA sum over the 64 batch rows (rows past
+// the batch hold zeros), bias = column sums, branch-free Adam, one-unit layers transposed.
+// where one weight-gradient tile of a wide static shape reads and writes
+struct WideTile {
+  int K, Nw, ldw, lda_p, ldd, aoff, doff, kb, cb;
+  int li[5], gi[5];  // LDS / packed-HBM index of the slots this lane updates (4 = the bias)
+  bool ok[5], transposed, want_bias;
+};
+
+template <int SHAPE>
+__device__ __forceinline__ WideTile wide_tile(int t) {
+  constexpr MlpLayout L = bore_static_layout(SHAPE, 1, BORE_BATCH_MAX);
+  const int lane = threadIdx.x & 63, m16 = lane & 15, q4 = lane >> 4;
+  WideTile w;
+  // tile t -> (layer, kb, cb); every per-layer quantity is picked by a scalar compare chain
+  int woff = 0, boff = 0, goff_w = 0, goff_b = 0, ncb = 1, r = t, start = 0;
+  w.K = w.Nw = w.ldw = w.lda_p = w.ldd = w.aoff = w.doff = 0;
+#pragma unroll
+  for (int l = 1; l <= L.n_layers; ++l) {
+    const int nt = (L.Np[l - 1] >> 4) * (L.Np[l] >> 4);
+    if (t >= start && t < start + nt) {
+      w.K = L.w[l - 1]; w.Nw = L.w[l]; w.ldw = L.ldw[l]; w.lda_p = L.lda[l - 1]; w.ldd = L.lda[l];
+      w.aoff = L.aoff[l - 1]; w.doff = L.doff[l]; woff = L.woff[l]; boff = L.boff[l];
+      goff_w = L.goff_w[l]; goff_b = L.goff_b[l]; ncb = L.Np[l] >> 4; r = t - start;
+    }
+    start += nt;
+  }
+  w.kb = r / ncb;
+  w.cb = r - w.kb * ncb;
+  w.transposed = w.Nw == 1;
+  w.want_bias = w.kb == 0;
+  const int col = w.cb * 16 + m16;
+  if (w.transposed) {  // register 0 of lanes 0..15 = dW_l[kb*16 + m16][0]; lane 16 = the bias
+    const bool is_b = w.want_bias && lane == 16;
+    w.li[0] = is_b ? boff : woff + (w.kb * 16 + m16) * w.ldw;
+    w.gi[0] = is_b ? goff_b : goff_w + (w.kb * 16 + m16) * w.Nw;
+    w.ok[0] = is_b || (q4 == 0 && w.kb * 16 + m16 < w.K);
+#pragma unroll
+    for (int q = 1; q < 5; ++q) { w.li[q] = w.li[0]; w.gi[q] = w.gi[0]; w.ok[q] = false; }
+  } else {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      w.li[q] = woff + (w.kb * 16 + q4 * 4 + q) * w.ldw + col;
+      w.gi[q] = goff_w + (w.kb * 16 + q4 * 4 + q) * w.Nw + col;
+      w.ok[q] = col < w.Nw && w.kb * 16 + q4 * 4 + q < w.K;
+    }
+    w.li[4] = boff + col;
+    w.gi[4] = goff_b + col;
+    w.ok[4] = w.want_bias && q4 == 0 && col < w.Nw;
+  }
+  return w;
+}
+
+// Weight gradients + Adam for a WIDE static shape (mlp_shapes.h: 64-wide hidden layers): too
+// many tiles to unroll (40 for 16->64-64-64-1), so the wave walks its tiles t = wv, wv + 4, ...
+// in a run-time loop; per tile the same plan as dw_task -- all 2 x 16 MFMA operands and the
+// tile's theta slots requested up front, k-ordered MFMA sum over the 64 batch rows (rows past
+// the batch hold zeros), bias = column sums, branch-free Adam, one-unit layers transposed.
+// m and v of such a net do not fit in LDS beside theta and the tile: they stay in HBM, and the
+// NEXT tile's slots are requested before this tile's MFMA chain (one tile of software
+// pipelining hides the HBM latency).
+template <int SHAPE, bool STATE_LDS>
+__device__ __forceinline__ void dw_adam_wide(const FitArgs &a, float *smem, float *m_g,
+                                             float *v_g, float alpha, float omb1, float omb2) {
+  constexpr MlpLayout L = bore_static_layout(SHAPE, 1, BORE_BATCH_MAX);
+  constexpr int KCH = BORE_BATCH_MAX / 4;
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, m16 = lane & 15, q4 = lane >> 4;
+  float *th = smem, *tile = smem + a.o_tile, *sm = smem + a.o_m, *sv = smem + a.o_v;
+  int total = 0;
+#pragma unroll
+  for (int l = 1; l <= L.n_layers; ++l) total += (L.Np[l - 1] >> 4) * (L.Np[l] >> 4);
+  constexpr int STEP = BORE_THREADS / 64;
+  if (wv >= total) return;
+  WideTile cur = wide_tile<SHAPE>(wv);
+  float mm[5], vv[5];
+#pragma unroll
+  for (int q = 0; q < 5; ++q) {
+    mm[q] = STATE_LDS ? sm[cur.li[q]] : (cur.ok[q] ? m_g[cur.gi[q]] : 0.f);
+    vv[q] = STATE_LDS ? sv[cur.li[q]] : (cur.ok[q] ? v_g[cur.gi[q]] : 0.f);
+  }
+  for (int t = wv; t < total; t += STEP) {
+    const bool more = t + STEP < total;
+    if (t == wv) BORE_TSTAMP(8);
+    const WideTile nxt = wide_tile<SHAPE>(more ? t + STEP : t);
+    float mn[5], vn[5];
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {  // the next tile's Adam slots (distinct from this tile's)
+      mn[q] = STATE_LDS ? sm[nxt.li[q]] : (more && nxt.ok[q] ? m_g[nxt.gi[q]] : 0.f);
+      vn[q] = STATE_LDS ? sv[nxt.li[q]] : (more && nxt.ok[q] ? v_g[nxt.gi[q]] : 0.f);
+    }
+    const float *ap = tile + cur.aoff + q4 * cur.lda_p + cur.kb * 16 + m16;
+    const float *bp = tile + cur.doff + q4 * cur.ldd + cur.cb * 16 + m16;
+    float av[KCH], bv[KCH], w[5];
+#pragma unroll
+    for (int kc = 0; kc < KCH; ++kc) {
+      av[kc] = ap[kc * 4 * cur.lda_p];
+      bv[kc] = bp[kc * 4 * cur.ldd];
+    }
+#pragma unroll
+    for (int q = 0; q < 5; ++q) w[q] = th[cur.li[q]];
+    __builtin_amdgcn_sched_barrier(0);
+    if (t == wv) BORE_TSTAMP(9);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    float bsum = 0.f;
+#pragma unroll
+    for (int kc = 0; kc < KCH; ++kc) {
+      const float x = cur.transposed ? bv[kc] : av[kc], y = cur.transposed ? av[kc] : bv[kc];
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x, y, acc, 0, 0, 0);
+      bsum += bv[kc];
+    }
+    float g[5] = {acc[0], acc[1], acc[2], acc[3], 0.f};
+    if (t == wv) BORE_TSTAMP(10);
+    if (cur.want_bias) {
+      const float gb = rows_sum4(bsum);
+      if (cur.transposed) g[0] = lane == 16 ? gb : g[0];
+      else g[4] = gb;
+    }
+    float wn[5];
+#pragma unroll
+    for (int q = 0; q < 5; ++q)
+      wn[q] = adam_update(w[q], g[q], mm[q], vv[q], alpha, omb1, omb2, a.eps);
+    // pin the five updates HERE: left alone the compiler sinks each one behind the predicate of
+    // its store, where a conservative s_waitcnt vmcnt(0) then waits for the previous slot's HBM
+    // store and the next tile's prefetch -- five HBM round trips per tile
+#pragma unroll
+    for (int q = 0; q < 5; ++q) asm volatile("" : "+v"(wn[q]), "+v"(mm[q]), "+v"(vv[q]));
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+      if (!cur.ok[q]) continue;
+      th[cur.li[q]] = wn[q];
+      if (STATE_LDS) {
+        sm[cur.li[q]] = mm[q];
+        sv[cur.li[q]] = vv[q];
+      } else {
+        m_g[cur.gi[q]] = mm[q];
+        v_g[cur.gi[q]] = vv[q];
+      }
+    }
+    if (t == wv) BORE_TSTAMP(11);
+    cur = nxt;
+#pragma unroll
+    for (int q = 0; q < 5; ++q) { mm[q] = mn[q]; vv[q] = vn[q]; }
+  }
+}
+
 template <int SHAPE>
 __global__ __launch_bounds__(BORE_THREADS) void fit_kernel(const FitArgs a) {
   extern __shared__ float smem[];
@@ -282,13 +431,16 @@ __global__ __launch_bounds__(BORE_THREADS) void fit_kernel(const FitArgs a) {
       }
       const float alpha = first_step ? alpha_first : misc[5];
       first_step = false;
-      if (wv * 16 < nb) {
+      // (wide shapes: every wave runs, rows past the batch are dead -- x = 0, delta = 0 -- so
+      // that the weight-gradient tiles can always sum over all 64 rows)
+      if (wv * 16 < nb || bore_shape_is_wide(SHAPE > 0 ? SHAPE : 0)) {
         const int rb = wv;
         if constexpr (SHAPE > 0) {
           // static shape: the row-block's activations and deltas stay in registers
           // (mlp_regs.h); LDS only receives the copies the weight-gradient phase sums over
           using Net = RegNet<SHAPE, 1>;
           Net net;
+          if constexpr (Net::RT_ACT) net.set_acts(a.L);
           const int row = rb * 16 + m16;
           const bool live = row < nb;
           float xin[Net::KC0];
@@ -314,7 +466,7 @@ __global__ __launch_bounds__(BORE_THREADS) void fit_kernel(const FitArgs a) {
           net.template load_bwd<Net::n, 2>(th);
           __builtin_amdgcn_sched_barrier(0);  // every operand load is in flight before the chain
           BORE_STAMP(1);
-          net.forward(xin, /*keep_logits=*/true);
+          net.forward(th, xin, /*keep_logits=*/true);
           BORE_STAMP(2);
           net.template store_A<1, Net::n - 1>(tile, rb);
           float delta = 0.f;
@@ -329,7 +481,7 @@ __global__ __launch_bounds__(BORE_THREADS) void fit_kernel(const FitArgs a) {
           if (lane < 16) tile[L.doff[Net::n] + row * L.lda[Net::n]] = delta;
           net.set_output_delta(delta);
           BORE_STAMP(3);
-          net.template backward<Net::n, 2>();
+          net.template backward<Net::n, 2>(th);
           net.template store_D<1, Net::n - 1>(tile, rb);
           BORE_STAMP(4);
         } else {
@@ -385,7 +537,10 @@ __global__ __launch_bounds__(BORE_THREADS) void fit_kernel(const FitArgs a) {
       const int kch = (nb + 3) >> 2;
       float reg = 0.f;
       int t = 0;
-      if constexpr (SHAPE > 0) {
+      if constexpr (bore_shape_is_wide(SHAPE > 0 ? SHAPE : 0)) {
+        if (a.state_in_lds) dw_adam_wide<SHAPE, true>(a, smem, m_g, v_g, alpha, omb1, omb2);
+        else dw_adam_wide<SHAPE, false>(a, smem, m_g, v_g, alpha, omb1, omb2);
+      } else if constexpr (SHAPE > 0) {
         switch ((nb + 15) >> 4) {
           case 1: dw_adam_static<SHAPE, 1>(a, smem, alpha, omb1, omb2); break;
           case 2: dw_adam_static<SHAPE, 2>(a, smem, alpha, omb1, omb2); break;
@@ -565,6 +720,7 @@ __global__ __launch_bounds__(BORE_THREADS) void rows_kernel(const RowArgs a) {
   using Net = RegNet<(SHAPE > 0 ? SHAPE : 1), WITH_GRAD ? 2 : 0>;
   Net net;  // static shapes: the weights stay in this lane's registers for every row-block
   if constexpr (SHAPE > 0) {
+    if constexpr (Net::RT_ACT) net.set_acts(a.L);
     net.load_fwd(th);
     if (WITH_GRAD) net.template load_bwd<Net::n, 1>(th);
   }
@@ -582,7 +738,7 @@ __global__ __launch_bounds__(BORE_THREADS) void rows_kernel(const RowArgs a) {
         xin[kc] = x;
       }
       if (WITH_GRAD) {
-        const float Tv = net.fg(xin, a.transform, a.sign);
+        const float Tv = net.fg(th, xin, a.transform, a.sign);
         if (lane < 16 && row < a.n_rows) out[row] = Tv;
         double *grad = a.grad + (model * a.n_rows) * D;
         if (row < a.n_rows) {
@@ -595,7 +751,7 @@ __global__ __launch_bounds__(BORE_THREADS) void rows_kernel(const RowArgs a) {
             }
         }
       } else {
-        net.forward(xin, false);
+        net.forward(th, xin, false);
         if (lane < 16 && row < a.n_rows) out[row] = net.h[Net::n][0][0];
       }
       continue;
@@ -769,7 +925,8 @@ extern "C" int bore_mlp_fit(const bore_mlp_desc *desc, int n_models, float *thet
   // the constexpr-layout instantiation needs the layout it was compiled for (64-row tile)
   // (and keeps the Adam slots in LDS unconditionally)
   int shape = bore_kernel_flavour(desc, batch_size == BORE_BATCH_MAX);
-  if (shape > 0 && !a.state_in_lds) shape = -desc->n_layers;
+  if (shape > 0 && (!bore_shape_has_static_fit(shape) || (!a.state_in_lds && !bore_shape_is_wide(shape))))
+    shape = -desc->n_layers;
 #define BORE_LAUNCH_FIT(S)                                                              \
   case S:                                                                               \
     rc = allow_lds(fit_kernel<S>, off * 4);                                             \
@@ -780,6 +937,7 @@ extern "C" int bore_mlp_fit(const bore_mlp_desc *desc, int n_models, float *thet
   switch (shape) {
     BORE_LAUNCH_FIT(1)
     BORE_LAUNCH_FIT(2)
+    BORE_LAUNCH_FIT(3)
     BORE_LAUNCH_FIT(-1)
     BORE_LAUNCH_FIT(-2)
     BORE_LAUNCH_FIT(-3)
@@ -808,7 +966,7 @@ static int row_launch(bool with_grad, int n_models, RowArgs &a, void *stream) {
   if (gy > cap) gy = cap < 1 ? 1 : cap;
   if (gy > 65535) gy = 65535;
   int rc = 0;
-  const int shape = a.shape > 0 && L.tb != BORE_BATCH_MAX ? -L.n_layers : a.shape;
+  const int shape = a.shape;  // (the static flavours keep their row-blocks in registers: no tile)
 #define BORE_LAUNCH_ROWS(G, S)                                                              \
   {                                                                                         \
     rc = allow_lds(rows_kernel<G, S>, off * 4);                                             \
@@ -819,6 +977,8 @@ static int row_launch(bool with_grad, int n_models, RowArgs &a, void *stream) {
   if (with_grad) {
     if (shape == 1) BORE_LAUNCH_ROWS(true, 1)
     else if (shape == 2) BORE_LAUNCH_ROWS(true, 2)
+    else if (shape == 3) BORE_LAUNCH_ROWS(true, 3)
+    else if (shape == 4) BORE_LAUNCH_ROWS(true, 4)
     else if (shape == -1) BORE_LAUNCH_ROWS(true, -1)
     else if (shape == -2) BORE_LAUNCH_ROWS(true, -2)
     else if (shape == -3) BORE_LAUNCH_ROWS(true, -3)
@@ -827,6 +987,8 @@ static int row_launch(bool with_grad, int n_models, RowArgs &a, void *stream) {
   } else {
     if (shape == 1) BORE_LAUNCH_ROWS(false, 1)
     else if (shape == 2) BORE_LAUNCH_ROWS(false, 2)
+    else if (shape == 3) BORE_LAUNCH_ROWS(false, 3)
+    else if (shape == 4) BORE_LAUNCH_ROWS(false, 4)
     else if (shape == -1) BORE_LAUNCH_ROWS(false, -1)
     else if (shape == -2) BORE_LAUNCH_ROWS(false, -2)
     else if (shape == -3) BORE_LAUNCH_ROWS(false, -3)

@@ -72,16 +72,74 @@ struct RegNet {
     return o;
   }
 
+  // Small nets: every layer's operands are requested up front and stay in registers (the
+  // lbfgsb / rows kernels reuse them across row-blocks).  Wide nets: one output tile's operands
+  // at a time, inside the layer.
+  static constexpr bool PRELOAD = fofs(L.n_layers + 1) + bofs(0) <= 64;
+  // Activations: part of the shape, or read at run time (set_acts) when the shape fixes only
+  // the widths (mlp_shapes.h: act[0] < 0).
+  static constexpr bool RT_ACT = kShapes[SHAPE].act[0] < 0;
+  int acts[n + 1];
+  __device__ __forceinline__ void set_acts(const MlpLayout &Lrt) {
+#pragma unroll
+    for (int l = 0; l <= n; ++l) acts[l] = Lrt.act[l];
+  }
+  template <int l>
+  __device__ __forceinline__ int act_of() const {
+    if constexpr (RT_ACT) return acts[l];
+    else return L.act[l];
+  }
+
+  // Activation over a layer's registers.  A run-time activation id is wave-uniform: ONE scalar
+  // branch per layer picks the loop (a per-element switch makes the compiler evaluate several
+  // activations and select).
+  template <int A, int NT>
+  static __device__ __forceinline__ void act_tiles(float (&v)[T][4]) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[t][r] = act_fwd(A, v[t][r]);
+  }
+  template <int NT>
+  static __device__ __forceinline__ void act_tiles_rt(int a, float (&v)[T][4]) {
+    switch (__builtin_amdgcn_readfirstlane(a)) {
+      case BORE_ACT_RELU: act_tiles<BORE_ACT_RELU, NT>(v); break;
+      case BORE_ACT_ELU: act_tiles<BORE_ACT_ELU, NT>(v); break;
+      case BORE_ACT_SIGMOID: act_tiles<BORE_ACT_SIGMOID, NT>(v); break;
+      case BORE_ACT_TANH: act_tiles<BORE_ACT_TANH, NT>(v); break;
+      default: break;
+    }
+  }
+  // v *= act'(h), same dispatch
+  template <int A, int NT>
+  static __device__ __forceinline__ void grad_tiles(float (&v)[T][4], const float (&hh)[T][4]) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[t][r] *= act_grad(A, hh[t][r]);
+  }
+  template <int NT>
+  static __device__ __forceinline__ void grad_tiles_rt(int a, float (&v)[T][4],
+                                                       const float (&hh)[T][4]) {
+    switch (__builtin_amdgcn_readfirstlane(a)) {
+      case BORE_ACT_RELU: grad_tiles<BORE_ACT_RELU, NT>(v, hh); break;
+      case BORE_ACT_ELU: grad_tiles<BORE_ACT_ELU, NT>(v, hh); break;
+      case BORE_ACT_SIGMOID: grad_tiles<BORE_ACT_SIGMOID, NT>(v, hh); break;
+      case BORE_ACT_TANH: grad_tiles<BORE_ACT_TANH, NT>(v, hh); break;
+      default: break;  // linear: derivative 1
+    }
+  }
+
   // h[l][t][r] = A_l[row m][unit 16t + 4q + r] (l >= 1);  d[l][t][r] = D_l, same map
   float h[n + 1][T][4];
   float d[n + 1][T][4];
   // this lane's MFMA A operands (weights) and biases, fetched ahead of the chain that uses them
-  float wf[fofs(n + 1)], bf[biasofs(n + 1)], wb[bofs(0)];
+  float wf[PRELOAD ? fofs(n + 1) : 1], bf[PRELOAD ? biasofs(n + 1) : 1], wb[PRELOAD ? bofs(0) : 1];
 
   // Request every forward operand: W_l[4kc + q][16t + m] and b_l[16t + 4q + r].
   template <int l = 1>
   __device__ __forceinline__ void load_fwd(const float *th) {
-    if constexpr (l <= n) {
+    if constexpr (PRELOAD && l <= n) {
       const int lane = threadIdx.x & 63, m = lane & 15, q = lane >> 4;
       constexpr int kch = fkch(l), ldw = L.ldw[l];
 #pragma unroll
@@ -100,7 +158,7 @@ struct RegNet {
   // Request the backward operands of layers from, from-1, .., to: W_l[16t + m][4kc + q].
   template <int from, int to>
   __device__ __forceinline__ void load_bwd(const float *th) {
-    if constexpr (from >= to) {
+    if constexpr (PRELOAD && from >= to) {
       const int lane = threadIdx.x & 63, m = lane & 15, q = lane >> 4;
       constexpr int kch = bkch(from), ldw = L.ldw[from];
 #pragma unroll
@@ -134,9 +192,10 @@ struct RegNet {
 
   // A_l = act_l(A_{l-1} W_l + b_l); xin = the input rows' B operands (layer 1 only)
   template <int l>
-  __device__ __forceinline__ void fwd_layer(const float (&xin)[KC0], bool keep_logits) {
-    const int q = (threadIdx.x & 63) >> 4;
-    constexpr int kch = fkch(l);
+  __device__ __forceinline__ void fwd_layer(const float *th, const float (&xin)[KC0],
+                                            bool keep_logits) {
+    const int lane = threadIdx.x & 63, m = lane & 15, q = lane >> 4;
+    constexpr int kch = fkch(l), ldw = L.ldw[l];
     float bop[4 * T];
     if constexpr (l == 1) {
 #pragma unroll
@@ -144,59 +203,102 @@ struct RegNet {
     } else {
       make_bop<L.w[l - 1]>(h[l - 1], bop);
     }
-    const int a = (keep_logits && l == n) ? BORE_ACT_LINEAR : L.act[l];
+    const int a = (keep_logits && l == n) ? BORE_ACT_LINEAR : act_of<l>();
 #pragma unroll
     for (int t = 0; t < ftiles(l); ++t) {
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      float bias[4];
+      if constexpr (PRELOAD) {
 #pragma unroll
-      for (int kc = 0; kc < kch; ++kc)
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[fofs(l) + t * kch + kc], bop[kc], acc, 0, 0, 0);
+        for (int kc = 0; kc < kch; ++kc)
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[fofs(l) + t * kch + kc], bop[kc], acc, 0, 0, 0);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const bool valid = 16 * t + 4 * q + r < L.w[l];
-        h[l][t][r] = valid ? act_fwd(a, acc[r] + bf[biasofs(l) + 4 * t + r]) : 0.f;
+        for (int r = 0; r < 4; ++r) bias[r] = bf[biasofs(l) + 4 * t + r];
+      } else {  // this tile's operands: W_l[4kc + q][16t + m], b_l[16t + 4q + r]
+        const float *wp = th + L.woff[l] + q * ldw + 16 * t + m;
+        const float *bp = th + L.boff[l] + 16 * t + 4 * q;
+        float wt[kch];
+#pragma unroll
+        for (int kc = 0; kc < kch; ++kc) wt[kc] = wp[kc * 4 * ldw];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bias[r] = bp[r];
+#pragma unroll
+        for (int kc = 0; kc < kch; ++kc)
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wt[kc], bop[kc], acc, 0, 0, 0);
       }
+      if constexpr (RT_ACT) {  // pre-activations; the activation follows for the whole layer
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h[l][t][r] = acc[r] + bias[r];
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const bool valid = 16 * t + 4 * q + r < L.w[l];
+          h[l][t][r] = valid ? act_fwd(a, acc[r] + bias[r]) : 0.f;
+        }
+      }
+    }
+    if constexpr (RT_ACT) {
+      act_tiles_rt<ftiles(l)>(a, h[l]);
+#pragma unroll
+      for (int t = 0; t < ftiles(l); ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (!(16 * t + 4 * q + r < L.w[l])) h[l][t][r] = 0.f;  // padding units stay zero
     }
   }
 
   // D_{l-1} = (D_l W_l^T) .* act'_{l-1}(A_{l-1})
   template <int l>
-  __device__ __forceinline__ void bwd_layer() {
-    const int q = (threadIdx.x & 63) >> 4;
-    constexpr int kch = bkch(l);
+  __device__ __forceinline__ void bwd_layer(const float *th) {
+    const int lane = threadIdx.x & 63, m = lane & 15, q = lane >> 4;
+    constexpr int kch = bkch(l), ldw = L.ldw[l];
     float bop[4 * T];
     make_bop<L.w[l]>(d[l], bop);
+    const int ap = act_of<(l > 1 ? l - 1 : 1)>();
 #pragma unroll
     for (int t = 0; t < btiles(l); ++t) {
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      if constexpr (PRELOAD) {
 #pragma unroll
-      for (int kc = 0; kc < kch; ++kc)
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[bofs(l) + t * kch + kc], bop[kc], acc, 0, 0, 0);
+        for (int kc = 0; kc < kch; ++kc)
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[bofs(l) + t * kch + kc], bop[kc], acc, 0, 0, 0);
+      } else {  // W_l[16t + m][4kc + q]
+        const float *wp = th + L.woff[l] + (16 * t + m) * ldw + q;
+        float wt[kch];
+#pragma unroll
+        for (int kc = 0; kc < kch; ++kc) wt[kc] = wp[kc * 4];
+#pragma unroll
+        for (int kc = 0; kc < kch; ++kc)
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wt[kc], bop[kc], acc, 0, 0, 0);
+      }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const bool valid = 16 * t + 4 * q + r < L.w[l - 1];
         float v = valid ? acc[r] : 0.f;
-        if (l > 1 && valid) v *= act_grad(L.act[l - 1], h[l - 1][t][r]);
+        if constexpr (!RT_ACT)
+          if (l > 1 && valid) v *= act_grad(ap, h[l - 1][t][r]);
         d[l - 1][t][r] = v;
       }
     }
+    if constexpr (RT_ACT && l > 1) grad_tiles_rt<btiles(l)>(ap, d[l - 1], h[l - 1]);
   }
 
-  // (operands requested by load_fwd)
+  // (small nets: operands requested by load_fwd; wide nets: fetched per tile from th)
   template <int l = 1>
-  __device__ __forceinline__ void forward(const float (&xin)[KC0], bool keep_logits) {
+  __device__ __forceinline__ void forward(const float *th, const float (&xin)[KC0],
+                                          bool keep_logits) {
     if constexpr (l <= n) {
-      fwd_layer<l>(xin, keep_logits);
-      forward<l + 1>(xin, keep_logits);
+      fwd_layer<l>(th, xin, keep_logits);
+      forward<l + 1>(th, xin, keep_logits);
     }
   }
 
   // bwd_layer for l = from, from-1, ..., to  (leaves D_{to-1}; operands requested by load_bwd)
   template <int from, int to>
-  __device__ __forceinline__ void backward() {
+  __device__ __forceinline__ void backward(const float *th) {
     if constexpr (from >= to) {
-      bwd_layer<from>();
-      backward<from - 1, to>();
+      bwd_layer<from>(th);
+      backward<from - 1, to>(th);
     }
   }
 
@@ -213,8 +315,9 @@ struct RegNet {
 
   // Objective + input gradient (the register form of fg_rowblock): returns T(sign*f) of row
   // m in the lanes < 16; D_0 (= d T / d x) is left in d[0].  Operands: load_fwd + load_bwd<n, 1>.
-  __device__ __forceinline__ float fg(const float (&xin)[KC0], int transform, float sign) {
-    forward(xin, false);
+  __device__ __forceinline__ float fg(const float *th, const float (&xin)[KC0], int transform,
+                                      float sign) {
+    forward(th, xin, false);
     const float f = h[n][0][0];
     const float u = sign * f;
     float Tv, dT;
@@ -228,8 +331,8 @@ struct RegNet {
       Tv = u;
       dT = 1.f;
     }
-    set_output_delta(sign * dT * act_grad(L.act[n], f));
-    backward<n, 1>();
+    set_output_delta(sign * dT * act_grad(act_of<n>(), f));
+    backward<n, 1>(th);
     return Tv;
   }
 

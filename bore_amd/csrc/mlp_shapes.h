@@ -9,21 +9,29 @@
 #pragma once
 #include "mlp_layout.h"
 
-#define BORE_N_SHAPES 2  // ids 1..BORE_N_SHAPES
+#define BORE_N_SHAPES 4  // ids 1..BORE_N_SHAPES
 
 struct ShapeSpec {
   int D, n_layers;
   int units[4];
-  int act[4];
+  int act[4];  // act[0] < 0: any activations (read at run time; only the widths are static)
 };
 
 // 1: README.rst:60-63 / BASELINE config 1 and 4 (Branin-2D, 16-16-1, relu relu sigmoid)
-// 2: BASELINE config 2 (Hartmann-6D, 32-32-1, relu relu + logit output)
+// 2: BASELINE config 2 (Hartmann-6D, 32-32-1)
+// 3: BASELINE config 3 (16-D, 64-64-64-1)
+// 4: BASELINE config 5 (32-D, 128-128-1; fp32 forward / input gradient / L-BFGS-B only)
 static constexpr ShapeSpec kShapes[BORE_N_SHAPES + 1] = {
     {0, 0, {0, 0, 0, 0}, {0, 0, 0, 0}},
     {2, 3, {16, 16, 1, 0}, {BORE_ACT_RELU, BORE_ACT_RELU, BORE_ACT_SIGMOID, 0}},
-    {6, 3, {32, 32, 1, 0}, {BORE_ACT_RELU, BORE_ACT_RELU, BORE_ACT_LINEAR, 0}},
+    {6, 3, {32, 32, 1, 0}, {-1, 0, 0, 0}},
+    {16, 4, {64, 64, 64, 1}, {-1, 0, 0, 0}},
+    {32, 3, {128, 128, 1, 0}, {-1, 0, 0, 0}},
 };
+// shapes with a register-row-block fit (4 does not fit fp32 theta + a 64-row tile in LDS)
+static constexpr bool bore_shape_has_static_fit(int shape) { return shape >= 1 && shape <= 3; }
+// wide shapes: the fit walks its weight-gradient tiles in a run-time loop, Adam slots in HBM
+static constexpr bool bore_shape_is_wide(int shape) { return shape >= 3; }
 
 static constexpr bore_mlp_desc bore_shape_desc(int shape) {
   bore_mlp_desc d{};
@@ -31,7 +39,7 @@ static constexpr bore_mlp_desc bore_shape_desc(int shape) {
   d.n_layers = kShapes[shape].n_layers;
   for (int i = 0; i < 4; ++i) {
     d.units[i] = kShapes[shape].units[i];
-    d.act[i] = kShapes[shape].act[i];
+    d.act[i] = kShapes[shape].act[0] < 0 ? BORE_ACT_LINEAR : kShapes[shape].act[i];  // placeholder
   }
   return d;
 }
@@ -54,7 +62,8 @@ static inline int bore_match_shape(const bore_mlp_desc *d) {
     if (d->input_dim != kShapes[s].D || d->n_layers != kShapes[s].n_layers) continue;
     bool ok = true;
     for (int i = 0; i < d->n_layers; ++i)
-      ok = ok && d->units[i] == kShapes[s].units[i] && d->act[i] == kShapes[s].act[i] &&
+      ok = ok && d->units[i] == kShapes[s].units[i] &&
+           (kShapes[s].act[0] < 0 || d->act[i] == kShapes[s].act[i]) &&
            d->l2_kernel[i] == 0.f && d->l2_bias[i] == 0.f;
     if (ok) return s;
   }

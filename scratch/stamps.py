@@ -18,4 +18,4 @@ def run(N,units=(16,16,1),D=2,acts=("relu","relu","sigmoid")):
     out=(C.c_longlong*64)(); lib.bore_debug_stamps(out)
     for w in range(4):
         a=np.array(out[16*w:16*w+12]); print(N,units,'wave',w,'deltas',np.diff(a[:8]),'task: pre',a[8]-a[5],'loads',a[9]-a[8],'mfma',a[10]-a[9],'adam',a[11]-a[10],'post',a[6]-a[11])
-run(16); run(64); run(64,(32,32,1),6,("relu","relu","linear"))
+run(64,(64,64,64,1),16,("relu","relu","relu","linear"))
