@@ -120,6 +120,29 @@ def test_device_lbfgsb_equals_host_build_and_tracks_scipy(gpu, D, units, acts, t
     assert np.median(dfun) < 1e-6 and np.mean(np.array(dfun) < 2e-5) >= 0.9
 
 
+def test_lbfgsb_one_problem_per_lane_mode_equals_one_per_wave(gpu):
+    """The launcher gives every problem a whole wave while models x ceil(R/4) workgroups stay
+    below 8192 and packs 64 problems per workgroup (one per lane) beyond that.  Both schedules
+    run the same optimiser code in the same operation order: identical bits."""
+    rs = np.random.RandomState(5)
+    for D, units, acts, tr in [(2, [16, 16, 1], ["relu", "relu", "sigmoid"], "identity"),
+                               (6, [32, 32, 1], ["elu", "elu", "linear"], "sigmoid"),
+                               (3, [8, 1], ["tanh", "linear"], "identity")]:
+        desc = _lib.make_desc(D, units, acts)
+        L, R = 64, 516                                   # 64 * 129 = 8256 workgroups > 8192
+        th = dev(np.stack([pack(rand_model(rs, D, units)) for _ in range(L)]))
+        X0 = rs.uniform(size=(L, R, D))
+        lo, hi = np.zeros(D), np.ones(D)
+        kw = dict(maxiter=6, ftol=1e-9)
+        big = [t.cpu().numpy() for t in ops.lbfgsb_minimize(desc, th, dev(X0), lo, hi, tr, True, **kw)]
+        for l in (0, 31, 63):                            # the same problems, one model at a time
+            one = [t.cpu().numpy()[0] for t in
+                   ops.lbfgsb_minimize(desc, th[l:l + 1], dev(X0[l:l + 1]), lo, hi, tr, True, **kw)]
+            for a, b in zip(big, one):
+                assert np.array_equal(a[l], b), (D, l)
+        assert (big[3][:, :, 0] <= 6).all() and (big[3][:, :, 1] >= 1).all()
+
+
 def test_device_lbfgsb_limits_and_open_bounds(gpu):
     rs = np.random.RandomState(0)
     D, units, acts = 4, [16, 1], ["tanh", "linear"]
