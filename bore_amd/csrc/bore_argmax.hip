@@ -402,6 +402,15 @@ __global__ __launch_bounds__(BORE_THREADS) void lbfgsb_kernel(const LbfgsbArgs a
   __syncthreads();  // weights staged; from here on the waves are independent
   if (wv >= np) return;  // wave without problems (np < 4)
 
+  // static shapes: the network (small ones: with its weight operands, 30 registers for shape 1)
+  // lives in registers for the whole optimisation
+  using Net = RegNet<(SHAPE > 0 ? SHAPE : 1), 2>;
+  Net net;
+  if constexpr (SHAPE > 0) {
+    if constexpr (Net::RT_ACT) net.set_acts(a.L);
+    net.load_fwd(th);
+    net.template load_bwd<Net::n, 1>(th);
+  }
   bool done = (myp < 0);
   long long t_adv = 0, t_fg = 0, n_rounds = 0;
   for (int round = 0; round < a.max_rounds; ++round) {
@@ -424,13 +433,8 @@ __global__ __launch_bounds__(BORE_THREADS) void lbfgsb_kernel(const LbfgsbArgs a
     const long long c1 = BORE_LCLOCK();
     if constexpr (SHAPE > 0) {
       // static shape: the 16-row block goes through the network in registers (mlp_regs.h)
-      using Net = RegNet<SHAPE, 2>;
-      Net net;
-      if constexpr (Net::RT_ACT) net.set_acts(a.L);
       const int m16 = lane & 15, q4 = lane >> 4;
       float xin[Net::KC0];
-      net.load_fwd(th);  // (per evaluation: the optimiser's own state fills the register file)
-      net.template load_bwd<Net::n, 1>(th);
       if (coop) {
         // one point per wave: every row of the block evaluates it, read straight from the
         // optimiser's fp64 x (Keras autocast fp64 -> fp32)

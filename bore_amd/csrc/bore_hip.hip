@@ -362,8 +362,10 @@ __global__ __launch_bounds__(BORE_THREADS) void fit_kernel(const FitArgs a) {
   float *tile = smem + a.o_tile;
   float *zt = smem + a.o_zt;
   float *misc = smem + a.o_misc;  // [0] l2 penalty of the current weights, [1..4] per-wave loss
-  int *perm_s = reinterpret_cast<int *>(smem + a.o_perm);
+  int *perm_all = reinterpret_cast<int *>(smem + a.o_perm);
+  int *perm_s = perm_all;  // the current epoch's permutation
   unsigned *keys = reinterpret_cast<unsigned *>(smem + a.o_keys);
+  const int PG = a.perm ? 1 : perm_group(a.N, BORE_THREADS);
 
   float *theta_g = a.theta + model * P;
   float *m_g = a.am + model * P;
@@ -415,6 +417,11 @@ __global__ __launch_bounds__(BORE_THREADS) void fit_kernel(const FitArgs a) {
       const int *pg = a.perm + (model * a.epochs + e) * (long long)N;
       for (int i = tid; i < N; i += nthr) perm_s[i] = pg[i];
       __syncthreads();
+    } else if (PG > 1) {  // small data set: the shuffles of PG consecutive epochs at once
+      if (e % PG == 0)
+        make_perm_group(a.seed, a.model0 + model, a.epoch0 + e, min(PG, a.epochs - e), N, keys,
+                        perm_all);
+      perm_s = perm_all + (e % PG) * N;
     } else {
       make_perm(shuffle_base(a.seed, a.model0 + model, a.epoch0 + e), N, keys, perm_s);
     }
@@ -899,9 +906,10 @@ extern "C" int bore_mlp_fit(const bore_mlp_desc *desc, int n_models, float *thet
   a.o_tile = (int)off; off += L.tile_floats;
   a.o_zt = (int)off; off += BORE_BATCH_MAX;
   a.o_misc = (int)off; off += 8;
-  a.o_perm = (int)off; off += N;
+  const int PG = perm ? 1 : perm_group(N, BORE_THREADS);  // epochs shuffled together (N <= 128)
+  a.o_perm = (int)off; off += (size_t)PG * N;
   off = (off + 3) & ~(size_t)3;  // keys: 64-bit words fetched two at a time
-  a.o_keys = (int)off; off += perm ? 0 : (size_t)perm_scratch_floats(N);
+  a.o_keys = (int)off; off += perm ? 0 : (size_t)perm_group_scratch_floats(N, PG);
   if ((off + BORE_LAYOUT_FLOATS + 4) * 4 > BORE_LDS_BYTES)
     return fail(BORE_E_UNSUPPORTED, "fit: theta+tile+perm need %zu B of LDS (> %d)", off * 4,
                 BORE_LDS_BYTES);

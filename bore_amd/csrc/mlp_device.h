@@ -352,4 +352,52 @@ __device__ __forceinline__ void make_perm(unsigned long long base, int N, unsign
   }
 }
 
+// ---- several epochs' shuffles at once -------------------------------------------------------
+// A data set of N <= 128 rows leaves most of the workgroup idle in make_perm (one key per row).
+// perm_group(N, threads) = how many consecutive epochs fit side by side (one thread per
+// (epoch, row)): their keys are drawn together and each thread ranks its row against the N
+// keys of its own epoch -- the same permutations as make_perm, three barriers per GROUP of
+// epochs instead of per epoch.
+__host__ __device__ __forceinline__ int perm_group(long long N, int threads) {
+  const long long slot = (N + 63) & ~63LL;  // rows of one epoch occupy whole waves
+  const long long g = threads / slot;
+  return g < 1 ? 1 : (int)(g > 4 ? 4 : g);
+}
+__host__ __device__ __forceinline__ long long perm_group_scratch_floats(long long N, int G) {
+  return G <= 1 ? perm_scratch_floats(N) : (long long)G * 2 * ((N + 15) & ~15LL);
+}
+
+// perm_out: [G][N] (LDS); epochs epoch .. epoch + n_ep - 1 (n_ep <= G) of `model`.
+__device__ __forceinline__ void make_perm_group(unsigned long long seed, long long model,
+                                                long long epoch, int n_ep, int N, unsigned *keys,
+                                                int *perm_out) {
+  unsigned long long *k64 = reinterpret_cast<unsigned long long *>(keys);
+  const int tid = threadIdx.x;
+  const int N16 = (N + 15) & ~15, slot = (N + 63) & ~63;
+  const int g = tid / slot, i = tid - g * slot;  // this thread's (epoch in the group, row)
+  const bool mine = g < n_ep && i < N16;
+  if (mine) {
+    const unsigned long long base = shuffle_base(seed, model, epoch + g);
+    k64[g * N16 + i] = i < N ? ((unsigned long long)shuffle_key(base, i) << 32) | (unsigned)i : ~0ULL;
+  }
+  __syncthreads();
+  if (mine && i < N) {
+    const ulonglong2 *kk = reinterpret_cast<const ulonglong2 *>(k64 + g * N16);
+    const unsigned long long ki = k64[g * N16 + i];
+    int r = 0;
+    for (int b = 0; b < (N16 >> 4); ++b) {
+      ulonglong2 k[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) k[j] = kk[b * 8 + j];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        r += k[j].x < ki;
+        r += k[j].y < ki;
+      }
+    }
+    perm_out[g * N + r] = i;
+  }
+  __syncthreads();
+}
+
 }  // namespace bore
