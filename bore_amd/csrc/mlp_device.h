@@ -361,7 +361,7 @@ __device__ __forceinline__ void make_perm(unsigned long long base, int N, unsign
 __host__ __device__ __forceinline__ int perm_group(long long N, int threads) {
   const long long slot = (N + 63) & ~63LL;  // rows of one epoch occupy whole waves
   const long long g = threads / slot;
-  return g < 1 ? 1 : (int)(g > 4 ? 4 : g);
+  return g >= 4 ? 4 : g >= 2 ? 2 : 1;  // (a power of two: the kernels mask the epoch index)
 }
 __host__ __device__ __forceinline__ long long perm_group_scratch_floats(long long N, int G) {
   return G <= 1 ? perm_scratch_floats(N) : (long long)G * 2 * ((N + 15) & ~15LL);
