@@ -418,10 +418,11 @@ __global__ __launch_bounds__(BORE_THREADS) void fit_kernel(const FitArgs a) {
       for (int i = tid; i < N; i += nthr) perm_s[i] = pg[i];
       __syncthreads();
     } else if (PG > 1) {  // small data set: the shuffles of PG consecutive epochs at once
-      if (e % PG == 0)
+      const int eg = e & (PG - 1);  // PG is 2 or 4
+      if (eg == 0)
         make_perm_group(a.seed, a.model0 + model, a.epoch0 + e, min(PG, a.epochs - e), N, keys,
                         perm_all);
-      perm_s = perm_all + (e % PG) * N;
+      perm_s = perm_all + eg * N;
     } else {
       make_perm(shuffle_base(a.seed, a.model0 + model, a.epoch0 + e), N, keys, perm_s);
     }
@@ -448,6 +449,10 @@ __global__ __launch_bounds__(BORE_THREADS) void fit_kernel(const FitArgs a) {
           using Net = RegNet<SHAPE, 1>;
           Net net;
           if constexpr (Net::RT_ACT) net.set_acts(a.L);
+          // the weight operands do not depend on the gather: request them first, so that they
+          // are in flight under the perm -> row -> A_0 chain below
+          net.load_fwd(th);
+          net.template load_bwd<Net::n, 2>(th);
           const int row = rb * 16 + m16;
           const bool live = row < nb;
           float xin[Net::KC0];
@@ -469,8 +474,6 @@ __global__ __launch_bounds__(BORE_THREADS) void fit_kernel(const FitArgs a) {
 #pragma unroll
           for (int kc = 0; kc < Net::KC0; ++kc)
             if (4 * kc + q4 < D) A0[4 * kc + q4] = xin[kc];
-          net.load_fwd(th);
-          net.template load_bwd<Net::n, 2>(th);
           __builtin_amdgcn_sched_barrier(0);  // every operand load is in flight before the chain
           BORE_STAMP(1);
           net.forward(th, xin, /*keep_logits=*/true);
