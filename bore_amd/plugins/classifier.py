@@ -59,18 +59,22 @@ class ClassifierSuggester:
         # generator (DenseConfigurationSpace(config_space, seed=seed), :100), not from
         # random_state: a separate stream here too
         self._space_rng = np.random.RandomState(seed)
+        self._net_rng = np.random.RandomState(seed)
         self.logger = logger or logging.getLogger("bore_amd.plugins")
         self.last_fit = None  # (loss, accuracy) of the most recent update
 
     # -- model -------------------------------------------------------------------------------
     def _build_compile_network(self):
         """:145-159 (note DenseSequential's num_layers + 1 hidden layers, bore/models.py:16-19)."""
+        # (the reference leaves weight init and shuffling to TF's global seed; here a seeded
+        # suggester is reproducible end to end: every network it builds draws from one stream)
+        net_seed = None if self.seed is None else int(self._net_rng.randint(0, 2**31 - 1))
         network = MaximizableDenseSequential(
             transform=self.transform, input_dim=self.input_dim, output_dim=1,
             num_layers=self.num_layers, num_units=self.num_units,
             layer_kws=dict(activation=self.activation,
                            kernel_regularizer=self.kernel_regularizer,
-                           bias_regularizer=self.bias_regularizer))
+                           bias_regularizer=self.bias_regularizer), seed=net_seed)
         network.compile(optimizer=self.optimizer, metrics=["accuracy"],
                         loss=BinaryCrossentropy(from_logits=True))
         network.summary(print_fn=self.logger.debug)

@@ -96,3 +96,14 @@ def test_suggester_runs_the_plugin_loop(gpu):
         x, info = s2.suggest()
         s2.observe(x, float(branin01(x)))
     assert s2.logit is None and info["source"] == "model"
+    # a seeded suggester is reproducible end to end (weights, shuffles, candidates)
+    runs = []
+    for _ in range(2):
+        s3 = ClassifierSuggester([(0.0, 1.0)] * 2, seed=7, num_random_init=4, num_steps_per_iter=100)
+        xs = []
+        for i in range(8):
+            x, _ = s3.suggest()
+            xs.append(x)
+            s3.observe(x, float(branin01(x)))
+        runs.append(np.array(xs))
+    assert np.array_equal(runs[0], runs[1])
