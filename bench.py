@@ -12,7 +12,8 @@ the results at the end, outside the timed region).
 Prints ONE JSON line on rank 0 (see the driver contract in the task statement) with the
 `roofline` of the dominant kernel (fit_kernel; algorithmic bytes per SURVEY.md §8d
 divided by its HIP-event duration) and a `cpu_baseline` (the numpy/scipy oracle, which
-mirrors the reference's per-step structure, timed on this host for a bounded sample).
+mirrors the reference's per-step structure, timed on this host's cores -- one single-threaded
+process per core -- for a bounded sample; `cpu_baseline_1core` is the one-core figure).
 """
 import argparse
 import json
@@ -32,12 +33,23 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 HBM_PEAK_GBS = 8000.0   # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
 
 
-def cpu_baseline(seconds, iters_per_loop=100, seed=0):
-    """Oracle BO loop (config 1) on one host core: label -> per-step eager fit -> predict ->
-    sequential scipy L-BFGS-B with one single-point f/g call per evaluation."""
+def _branin01(X):
+    """Branin-Hoo rescaled to [0, 1]^2 (same as bore_amd.engine.branin01; kept here so that the
+    CPU workers do not import the GPU package)."""
+    x1, x2 = 15.0 * X[..., 0] - 5.0, 15.0 * X[..., 1]
+    return ((x2 - 5.1 / (4 * np.pi ** 2) * x1 ** 2 + 5 / np.pi * x1 - 6) ** 2
+            + 10 * (1 - 1 / (8 * np.pi)) * np.cos(x1) + 10)
+
+
+def _cpu_worker(job):
+    """Oracle BO loops (config 1) on ONE host core for `seconds`: label -> per-step eager fit ->
+    predict -> sequential scipy L-BFGS-B with one single-point f/g call per evaluation.
+    Returns (BO iterations done, seconds)."""
+    seconds, iters_per_loop, seed = job
+    for k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+        os.environ[k] = "1"
     from scipy.optimize import Bounds
     from oracle import bore_oracle as O
-    from bore_amd.engine import branin01
     try:
         from threadpoolctl import threadpool_limits
         ctx = threadpool_limits(limits=1)
@@ -49,11 +61,11 @@ def cpu_baseline(seconds, iters_per_loop=100, seed=0):
         bounds = Bounds(np.zeros(2), np.ones(2))
         it, loops, t0 = 0, 0, time.perf_counter()
         while time.perf_counter() - t0 < seconds:      # fresh loops of `iters_per_loop` iterations:
-            rs = np.random.RandomState(seed + loops)   # the same N range the GPU run covers
+            rs = np.random.RandomState(seed + 1000 * loops)   # the same N range the GPU run covers
             p = O.glorot_uniform_params(2, [16, 16, 1], rs)
             st = O.AdamState(p)
             X = rs.uniform(size=(10, 2))
-            y = branin01(X)
+            y = _branin01(X)
             loops += 1
             for _ in range(iters_per_loop):
                 z, _ = O.labels(y, 0.25)
@@ -62,15 +74,44 @@ def cpu_baseline(seconds, iters_per_loop=100, seed=0):
                 res = O.argmax(p, acts, bounds, num_starts=3, num_samples=1024, random_state=rs)
                 x = res.x if res is not None else rs.uniform(size=2)
                 X = np.vstack([X, x])
-                y = np.append(y, branin01(x))
+                y = np.append(y, _branin01(x))
                 it += 1
                 if time.perf_counter() - t0 >= seconds:
                     break
-        dt = time.perf_counter() - t0
-    return dict(value=it / dt, unit="BO-iterations/s", cores=1, kind="port",
-                sample=f"{it} BO iterations over {loops} Branin loop(s) of <= {iters_per_loop} "
-                       f"iterations (N 10->{10 + iters_per_loop}) in {dt:.1f} s, numpy fp32 oracle + "
-                       "scipy L-BFGS-B (sequential restarts, single-point f/g), 1 thread")
+        return it, time.perf_counter() - t0
+
+
+def cpu_baseline(seconds, iters_per_loop=100, max_workers=64):
+    """The CPU restatement of the reference's loop on the host cores of this box: independent
+    BO loops, one single-threaded process per core (all cores, count stated), plus
+    the one-core figure.  Bounded: `seconds` of wall time for the all-core run, a third of it
+    for the one-core run."""
+    import multiprocessing as mp
+    cores = min(len(os.sched_getaffinity(0)), max_workers)
+    it1, dt1 = _cpu_worker((seconds / 3.0, iters_per_loop, 0))
+    what = ("numpy fp32 oracle + scipy L-BFGS-B (sequential restarts, single-point f/g), "
+            f"loops of <= {iters_per_loop} iterations (N 10->{10 + iters_per_loop})")
+    one = dict(value=it1 / dt1, unit="BO-iterations/s", cores=1, kind="port",
+               sample=f"{it1} BO iterations in {dt1:.1f} s on one core; {what}")
+    if cores <= 1:
+        return one, None
+    try:
+        with mp.get_context("spawn").Pool(cores) as pool:   # (spawn: the parent holds a HIP context)
+            t0 = time.perf_counter()
+            res = pool.map_async(_cpu_worker, [(seconds, iters_per_loop, 17 + w)
+                                               for w in range(cores)]).get(timeout=3 * seconds + 90)
+            wall = time.perf_counter() - t0
+    except Exception as e:                                   # pragma: no cover
+        one["sample"] += f" (all-core run failed: {e})"
+        return one, None
+    its = sum(r[0] for r in res)
+    rate = sum(r[0] / r[1] for r in res)          # steady state: process start-up not counted
+    allc = dict(value=rate, unit="BO-iterations/s", cores=cores, kind="port",
+                sample=f"{its} BO iterations by {cores} single-threaded processes (of "
+                       f"{len(os.sched_getaffinity(0))} hardware threads available; one per core, "
+                       f"independent loops) running {seconds:.0f} s each ({wall:.1f} s wall with "
+                       f"start-up); {what}")
+    return allc, one
 
 
 def main():
@@ -180,8 +221,12 @@ def main():
                        "host_finalize_ms_per_step": 1e3 * eng.stats.get("host_finalize_s", 0.0) / (args.steps + args.warmup)},
             "best_y_median": float(np.median(results[:, -1])),
         }
-        out["cpu_baseline"] = (cpu_baseline(args.cpu_seconds, iters_per_loop=args.steps + args.warmup)
-                               if args.cpu_seconds > 0 else None)
+        out["cpu_baseline"] = None
+        if args.cpu_seconds > 0 and world == 1:              # (rank 0 at N = 1 only)
+            allc, one = cpu_baseline(args.cpu_seconds, iters_per_loop=args.steps + args.warmup)
+            out["cpu_baseline"] = allc
+            if one is not None:
+                out["cpu_baseline_1core"] = one
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
