@@ -27,7 +27,7 @@ TRANSFORM = dict(identity=0, sigmoid=1, exp=2)
 # every symbol include/bore_hip.h declares (tests check the .so exports them all)
 EXPORTS = [
     "bore_abi_version", "bore_last_error", "bore_param_count", "bore_mlp_forward",
-    "bore_mlp_value_and_input_grad", "bore_mlp_fit", "bore_mlp_evaluate",
+    "bore_mlp_value_and_input_grad", "bore_mlp_fit", "bore_mlp_fit_bf16", "bore_mlp_evaluate",
     "bore_shuffle_perm", "bore_labels", "bore_uniform_candidates", "bore_screen_topk",
     "bore_lbfgsb_minimize",
 ]
@@ -104,6 +104,7 @@ def lib():
     L.bore_mlp_value_and_input_grad.argtypes = [dp, i32, vp, vp, i64, i32, i32, vp, vp, vp]
     L.bore_mlp_fit.argtypes = [dp, i32, vp, vp, vp, vp, vp, vp, i64, i32, i32, vp, u64, i64,
                                i64, C.POINTER(AdamCfg), vp, vp]
+    L.bore_mlp_fit_bf16.argtypes = L.bore_mlp_fit.argtypes
     L.bore_mlp_evaluate.argtypes = [dp, i32, vp, vp, vp, i64, vp, vp, vp]
     L.bore_shuffle_perm.argtypes = [u64, i64, i32, i64, i32, i64, vp, vp]
     L.bore_labels.argtypes = [i32, vp, i64, C.c_double, vp, vp, vp]

@@ -694,6 +694,222 @@ __global__ __launch_bounds__(BORE_THREADS) void fit_kernel(const FitArgs a) {
 }
 
 // ---------------------------------------------------------------------------
+// mixed-precision fit (BASELINE config 5: "128-128-1 MLP bf16 ... fused Adam"): bf16 weights and
+// activations, fp32 accumulate, fp32 master weights + Adam.  Wide static shapes only.
+//
+// LDS holds the bf16 image of theta (same padded tile layout, 2-byte elements) and the bf16
+// copies of A_l / D_l for the weight-gradient tiles: half the bytes of the fp32 fit, which is
+// what lets a 128-wide net fit at all (fp32: 248 KB > 160 KB).  The fp32 master weights, m and
+// v stay in HBM; a tile's slots are prefetched one tile ahead (dw_adam_bf16), updated in fp32
+// and written back together with the tile's new bf16 image.  Products run on the fp32 MFMA
+// (bf16 x bf16 is exact in fp32; k-ordered fp32 sums) -- the step is bound by the Adam chains
+// and the barrier structure, not by MFMA rate.  Every layer output, logit and delta is rounded
+// to bf16 (RegNet<.., BF16>); loss and d loss / d logit are fp32.
+// ---------------------------------------------------------------------------
+struct FitBf16Args {
+  MlpLayout L;  // run-time layout (activations)
+  float *theta, *am, *av;
+  long long *at;
+  const float *X, *z;
+  const int *perm;
+  float *epoch_loss;
+  unsigned long long seed;
+  long long model0, epoch0;
+  int N, epochs, B;
+  float lr, beta1, beta2, eps;
+  int o_tile, o_misc, o_perm, o_keys, total;  // BYTE offsets into the dynamic LDS
+};
+
+template <int SHAPE>
+__device__ __forceinline__ void dw_adam_bf16(const FitBf16Args &a, unsigned short *th16,
+                                             const unsigned short *tile16, float *theta_g,
+                                             float *m_g, float *v_g, float alpha, float omb1,
+                                             float omb2) {
+  constexpr MlpLayout L = bore_static_layout(SHAPE, 1, BORE_BATCH_MAX);
+  constexpr int KCH = BORE_BATCH_MAX / 4;
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, m16 = lane & 15, q4 = lane >> 4;
+  int total = 0;
+#pragma unroll
+  for (int l = 1; l <= L.n_layers; ++l) total += (L.Np[l - 1] >> 4) * (L.Np[l] >> 4);
+  constexpr int STEP = BORE_THREADS / 64;
+  if (wv >= total) return;
+  WideTile cur = wide_tile<SHAPE>(wv);
+  float w[5], mm[5], vv[5];
+#pragma unroll
+  for (int q = 0; q < 5; ++q) {
+    w[q] = cur.ok[q] ? theta_g[cur.gi[q]] : 0.f;
+    mm[q] = cur.ok[q] ? m_g[cur.gi[q]] : 0.f;
+    vv[q] = cur.ok[q] ? v_g[cur.gi[q]] : 0.f;
+  }
+  for (int t = wv; t < total; t += STEP) {
+    const bool more = t + STEP < total;
+    const WideTile nxt = wide_tile<SHAPE>(more ? t + STEP : t);
+    float wx[5], mn[5], vn[5];
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {  // the next tile's master weights and Adam slots
+      const bool go = more && nxt.ok[q];
+      wx[q] = go ? theta_g[nxt.gi[q]] : 0.f;
+      mn[q] = go ? m_g[nxt.gi[q]] : 0.f;
+      vn[q] = go ? v_g[nxt.gi[q]] : 0.f;
+    }
+    const unsigned short *ap = tile16 + cur.aoff + q4 * cur.lda_p + cur.kb * 16 + m16;
+    const unsigned short *bp = tile16 + cur.doff + q4 * cur.ldd + cur.cb * 16 + m16;
+    float av[KCH], bv[KCH];
+#pragma unroll
+    for (int kc = 0; kc < KCH; ++kc) {
+      av[kc] = bf16_to_f32(ap[kc * 4 * cur.lda_p]);
+      bv[kc] = bf16_to_f32(bp[kc * 4 * cur.ldd]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    float bsum = 0.f;
+#pragma unroll
+    for (int kc = 0; kc < KCH; ++kc) {
+      const float x = cur.transposed ? bv[kc] : av[kc], y = cur.transposed ? av[kc] : bv[kc];
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x, y, acc, 0, 0, 0);
+      bsum += bv[kc];
+    }
+    float g[5] = {acc[0], acc[1], acc[2], acc[3], 0.f};
+    if (cur.want_bias) {
+      const float gb = rows_sum4(bsum);
+      if (cur.transposed) g[0] = lane == 16 ? gb : g[0];
+      else g[4] = gb;
+    }
+    float wn[5];
+#pragma unroll
+    for (int q = 0; q < 5; ++q)
+      wn[q] = adam_update(w[q], g[q], mm[q], vv[q], alpha, omb1, omb2, a.eps);
+#pragma unroll
+    for (int q = 0; q < 5; ++q) asm volatile("" : "+v"(wn[q]), "+v"(mm[q]), "+v"(vv[q]));
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+      if (!cur.ok[q]) continue;
+      th16[cur.li[q]] = f32_to_bf16(wn[q]);
+      theta_g[cur.gi[q]] = wn[q];
+      m_g[cur.gi[q]] = mm[q];
+      v_g[cur.gi[q]] = vv[q];
+    }
+    cur = nxt;
+#pragma unroll
+    for (int q = 0; q < 5; ++q) { w[q] = wx[q]; mm[q] = mn[q]; vv[q] = vn[q]; }
+  }
+}
+
+template <int SHAPE>
+__global__ __launch_bounds__(BORE_THREADS) void fit_bf16_kernel(const FitBf16Args a) {
+  extern __shared__ float smem[];
+  constexpr MlpLayout L = bore_static_layout(SHAPE, 1, BORE_BATCH_MAX);
+  using Net = RegNet<SHAPE, 1, true>;
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int wv = tid >> 6, lane = tid & 63, m16 = lane & 15, q4 = lane >> 4;
+  const long long model = blockIdx.x;
+  constexpr int P = L.P, n = L.n_layers, D = L.w[0];
+  const int N = a.N;
+  for (int i = tid; i < (a.total >> 2); i += nthr) smem[i] = 0.f;
+  __syncthreads();
+  char *base = reinterpret_cast<char *>(smem);
+  unsigned short *th16 = reinterpret_cast<unsigned short *>(base);
+  unsigned short *tile16 = reinterpret_cast<unsigned short *>(base + a.o_tile);
+  float *misc = reinterpret_cast<float *>(base + a.o_misc);
+  int *perm_all = reinterpret_cast<int *>(base + a.o_perm);
+  int *perm_s = perm_all;
+  unsigned *keys = reinterpret_cast<unsigned *>(base + a.o_keys);
+  const int PG = a.perm ? 1 : perm_group(N, BORE_THREADS);
+
+  float *theta_g = a.theta + model * P;
+  float *m_g = a.am + model * P;
+  float *v_g = a.av + model * P;
+  const float *X_g = a.X + model * (long long)N * D;
+  const float *z_g = a.z + model * (long long)N;
+  for (int p = tid; p < P; p += nthr) th16[param_ref(L, p, n).lds] = f32_to_bf16(theta_g[p]);
+
+  const long long t0 = a.at[model];
+  double b1p = pow((double)a.beta1, (double)t0);
+  double b2p = pow((double)a.beta2, (double)t0);
+  const float omb1 = 1.f - a.beta1, omb2 = 1.f - a.beta2;
+  const int steps = (N + a.B - 1) / a.B;
+  b1p *= (double)a.beta1;
+  b2p *= (double)a.beta2;
+  const float alpha_first = a.lr * sqrtf(1.f - (float)b2p) / (1.f - (float)b1p);
+  bool first_step = true;
+  __syncthreads();
+
+  for (int e = 0; e < a.epochs; ++e) {
+    if (a.perm) {
+      const int *pg = a.perm + (model * a.epochs + e) * (long long)N;
+      for (int i = tid; i < N; i += nthr) perm_s[i] = pg[i];
+      __syncthreads();
+    } else if (PG > 1) {
+      const int eg = e & (PG - 1);
+      if (eg == 0)
+        make_perm_group(a.seed, a.model0 + model, a.epoch0 + e, min(PG, a.epochs - e), N, keys,
+                        perm_all);
+      perm_s = perm_all + eg * N;
+    } else {
+      make_perm(shuffle_base(a.seed, a.model0 + model, a.epoch0 + e), N, keys, perm_s);
+    }
+    float eloss = 0.f;
+    for (int s = 0; s < steps; ++s) {
+      const int row0 = s * a.B;
+      const int nb = min(a.B, N - row0);
+      const float alpha = first_step ? alpha_first : misc[5];
+      first_step = false;
+      {  // every wave runs its 16 rows; rows past the batch are dead (x = 0, delta = 0)
+        Net net;
+        if constexpr (Net::RT_ACT) net.set_acts(a.L);
+        const int rb = wv, row = rb * 16 + m16;
+        const bool live = row < nb;
+        const int src = live ? perm_s[row0 + row] : 0;
+        float xin[Net::KC0];
+        unsigned short *A0 = tile16 + L.aoff[0] + row * L.lda[0];
+#pragma unroll
+        for (int kc = 0; kc < Net::KC0; ++kc) {
+          const int d = 4 * kc + q4;
+          float x = 0.f;
+          if (d < D && live) x = bf16_round(X_g[src * D + d]);
+          xin[kc] = x;
+          if (d < D) A0[d] = f32_to_bf16(x);
+        }
+        float zz = 0.f;
+        if (q4 == 0 && live) zz = z_g[src];
+        net.forward(th16, xin, /*keep_logits=*/true);
+        net.template store_A<1, n - 1>(tile16, rb);
+        float delta = 0.f;
+        if (lane < 16 && live) {
+          const float x = net.h[n][0][0];
+          const float ex = expf(-fabsf(x));
+          const float den = 1.f + ex;
+          const float sig = x >= 0.f ? 1.f / den : ex / den;
+          if (a.epoch_loss) eloss += fmaxf(x, 0.f) - x * zz + log1pf(ex);
+          delta = bf16_round((sig - zz) / (float)nb);
+        }
+        if (lane < 16) tile16[L.doff[n] + row * L.lda[n]] = f32_to_bf16(delta);
+        net.set_output_delta(delta);
+        net.template backward<n, 2>(th16);
+        net.template store_D<1, n - 1>(tile16, rb);
+      }
+      __syncthreads();
+      dw_adam_bf16<SHAPE>(a, th16, tile16, theta_g, m_g, v_g, alpha, omb1, omb2);
+      if (wv == (BORE_THREADS / 64) - 1) {
+        b1p *= (double)a.beta1;
+        b2p *= (double)a.beta2;
+        const float an = a.lr * sqrtf(1.f - (float)b2p) / (1.f - (float)b1p);
+        if (lane == 0) misc[5] = an;
+      }
+      __syncthreads();
+    }
+    if (a.epoch_loss) {
+      eloss = wave_sum(eloss);
+      if (lane == 0) misc[1 + wv] = eloss;
+      __syncthreads();
+      if (tid == 0)
+        a.epoch_loss[model * a.epochs + e] = (misc[1] + misc[2] + misc[3] + misc[4]) / (float)N;
+    }
+  }
+  if (tid == 0) a.at[model] = t0 + (long long)a.epochs * steps;
+}
+
+// ---------------------------------------------------------------------------
 // forward (predict) / value + input gradient: grid = (models, workgroups); every wave walks
 // its own 16-row blocks of the input -- no barrier after the weights are staged
 // ---------------------------------------------------------------------------
@@ -957,6 +1173,64 @@ extern "C" int bore_mlp_fit(const bore_mlp_desc *desc, int n_models, float *thet
     BORE_LAUNCH_FIT(0)
   }
 #undef BORE_LAUNCH_FIT
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+extern "C" int bore_mlp_fit_bf16(const bore_mlp_desc *desc, int n_models, float *theta,
+                                 float *adam_m, float *adam_v, int64_t *adam_t, const float *X,
+                                 const float *z, int64_t N, int epochs, int batch_size,
+                                 const int32_t *perm, uint64_t seed, int64_t model_index0,
+                                 int64_t epoch0, const bore_adam_cfg *adam, float *epoch_loss,
+                                 void *stream) {
+  FitBf16Args a;
+  if (batch_size != BORE_BATCH_MAX)
+    return fail(BORE_E_UNSUPPORTED, "fit_bf16: batch_size must be %d (got %d)", BORE_BATCH_MAX,
+                batch_size);
+  if (N < 1 || N > (1 << 20)) return fail(BORE_E_INVALID, "fit_bf16: N=%lld out of range", (long long)N);
+  if (epochs < 0) return fail(BORE_E_INVALID, "fit_bf16: epochs < 0");
+  if (n_models < 1) return fail(BORE_E_INVALID, "n_models must be >= 1 (got %d)", n_models);
+  if (!desc || !theta || !adam_m || !adam_v || !adam_t || !X || !z || !adam)
+    return fail(BORE_E_INVALID, "fit_bf16: null pointer");
+  const int shape = bore_match_shape(desc);
+  if (!bore_shape_is_wide(shape))
+    return fail(BORE_E_UNSUPPORTED,
+                "fit_bf16: only the wide static shapes (16->64-64-64-1, 32->128-128-1; no l2) have a "
+                "bf16 fit");
+  if (bore_make_layout(desc, 1, BORE_BATCH_MAX, &a.L)) return fail(BORE_E_INVALID, "bad bore_mlp_desc");
+  if (epochs == 0) return 0;
+  a.theta = theta; a.am = adam_m; a.av = adam_v; a.at = (long long *)adam_t;
+  a.X = X; a.z = z; a.perm = perm; a.epoch_loss = epoch_loss;
+  a.seed = seed; a.model0 = model_index0; a.epoch0 = epoch0;
+  a.N = (int)N; a.epochs = epochs; a.B = batch_size;
+  a.lr = adam->lr; a.beta1 = adam->beta1; a.beta2 = adam->beta2; a.eps = adam->eps;
+  // LDS carve (bytes): theta bf16 | A/D copies bf16 | misc | perm | keys
+  size_t off = 2 * (size_t)a.L.P_lds;
+  off = (off + 15) & ~(size_t)15;
+  a.o_tile = (int)off; off += 2 * (size_t)a.L.tile_floats;
+  off = (off + 15) & ~(size_t)15;
+  a.o_misc = (int)off; off += 8 * 4;
+  const int PG = perm ? 1 : perm_group(N, BORE_THREADS);
+  a.o_perm = (int)off; off += 4 * (size_t)PG * N;
+  off = (off + 15) & ~(size_t)15;
+  a.o_keys = (int)off; off += perm ? 0 : 4 * (size_t)perm_group_scratch_floats(N, PG);
+  off = (off + 15) & ~(size_t)15;
+  a.total = (int)off;
+  if (off > BORE_LDS_BYTES)
+    return fail(BORE_E_UNSUPPORTED, "fit_bf16: theta+tile+perm need %zu B of LDS (> %d)", off,
+                BORE_LDS_BYTES);
+  int rc = 0;
+  if (shape == 3) {
+    rc = allow_lds(fit_bf16_kernel<3>, off);
+    if (rc) return rc;
+    hipLaunchKernelGGL(fit_bf16_kernel<3>, dim3(n_models), dim3(BORE_THREADS), off,
+                       (hipStream_t)stream, a);
+  } else {
+    rc = allow_lds(fit_bf16_kernel<4>, off);
+    if (rc) return rc;
+    hipLaunchKernelGGL(fit_bf16_kernel<4>, dim3(n_models), dim3(BORE_THREADS), off,
+                       (hipStream_t)stream, a);
+  }
   HIP_TRY(hipGetLastError());
   return 0;
 }

@@ -18,6 +18,8 @@
 // Arithmetic: identical to the LDS path, bit for bit -- the same k-ordered fmaf chain per
 // output (a*b commutes), the same bias add and activation expressions.
 #pragma once
+#include <type_traits>
+
 #include "mlp_device.h"
 
 namespace bore {
@@ -38,8 +40,33 @@ __device__ __forceinline__ void rows_transpose4(float (&v)[4]) {
   v[3] = __uint_as_float(d[1]);
 }
 
-template <int SHAPE, int DELTAS>
+// bf16 <-> fp32 (round to nearest even; NaN kept quiet)
+__device__ __forceinline__ unsigned short f32_to_bf16(float x) {
+  unsigned u = __float_as_uint(x);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40u);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ float bf16_to_f32(unsigned short h) {
+  return __uint_as_float((unsigned)h << 16);
+}
+__device__ __forceinline__ float bf16_round(float x) { return bf16_to_f32(f32_to_bf16(x)); }
+
+// BF16 = true: the LDS images (weights, and the A_l / D_l copies) hold bfloat16 and every
+// layer output / delta is rounded to bfloat16 -- "bf16 weights and activations, fp32
+// accumulate"; the products still run on the fp32 MFMA (bf16 x bf16 is exact in fp32), so the
+// lane maps and the k-ordered sums are those of the fp32 path.
+template <int SHAPE, int DELTAS, bool BF16 = false>
 struct RegNet {
+  using WT = typename std::conditional<BF16, unsigned short, float>::type;  // LDS element
+  static __device__ __forceinline__ float ld(const WT *p) {
+    if constexpr (BF16) return bf16_to_f32(*p);
+    else return *p;
+  }
+  static __device__ __forceinline__ float rnd(float x) {
+    if constexpr (BF16) return bf16_round(x);
+    else return x;
+  }
   static constexpr MlpLayout L = bore_static_layout(SHAPE, DELTAS, BORE_BATCH_MAX);
   static constexpr int n = L.n_layers;
   static constexpr int max_tiles() {
@@ -138,18 +165,18 @@ struct RegNet {
 
   // Request every forward operand: W_l[4kc + q][16t + m] and b_l[16t + 4q + r].
   template <int l = 1>
-  __device__ __forceinline__ void load_fwd(const float *th) {
+  __device__ __forceinline__ void load_fwd(const WT *th) {
     if constexpr (PRELOAD && l <= n) {
       const int lane = threadIdx.x & 63, m = lane & 15, q = lane >> 4;
       constexpr int kch = fkch(l), ldw = L.ldw[l];
 #pragma unroll
       for (int t = 0; t < ftiles(l); ++t) {
-        const float *wp = th + L.woff[l] + q * ldw + 16 * t + m;
+        const WT *wp = th + L.woff[l] + q * ldw + 16 * t + m;
 #pragma unroll
-        for (int kc = 0; kc < kch; ++kc) wf[fofs(l) + t * kch + kc] = wp[kc * 4 * ldw];
-        const float *bp = th + L.boff[l] + 16 * t + 4 * q;
+        for (int kc = 0; kc < kch; ++kc) wf[fofs(l) + t * kch + kc] = ld(wp + kc * 4 * ldw);
+        const WT *bp = th + L.boff[l] + 16 * t + 4 * q;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) bf[biasofs(l) + 4 * t + r] = bp[r];
+        for (int r = 0; r < 4; ++r) bf[biasofs(l) + 4 * t + r] = ld(bp + r);
       }
       load_fwd<l + 1>(th);
     }
@@ -157,15 +184,15 @@ struct RegNet {
 
   // Request the backward operands of layers from, from-1, .., to: W_l[16t + m][4kc + q].
   template <int from, int to>
-  __device__ __forceinline__ void load_bwd(const float *th) {
+  __device__ __forceinline__ void load_bwd(const WT *th) {
     if constexpr (PRELOAD && from >= to) {
       const int lane = threadIdx.x & 63, m = lane & 15, q = lane >> 4;
       constexpr int kch = bkch(from), ldw = L.ldw[from];
 #pragma unroll
       for (int t = 0; t < btiles(from); ++t) {
-        const float *wp = th + L.woff[from] + (16 * t + m) * ldw + q;
+        const WT *wp = th + L.woff[from] + (16 * t + m) * ldw + q;
 #pragma unroll
-        for (int kc = 0; kc < kch; ++kc) wb[bofs(from) + t * kch + kc] = wp[kc * 4];
+        for (int kc = 0; kc < kch; ++kc) wb[bofs(from) + t * kch + kc] = ld(wp + kc * 4);
       }
       load_bwd<from - 1, to>(th);
     }
@@ -192,7 +219,7 @@ struct RegNet {
 
   // A_l = act_l(A_{l-1} W_l + b_l); xin = the input rows' B operands (layer 1 only)
   template <int l>
-  __device__ __forceinline__ void fwd_layer(const float *th, const float (&xin)[KC0],
+  __device__ __forceinline__ void fwd_layer(const WT *th, const float (&xin)[KC0],
                                             bool keep_logits) {
     const int lane = threadIdx.x & 63, m = lane & 15, q = lane >> 4;
     constexpr int kch = fkch(l), ldw = L.ldw[l];
@@ -215,13 +242,13 @@ struct RegNet {
 #pragma unroll
         for (int r = 0; r < 4; ++r) bias[r] = bf[biasofs(l) + 4 * t + r];
       } else {  // this tile's operands: W_l[4kc + q][16t + m], b_l[16t + 4q + r]
-        const float *wp = th + L.woff[l] + q * ldw + 16 * t + m;
-        const float *bp = th + L.boff[l] + 16 * t + 4 * q;
+        const WT *wp = th + L.woff[l] + q * ldw + 16 * t + m;
+        const WT *bp = th + L.boff[l] + 16 * t + 4 * q;
         float wt[kch];
 #pragma unroll
-        for (int kc = 0; kc < kch; ++kc) wt[kc] = wp[kc * 4 * ldw];
+        for (int kc = 0; kc < kch; ++kc) wt[kc] = ld(wp + kc * 4 * ldw);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) bias[r] = bp[r];
+        for (int r = 0; r < 4; ++r) bias[r] = ld(bp + r);
 #pragma unroll
         for (int kc = 0; kc < kch; ++kc)
           acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wt[kc], bop[kc], acc, 0, 0, 0);
@@ -233,7 +260,7 @@ struct RegNet {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const bool valid = 16 * t + 4 * q + r < L.w[l];
-          h[l][t][r] = valid ? act_fwd(a, acc[r] + bias[r]) : 0.f;
+          h[l][t][r] = valid ? rnd(act_fwd(a, acc[r] + bias[r])) : 0.f;
         }
       }
     }
@@ -243,13 +270,13 @@ struct RegNet {
       for (int t = 0; t < ftiles(l); ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          if (!(16 * t + 4 * q + r < L.w[l])) h[l][t][r] = 0.f;  // padding units stay zero
+          h[l][t][r] = 16 * t + 4 * q + r < L.w[l] ? rnd(h[l][t][r]) : 0.f;  // padding stays zero
     }
   }
 
   // D_{l-1} = (D_l W_l^T) .* act'_{l-1}(A_{l-1})
   template <int l>
-  __device__ __forceinline__ void bwd_layer(const float *th) {
+  __device__ __forceinline__ void bwd_layer(const WT *th) {
     const int lane = threadIdx.x & 63, m = lane & 15, q = lane >> 4;
     constexpr int kch = bkch(l), ldw = L.ldw[l];
     float bop[4 * T];
@@ -263,10 +290,10 @@ struct RegNet {
         for (int kc = 0; kc < kch; ++kc)
           acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[bofs(l) + t * kch + kc], bop[kc], acc, 0, 0, 0);
       } else {  // W_l[16t + m][4kc + q]
-        const float *wp = th + L.woff[l] + (16 * t + m) * ldw + q;
+        const WT *wp = th + L.woff[l] + (16 * t + m) * ldw + q;
         float wt[kch];
 #pragma unroll
-        for (int kc = 0; kc < kch; ++kc) wt[kc] = wp[kc * 4];
+        for (int kc = 0; kc < kch; ++kc) wt[kc] = ld(wp + kc * 4);
 #pragma unroll
         for (int kc = 0; kc < kch; ++kc)
           acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wt[kc], bop[kc], acc, 0, 0, 0);
@@ -275,17 +302,27 @@ struct RegNet {
       for (int r = 0; r < 4; ++r) {
         const bool valid = 16 * t + 4 * q + r < L.w[l - 1];
         float v = valid ? acc[r] : 0.f;
-        if constexpr (!RT_ACT)
+        if constexpr (!RT_ACT) {
           if (l > 1 && valid) v *= act_grad(ap, h[l - 1][t][r]);
+          v = rnd(v);
+        }
         d[l - 1][t][r] = v;
       }
     }
-    if constexpr (RT_ACT && l > 1) grad_tiles_rt<btiles(l)>(ap, d[l - 1], h[l - 1]);
+    if constexpr (RT_ACT && l > 1) {
+      grad_tiles_rt<btiles(l)>(ap, d[l - 1], h[l - 1]);
+      if constexpr (BF16) {
+#pragma unroll
+        for (int t = 0; t < btiles(l); ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) d[l - 1][t][r] = rnd(d[l - 1][t][r]);
+      }
+    }
   }
 
   // (small nets: operands requested by load_fwd; wide nets: fetched per tile from th)
   template <int l = 1>
-  __device__ __forceinline__ void forward(const float *th, const float (&xin)[KC0],
+  __device__ __forceinline__ void forward(const WT *th, const float (&xin)[KC0],
                                           bool keep_logits) {
     if constexpr (l <= n) {
       fwd_layer<l>(th, xin, keep_logits);
@@ -295,7 +332,7 @@ struct RegNet {
 
   // bwd_layer for l = from, from-1, ..., to  (leaves D_{to-1}; operands requested by load_bwd)
   template <int from, int to>
-  __device__ __forceinline__ void backward(const float *th) {
+  __device__ __forceinline__ void backward(const WT *th) {
     if constexpr (from >= to) {
       bwd_layer<from>(th);
       backward<from - 1, to>(th);
@@ -310,12 +347,12 @@ struct RegNet {
     for (int t = 0; t < T; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r) d[n][t][r] = 0.f;
-    d[n][0][0] = lane < 16 ? delta : 0.f;
+    d[n][0][0] = lane < 16 ? rnd(delta) : 0.f;
   }
 
   // Objective + input gradient (the register form of fg_rowblock): returns T(sign*f) of row
   // m in the lanes < 16; D_0 (= d T / d x) is left in d[0].  Operands: load_fwd + load_bwd<n, 1>.
-  __device__ __forceinline__ float fg(const float *th, const float (&xin)[KC0], int transform,
+  __device__ __forceinline__ float fg(const WT *th, const float (&xin)[KC0], int transform,
                                       float sign) {
     forward(th, xin, false);
     const float f = h[n][0][0];
@@ -337,14 +374,14 @@ struct RegNet {
   }
 
   template <int l, int hi>
-  __device__ __forceinline__ void store_A(float *tile, int rb) const {
+  __device__ __forceinline__ void store_A(WT *tile, int rb) const {
     if constexpr (l <= hi) {
       store_rows<l>(h[l], tile + L.aoff[l], rb);
       store_A<l + 1, hi>(tile, rb);
     }
   }
   template <int l, int hi>
-  __device__ __forceinline__ void store_D(float *tile, int rb) const {
+  __device__ __forceinline__ void store_D(WT *tile, int rb) const {
     if constexpr (l <= hi) {
       store_rows<l>(d[l], tile + L.doff[l], rb);
       store_D<l + 1, hi>(tile, rb);
@@ -354,13 +391,16 @@ struct RegNet {
   // Store layer l's C-layout registers into the padded LDS image rows [16 rb, 16 rb + 16)
   // (the weight-gradient phase reads A_l / D_l of ALL rows from there).
   template <int l>
-  static __device__ __forceinline__ void store_rows(const float (&src)[T][4], float *img, int rb) {
+  static __device__ __forceinline__ void store_rows(const float (&src)[T][4], WT *img, int rb) {
     const int lane = threadIdx.x & 63, m = lane & 15, q = lane >> 4;
-    float *p = img + (rb * 16 + m) * L.lda[l] + 4 * q;
+    WT *p = img + (rb * 16 + m) * L.lda[l] + 4 * q;
 #pragma unroll
     for (int t = 0; t < L.Np[l] / 16; ++t)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) p[16 * t + r] = src[t][r];
+      for (int r = 0; r < 4; ++r) {
+        if constexpr (BF16) p[16 * t + r] = f32_to_bf16(src[t][r]);  // (exact: already rounded)
+        else p[16 * t + r] = src[t][r];
+      }
   }
 };
 

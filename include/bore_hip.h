@@ -131,6 +131,19 @@ int bore_mlp_fit(const bore_mlp_desc *desc, int n_models, float *theta,
                  int64_t epoch0, const bore_adam_cfg *adam, float *epoch_loss,
                  void *stream);
 
+/* Mixed-precision fit -- BASELINE.json config 5 ("128-128-1 MLP bf16 ... fused Adam"): same
+ * arguments and state contract as bore_mlp_fit (theta/adam_m/adam_v are the fp32 MASTER copies,
+ * updated in place; Keras `fit` under a mixed_bfloat16 policy at README.rst:93 /
+ * bore/plugins/hpbandster/base.py:184).  Weights, layer outputs, logits and deltas are rounded
+ * to bfloat16, sums are fp32, Adam runs in fp32 on the master weights.  Available for the wide
+ * static shapes (16->64-64-64-1, 32->128-128-1, no l2) and batch_size 64; anything else:
+ * BORE_E_UNSUPPORTED.  Prediction / argmax use the fp32 master weights. */
+int bore_mlp_fit_bf16(const bore_mlp_desc *desc, int n_models, float *theta, float *adam_m,
+                      float *adam_v, int64_t *adam_t, const float *X, const float *z, int64_t N,
+                      int epochs, int batch_size, const int32_t *perm, uint64_t seed,
+                      int64_t model_index0, int64_t epoch0, const bore_adam_cfg *adam,
+                      float *epoch_loss, void *stream);
+
 /*
  * Keras evaluate(X, z): mean BCE(+l2) and binary accuracy (threshold 0.5 on the
  * model output) over all N rows (bore/plugins/hpbandster/base.py:186).

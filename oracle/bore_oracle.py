@@ -287,6 +287,58 @@ def fit(params, acts, st, X, z, perms, batch_size=64, lr=1e-3, beta1=0.9,
     return np.asarray(hist)
 
 
+def bf16_round(x):
+    """Round float32 values to the nearest bfloat16 (ties to even), returned as float32."""
+    u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32)
+    r = (u + np.uint32(0x7FFF) + ((u >> np.uint32(16)) & np.uint32(1))) & np.uint32(0xFFFF0000)
+    return r.view(np.float32).reshape(np.shape(x))
+
+
+def loss_and_grads_bf16(params, acts, Xb, zb):
+    """The mixed-precision step bore_mlp_fit_bf16 defines (include/bore_hip.h): weights, biases,
+    inputs, every layer output, the logits and every delta rounded to bfloat16; products and
+    sums in float32; loss and d loss / d logit in float32.  Returns (loss, float32 grads)."""
+    f32 = np.float32
+    nb = Xb.shape[0]
+    n_layers = len(acts)
+    Wb = [bf16_round(params[2 * l]) for l in range(n_layers)]
+    bb = [bf16_round(params[2 * l + 1]) for l in range(n_layers)]
+    hs = [bf16_round(np.asarray(Xb, dtype=f32))]
+    for l in range(n_layers):
+        pre = hs[-1] @ Wb[l] + bb[l]
+        a = pre if l == n_layers - 1 else _act(acts[l], pre)
+        hs.append(bf16_round(a.astype(f32)))
+    a = hs[-1]
+    zcol = zb.reshape(nb, 1).astype(f32)
+    loss = bce_with_logits(a, zcol).mean(dtype=f32)
+    delta = bf16_round(((_sigmoid(a) - zcol) / f32(nb)).astype(f32))
+    grads = [None] * len(params)
+    for l in range(n_layers - 1, -1, -1):
+        grads[2 * l] = (hs[l].T @ delta).astype(f32)
+        grads[2 * l + 1] = delta.sum(axis=0, dtype=f32)
+        if l > 0:
+            delta = bf16_round(((delta @ Wb[l].T) * _act_grad_from_output(acts[l - 1], hs[l])).astype(f32))
+    return loss, grads
+
+
+def fit_bf16(params, acts, st, X, z, perms, batch_size=64, lr=1e-3, beta1=0.9, beta2=0.999,
+             eps=1e-7):
+    """``fit`` with the mixed-precision step above; ``params`` are the float32 master weights."""
+    Xc = np.asarray(X, dtype=np.float32)
+    zc = np.asarray(z).astype(np.float32)
+    N = Xc.shape[0]
+    hist = []
+    for perm in np.asarray(perms):
+        tot = 0.0
+        for s in range(0, N, batch_size):
+            idx = perm[s:s + batch_size]
+            loss, grads = loss_and_grads_bf16(params, acts, Xc[idx], zc[idx])
+            adam_step(params, grads, st, lr, beta1, beta2, eps)
+            tot += float(loss) * len(idx)
+        hist.append(tot / N)
+    return np.asarray(hist)
+
+
 def evaluate(params, acts, X, z, dtype=np.float32, l2=None):
     """Keras ``evaluate``: mean BCE over all rows and ``metrics=["accuracy"]``.
 

@@ -168,3 +168,29 @@ def test_get_set_weights_roundtrip_keras_order(gpu):
     assert all(np.array_equal(a, b) for a, b in zip(model.get_weights(), w2))
     with pytest.raises(ValueError):
         model.set_weights(w2[:2])
+
+
+def test_mixed_bfloat16_policy_runs_config5(gpu):
+    """BASELINE config 5 through the model API: 32-D, 128-128-1, bf16 compute, fp32 masters;
+    fit + argmax with many restarts on the device."""
+    from bore_amd.models import MaximizableSequential
+    rs = np.random.RandomState(2)
+    D = 32
+    X = rs.uniform(size=(256, D))
+    y = ((X - 0.35) ** 2).sum(axis=1)
+    z = y < np.quantile(y, 0.25)
+    model = MaximizableSequential(seed=4, dtype_policy="mixed_bfloat16", transform="sigmoid")
+    model.add(Dense(128, activation="relu", input_dim=D))
+    model.add(Dense(128, activation="relu"))
+    model.add(Dense(1))
+    model.compile(optimizer="adam", loss=BinaryCrossentropy(from_logits=True), metrics=["accuracy"])
+    h = model.fit(X, z, epochs=40, batch_size=64)
+    assert h.history["loss"][-1] < 0.5 * h.history["loss"][0]
+    loss, acc = model.evaluate(X, z)
+    assert acc > 0.9
+    model.restart_mode = "device"
+    res = model.argmax([(0.0, 1.0)] * D, num_starts=64, num_samples=1024, random_state=0)
+    assert res is not None and res.x.shape == (D,)
+    assert model.predict(res.x[None])[0, 0] >= np.quantile(model.predict(X), 0.99)
+    with pytest.raises(ValueError):
+        MaximizableSequential(dtype_policy="float16")

@@ -297,3 +297,74 @@ def test_bad_arguments_fail_loudly(gpu):
     with pytest.raises(RuntimeError, match="1 unit"):
         ops.mlp_forward(d2, torch.zeros(1, ops.param_count(d2), device="cuda"), X[0])
     assert ops.mlp_forward(desc, th, torch.zeros(0, 2, device="cuda")).shape == (1, 0)
+
+
+# ---- mixed-precision fit (BASELINE config 5) -------------------------------------------------
+@pytest.mark.parametrize("D,units,acts", [
+    (32, [128, 128, 1], ["relu", "relu", "linear"]),          # config 5
+    (16, [64, 64, 64, 1], ["relu", "elu", "tanh", "sigmoid"]),  # config 3 shape, mixed activations
+])
+def test_bf16_fit_tracks_the_bf16_oracle(gpu, D, units, acts):
+    """bore_mlp_fit_bf16 against oracle.fit_bf16 (bf16 weights/activations/deltas, fp32 sums,
+    fp32 master + Adam).  Stated tolerance: a bf16 rounding can flip on a last-bit difference of
+    the fp32 sum (BLAS order vs the kernel's k-ordered chain), i.e. one activation moves by
+    2^-8 relative; over 12 Adam steps the master weights stay within 1.5e-3 + 2 % and the
+    per-epoch loss within 1 %."""
+    rs = np.random.RandomState(3)
+    N, E = 200, 3                                              # 4 steps per epoch, last one partial
+    p0 = O.glorot_uniform_params(D, units, rs)
+    for i in range(1, len(p0), 2):
+        p0[i] = rs.normal(scale=0.1, size=p0[i].shape).astype(np.float32)
+    X = rs.uniform(size=(N, D)).astype(np.float32)
+    z = (rs.uniform(size=N) < 0.3).astype(np.float32)
+    perms = np.stack([rs.permutation(N) for _ in range(E)]).astype(np.int32)
+    desc = _lib.make_desc(D, units, acts)
+    th = dev(pack(p0)).reshape(1, -1)
+    m, v = torch.zeros_like(th), torch.zeros_like(th)
+    t = torch.zeros(1, dtype=torch.int64, device=th.device)
+    loss = ops.mlp_fit(desc, th, m, v, t, dev(X[None]), dev(z[None]), E, 64,
+                       perm=dev(perms[None], torch.int32), compute="bfloat16")
+    ref = [q.copy() for q in p0]
+    st = O.AdamState(ref)
+    hist = O.fit_bf16(ref, ["linear" if a is None else a for a in acts], st, X, z, perms)
+    assert int(t[0]) == E * 4 == st.t
+    np.testing.assert_allclose(loss.cpu().numpy()[0], hist, rtol=1e-2)
+    np.testing.assert_allclose(th.cpu().numpy()[0], pack(ref), atol=1.5e-3, rtol=2e-2)
+    np.testing.assert_allclose(m.cpu().numpy()[0], pack(st.m), atol=2e-4, rtol=5e-2)
+    # deterministic, and the in-kernel shuffle stream drives it like the fp32 fit
+    th2 = dev(pack(p0)).reshape(1, -1)
+    m2, v2, t2 = torch.zeros_like(th2), torch.zeros_like(th2), torch.zeros_like(t)
+    loss2 = ops.mlp_fit(desc, th2, m2, v2, t2, dev(X[None]), dev(z[None]), E, 64,
+                        perm=dev(perms[None], torch.int32), compute="bfloat16")
+    assert torch.equal(th, th2) and torch.equal(loss, loss2)
+
+
+def test_bf16_fit_learns_like_fp32_and_rejects_other_shapes(gpu):
+    rs = np.random.RandomState(11)
+    D, units, acts = 32, [128, 128, 1], ["relu", "relu", "linear"]
+    N = 256
+    X = rs.uniform(size=(N, D)).astype(np.float32)
+    y = ((X - 0.4) ** 2).sum(axis=1)
+    z = (y < np.quantile(y, 0.25)).astype(np.float32)
+    desc = _lib.make_desc(D, units, acts)
+    p0 = O.glorot_uniform_params(D, units, rs)
+    th = dev(pack(p0)).reshape(1, -1)
+    m, v = torch.zeros_like(th), torch.zeros_like(th)
+    t = torch.zeros(1, dtype=torch.int64, device=th.device)
+    loss = ops.mlp_fit(desc, th, m, v, t, dev(X[None]), dev(z[None]), 60, 64, seed=5,
+                       compute="bfloat16").cpu().numpy()[0]
+    pred = ops.mlp_forward(desc, th, dev(X[None]))[0].cpu().numpy()
+    assert loss[-1] < 0.35 * loss[0] and np.isfinite(loss).all()
+    assert np.mean((pred > 0) == (z > 0.5)) > 0.93          # fp32 master weights classify
+    # the float32 oracle from the same start ends at a similar loss (same shuffle stream)
+    perms = shuffle.permutations(5, 1, 60, N)[0]
+    ref = [q.copy() for q in p0]
+    hist = O.fit(ref, acts, O.AdamState(ref), X, z, perms)
+    assert abs(hist[-1] - loss[-1]) < 0.15 * hist[-1] + 0.01
+    small = _lib.make_desc(2, [16, 16, 1], ["relu", "relu", "sigmoid"])
+    ths = torch.zeros(1, ops.param_count(small), device=th.device)
+    with pytest.raises(RuntimeError, match="wide static shapes"):
+        ops.mlp_fit(small, ths, ths.clone(), ths.clone(), torch.zeros(1, dtype=torch.int64, device=th.device),
+                    dev(X[None, :, :2].copy()), dev(z[None]), 1, 64, compute="bfloat16")
+    with pytest.raises(ValueError):
+        ops.mlp_fit(desc, th, m, v, t, dev(X[None]), dev(z[None]), 1, 64, compute="fp8")
