@@ -27,7 +27,7 @@ TRANSFORM = dict(identity=0, sigmoid=1, exp=2)
 # every symbol include/bore_hip.h declares (tests check the .so exports them all)
 EXPORTS = [
     "bore_abi_version", "bore_last_error", "bore_param_count", "bore_mlp_forward",
-    "bore_mlp_value_and_input_grad", "bore_mlp_fit", "bore_mlp_fit_bf16", "bore_mlp_evaluate",
+    "bore_mlp_value_and_input_grad", "bore_mlp_fit", "bore_mlp_evaluate",
     "bore_shuffle_perm", "bore_labels", "bore_uniform_candidates", "bore_screen_topk",
     "bore_lbfgsb_minimize",
 ]
@@ -36,7 +36,8 @@ EXPORTS = [
 class MlpDesc(C.Structure):
     _fields_ = [("input_dim", C.c_int32), ("n_layers", C.c_int32),
                 ("units", C.c_int32 * MAX_LAYERS), ("act", C.c_int32 * MAX_LAYERS),
-                ("l2_kernel", C.c_float * MAX_LAYERS), ("l2_bias", C.c_float * MAX_LAYERS)]
+                ("l2_kernel", C.c_float * MAX_LAYERS), ("l2_bias", C.c_float * MAX_LAYERS),
+                ("compute", C.c_int32)]
 
 
 class LbfgsbOpts(C.Structure):
@@ -104,7 +105,6 @@ def lib():
     L.bore_mlp_value_and_input_grad.argtypes = [dp, i32, vp, vp, i64, i32, i32, vp, vp, vp]
     L.bore_mlp_fit.argtypes = [dp, i32, vp, vp, vp, vp, vp, vp, i64, i32, i32, vp, u64, i64,
                                i64, C.POINTER(AdamCfg), vp, vp]
-    L.bore_mlp_fit_bf16.argtypes = L.bore_mlp_fit.argtypes
     L.bore_mlp_evaluate.argtypes = [dp, i32, vp, vp, vp, i64, vp, vp, vp]
     L.bore_shuffle_perm.argtypes = [u64, i64, i32, i64, i32, i64, vp, vp]
     L.bore_labels.argtypes = [i32, vp, i64, C.c_double, vp, vp, vp]
@@ -125,8 +125,13 @@ def check(rc):
         raise RuntimeError(f"libbore_hip: {lib().bore_last_error().decode()} (code {rc})")
 
 
-def make_desc(input_dim, units, acts, l2_kernel=None, l2_bias=None):
+COMPUTE = dict(float32=0, bfloat16=1)
+
+
+def make_desc(input_dim, units, acts, l2_kernel=None, l2_bias=None, compute="float32"):
     n = len(units)
+    if compute not in COMPUTE:
+        raise ValueError(f"compute must be one of {sorted(COMPUTE)}, got {compute!r}")
     if not 1 <= n <= MAX_LAYERS:
         raise ValueError(f"1..{MAX_LAYERS} Dense layers supported, got {n}")
     d = MlpDesc()
@@ -140,6 +145,7 @@ def make_desc(input_dim, units, acts, l2_kernel=None, l2_bias=None):
         d.act[i] = ACT[a]
         d.l2_kernel[i] = float(l2_kernel[i]) if l2_kernel and l2_kernel[i] else 0.0
         d.l2_bias[i] = float(l2_bias[i]) if l2_bias and l2_bias[i] else 0.0
+    d.compute = COMPUTE[compute]
     return d
 
 

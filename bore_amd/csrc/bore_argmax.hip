@@ -156,7 +156,7 @@ __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
   return v;
 }
 
-template <int SHAPE>
+template <int SHAPE, bool BF16 = false>
 __global__ __launch_bounds__(BORE_THREADS) void screen_topk_kernel(const ScreenArgs a) {
   extern __shared__ float smem[];
   constexpr MlpLayout Lc = bore_static_layout(SHAPE > 0 ? SHAPE : 0, 0, BORE_BATCH_MAX);
@@ -168,18 +168,19 @@ __global__ __launch_bounds__(BORE_THREADS) void screen_topk_kernel(const ScreenA
   float *th = smem, *tile = smem + a.o_tile;
   unsigned long long *keys = reinterpret_cast<unsigned long long *>(smem + a.o_keys);
   const int wv = tid >> 6, lane = tid & 63, m16 = lane & 15, q4 = lane >> 4;
-  load_theta(L, n, a.theta + model * L.P, th);
+  stage_theta<BF16>(L, n, a.theta + model * L.P, smem);
   const double *X = a.X + (a.x_shared ? 0 : model * a.n_samples * D);
   __syncthreads();
   // predictions -> sort keys: ascending key == descending prediction, ties to the lower row.
   // Every wave walks its own 16-row blocks of the candidates.
   const int waves = L.tbp >> 4;
   const int n_blocks = (Ns + 15) >> 4;
-  using Net = RegNet<(SHAPE > 0 ? SHAPE : 1), 0>;
+  using Net = RegNet<(SHAPE > 0 ? SHAPE : 1), 0, BF16>;
+  const typename Net::WT *thw = reinterpret_cast<const typename Net::WT *>(smem);
   Net net;  // static shapes: the weights stay in this lane's registers for every row-block
   if constexpr (SHAPE > 0) {
     if constexpr (Net::RT_ACT) net.set_acts(a.L);
-    net.load_fwd(th);
+    net.load_fwd(thw);
   }
   if (wv < waves)
     for (int g = wv; g < n_blocks; g += waves) {
@@ -190,9 +191,9 @@ __global__ __launch_bounds__(BORE_THREADS) void screen_topk_kernel(const ScreenA
 #pragma unroll
         for (int kc = 0; kc < Net::KC0; ++kc) {
           const int d = 4 * kc + q4;
-          xin[kc] = (d < D && row < Ns) ? (float)X[(long long)row * D + d] : 0.f;
+          xin[kc] = (d < D && row < Ns) ? Net::rnd((float)X[(long long)row * D + d]) : 0.f;
         }
-        net.forward(th, xin, false);
+        net.forward(thw, xin, false);
         p = net.h[Net::n][0][0];
       } else {
         float *A0 = tile + L.aoff[0] + (wv * 16 + m16) * L.lda[0];
@@ -291,6 +292,22 @@ extern "C" int bore_screen_topk(const bore_mlp_desc *desc, int n_models, const f
   off = (off + 3) & ~(size_t)3;
   a.o_layout = (int)off; off += BORE_LAYOUT_FLOATS;
   const int shape = bore_kernel_flavour(desc, true);  // (static flavours do not use the tile)
+  if (desc->compute == BORE_COMPUTE_BF16) {
+    if (!bore_shape_is_wide(shape)) return fail(BORE_E_UNSUPPORTED, kBf16Shapes);
+    if (shape == 3) {
+      rc = allow_lds((screen_topk_kernel<3, true>), off * 4);
+      if (rc) return rc;
+      hipLaunchKernelGGL((screen_topk_kernel<3, true>), dim3(n_models), dim3(BORE_THREADS), off * 4,
+                         (hipStream_t)stream, a);
+    } else {
+      rc = allow_lds((screen_topk_kernel<4, true>), off * 4);
+      if (rc) return rc;
+      hipLaunchKernelGGL((screen_topk_kernel<4, true>), dim3(n_models), dim3(BORE_THREADS), off * 4,
+                         (hipStream_t)stream, a);
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+  }
 #define BORE_LAUNCH_SCREEN(S)                                                                 \
   case S:                                                                                     \
     rc = allow_lds(screen_topk_kernel<S>, off * 4);                                           \
@@ -357,7 +374,7 @@ extern "C" int bore_debug_lphases_reset(void) {
 #define BORE_LCLOCK() 0LL
 #endif
 
-template <int SHAPE>
+template <int SHAPE, bool BF16 = false>
 __global__ __launch_bounds__(BORE_THREADS) void lbfgsb_kernel(const LbfgsbArgs a) {
   extern __shared__ float smem[];
   constexpr MlpLayout Lc = bore_static_layout(SHAPE > 0 ? SHAPE : 0, 2, BORE_BATCH_MAX);
@@ -377,7 +394,7 @@ __global__ __launch_bounds__(BORE_THREADS) void lbfgsb_kernel(const LbfgsbArgs a
     bhi[tid] = a.box.hi[tid];
     bnbd[tid] = a.nbd[tid];
   }
-  load_theta(L, n_lay, a.theta + model * L.P, th);
+  stage_theta<BF16>(L, n_lay, a.theta + model * L.P, smem);
   __syncthreads();
 
   // Which problem this thread works on.  With at most one problem per wave (np <= 4: the
@@ -404,12 +421,13 @@ __global__ __launch_bounds__(BORE_THREADS) void lbfgsb_kernel(const LbfgsbArgs a
 
   // static shapes: the network (small ones: with its weight operands, 30 registers for shape 1)
   // lives in registers for the whole optimisation
-  using Net = RegNet<(SHAPE > 0 ? SHAPE : 1), 2>;
+  using Net = RegNet<(SHAPE > 0 ? SHAPE : 1), 2, BF16>;
+  const typename Net::WT *thw = reinterpret_cast<const typename Net::WT *>(smem);
   Net net;
   if constexpr (SHAPE > 0) {
     if constexpr (Net::RT_ACT) net.set_acts(a.L);
-    net.load_fwd(th);
-    net.template load_bwd<Net::n, 1>(th);
+    net.load_fwd(thw);
+    net.template load_bwd<Net::n, 1>(thw);
   }
   bool done = (myp < 0);
   long long t_adv = 0, t_fg = 0, n_rounds = 0;
@@ -441,10 +459,10 @@ __global__ __launch_bounds__(BORE_THREADS) void lbfgsb_kernel(const LbfgsbArgs a
 #pragma unroll
         for (int kc = 0; kc < Net::KC0; ++kc) {
           const int d = 4 * kc + q4;
-          xin[kc] = d < D ? (float)wk.x[d] : 0.f;
+          xin[kc] = d < D ? Net::rnd((float)wk.x[d]) : 0.f;
         }
         __builtin_amdgcn_sched_barrier(0);
-        const float Tv = net.fg(th, xin, a.transform, a.sign);
+        const float Tv = net.fg(thw, xin, a.transform, a.sign);
         st.f = (double)__uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(Tv)));
         if (m16 == 0) {
 #pragma unroll
@@ -458,10 +476,10 @@ __global__ __launch_bounds__(BORE_THREADS) void lbfgsb_kernel(const LbfgsbArgs a
       } else {
         const float *A0 = tile + L.aoff[0] + (wv * 16 + m16) * L.lda[0];
 #pragma unroll
-        for (int kc = 0; kc < Net::KC0; ++kc) xin[kc] = A0[4 * kc + q4];
+        for (int kc = 0; kc < Net::KC0; ++kc) xin[kc] = Net::rnd(A0[4 * kc + q4]);
         __builtin_amdgcn_sched_barrier(0);
-        const float Tv = net.fg(th, xin, a.transform, a.sign);
-        Net::template store_rows<0>(net.d[0], tile + BORE_BATCH_MAX * L.lda[0], wv);
+        const float Tv = net.fg(thw, xin, a.transform, a.sign);
+        Net::template store_rows_f32<0>(net.d[0], tile + BORE_BATCH_MAX * L.lda[0], wv);
         wave_lds_sync();
         if (pending) {  // lane s < 16 owns row s: its value is already in this lane
           st.f = (double)Tv;
@@ -591,6 +609,22 @@ extern "C" int bore_lbfgsb_minimize(const bore_mlp_desc *desc, int n_models, con
   int rc = 0;
   const int blocks = (num_starts + PB - 1) / PB;
   if (blocks > 65535) return fail(BORE_E_UNSUPPORTED, "lbfgsb_minimize: too many restarts");
+  if (desc->compute == BORE_COMPUTE_BF16) {
+    if (!bore_shape_is_wide(flavour)) return fail(BORE_E_UNSUPPORTED, kBf16Shapes);
+    if (flavour == 3) {
+      rc = allow_lds((lbfgsb_kernel<3, true>), off * 4);
+      if (rc) return rc;
+      hipLaunchKernelGGL((lbfgsb_kernel<3, true>), dim3(n_models, blocks), dim3(BORE_THREADS),
+                         off * 4, (hipStream_t)stream, a);
+    } else {
+      rc = allow_lds((lbfgsb_kernel<4, true>), off * 4);
+      if (rc) return rc;
+      hipLaunchKernelGGL((lbfgsb_kernel<4, true>), dim3(n_models, blocks), dim3(BORE_THREADS),
+                         off * 4, (hipStream_t)stream, a);
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+  }
 #define BORE_LAUNCH_LBFGSB(S)                                                                  \
   case S:                                                                                      \
     rc = allow_lds(lbfgsb_kernel<S>, off * 4);                                                 \

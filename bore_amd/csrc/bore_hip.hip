@@ -923,10 +923,10 @@ struct RowArgs {
   long long n_rows;
   int x_shared, transform;
   float sign;  // -1: T(-f) (minimisation form), +1: T(f)
-  int o_tile, o_vals, o_layout, total, shape;
+  int o_tile, o_vals, o_layout, total, shape, bf16;
 };
 
-template <bool WITH_GRAD, int SHAPE>
+template <bool WITH_GRAD, int SHAPE, bool BF16 = false>
 __global__ __launch_bounds__(BORE_THREADS) void rows_kernel(const RowArgs a) {
   extern __shared__ float smem[];
   constexpr MlpLayout Lc = bore_static_layout(SHAPE > 0 ? SHAPE : 0, WITH_GRAD ? 2 : 0, BORE_BATCH_MAX);
@@ -936,19 +936,20 @@ __global__ __launch_bounds__(BORE_THREADS) void rows_kernel(const RowArgs a) {
   const long long model = blockIdx.x;
   const int n = layer_count<SHAPE>(L), D = L.w[0];
   float *th = smem, *tile = smem + a.o_tile, *vals = smem + a.o_vals;
-  load_theta(L, n, a.theta + model * L.P, th);
+  stage_theta<BF16>(L, n, a.theta + model * L.P, smem);
   __syncthreads();
   const int waves = L.tbp >> 4;  // waves that own a 16-row slice of the tile buffers
   if (wv >= waves) return;
   const long long xoff = a.x_shared ? 0 : model * a.n_rows * D;
   float *out = a.out + model * a.n_rows;
   const long long n_blocks = (a.n_rows + 15) >> 4;
-  using Net = RegNet<(SHAPE > 0 ? SHAPE : 1), WITH_GRAD ? 2 : 0>;
+  using Net = RegNet<(SHAPE > 0 ? SHAPE : 1), WITH_GRAD ? 2 : 0, BF16>;
+  const typename Net::WT *thw = reinterpret_cast<const typename Net::WT *>(smem);
   Net net;  // static shapes: the weights stay in this lane's registers for every row-block
   if constexpr (SHAPE > 0) {
     if constexpr (Net::RT_ACT) net.set_acts(a.L);
-    net.load_fwd(th);
-    if (WITH_GRAD) net.template load_bwd<Net::n, 1>(th);
+    net.load_fwd(thw);
+    if (WITH_GRAD) net.template load_bwd<Net::n, 1>(thw);
   }
   for (long long g = (long long)blockIdx.y * waves + wv; g < n_blocks;
        g += (long long)gridDim.y * waves) {
@@ -961,10 +962,10 @@ __global__ __launch_bounds__(BORE_THREADS) void rows_kernel(const RowArgs a) {
         float x = 0.f;
         if (d < D && row < a.n_rows)
           x = WITH_GRAD ? (float)a.Xd[xoff + row * D + d] : a.Xf[xoff + row * D + d];
-        xin[kc] = x;
+        xin[kc] = Net::rnd(x);
       }
       if (WITH_GRAD) {
-        const float Tv = net.fg(th, xin, a.transform, a.sign);
+        const float Tv = net.fg(thw, xin, a.transform, a.sign);
         if (lane < 16 && row < a.n_rows) out[row] = Tv;
         double *grad = a.grad + (model * a.n_rows) * D;
         if (row < a.n_rows) {
@@ -977,7 +978,7 @@ __global__ __launch_bounds__(BORE_THREADS) void rows_kernel(const RowArgs a) {
             }
         }
       } else {
-        net.forward(th, xin, false);
+        net.forward(thw, xin, false);
         if (lane < 16 && row < a.n_rows) out[row] = net.h[Net::n][0][0];
       }
       continue;
@@ -1088,11 +1089,18 @@ __global__ __launch_bounds__(BORE_THREADS) void shuffle_kernel(unsigned long lon
 // ---------------------------------------------------------------------------
 // host side of the C-ABI
 // ---------------------------------------------------------------------------
+static int fit_bf16_impl(const bore_mlp_desc *, int, float *, float *, float *, int64_t *,
+                         const float *, const float *, int64_t, int, int, const int32_t *, uint64_t,
+                         int64_t, int64_t, const bore_adam_cfg *, float *, void *);
+
 extern "C" int bore_mlp_fit(const bore_mlp_desc *desc, int n_models, float *theta, float *adam_m,
                             float *adam_v, int64_t *adam_t, const float *X, const float *z,
                             int64_t N, int epochs, int batch_size, const int32_t *perm,
                             uint64_t seed, int64_t model_index0, int64_t epoch0,
                             const bore_adam_cfg *adam, float *epoch_loss, void *stream) {
+  if (desc && desc->compute == BORE_COMPUTE_BF16)
+    return fit_bf16_impl(desc, n_models, theta, adam_m, adam_v, adam_t, X, z, N, epochs, batch_size,
+                         perm, seed, model_index0, epoch0, adam, epoch_loss, stream);
   FitArgs a;
   if (batch_size < 1 || batch_size > BORE_BATCH_MAX)
     return fail(BORE_E_UNSUPPORTED, "fit: batch_size must be 1..%d (got %d)", BORE_BATCH_MAX,
@@ -1177,12 +1185,11 @@ extern "C" int bore_mlp_fit(const bore_mlp_desc *desc, int n_models, float *thet
   return 0;
 }
 
-extern "C" int bore_mlp_fit_bf16(const bore_mlp_desc *desc, int n_models, float *theta,
-                                 float *adam_m, float *adam_v, int64_t *adam_t, const float *X,
-                                 const float *z, int64_t N, int epochs, int batch_size,
-                                 const int32_t *perm, uint64_t seed, int64_t model_index0,
-                                 int64_t epoch0, const bore_adam_cfg *adam, float *epoch_loss,
-                                 void *stream) {
+static int fit_bf16_impl(const bore_mlp_desc *desc, int n_models, float *theta, float *adam_m,
+                         float *adam_v, int64_t *adam_t, const float *X, const float *z, int64_t N,
+                         int epochs, int batch_size, const int32_t *perm, uint64_t seed,
+                         int64_t model_index0, int64_t epoch0, const bore_adam_cfg *adam,
+                         float *epoch_loss, void *stream) {
   FitBf16Args a;
   if (batch_size != BORE_BATCH_MAX)
     return fail(BORE_E_UNSUPPORTED, "fit_bf16: batch_size must be %d (got %d)", BORE_BATCH_MAX,
@@ -1194,9 +1201,7 @@ extern "C" int bore_mlp_fit_bf16(const bore_mlp_desc *desc, int n_models, float 
     return fail(BORE_E_INVALID, "fit_bf16: null pointer");
   const int shape = bore_match_shape(desc);
   if (!bore_shape_is_wide(shape))
-    return fail(BORE_E_UNSUPPORTED,
-                "fit_bf16: only the wide static shapes (16->64-64-64-1, 32->128-128-1; no l2) have a "
-                "bf16 fit");
+    return fail(BORE_E_UNSUPPORTED, kBf16Shapes);
   if (bore_make_layout(desc, 1, BORE_BATCH_MAX, &a.L)) return fail(BORE_E_INVALID, "bad bore_mlp_desc");
   if (epochs == 0) return 0;
   a.theta = theta; a.am = adam_m; a.av = adam_v; a.at = (long long *)adam_t;
@@ -1259,7 +1264,22 @@ static int row_launch(bool with_grad, int n_models, RowArgs &a, void *stream) {
     hipLaunchKernelGGL((rows_kernel<G, S>), dim3(n_models, (unsigned)gy), dim3(BORE_THREADS), \
                        off * 4, (hipStream_t)stream, a);                                    \
   }
-  if (with_grad) {
+#define BORE_LAUNCH_ROWS16(G, S)                                                               \
+  {                                                                                            \
+    rc = allow_lds((rows_kernel<G, S, true>), off * 4);                                        \
+    if (rc) return rc;                                                                         \
+    hipLaunchKernelGGL((rows_kernel<G, S, true>), dim3(n_models, (unsigned)gy),                \
+                       dim3(BORE_THREADS), off * 4, (hipStream_t)stream, a);                   \
+  }
+  if (a.bf16) {  // (the entry points have checked: wide static shape)
+    if (with_grad) {
+      if (shape == 3) BORE_LAUNCH_ROWS16(true, 3)
+      else BORE_LAUNCH_ROWS16(true, 4)
+    } else {
+      if (shape == 3) BORE_LAUNCH_ROWS16(false, 3)
+      else BORE_LAUNCH_ROWS16(false, 4)
+    }
+  } else if (with_grad) {
     if (shape == 1) BORE_LAUNCH_ROWS(true, 1)
     else if (shape == 2) BORE_LAUNCH_ROWS(true, 2)
     else if (shape == 3) BORE_LAUNCH_ROWS(true, 3)
@@ -1281,6 +1301,7 @@ static int row_launch(bool with_grad, int n_models, RowArgs &a, void *stream) {
     else BORE_LAUNCH_ROWS(false, 0)
   }
 #undef BORE_LAUNCH_ROWS
+#undef BORE_LAUNCH_ROWS16
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -1300,6 +1321,8 @@ extern "C" int bore_mlp_forward(const bore_mlp_desc *desc, int n_models, const f
   a.theta = theta; a.Xf = X; a.Xd = nullptr; a.out = out; a.grad = nullptr;
   a.n_rows = n_rows; a.x_shared = x_shared; a.transform = 0; a.sign = 1.f;
   a.shape = bore_kernel_flavour(desc, true);
+  a.bf16 = desc->compute == BORE_COMPUTE_BF16;
+  if (a.bf16 && !bore_shape_is_wide(a.shape)) return fail(BORE_E_UNSUPPORTED, kBf16Shapes);
   return row_launch(false, n_models, a, stream);
 }
 
@@ -1321,6 +1344,8 @@ extern "C" int bore_mlp_value_and_input_grad(const bore_mlp_desc *desc, int n_mo
   a.theta = theta; a.Xf = nullptr; a.Xd = X; a.out = val; a.grad = grad;
   a.n_rows = n_rows; a.x_shared = 0; a.transform = transform; a.sign = negate ? -1.f : 1.f;
   a.shape = bore_kernel_flavour(desc, true);
+  a.bf16 = desc->compute == BORE_COMPUTE_BF16;
+  if (a.bf16 && !bore_shape_is_wide(a.shape)) return fail(BORE_E_UNSUPPORTED, kBf16Shapes);
   return row_launch(true, n_models, a, stream);
 }
 

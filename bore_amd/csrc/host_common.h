@@ -50,6 +50,10 @@ inline int allow_lds(K kernel, size_t bytes) {
 // Builds the layout with the largest tile (max_rows, then 16 rows fewer each try: a wave's
 // unit of work is a 16-row block) whose theta + tile + `extra_floats` fit the CU's LDS; the
 // tile may shrink only when `may_shrink`.
+static const char kBf16Shapes[] =
+    "compute = bfloat16 is available for the wide static shapes only (16->64-64-64-1, "
+    "32->128-128-1; any activations, no l2)";
+
 inline int check_common(const bore_mlp_desc *desc, int n_models, int with_deltas, int max_rows,
                         bool may_shrink, size_t extra_floats, MlpLayout *L) {
   if (n_models < 1) return fail(BORE_E_INVALID, "n_models must be >= 1 (got %d)", n_models);

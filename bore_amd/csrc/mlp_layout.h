@@ -50,6 +50,7 @@ static constexpr int bore_round_up(int x, int m) { return (x + m - 1) / m * m; }
 static constexpr int bore_make_layout(const bore_mlp_desc *d, int with_deltas, int tile_rows,
                                       MlpLayout *L) {
   if (!d || d->n_layers < 1 || d->n_layers > BORE_MAX_LAYERS || d->input_dim < 1) return -1;
+  if (d->compute != BORE_COMPUTE_F32 && d->compute != BORE_COMPUTE_BF16) return -1;
   if (tile_rows < 1 || tile_rows > BORE_BATCH_MAX) return -1;
   L->tb = tile_rows;
   L->tbp = bore_round_up(tile_rows, 16);

@@ -373,6 +373,18 @@ struct RegNet {
     return Tv;
   }
 
+  // float32 rows regardless of the compute type (staging for per-lane consumers)
+  template <int l>
+  static __device__ __forceinline__ void store_rows_f32(const float (&src)[T][4], float *img,
+                                                        int rb) {
+    const int lane = threadIdx.x & 63, m = lane & 15, q = lane >> 4;
+    float *p = img + (rb * 16 + m) * L.lda[l] + 4 * q;
+#pragma unroll
+    for (int t = 0; t < L.Np[l] / 16; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) p[16 * t + r] = src[t][r];
+  }
+
   template <int l, int hi>
   __device__ __forceinline__ void store_A(WT *tile, int rb) const {
     if constexpr (l <= hi) {
@@ -403,5 +415,18 @@ struct RegNet {
       }
   }
 };
+
+// HBM -> LDS image of theta: float32 (load_theta) or rounded to bfloat16 (2-byte elements at the
+// same padded indices).
+template <bool BF16>
+__device__ __forceinline__ void stage_theta(const MlpLayout &L, int n, const float *__restrict__ g,
+                                            float *smem) {
+  if constexpr (BF16) {
+    unsigned short *t16 = reinterpret_cast<unsigned short *>(smem);
+    for (int p = threadIdx.x; p < L.P; p += blockDim.x) t16[param_ref(L, p, n).lds] = f32_to_bf16(g[p]);
+  } else {
+    load_theta(L, n, g, smem);
+  }
+}
 
 }  // namespace bore

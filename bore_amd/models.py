@@ -34,8 +34,9 @@ class Sequential:
     def __init__(self, layers=None, name=None, seed=None, dtype_policy="float32"):
         """``dtype_policy``: "float32", or "mixed_bfloat16" (what
         ``tf.keras.mixed_precision.set_global_policy("mixed_bfloat16")`` does to a Keras model:
-        float32 variables, bfloat16 compute) -- ``fit`` then runs bore_mlp_fit_bf16 (wide static
-        shapes only); prediction and argmax read the float32 master weights."""
+        float32 variables, bfloat16 compute; wide static shapes only, include/bore_hip.h enum
+        bore_compute): fit, predict and the argmax objective all round like bfloat16 math;
+        ``evaluate`` reads the float32 master weights."""
         if dtype_policy not in ("float32", "mixed_bfloat16"):
             raise ValueError(f"dtype_policy must be 'float32' or 'mixed_bfloat16', got {dtype_policy!r}")
         self.dtype_policy = dtype_policy
@@ -86,7 +87,9 @@ class Sequential:
         self._desc = _lib.make_desc(self._input_dim, [l.units for l in self.layers],
                                     [l.activation for l in self.layers],
                                     [l.l2_kernel for l in self.layers],
-                                    [l.l2_bias for l in self.layers])
+                                    [l.l2_bias for l in self.layers],
+                                    compute="bfloat16" if self.dtype_policy == "mixed_bfloat16"
+                                    else "float32")
         ws = []
         fan_in = self._input_dim
         for l in self.layers:
@@ -169,8 +172,7 @@ class Sequential:
         loss = ops.mlp_fit(self._desc, self.theta, self.adam_m, self.adam_v, self.adam_t, X, z,
                            epochs, batch_size, perm=perm, seed=self._shuffle_seed,
                            epoch0=self._epochs_seen, lr=o.learning_rate, beta1=o.beta_1,
-                           beta2=o.beta_2, eps=o.epsilon,
-                           compute="bfloat16" if self.dtype_policy == "mixed_bfloat16" else "float32")
+                           beta2=o.beta_2, eps=o.epsilon)
         self._epochs_seen += epochs
         return History(loss[0].cpu().numpy())
 

@@ -80,13 +80,9 @@ def mlp_value_and_input_grad(desc, theta, X, transform="identity", negate=True, 
 
 
 def mlp_fit(desc, theta, m, v, t, X, z, epochs, batch_size, perm=None, seed=0, model_index0=0,
-            epoch0=0, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-7, want_loss=True,
-            compute="float32"):
+            epoch0=0, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-7, want_loss=True):
     """In-place Keras-form fit of L models.  Returns epoch_loss [L,epochs] f32 (or None).
-    compute="bfloat16": mixed precision (bf16 weights/activations, fp32 sums, fp32 master weights
-    and Adam; include/bore_hip.h bore_mlp_fit_bf16) -- wide static shapes only."""
-    if compute not in ("float32", "bfloat16"):
-        raise ValueError(f"compute must be 'float32' or 'bfloat16', got {compute!r}")
+    (desc.compute = bfloat16: mixed precision, include/bore_hip.h enum bore_compute.)"""
     L, P = theta.shape
     D = desc.input_dim
     _chk(theta, torch.float32, (L, param_count(desc)), "theta")
@@ -106,8 +102,7 @@ def mlp_fit(desc, theta, m, v, t, X, z, epochs, batch_size, perm=None, seed=0, m
             raise ValueError("perm: entries must lie in [0, N)")
     loss = torch.empty((L, epochs), dtype=torch.float32, device=theta.device) if want_loss else None
     cfg = _lib.AdamCfg(lr, beta1, beta2, eps)
-    entry = _lib.lib().bore_mlp_fit if compute == "float32" else _lib.lib().bore_mlp_fit_bf16
-    _lib.check(entry(
+    _lib.check(_lib.lib().bore_mlp_fit(
         C.byref(desc), L, _lib.ptr(theta), _lib.ptr(m), _lib.ptr(v), _lib.ptr(t), _lib.ptr(X),
         _lib.ptr(z), N, epochs, int(batch_size), _lib.ptr(perm), C.c_uint64(seed & (2**64 - 1)),
         int(model_index0), int(epoch0), C.byref(cfg), _lib.ptr(loss), _lib.stream_ptr()))

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define BORE_ABI_VERSION 1
+#define BORE_ABI_VERSION 2
 #define BORE_MAX_LAYERS 8
 #define BORE_BATCH_MAX 64 /* rows per tile == wavefront width */
 #define BORE_DIM_MAX 64   /* largest input dimension for the by-value bound arrays */
@@ -61,6 +61,18 @@ enum bore_transform {
   BORE_T_EXP = 2
 };
 
+/* Arithmetic of the network (what a Keras dtype policy selects).  BORE_COMPUTE_BF16 =
+ * "mixed_bfloat16" (BASELINE.json config 5): weights, layer outputs, logits and deltas rounded to
+ * bfloat16, sums in float32, float32 master weights (`theta`) and Adam slots; the objective value
+ * and input gradient of the argmax are evaluated with the same rounding.  Available for the wide
+ * static shapes (16->64-64-64-1 and 32->128-128-1, any activations, no l2), fit with
+ * batch_size 64; every entry point returns BORE_E_UNSUPPORTED otherwise (bore_mlp_evaluate
+ * always reads the float32 master weights). */
+enum bore_compute {
+  BORE_COMPUTE_F32 = 0,
+  BORE_COMPUTE_BF16 = 1
+};
+
 /* A stack of Dense layers (bore/models.py:9-33; README.rst:60-63). */
 typedef struct bore_mlp_desc {
   int32_t input_dim;                 /* D */
@@ -69,6 +81,7 @@ typedef struct bore_mlp_desc {
   int32_t act[BORE_MAX_LAYERS];      /* enum bore_activation */
   float l2_kernel[BORE_MAX_LAYERS];  /* kernel_regularizer=l2(f): f (0 = none) */
   float l2_bias[BORE_MAX_LAYERS];    /* bias_regularizer=l2(f) */
+  int32_t compute;                   /* enum bore_compute */
 } bore_mlp_desc;
 
 /* tf.keras.optimizers.Adam hyper-parameters (README.rst:66 optimizer="adam":
@@ -130,19 +143,6 @@ int bore_mlp_fit(const bore_mlp_desc *desc, int n_models, float *theta,
                  const int32_t *perm, uint64_t seed, int64_t model_index0,
                  int64_t epoch0, const bore_adam_cfg *adam, float *epoch_loss,
                  void *stream);
-
-/* Mixed-precision fit -- BASELINE.json config 5 ("128-128-1 MLP bf16 ... fused Adam"): same
- * arguments and state contract as bore_mlp_fit (theta/adam_m/adam_v are the fp32 MASTER copies,
- * updated in place; Keras `fit` under a mixed_bfloat16 policy at README.rst:93 /
- * bore/plugins/hpbandster/base.py:184).  Weights, layer outputs, logits and deltas are rounded
- * to bfloat16, sums are fp32, Adam runs in fp32 on the master weights.  Available for the wide
- * static shapes (16->64-64-64-1, 32->128-128-1, no l2) and batch_size 64; anything else:
- * BORE_E_UNSUPPORTED.  Prediction / argmax use the fp32 master weights. */
-int bore_mlp_fit_bf16(const bore_mlp_desc *desc, int n_models, float *theta, float *adam_m,
-                      float *adam_v, int64_t *adam_t, const float *X, const float *z, int64_t N,
-                      int epochs, int batch_size, const int32_t *perm, uint64_t seed,
-                      int64_t model_index0, int64_t epoch0, const bore_adam_cfg *adam,
-                      float *epoch_loss, void *stream);
 
 /*
  * Keras evaluate(X, z): mean BCE(+l2) and binary accuracy (threshold 0.5 on the

@@ -321,6 +321,39 @@ def loss_and_grads_bf16(params, acts, Xb, zb):
     return loss, grads
 
 
+def forward_bf16(params, acts, X, return_all=False):
+    """Model output with bfloat16 weights / activations and float32 sums (enum bore_compute,
+    BORE_COMPUTE_BF16): inputs and every layer output (the last one included) rounded."""
+    f32 = np.float32
+    hs = [bf16_round(np.asarray(X, dtype=f32))]
+    for l, act in enumerate(acts):
+        pre = hs[-1] @ bf16_round(params[2 * l]) + bf16_round(params[2 * l + 1])
+        hs.append(bf16_round(_act(act, pre).astype(f32)))
+    return hs if return_all else hs[-1]
+
+
+def value_and_input_grad_bf16(params, acts, X, transform="identity", negate=True):
+    """``x -> [T(+-f(x)), grad]`` in the mixed-precision arithmetic: the deltas of every layer
+    are rounded to bfloat16, the input gradient itself is the float32 sum."""
+    f32 = np.float32
+    X = np.atleast_2d(np.asarray(X))
+    hs = forward_bf16(params, acts, X.astype(f32), return_all=True)
+    f = hs[-1]
+    sign = f32(-1.0 if negate else 1.0)
+    u = sign * f
+    if transform == "sigmoid":
+        T = _sigmoid(u); dT = T * (f32(1) - T)
+    elif transform == "exp":
+        T = np.exp(u); dT = T
+    else:
+        T = u; dT = np.ones_like(u)
+    delta = bf16_round((sign * dT * _act_grad_from_output(acts[-1], f)).astype(f32))
+    for l in range(len(acts) - 1, -1, -1):
+        back = delta @ bf16_round(params[2 * l]).T
+        delta = back if l == 0 else bf16_round((back * _act_grad_from_output(acts[l - 1], hs[l])).astype(f32))
+    return T[:, 0].astype(f32), delta.astype(np.float64)
+
+
 def fit_bf16(params, acts, st, X, z, perms, batch_size=64, lr=1e-3, beta1=0.9, beta2=0.999,
              eps=1e-7):
     """``fit`` with the mixed-precision step above; ``params`` are the float32 master weights."""

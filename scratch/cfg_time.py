@@ -3,14 +3,14 @@ import numpy as np, torch, time
 from bore_amd import _lib, ops
 from test_gpu_parity import dev, pack, rand_model
 def run(name, D, units, acts, tr, R, Ns, N=256, fit=True, compute='float32'):
-    rs=np.random.RandomState(0); desc=_lib.make_desc(D,units,acts); P=ops.param_count(desc)
+    rs=np.random.RandomState(0); desc=_lib.make_desc(D,units,acts,compute=compute); P=ops.param_count(desc)
     th=dev(pack(rand_model(rs,D,units))).reshape(1,-1); m=torch.zeros_like(th); v=torch.zeros_like(th); t=torch.zeros(1,dtype=torch.int64,device='cuda')
     X=rs.uniform(size=(1,N,D)); y=np.sum((X-0.4)**2,axis=2); z=(y<np.quantile(y,0.25)).astype(np.float32)
     torch.cuda.synchronize(); t0=time.perf_counter()
     if fit:
         try:
-            ops.mlp_fit(desc,th,m,v,t,dev(X,torch.float32),dev(z),200,64,want_loss=False,compute=compute); torch.cuda.synchronize()
-            t0=time.perf_counter(); ops.mlp_fit(desc,th,m,v,t,dev(X,torch.float32),dev(z),200,64,want_loss=False,compute=compute); torch.cuda.synchronize()
+            ops.mlp_fit(desc,th,m,v,t,dev(X,torch.float32),dev(z),200,64,want_loss=False); torch.cuda.synchronize()
+            t0=time.perf_counter(); ops.mlp_fit(desc,th,m,v,t,dev(X,torch.float32),dev(z),200,64,want_loss=False); torch.cuda.synchronize()
             tf=time.perf_counter()-t0
         except RuntimeError as e:
             tf=float('nan'); print("  fit:",str(e)[:100])

@@ -237,3 +237,39 @@ def test_replica_engine_device_mode_runs_bo(gpu):
     assert [g.b - g.a for g in eng3.groups] == [2, 3, 3] and len(eng3.stats["fit_ms"]) == 24
     assert np.array_equal(eng3.X, eng.X) and np.array_equal(eng3.y, eng.y)
     assert torch.equal(eng3.theta, eng.theta) and torch.equal(eng3.adam_t, eng.adam_t)
+
+
+def test_bf16_argmax_kernels_equal_their_host_build(gpu):
+    """desc.compute = bfloat16: screening and the in-kernel L-BFGS-B evaluate the network with
+    bf16 rounding -- bit for bit the f/g that mlp_value_and_input_grad returns for that
+    descriptor, so the device optimiser again equals its host build fed through the public
+    f/g entry point."""
+    rs = np.random.RandomState(21)
+    D, units, acts, tr = 16, [64, 64, 64, 1], ["relu", "relu", "relu", "linear"], "sigmoid"
+    desc = _lib.make_desc(D, units, acts, compute="bfloat16")
+    th = dev(np.stack([pack(rand_model(rs, D, units)) for _ in range(2)]))
+    lo, hi = np.zeros(D), np.ones(D)
+    # screen: top-R of the bf16 predictions (ties to the lower row)
+    Xc = ops.uniform_candidates(3, 2, 512, lo, hi)
+    x0, idx = ops.screen_topk(desc, th, Xc, 6)
+    for l in range(2):
+        pred = ops.mlp_forward(desc, th[l:l + 1], dev(Xc[l:l + 1].cpu().numpy().astype(np.float32)))[0].cpu().numpy()
+        order = np.lexsort((np.arange(512), -pred))[:6]
+        assert np.array_equal(idx[l].cpu().numpy(), order)
+    opts = dict(maxiter=30, ftol=1e-9)
+    x, fun, jac, info = (t.cpu().numpy() for t in
+                         ops.lbfgsb_minimize(desc, th, x0, lo, hi, tr, True, **opts))
+    for l in range(2):
+        def fg_gpu(xx):
+            v, g = ops.mlp_value_and_input_grad(desc, th[l:l + 1], dev(np.atleast_2d(xx)[None]), tr, True)
+            return v.cpu().numpy()[0, 0], g.cpu().numpy()[0, 0]
+        for r in range(6):
+            h = H.minimize(fg_gpu, x0[l, r].cpu().numpy(), (lo, hi), **opts)
+            assert np.array_equal(h.x, x[l, r]) and h.fun == fun[l, r]
+            assert (h.nit, h.nfev, h.status) == tuple(info[l, r, :3])
+    small = _lib.make_desc(2, [16, 16, 1], ["relu", "relu", "sigmoid"], compute="bfloat16")
+    ths = torch.zeros(1, ops.param_count(small), device=th.device)
+    with pytest.raises(RuntimeError, match="wide static shapes"):
+        ops.lbfgsb_minimize(small, ths, dev(rs.uniform(size=(1, 3, 2))), np.zeros(2), np.ones(2))
+    with pytest.raises(RuntimeError, match="wide static shapes"):
+        ops.mlp_forward(small, ths, dev(rs.uniform(size=(1, 4, 2)).astype(np.float32)))

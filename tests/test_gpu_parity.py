@@ -318,12 +318,12 @@ def test_bf16_fit_tracks_the_bf16_oracle(gpu, D, units, acts):
     X = rs.uniform(size=(N, D)).astype(np.float32)
     z = (rs.uniform(size=N) < 0.3).astype(np.float32)
     perms = np.stack([rs.permutation(N) for _ in range(E)]).astype(np.int32)
-    desc = _lib.make_desc(D, units, acts)
+    desc = _lib.make_desc(D, units, acts, compute="bfloat16")
     th = dev(pack(p0)).reshape(1, -1)
     m, v = torch.zeros_like(th), torch.zeros_like(th)
     t = torch.zeros(1, dtype=torch.int64, device=th.device)
     loss = ops.mlp_fit(desc, th, m, v, t, dev(X[None]), dev(z[None]), E, 64,
-                       perm=dev(perms[None], torch.int32), compute="bfloat16")
+                       perm=dev(perms[None], torch.int32))
     ref = [q.copy() for q in p0]
     st = O.AdamState(ref)
     hist = O.fit_bf16(ref, ["linear" if a is None else a for a in acts], st, X, z, perms)
@@ -335,7 +335,7 @@ def test_bf16_fit_tracks_the_bf16_oracle(gpu, D, units, acts):
     th2 = dev(pack(p0)).reshape(1, -1)
     m2, v2, t2 = torch.zeros_like(th2), torch.zeros_like(th2), torch.zeros_like(t)
     loss2 = ops.mlp_fit(desc, th2, m2, v2, t2, dev(X[None]), dev(z[None]), E, 64,
-                        perm=dev(perms[None], torch.int32), compute="bfloat16")
+                        perm=dev(perms[None], torch.int32))
     assert torch.equal(th, th2) and torch.equal(loss, loss2)
 
 
@@ -346,13 +346,12 @@ def test_bf16_fit_learns_like_fp32_and_rejects_other_shapes(gpu):
     X = rs.uniform(size=(N, D)).astype(np.float32)
     y = ((X - 0.4) ** 2).sum(axis=1)
     z = (y < np.quantile(y, 0.25)).astype(np.float32)
-    desc = _lib.make_desc(D, units, acts)
+    desc = _lib.make_desc(D, units, acts, compute="bfloat16")
     p0 = O.glorot_uniform_params(D, units, rs)
     th = dev(pack(p0)).reshape(1, -1)
     m, v = torch.zeros_like(th), torch.zeros_like(th)
     t = torch.zeros(1, dtype=torch.int64, device=th.device)
-    loss = ops.mlp_fit(desc, th, m, v, t, dev(X[None]), dev(z[None]), 60, 64, seed=5,
-                       compute="bfloat16").cpu().numpy()[0]
+    loss = ops.mlp_fit(desc, th, m, v, t, dev(X[None]), dev(z[None]), 60, 64, seed=5).cpu().numpy()[0]
     pred = ops.mlp_forward(desc, th, dev(X[None]))[0].cpu().numpy()
     assert loss[-1] < 0.35 * loss[0] and np.isfinite(loss).all()
     assert np.mean((pred > 0) == (z > 0.5)) > 0.93          # fp32 master weights classify
@@ -361,10 +360,39 @@ def test_bf16_fit_learns_like_fp32_and_rejects_other_shapes(gpu):
     ref = [q.copy() for q in p0]
     hist = O.fit(ref, acts, O.AdamState(ref), X, z, perms)
     assert abs(hist[-1] - loss[-1]) < 0.15 * hist[-1] + 0.01
-    small = _lib.make_desc(2, [16, 16, 1], ["relu", "relu", "sigmoid"])
+    small = _lib.make_desc(2, [16, 16, 1], ["relu", "relu", "sigmoid"], compute="bfloat16")
     ths = torch.zeros(1, ops.param_count(small), device=th.device)
     with pytest.raises(RuntimeError, match="wide static shapes"):
         ops.mlp_fit(small, ths, ths.clone(), ths.clone(), torch.zeros(1, dtype=torch.int64, device=th.device),
-                    dev(X[None, :, :2].copy()), dev(z[None]), 1, 64, compute="bfloat16")
+                    dev(X[None, :, :2].copy()), dev(z[None]), 1, 64)
     with pytest.raises(ValueError):
-        ops.mlp_fit(desc, th, m, v, t, dev(X[None]), dev(z[None]), 1, 64, compute="fp8")
+        _lib.make_desc(D, units, acts, compute="fp8")
+
+
+@pytest.mark.parametrize("D,units,acts,transform", [
+    (32, [128, 128, 1], ["relu", "relu", "linear"], "sigmoid"),
+    (16, [64, 64, 64, 1], ["tanh", "relu", "elu", "sigmoid"], "identity"),
+])
+def test_bf16_forward_and_input_grad_match_the_bf16_oracle(gpu, D, units, acts, transform):
+    """predict / convert for a mixed_bfloat16 model (desc.compute = bfloat16): the same rounding
+    points as oracle.forward_bf16 / value_and_input_grad_bf16.  Tolerance: one bf16 ulp (2^-8
+    relative) on values -- a last-bit difference of an fp32 sum can flip a rounding -- and
+    2 % + 2e-3 on the input gradient."""
+    rs = np.random.RandomState(9)
+    p = rand_model(rs, D, units)
+    desc = _lib.make_desc(D, units, acts, compute="bfloat16")
+    th = dev(pack(p)).reshape(1, -1)
+    X = rs.uniform(size=(133, D))
+    pred = ops.mlp_forward(desc, th, dev(X[None].astype(np.float32)))[0].cpu().numpy()
+    want = O.forward_bf16(p, acts, X)[:, 0]
+    np.testing.assert_allclose(pred, want, rtol=2 ** -7, atol=1e-4)
+    assert np.mean(pred == want) > 0.9                      # mostly the very same bf16 values
+    assert np.array_equal(pred, O.bf16_round(pred))         # outputs are bf16-representable
+    val, grad = ops.mlp_value_and_input_grad(desc, th, dev(X[None]), transform, True)
+    v_ref, g_ref = O.value_and_input_grad_bf16(p, acts, X, transform, True)
+    np.testing.assert_allclose(val[0].cpu().numpy(), v_ref, rtol=2 ** -7, atol=1e-4)
+    np.testing.assert_allclose(grad[0].cpu().numpy(), g_ref, rtol=2e-2, atol=2e-3)
+    # and they differ from the float32 arithmetic (this is not the fp32 path in disguise)
+    desc32 = _lib.make_desc(D, units, acts)
+    p32 = ops.mlp_forward(desc32, th, dev(X[None].astype(np.float32)))[0].cpu().numpy()
+    assert not np.array_equal(p32, pred) and np.abs(p32 - pred).max() < 0.05 * (1 + np.abs(p32).max())
