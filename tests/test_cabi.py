@@ -56,5 +56,5 @@ def test_param_count_and_descriptor_validation(built):
 
 
 def test_struct_layout_matches_header():
-    assert ctypes.sizeof(_lib.MlpDesc) == 4 * (2 + 4 * _lib.MAX_LAYERS)
+    assert ctypes.sizeof(_lib.MlpDesc) == 4 * (2 + 4 * _lib.MAX_LAYERS + 1)      # + compute
     assert ctypes.sizeof(_lib.AdamCfg) == 16
