@@ -10,8 +10,9 @@ step.  Loops are sharded over ranks (weak scaling, no data-path collective; one 
 the results at the end, outside the timed region).
 
 Prints ONE JSON line on rank 0 (see the driver contract in the task statement) with the
-`roofline` of the dominant kernel (fit_kernel; algorithmic bytes per SURVEY.md §8d
-divided by its HIP-event duration) and a `cpu_baseline` (the numpy/scipy oracle, which
+`roofline` of the dominant kernel (the one with the largest share of the step -- lbfgsb_kernel;
+algorithmic bytes per SURVEY.md §8d divided by its HIP-event duration; `kernels` lists
+fit_kernel too) and a `cpu_baseline` (the numpy/scipy oracle, which
 mirrors the reference's per-step structure, timed on this host's cores -- one single-threaded
 process per core -- for a bounded sample; `cpu_baseline_1core` is the one-core figure).
 """

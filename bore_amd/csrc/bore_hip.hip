@@ -321,9 +321,12 @@ __device__ __forceinline__ void dw_adam_wide(const FitArgs &a, float *smem, floa
       else g[4] = gb;
     }
     float wn[5];
+    wn[4] = 0.f;
 #pragma unroll
-    for (int q = 0; q < 5; ++q)
+    for (int q = 0; q < 5; ++q) {
+      if (q == 4 && !cur.want_bias) continue;  // (wave-uniform: only kb == 0 tiles carry a bias)
       wn[q] = adam_update(w[q], g[q], mm[q], vv[q], alpha, omb1, omb2, a.eps);
+    }
     // pin the five updates HERE: left alone the compiler sinks each one behind the predicate of
     // its store, where a conservative s_waitcnt vmcnt(0) then waits for the previous slot's HBM
     // store and the next tile's prefetch -- five HBM round trips per tile
@@ -776,9 +779,12 @@ __device__ __forceinline__ void dw_adam_bf16(const FitBf16Args &a, unsigned shor
       else g[4] = gb;
     }
     float wn[5];
+    wn[4] = 0.f;
 #pragma unroll
-    for (int q = 0; q < 5; ++q)
+    for (int q = 0; q < 5; ++q) {
+      if (q == 4 && !cur.want_bias) continue;  // (wave-uniform: only kb == 0 tiles carry a bias)
       wn[q] = adam_update(w[q], g[q], mm[q], vv[q], alpha, omb1, omb2, a.eps);
+    }
 #pragma unroll
     for (int q = 0; q < 5; ++q) asm volatile("" : "+v"(wn[q]), "+v"(mm[q]), "+v"(vv[q]));
 #pragma unroll
