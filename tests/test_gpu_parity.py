@@ -202,24 +202,31 @@ def test_shuffle_stream_is_bit_exact_and_drives_fit(gpu):
         d = ops.shuffle_perm(1234, 3, 5, N, model_index0=2, epoch0=7).cpu().numpy()
         h = shuffle.permutations(1234, 3, 5, N, model_index0=2, epoch0=7)
         assert np.array_equal(d, h), N
-    # perm=None inside fit == the same stream passed explicitly (same kernel arithmetic)
+    # perm=None inside fit == the same stream passed explicitly (same kernel arithmetic); small
+    # data sets draw the shuffles of 2 or 4 consecutive epochs together (make_perm_group):
+    # N <= 64 -> groups of 4, N <= 128 -> 2, larger -> one epoch at a time; E = 5 leaves a
+    # partial last group
     rs = np.random.RandomState(0)
-    D, units, acts = 2, [16, 16, 1], ["relu", "relu", "sigmoid"]
-    desc = _lib.make_desc(D, units, acts)
-    L, N, E = 3, 110, 5
-    th0 = np.stack([pack(rand_model(rs, D, units)) for _ in range(L)])
-    X = dev(rs.uniform(size=(L, N, D)), torch.float32)
-    z = dev((rs.uniform(size=(L, N)) < 0.25).astype(np.float32))
-    outs = []
-    for explicit in (False, True):
-        th = dev(th0)
-        m, v = torch.zeros_like(th), torch.zeros_like(th)
-        t = torch.zeros(L, dtype=torch.int64, device="cuda")
-        perm = ops.shuffle_perm(99, L, E, N, model_index0=4, epoch0=20) if explicit else None
-        loss = ops.mlp_fit(desc, th, m, v, t, X, z, E, 64, perm=perm, seed=99, model_index0=4,
-                           epoch0=20)
-        outs.append((th.cpu().numpy(), loss.cpu().numpy()))
-    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    for D, units, acts, N in [(2, [16, 16, 1], ["relu", "relu", "sigmoid"], 110),
+                              (2, [16, 16, 1], ["relu", "relu", "sigmoid"], 30),
+                              (2, [16, 16, 1], ["relu", "relu", "sigmoid"], 200),
+                              (3, [8, 1], ["tanh", "linear"], 13),
+                              (6, [32, 32, 1], ["elu", "elu", "linear"], 64)]:
+        desc = _lib.make_desc(D, units, acts)
+        L, E = 3, 5
+        th0 = np.stack([pack(rand_model(rs, D, units)) for _ in range(L)])
+        X = dev(rs.uniform(size=(L, N, D)), torch.float32)
+        z = dev((rs.uniform(size=(L, N)) < 0.25).astype(np.float32))
+        outs = []
+        for explicit in (False, True):
+            th = dev(th0)
+            m, v = torch.zeros_like(th), torch.zeros_like(th)
+            t = torch.zeros(L, dtype=torch.int64, device="cuda")
+            perm = ops.shuffle_perm(99, L, E, N, model_index0=4, epoch0=20) if explicit else None
+            loss = ops.mlp_fit(desc, th, m, v, t, X, z, E, 64, perm=perm, seed=99, model_index0=4,
+                               epoch0=20)
+            outs.append((th.cpu().numpy(), loss.cpu().numpy()))
+        assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1]), N
 
 
 def test_replicas_are_independent_and_equal_single_model_runs(gpu):
