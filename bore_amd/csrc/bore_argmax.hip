@@ -367,7 +367,13 @@ extern "C" int bore_debug_lphases(long long *out) {
 }
 extern "C" int bore_debug_lphases_reset(void) {
   long long z[16] = {0};
+  static unsigned long long zz[LB_PP_MAX][16];
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(lbfgsb::g_lb_pp), zz, sizeof(zz));
   return (int)hipMemcpyToSymbol(HIP_SYMBOL(lbfgsb::g_lb_phase), z, sizeof(z));
+}
+extern "C" int bore_debug_lpp(unsigned long long *out) {  // [LB_PP_MAX][16]
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(lbfgsb::g_lb_pp),
+                                  sizeof(unsigned long long) * LB_PP_MAX * 16);
 }
 #define BORE_LCLOCK() clock64()
 #else
@@ -504,6 +510,10 @@ __global__ __launch_bounds__(BORE_THREADS) void lbfgsb_kernel(const LbfgsbArgs a
 #ifdef BORE_STAMPS
   if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) {
     g_lstamps[0] = t_adv; g_lstamps[1] = t_fg; g_lstamps[2] = n_rounds; g_lstamps[3] = st.nit;
+  }
+  if (coop && lane == 0 && 4 * blockIdx.x + wv < LB_PP_MAX) {
+    atomicAdd(&lbfgsb::g_lb_pp[4 * blockIdx.x + wv][7], (unsigned long long)t_adv);
+    atomicAdd(&lbfgsb::g_lb_pp[4 * blockIdx.x + wv][15], (unsigned long long)t_fg);
   }
 #endif
 

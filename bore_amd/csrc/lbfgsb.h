@@ -85,7 +85,7 @@ struct State {
 // host/device mismatch for odd n; see tests/test_gpu_argmax.py).
 LB_HD int dwork_size(int n, int m) {
   const int ne = (n + 1) & ~1, mne = (m * n + 1) & ~1, mm = (m * m + 1) & ~1;
-  return 2 * mne + 3 * mm + 8 * m * m + 8 * m + 9 * ne;
+  return 2 * mne + 3 * mm + 8 * m * m + 8 * m + 9 * ne + 6 * m;
 }
 LB_HD int iwork_size(int n) { return 3 * n; }
 
@@ -97,6 +97,11 @@ struct Work {
   double *z, *r, *d, *t, *xp, *x, *g;
   double *xlast, *glast;    // last point actually evaluated (SciPy's ScalarFunction cache)
   double *wa;               // 8m: p | c | wbp | v
+  // Reciprocals kept beside the factors: the substitution chains multiply by them instead of
+  // dividing (an fp64 divide is ~150 cycles of dependent issue per unknown on the device).
+  double *rwt;              // m:  1 / diag of the Cholesky factor in wt
+  double *rwn;              // 2m: 1 / diag of the two Cholesky factors in wn
+  double *rsy, *rsq;        // m each: 1 / sy_ii and 1 / sqrt(sy_ii)
   int *index, *iwhere, *indx2;
 };
 
@@ -119,7 +124,11 @@ LB_HD Work make_work(double *dw, int *iw, int n, int m) {
   w.g = dw; dw += ne;
   w.xlast = dw; dw += ne;
   w.glast = dw; dw += ne;
-  w.wa = dw;
+  w.wa = dw; dw += 8 * m;
+  w.rwt = dw; dw += m;
+  w.rwn = dw; dw += 2 * m;
+  w.rsy = dw; dw += m;
+  w.rsq = dw;
   w.index = iw;
   w.iwhere = iw + n;
   w.indx2 = iw + 2 * n;
@@ -144,17 +153,27 @@ struct Coop {
 #define LB_LANES_SYNC() ((void)0)
 #endif
 
-// -DBORE_STAMPS: per-phase cycle accumulators (workgroup 0, thread 0); diagnostics only
+// -DBORE_STAMPS: per-phase cycle accumulators, diagnostics only.  g_lb_phase: workgroup 0,
+// thread 0.  g_lb_pp[q][i]: every problem q = 4*blockIdx.x + wave of a one-problem-per-wave launch
+// (i < 7: cycles in phase i, 8 + i: calls; 7 / 15: whole advance / f-g cycles, added by the kernel).
 #if defined(BORE_STAMPS) && defined(__HIPCC__)
 __device__ long long g_lb_phase[16];
+#define LB_PP_MAX 4096
+__device__ unsigned long long g_lb_pp[LB_PP_MAX][16];
 #endif
 #if defined(BORE_STAMPS) && defined(__HIP_DEVICE_COMPILE__)
 #define LB_PHASE_BEGIN() const long long lb_t0_ = clock64()
 #define LB_PHASE_END(i)                                                                   \
   do {                                                                                    \
+    const long long lb_dt_ = clock64() - lb_t0_;                                          \
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {                         \
-      g_lb_phase[i] += clock64() - lb_t0_;                                                \
+      g_lb_phase[i] += lb_dt_;                                                            \
       g_lb_phase[8 + (i)] += 1;                                                           \
+    }                                                                                     \
+    const unsigned lb_q_ = 4u * blockIdx.x + (threadIdx.x >> 6);                          \
+    if ((threadIdx.x & 63) == 0 && lb_q_ < LB_PP_MAX) {                                   \
+      atomicAdd(&g_lb_pp[lb_q_][i], (unsigned long long)lb_dt_);                          \
+      atomicAdd(&g_lb_pp[lb_q_][8 + (i)], 1ull);                                          \
     }                                                                                     \
   } while (0)
 #else
@@ -198,21 +217,22 @@ LB_HD double ddot(int n, const double *a, const double *b) {
   return s;
 }
 
-// sum_i a[i*sa] * b[i*sb] / d[i*sd], left to right, operands fetched four terms at a time
-LB_HD double dot_div(int n, const double *a, int sa, const double *b, int sb, const double *d,
-                     int sd) {
+// sum_i a[i*sa] * b[i*sb] * r[i*sr], left to right (r: stored reciprocals), operands fetched
+// four terms at a time
+LB_HD double dot_rcp(int n, const double *a, int sa, const double *b, int sb, const double *r,
+                     int sr) {
   double s = 0.0;
   int i = 0;
   for (; i + 4 <= n; i += 4) {
     const double a0 = a[i * sa], a1 = a[(i + 1) * sa], a2 = a[(i + 2) * sa], a3 = a[(i + 3) * sa];
     const double b0 = b[i * sb], b1 = b[(i + 1) * sb], b2 = b[(i + 2) * sb], b3 = b[(i + 3) * sb];
-    const double d0 = d[i * sd], d1 = d[(i + 1) * sd], d2 = d[(i + 2) * sd], d3 = d[(i + 3) * sd];
-    s += a0 * b0 / d0;
-    s += a1 * b1 / d1;
-    s += a2 * b2 / d2;
-    s += a3 * b3 / d3;
+    const double r0 = r[i * sr], r1 = r[(i + 1) * sr], r2 = r[(i + 2) * sr], r3 = r[(i + 3) * sr];
+    s += a0 * b0 * r0;
+    s += a1 * b1 * r1;
+    s += a2 * b2 * r2;
+    s += a3 * b3 * r3;
   }
-  for (; i < n; ++i) s += a[i * sa] * b[i * sb] / d[i * sd];
+  for (; i < n; ++i) s += a[i * sa] * b[i * sb] * r[i * sr];
   return s;
 }
 
@@ -239,22 +259,31 @@ LB_HD void daxpy(int n, double alpha, const double *x, double *y) {
 // produced by the same operations in the same order as in the sequential loop nest (its
 // dot product runs over i ascending, the column's sum of squares over k ascending), so the
 // two forms give identical bits; the chain is n steps long instead of n^2/2.
-LB_HD int dpofa(double *a, int ld, int n, const Coop c = Coop{0, 1}) {
+//
+// rd[k] receives 1/R_kk, formed as sqrt(d) * (1/d) from the pivot d = R_kk^2: the square root and
+// the reciprocal do not depend on each other, so a step's chain is one of them plus two
+// multiplies instead of a square root followed by a divide.  The entries R_kj are scaled by it.
+LB_HD int dpofa(double *a, int ld, int n, double *rd, const Coop c = Coop{0, 1}) {
   if (c.nl >= n && c.nl > 1) {
     const int j = c.lane;
     double s = 0.0;
     for (int k = 0; k < n; ++k) {
       // every lane forms "its" diagonal; lane k's is the real one (v_readlane broadcast)
-      const double dkk = a[k * ld + k] - s;
-      const double rkk = lane_bcast(dkk <= 0.0 ? dkk : sqrt(dkk), k);  // <= 0: not positive definite
-      if (j == k) a[k * ld + k] = rkk;
-      if (rkk <= 0.0) {
+      const double dkk = lane_bcast(a[k * ld + k] - s, k);
+      if (dkk <= 0.0) {  // not positive definite
+        if (j == k) a[k * ld + k] = dkk;
         LB_LANES_SYNC();
         return k + 1;
       }
+      const double rkk = sqrt(dkk);
+      const double rinv = rkk * (1.0 / dkk);
+      if (j == k) {
+        a[k * ld + k] = rkk;
+        rd[k] = rinv;
+      }
       if (j > k && j < n) {
         double t = a[j * ld + k] - ddot(k, a + k * ld, a + j * ld);
-        t = t / rkk;
+        t = t * rinv;
         a[j * ld + k] = t;
         s += t * t;
       }
@@ -266,13 +295,15 @@ LB_HD int dpofa(double *a, int ld, int n, const Coop c = Coop{0, 1}) {
     double s = 0.0;
     for (int k = 0; k < j; ++k) {
       double t = a[j * ld + k] - ddot(k, a + k * ld, a + j * ld);
-      t = t / a[k * ld + k];
+      t = t * rd[k];
       a[j * ld + k] = t;
       s += t * t;
     }
     s = a[j * ld + j] - s;
     if (s <= 0.0) return j + 1;
-    a[j * ld + j] = sqrt(s);
+    const double r = sqrt(s);
+    a[j * ld + j] = r;
+    rd[j] = r * (1.0 / s);
   }
   return 0;
 }
@@ -282,7 +313,8 @@ LB_HD int dpofa(double *a, int ld, int n, const Coop c = Coop{0, 1}) {
 // c.nl >= n: lane i owns x_i.  As soon as an unknown is final it is broadcast and every lane
 // still waiting folds it into its own running sum -- the same products, added in the same
 // order, as the sequential substitution (identical bits), n steps instead of n^2/2.
-LB_HD int dtrsl_upper(const double *t, int ld, int n, double *b, int trans,
+// rd[j] = 1 / T_jj (stored by dpofa): every unknown is a product with it, not a quotient.
+LB_HD int dtrsl_upper(const double *t, int ld, int n, double *b, int trans, const double *rd,
                       const Coop c = Coop{0, 1}) {
   if (c.nl >= n && c.nl > 1) {
     if (lanes_any(c.lane < n && t[(c.lane < n ? c.lane : 0) * (ld + 1)] == 0.0)) {
@@ -294,36 +326,36 @@ LB_HD int dtrsl_upper(const double *t, int ld, int n, double *b, int trans,
       if (t[j * ld + j] == 0.0) return j + 1;
   }
   if (c.nl >= n && c.nl > 1) {
-    // Every lane runs the divide on its own running value; the owner's quotient is broadcast
-    // with v_readlane (no LDS round trip in the chain) and T's entries for the next step are
-    // requested before the divide of this one.
+    // Every lane scales its own running value; the owner's result is broadcast with v_readlane
+    // (no LDS round trip in the chain) and T's entries for the next step are requested before
+    // the product of this one.
     const int me = c.lane;
     const bool mine = me < n;
     const int mc = mine ? me : 0;  // (lanes without an unknown read a valid address)
     double xme = 0.0;
     if (!trans) {  // T x = b, backward; the sequential form applies b[i] += (-x_j) T_ij, j descending
       double bi = mine ? b[me] : 0.0;
-      double tjj = t[(n - 1) * ld + (n - 1)], tji = t[(n - 1) * ld + mc];
+      double rjj = rd[n - 1], tji = t[(n - 1) * ld + mc];
       for (int j = n - 1; j >= 0; --j) {
         const int jn = j > 0 ? j - 1 : 0;
-        const double tjj_n = t[jn * ld + jn], tji_n = t[jn * ld + mc];
-        const double xj = lane_bcast(bi / tjj, j);
+        const double rjj_n = rd[jn], tji_n = t[jn * ld + mc];
+        const double xj = lane_bcast(bi * rjj, j);
         if (me == j) xme = xj;
         if (mine && me < j) bi = bi + (-xj) * tji;
-        tjj = tjj_n;
+        rjj = rjj_n;
         tji = tji_n;
       }
     } else {  // T' x = b, forward; the sequential form is x_j = (b_j - sum_{i<j} T_ij x_i) / T_jj
       const double bj = mine ? b[me] : 0.0;
       double acc = 0.0;
-      double tii = t[0], tmi = t[mc * ld];
+      double rii = rd[0], tmi = t[mc * ld];
       for (int i = 0; i < n; ++i) {
         const int in = i + 1 < n ? i + 1 : i;
-        const double tii_n = t[in * ld + in], tmi_n = t[mc * ld + in];
-        const double xi = lane_bcast(i == 0 ? bj / tii : (bj - acc) / tii, i);
+        const double rii_n = rd[in], tmi_n = t[mc * ld + in];
+        const double xi = lane_bcast(i == 0 ? bj * rii : (bj - acc) * rii, i);
         if (me == i) xme = xi;
         if (mine && me > i) acc += tmi * xi;
-        tii = tii_n;
+        rii = rii_n;
         tmi = tmi_n;
       }
     }
@@ -333,16 +365,16 @@ LB_HD int dtrsl_upper(const double *t, int ld, int n, double *b, int trans,
     return 0;
   }
   if (!trans) {
-    b[n - 1] = b[n - 1] / t[(n - 1) * ld + (n - 1)];
+    b[n - 1] = b[n - 1] * rd[n - 1];
     for (int j = n - 2; j >= 0; --j) {
       daxpy(j + 1, -b[j + 1], t + (j + 1) * ld, b);
-      b[j] = b[j] / t[j * ld + j];
+      b[j] = b[j] * rd[j];
     }
   } else {
-    b[0] = b[0] / t[0];
+    b[0] = b[0] * rd[0];
     for (int j = 1; j < n; ++j) {
       b[j] = b[j] - ddot(j, t + j * ld, b);
-      b[j] = b[j] / t[j * ld + j];
+      b[j] = b[j] * rd[j];
     }
   }
   return 0;
@@ -350,11 +382,11 @@ LB_HD int dtrsl_upper(const double *t, int ld, int n, double *b, int trans,
 
 // T' x = b for one right-hand side by the calling thread alone; the caller has checked the
 // diagonal (same operations as dtrsl_upper(.., trans = 1) past its check).
-LB_HD void dtrsl_lower_rhs(const double *t, int ld, int n, double *b) {
-  b[0] = b[0] / t[0];
+LB_HD void dtrsl_lower_rhs(const double *t, int ld, int n, double *b, const double *rd) {
+  b[0] = b[0] * rd[0];
   for (int j = 1; j < n; ++j) {
     b[j] = b[j] - ddot(j, t + j * ld, b);
-    b[j] = b[j] / t[j * ld + j];
+    b[j] = b[j] * rd[j];
   }
 }
 
@@ -386,41 +418,42 @@ LB_HD void ddot3(int n, const double *a, const double *b, const double *c, const
 
 // ---- limited-memory matrix products ---------------------------------------------
 // Product of the 2col x 2col middle matrix of the compact L-BFGS formula with v -> p.
-LB_HD int bmv(int m, const double *sy, const double *wt, int col, const double *v, double *p,
-              const Coop c) {
+LB_HD int bmv(int m, const Work &w, int col, const double *v, double *p, const Coop c) {
+  const double *sy = w.sy, *wt = w.wt;
   if (col == 0) return 0;
   // solve [  D^(1/2)      O ] [ p1 ] = [ v1 ]
   //       [ -L*D^(-1/2)   J ] [ p2 ]   [ v2 ]
   for (int i = c.lane; i < col; i += c.nl)
-    p[col + i] = i == 0 ? v[col] : v[col + i] + dot_div(i, sy + i, m, v, 1, sy, m + 1);
+    p[col + i] = i == 0 ? v[col] : v[col + i] + dot_rcp(i, sy + i, m, v, 1, w.rsy, 1);
   LB_LANES_SYNC();
-  int info = dtrsl_upper(wt, m, col, p + col, 1, c);
+  int info = dtrsl_upper(wt, m, col, p + col, 1, w.rwt, c);
   if (info) return info;
   // solve [ -D^(1/2)   D^(-1/2)*L' ] [ p1 ] = [ p1 ]
   //       [  0         J'          ] [ p2 ]   [ p2 ]
-  info = dtrsl_upper(wt, m, col, p + col, 0, c);
+  info = dtrsl_upper(wt, m, col, p + col, 0, w.rwt, c);
   if (info) return info;
   for (int i = c.lane; i < col; i += c.nl) {
-    const double sq = sqrt(sy[i * m + i]);
-    double pi = v[i] / sq;
-    pi = -pi / sq;
-    p[i] = pi + dot_div(col - i - 1, sy + i * m + i + 1, 1, p + col + i + 1, 1, sy + i * m + i, 0);
+    const double rs = w.rsq[i];
+    double pi = v[i] * rs;
+    pi = -pi * rs;
+    p[i] = pi + dot_rcp(col - i - 1, sy + i * m + i + 1, 1, p + col + i + 1, 1, w.rsy + i, 0);
   }
   LB_LANES_SYNC();
   return 0;
 }
 
 // T = theta*SS + L*D^(-1)*L' (upper triangle), then its Cholesky factor J' in wt.
-LB_HD int formt(int m, double *wt, const double *sy, const double *ss, int col, double theta,
-                const Coop c) {
+LB_HD int formt(int m, const Work &w, int col, double theta, const Coop c) {
+  double *wt = w.wt;
+  const double *sy = w.sy, *ss = w.ss;
   for (int e = c.lane; e < col * col; e += c.nl) {  // the entries (i, j >= i) are independent
     const int i = e / col, j = e - i * col;
     if (j < i) continue;
     if (i == 0) wt[j * m] = theta * ss[j * m];
-    else wt[j * m + i] = dot_div(i, sy + i, m, sy + j, m, sy, m + 1) + theta * ss[j * m + i];
+    else wt[j * m + i] = dot_rcp(i, sy + i, m, sy + j, m, w.rsy, 1) + theta * ss[j * m + i];
   }
   LB_LANES_SYNC();
-  return dpofa(wt, m, col, c) ? -3 : 0;
+  return dpofa(wt, m, col, w.rwt, c) ? -3 : 0;
 }
 
 // ---- projected gradient norm -------------------------------------------------------
@@ -600,7 +633,7 @@ LB_HDN int cauchy(const IterArgs s, const Work w, const double *l, const double 
   double f2 = -theta * f1;
   const double f2_org = f2;
   if (col > 0) {
-    const int info = bmv(m, w.sy, w.wt, col, p, v, s.c);
+    const int info = bmv(m, w, col, p, v, s.c);
     if (info) return LB_CAUCHY_RET(info);
     f2 -= ddot(col2, v, p);
   }
@@ -662,7 +695,7 @@ LB_HDN int cauchy(const IterArgs s, const Work w, const double *l, const double 
           wbp[col + j] = theta * w.ws[pj * n + (ibp - 1)];
         }
         LB_LANES_SYNC();
-        const int info = bmv(m, w.sy, w.wt, col, wbp, v, s.c);
+        const int info = bmv(m, w, col, wbp, v, s.c);
         if (info) return LB_CAUCHY_RET(info);
         double wmc, wmp, wmw;
         ddot3(col2, c, p, wbp, v, wmc, wmp, wmw);
@@ -837,12 +870,12 @@ LB_HDN int formk(const IterArgs s, const Work w) {
   LB_LANES_SYNC();
   // upper triangle of WN = [D+Y'ZZ'Y/theta   -L_a'+R_z'] [-L_a+R_z   S'AA'S*theta]
   // (each iy writes its own columns iy and col+iy)
-  const double theta = s.theta;
+  const double theta = s.theta, rtheta = 1.0 / s.theta;
   for (int iy = c.lane; iy < col; iy += c.nl) {
     const int is = col + iy, is1 = m + iy;
     for (int jy = 0; jy <= iy; ++jy) {
       const int js = col + jy, js1 = m + jy;
-      WN(jy, iy) = WN1(iy, jy) / theta;
+      WN(jy, iy) = WN1(iy, jy) * rtheta;
       WN(js, is) = WN1(is1, js1) * theta;
     }
     for (int jy = 0; jy < iy; ++jy) WN(jy, is) = -WN1(is1, jy);
@@ -852,7 +885,7 @@ LB_HDN int formk(const IterArgs s, const Work w) {
   LB_LANES_SYNC();
   // Cholesky of the (1,1) block, then L^-1(-L_a'+R_z') in the (1,2) block (one right-hand
   // side per lane)
-  if (dpofa(wn, m2, col, c)) return -1;
+  if (dpofa(wn, m2, col, w.rwn, c)) return -1;
   const int col2 = 2 * col;
   if (c.nl > 1 && c.nl >= col) {
     if (lanes_any(c.lane < col && wn[(c.lane < col ? c.lane : 0) * (m2 + 1)] == 0.0)) return -1;
@@ -860,7 +893,8 @@ LB_HDN int formk(const IterArgs s, const Work w) {
     for (int j = 0; j < col; ++j)
       if (wn[j * m2 + j] == 0.0) return -1;
   }
-  for (int js = col + c.lane; js < col2; js += c.nl) dtrsl_lower_rhs(wn, m2, col, wn + js * m2);
+  for (int js = col + c.lane; js < col2; js += c.nl)
+    dtrsl_lower_rhs(wn, m2, col, wn + js * m2, w.rwn);
   LB_LANES_SYNC();
   // (2,2) block: S'AA'S*theta + (L^-1(-L_a'+R_z'))'(L^-1(-L_a'+R_z')), then its Cholesky
   for (int e = c.lane; e < col * col; e += c.nl) {
@@ -868,7 +902,7 @@ LB_HDN int formk(const IterArgs s, const Work w) {
     if (js >= is) WN(is, js) += ddot(col, wn + is * m2, wn + js * m2);
   }
   LB_LANES_SYNC();
-  if (dpofa(wn + col * m2 + col, m2, col, c)) return -2;
+  if (dpofa(wn + col * m2 + col, m2, col, w.rwn + col, c)) return -2;
   return 0;
 #undef WN
 #undef WN1
@@ -884,7 +918,7 @@ LB_HD int cmprlb(State &s, const Work &w, const Coop c) {
     LB_LANES_SYNC();
     return 0;
   }
-  if (bmv(m, w.sy, w.wt, col, w.wa + 2 * m, w.wa, c)) return -8;
+  if (bmv(m, w, col, w.wa + 2 * m, w.wa, c)) return -8;
   for (int i = c.lane; i < s.nfree; i += c.nl) {  // each r[i]: its terms in the order j = 0, 1, ...
     const int k = w.index[i] - 1;
     double ri = -s.theta * (w.z[k] - w.x[k]) - w.g[k];
@@ -932,10 +966,11 @@ LB_HDN int subsm(const IterArgs s, const Work w, const double *l, const double *
     wv[col + i] = theta * temp2;
   }
   LB_LANES_SYNC();
-  if (dtrsl_upper(w.wn, m2, col2, wv, 1, c)) return 1;
+  if (dtrsl_upper(w.wn, m2, col2, wv, 1, w.rwn, c)) return 1;
   for (int i = c.lane; i < col; i += c.nl) wv[i] = -wv[i];
   LB_LANES_SYNC();
-  if (dtrsl_upper(w.wn, m2, col2, wv, 0, c)) return 1;
+  if (dtrsl_upper(w.wn, m2, col2, wv, 0, w.rwn, c)) return 1;
+  const double rtheta = 1.0 / theta;
   for (int i = c.lane; i < n; i += c.nl) xp[i] = x[i];  // (the free variables are saved below too)
   for (int i = c.lane; i < nsub; i += c.nl) {  // d = (1/theta)d + (1/theta^2)Z'W wv, per entry
     const int k = ind[i] - 1;
@@ -947,12 +982,12 @@ LB_HDN int subsm(const IterArgs s, const Work w, const double *l, const double *
       const double v0 = wv[jy], v1 = wv[jy + 1], u0 = wv[col + jy], u1 = wv[col + jy + 1];
       const double y0 = w.wy[p0 * n + k], s0 = w.ws[p0 * n + k];
       const double y1 = w.wy[p1 * n + k], s1 = w.ws[p1 * n + k];
-      di += y0 * v0 / theta + s0 * u0;
-      di += y1 * v1 / theta + s1 * u1;
+      di += y0 * v0 * rtheta + s0 * u0;
+      di += y1 * v1 * rtheta + s1 * u1;
       p0 = p1 + 1 == m ? 0 : p1 + 1;
     }
-    if (jy < col) di += w.wy[p0 * n + k] * wv[jy] / theta + w.ws[p0 * n + k] * wv[col + jy];
-    di = di * (1.0 / theta);
+    if (jy < col) di += w.wy[p0 * n + k] * wv[jy] * rtheta + w.ws[p0 * n + k] * wv[col + jy];
+    di = di * rtheta;
     d[i] = di;
     // projected Newton step of this free variable (distinct k per i)
     const double xk = x[k];
@@ -1084,12 +1119,15 @@ LB_HD void dcstep(double &stx, double &fx, double &dx, double &sty, double &fy, 
       stpf = stpmin;
     }
   }
-  if (fp > fx) {
-    sty = stp; fy = fp; dy = dp;
-  } else {
-    if (sgnd < 0.0) { sty = stx; fy = fx; dy = dx; }
-    stx = stp; fx = fp; dx = dp;
-  }
+  // (value selects, not conditional stores: the device compiler turned the latter into stores
+  // through a selected ADDRESS, which forced all six variables into scratch memory)
+  const bool higher = fp > fx, opposite = !higher && sgnd < 0.0;
+  const double nsty = higher ? stp : (opposite ? stx : sty);
+  const double nfy = higher ? fp : (opposite ? fx : fy);
+  const double ndy = higher ? dp : (opposite ? dx : dy);
+  const double nstx = higher ? stx : stp, nfx = higher ? fx : fp, ndx = higher ? dx : dp;
+  sty = nsty; fy = nfy; dy = ndy;
+  stx = nstx; fx = nfx; dx = ndx;
   stp = stpf;
 }
 
@@ -1130,18 +1168,30 @@ LB_HD void dcsrch(State &s, double f, double g, double &stp, double ftol, double
     s.ls_task = task;
     return;
   }
-  if (s.ls_stage == 1 && f <= s.fx && f > ftest) {
-    const double fm = f - stp * s.gtest;
-    double fxm = s.fx - s.stx * s.gtest, fym = s.fy - s.sty * s.gtest;
-    const double gm = g - s.gtest;
-    double gxm = s.gx - s.gtest, gym = s.gy - s.gtest;
-    dcstep(s.stx, fxm, gxm, s.sty, fym, gym, stp, fm, gm, s.brackt, s.stmin, s.stmax);
-    s.fx = fxm + s.stx * s.gtest;
-    s.fy = fym + s.sty * s.gtest;
-    s.gx = gxm + s.gtest;
-    s.gy = gym + s.gtest;
-  } else {
-    dcstep(s.stx, s.fx, s.gx, s.sty, s.fy, s.gy, stp, f, g, s.brackt, s.stmin, s.stmax);
+  {
+    // ONE set of locals goes through dcstep whichever branch is taken: handing it either the
+    // state's fields or modified copies by reference made the device compiler keep all eight in
+    // scratch memory (a dozen dependent ~500-cycle round trips per evaluation).
+    const bool modified = s.ls_stage == 1 && f <= s.fx && f > ftest;
+    double stx = s.stx, sty = s.sty, fx = s.fx, fy = s.fy, gx = s.gx, gy = s.gy, fp = f, gp = g;
+    int brackt = s.brackt;
+    if (modified) {
+      fp = f - stp * s.gtest;
+      fx = s.fx - s.stx * s.gtest;
+      fy = s.fy - s.sty * s.gtest;
+      gp = g - s.gtest;
+      gx = s.gx - s.gtest;
+      gy = s.gy - s.gtest;
+    }
+    dcstep(stx, fx, gx, sty, fy, gy, stp, fp, gp, brackt, s.stmin, s.stmax);
+    if (modified) {
+      fx = fx + stx * s.gtest;
+      fy = fy + sty * s.gtest;
+      gx = gx + s.gtest;
+      gy = gy + s.gtest;
+    }
+    s.stx = stx; s.sty = sty; s.fx = fx; s.fy = fy; s.gx = gx; s.gy = gy;
+    s.brackt = brackt;
   }
   if (s.brackt) {
     if (fabs(s.sty - s.stx) >= p66 * s.width1) stp = s.stx + p5 * (s.sty - s.stx);
@@ -1252,6 +1302,8 @@ LB_HD void matupd(State &s, const Work &w, double rr, double dr) {
   const int col = s.col;
   if (s.iupdat > m) {  // move old information
     for (int j = 0; j < col - 1; ++j) {
+      w.rsy[j] = w.rsy[j + 1];
+      w.rsq[j] = w.rsq[j + 1];
       for (int i = 0; i <= j; ++i) w.ss[j * m + i] = w.ss[(j + 1) * m + (i + 1)];
       for (int i = 0; i < col - 1 - j; ++i) w.sy[j * m + (j + i)] = w.sy[(j + 1) * m + (j + 1 + i)];
     }
@@ -1265,6 +1317,8 @@ LB_HD void matupd(State &s, const Work &w, double rr, double dr) {
   if (s.stp == 1.0) w.ss[(col - 1) * m + (col - 1)] = s.dtd;
   else w.ss[(col - 1) * m + (col - 1)] = s.stp * s.stp * s.dtd;
   w.sy[(col - 1) * m + (col - 1)] = dr;
+  w.rsy[col - 1] = 1.0 / dr;
+  w.rsq[col - 1] = 1.0 / sqrt(dr);
 }
 
 LB_HD void refresh_memory(State &s) {
@@ -1521,7 +1575,7 @@ LB_HD int lbfgsb_advance(State &s, const Work &w, const double *l, const double 
       int ft;
       {
         LB_PHASE_BEGIN();
-        ft = formt(m, w.wt, w.sy, w.ss, s.col, s.theta, coop);
+        ft = formt(m, w, s.col, s.theta, coop);
         LB_PHASE_END(6);
       }
       if (ft) {
