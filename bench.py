@@ -124,6 +124,9 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--groups", type=int, default=4,
                     help="loop groups stepping on separate streams (overlaps L-BFGS-B tails)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend for N > 1 (nccl = RCCL; gloo only to rehearse the "
+                         "multi-rank flow on a one-GPU box together with BORE_BENCH_ONE_DEVICE=1)")
     ap.add_argument("--mode", default="device", choices=["device", "lockstep"],
                     help="device: L-BFGS-B restarts inside one kernel; lockstep: scipy on the host")
     args = ap.parse_args()
@@ -135,9 +138,14 @@ def main():
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
+    if os.environ.get("BORE_BENCH_ONE_DEVICE") == "1":     # rehearsal: every rank on cuda:0
+        local = 0
     torch.cuda.set_device(local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group("gloo")
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     loop_ids = shard_loop_ids(rank, world, args.loops)     # contiguous shard per rank
@@ -163,7 +171,8 @@ def main():
     dt = time.perf_counter() - t0
     eng.finish_timing()
 
-    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    tmax = torch.tensor([dt], dtype=torch.float64,
+                        device="cuda" if args.backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax[0])
