@@ -29,7 +29,7 @@ EXPORTS = [
     "bore_abi_version", "bore_last_error", "bore_param_count", "bore_mlp_forward",
     "bore_mlp_value_and_input_grad", "bore_mlp_fit", "bore_mlp_evaluate",
     "bore_shuffle_perm", "bore_labels", "bore_uniform_candidates", "bore_screen_topk",
-    "bore_lbfgsb_minimize",
+    "bore_lbfgsb_minimize", "bore_append_observations", "bore_select_best",
 ]
 
 
@@ -113,6 +113,9 @@ def lib():
     L.bore_screen_topk.argtypes = [dp, i32, vp, vp, i64, i32, i32, vp, vp, vp, vp]
     L.bore_lbfgsb_minimize.argtypes = [dp, i32, vp, i32, i32, vp, i32, dpp, dpp,
                                        C.POINTER(LbfgsbOpts), vp, vp, vp, vp, vp]
+    L.bore_append_observations.argtypes = [i32, i32, vp, vp, i64, i64, vp, vp, vp, vp, vp]
+    L.bore_select_best.argtypes = [i32, i32, i32, vp, vp, vp, vp, i64, i64, C.c_double,
+                                   C.c_double, vp, vp, vp]
     for name in EXPORTS:
         if name not in ("bore_last_error", "bore_param_count"):
             getattr(L, name).restype = i32

@@ -658,3 +658,116 @@ extern "C" int bore_lbfgsb_minimize(const bore_mlp_desc *desc, int n_models, con
   HIP_TRY(hipGetLastError());
   return 0;
 }
+
+// ---------------------------------------------------------------------------
+// device-resident observation store (Record.append / load_regression_data) and the
+// selection of argmax() with the plugin's duplicate filter
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(BORE_THREADS) void append_kernel(int D, double *X_seen, double *y_seen,
+                                                              long long n_seen, long long cap,
+                                                              const double *x_new,
+                                                              const double *y_new, float *X32,
+                                                              double *y_dense) {
+  const long long model = blockIdx.x;
+  double *Xs = X_seen + model * cap * D, *ys = y_seen + model * cap;
+  if (x_new) {  // row n_seen of the store; the same threads read it back below
+    for (int d = threadIdx.x; d < D; d += blockDim.x) Xs[n_seen * D + d] = x_new[model * D + d];
+    if (threadIdx.x == 0) ys[n_seen] = y_new[model];
+    __syncthreads();
+  }
+  const long long n = n_seen + (x_new ? 1 : 0);
+  float *Xo = X32 + model * n * D;
+  double *yo = y_dense + model * n;
+  for (long long i = threadIdx.x; i < n * D; i += blockDim.x) Xo[i] = (float)Xs[i];
+  for (long long i = threadIdx.x; i < n; i += blockDim.x) yo[i] = ys[i];
+}
+
+extern "C" int bore_append_observations(int n_models, int D, double *X_seen, double *y_seen,
+                                        int64_t n_seen, int64_t cap, const double *x_new,
+                                        const double *y_new, float *X32, double *y_dense,
+                                        void *stream) {
+  if (n_models < 1 || D < 1 || !X_seen || !y_seen || !X32 || !y_dense)
+    return fail(BORE_E_INVALID, "append_observations: bad argument");
+  if ((x_new == nullptr) != (y_new == nullptr))
+    return fail(BORE_E_INVALID, "append_observations: x_new and y_new go together");
+  if (n_seen < 0 || n_seen + (x_new ? 1 : 0) > cap || n_seen + (x_new ? 1 : 0) < 1)
+    return fail(BORE_E_INVALID, "append_observations: %lld rows (+%d) do not fit cap %lld",
+                (long long)n_seen, x_new ? 1 : 0, (long long)cap);
+  hipLaunchKernelGGL(append_kernel, dim3(n_models), dim3(BORE_THREADS), 0, (hipStream_t)stream, D,
+                     X_seen, y_seen, (long long)n_seen, (long long)cap, x_new, y_new, X32, y_dense);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// fun as a key that orders like the doubles do (NaN cannot occur: sigmoid/exp/identity of a
+// finite logit); the restart number below it breaks ties towards the earliest
+__device__ __forceinline__ unsigned long long orderable64(double v) {
+  const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+  return (u >> 63) ? ~u : (u | 0x8000000000000000ULL);
+}
+
+__global__ __launch_bounds__(BORE_THREADS) void select_kernel(int R, int D, const double *x,
+                                                              const double *fun, const int *info,
+                                                              const double *X_seen,
+                                                              long long n_seen, long long cap,
+                                                              double rtol, double atol,
+                                                              double *x_best, int *best) {
+  __shared__ unsigned long long s_key;
+  __shared__ int s_idx;
+  const long long model = blockIdx.x;
+  if (threadIdx.x == 0) {
+    s_key = ~0ULL;
+    s_idx = 0x7fffffff;
+  }
+  __syncthreads();
+  const double *Xs = X_seen ? X_seen + model * cap * D : nullptr;
+  unsigned long long my_key = ~0ULL;
+  int my_idx = 0x7fffffff;
+  for (int r = threadIdx.x; r < R; r += blockDim.x) {
+    const long long q = model * R + r;
+    const int status = info[q * 5 + 2];
+    if (status != 0 && status != 1) continue;  // res.success or res.status == 1
+    const double *xr = x + q * D;
+    bool dup = false;
+    if (Xs) {
+      for (long long i = 0; i < n_seen && !dup; ++i) {  // any(np.allclose(x_prev, x) ...)
+        bool close = true;
+        for (int d = 0; d < D && close; ++d) {
+          const double b = xr[d];
+          close = fabs(Xs[i * D + d] - b) <= atol + rtol * fabs(b);
+        }
+        dup = close;
+      }
+    }
+    if (dup) continue;
+    const unsigned long long k = orderable64(fun[q]);
+    if (k < my_key) {  // (r ascends within a thread: the earliest of equal keys stays)
+      my_key = k;
+      my_idx = r;
+    }
+  }
+  if (my_idx != 0x7fffffff) atomicMin(&s_key, my_key);
+  __syncthreads();
+  if (my_idx != 0x7fffffff && my_key == s_key) atomicMin(&s_idx, my_idx);
+  __syncthreads();
+  const int b = s_idx == 0x7fffffff ? -1 : s_idx;
+  if (threadIdx.x == 0) best[model] = b;
+  if (b >= 0)
+    for (int d = threadIdx.x; d < D; d += blockDim.x) x_best[model * D + d] = x[(model * R + b) * D + d];
+}
+
+extern "C" int bore_select_best(int n_models, int num_starts, int D, const double *x,
+                                const double *fun, const int32_t *info, const double *X_seen,
+                                int64_t n_seen, int64_t cap, double rtol, double atol,
+                                double *x_best, int32_t *best, void *stream) {
+  if (n_models < 1 || num_starts < 1 || D < 1 || !x || !fun || !info || !x_best || !best)
+    return fail(BORE_E_INVALID, "select_best: bad argument");
+  if (X_seen && (n_seen < 0 || n_seen > cap))
+    return fail(BORE_E_INVALID, "select_best: n_seen %lld outside 0..cap %lld", (long long)n_seen,
+                (long long)cap);
+  hipLaunchKernelGGL(select_kernel, dim3(n_models), dim3(BORE_THREADS), 0, (hipStream_t)stream,
+                     num_starts, D, x, fun, info, X_seen, (long long)n_seen, (long long)cap, rtol,
+                     atol, x_best, best);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}

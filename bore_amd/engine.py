@@ -40,7 +40,8 @@ class ReplicaEngine:
     def __init__(self, loop_ids, input_dim=2, units=(16, 16, 1), acts=("relu", "relu", "sigmoid"),
                  transform="identity", gamma=0.25, epochs=200, batch_size=64, num_starts=3,
                  num_samples=1024, n_init=10, objective=branin01, max_points=None,
-                 options=None, device=None, mode="device", seed=0, groups=1):
+                 options=None, device=None, mode="device", seed=0, groups=1, select="device",
+                 deduplicate=False):
         """mode "device": label, fit, candidate draw, screening and all L-BFGS-B restarts run
         as five launches per BO iteration with ONE host sync (candidates from the device
         counter stream).  mode "lockstep": candidates from each loop's numpy RandomState and
@@ -51,7 +52,16 @@ class ReplicaEngine:
         L-BFGS-B restart does; with several groups in flight one group's tail overlaps the
         others' fit/argmax instead of idling the GPU (loops never interact, so grouping only
         changes scheduling -- every loop's trajectory is the same; tested)."""
+        """select "device" (device mode): the observations live on the device in fp64
+        (``ops.ObservationStore``: one [L, D+1] upload per iteration instead of the whole data
+        set) and ``bore_select_best`` picks each loop's suggestion there; "host": the numpy
+        statement of the same rule on downloaded results (kept as the check of the device path).
+        deduplicate: reject results that ``Record.is_duplicate`` finds among the loop's
+        observations, as the plugin's filter_fn does (bore/plugins/hpbandster/base.py:210-214;
+        the README loop has no filter -- the default)."""
         assert mode in ("device", "lockstep")
+        assert select in ("device", "host")
+        self.select, self.deduplicate = select, bool(deduplicate)
         self.mode, self.seed = mode, int(seed)
         self.device = device or _lib.require_gpu()
         self.loop_ids = np.asarray(loop_ids, dtype=np.int64)
@@ -191,18 +201,39 @@ class ReplicaEngine:
         buffers were made)."""
         t_host0 = time.perf_counter()
         Lg, N, D, R = g.b - g.a, g.X.shape[1], self.D, self.num_starts
-        if N > g.cap:
-            g.alloc_inputs(self, max(2 * g.cap, N))
         lib, C, ptr = _lib.lib(), _lib_ctypes, _lib.ptr
-        # stage the observations in pinned memory, contiguous [Lg, N, D] / [Lg, N]
-        np.copyto(g.X_pin_np[:Lg * N * D].reshape(Lg, N, D), g.X, casting="same_kind")
-        np.copyto(g.y_pin_np[:Lg * N].reshape(Lg, N), g.y)
+        dev_sel = self.select == "device"
+        if dev_sel:
+            if g.store.n + 1 > g.store.cap:
+                g.store.grow(2 * g.store.cap)
+                g.z_dev = torch.empty(Lg * g.store.cap, dtype=torch.float32, device=self.device)
+            if g.store.n == N - 1:          # the newest row is still on the host
+                g.new_x_pin_np[:] = g.X[:, -1]
+                g.new_y_pin_np[:] = g.y[:, -1]
+        else:
+            if N > g.cap:
+                g.alloc_inputs(self, max(2 * g.cap, N))
+            # stage the observations in pinned memory, contiguous [Lg, N, D] / [Lg, N]
+            np.copyto(g.X_pin_np[:Lg * N * D].reshape(Lg, N, D), g.X, casting="same_kind")
+            np.copyto(g.y_pin_np[:Lg * N].reshape(Lg, N), g.y)
         th, m, v, t = (x[g.a:g.b] for x in (self.theta, self.adam_m, self.adam_v, self.adam_t))
         tr = self.transform.negated()
         with torch.cuda.stream(g.stream):
             sp = _lib.stream_ptr()
-            g.X_dev[:Lg * N * D].copy_(g.X_pin[:Lg * N * D], non_blocking=True)
-            g.y_dev[:Lg * N].copy_(g.y_pin[:Lg * N], non_blocking=True)
+            if dev_sel:
+                st = g.store
+                if st.n == N - 1:
+                    g.new_x.copy_(g.new_x_pin, non_blocking=True)
+                    g.new_y.copy_(g.new_y_pin, non_blocking=True)
+                    _lib.check(lib.bore_append_observations(
+                        Lg, D, ptr(st.X), ptr(st.y), st.n, st.cap, ptr(g.new_x), ptr(g.new_y),
+                        ptr(st.X32), ptr(st.y_dense), sp))
+                    st.n += 1
+                assert st.n == N
+                g.X_dev, g.y_dev = st.X32, st.y_dense
+            else:
+                g.X_dev[:Lg * N * D].copy_(g.X_pin[:Lg * N * D], non_blocking=True)
+                g.y_dev[:Lg * N].copy_(g.y_pin[:Lg * N], non_blocking=True)
             _lib.check(lib.bore_labels(Lg, ptr(g.y_dev), N, float(self.gamma), ptr(g.z_dev),
                                        None, sp))
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -234,9 +265,18 @@ class ReplicaEngine:
                                                 ptr(g.jac), ptr(g.info), sp))
             e3.record()
             self._ev2.append((e2, e3))
-            g.x_pin.copy_(g.x, non_blocking=True)
-            g.fun_pin.copy_(g.fun, non_blocking=True)
-            g.info_pin.copy_(g.info, non_blocking=True)
+            if dev_sel:
+                st = g.store
+                _lib.check(lib.bore_select_best(
+                    Lg, R, D, ptr(g.x), ptr(g.fun), ptr(g.info),
+                    ptr(st.X) if self.deduplicate else ptr(None), st.n, st.cap, 1e-5, 1e-8,
+                    ptr(g.x_best), ptr(g.best), sp))
+                g.x_best_pin.copy_(g.x_best, non_blocking=True)
+                g.best_pin.copy_(g.best, non_blocking=True)
+            else:
+                g.x_pin.copy_(g.x, non_blocking=True)
+                g.fun_pin.copy_(g.fun, non_blocking=True)
+            g.info_pin.copy_(g.info, non_blocking=True)     # (nit, nfev: the bench's byte counts)
             g.done.record()
         g.inflight = True
         self.stats["host_enqueue_s"] = self.stats.get("host_enqueue_s", 0.0) + time.perf_counter() - t_host0
@@ -246,7 +286,7 @@ class ReplicaEngine:
         the objective, append."""
         t_host0 = time.perf_counter()
         D = self.D
-        x, fun, info = g.x_pin.numpy(), g.fun_pin.numpy(), g.info_pin.numpy()
+        info = g.info_pin.numpy()
         nfev = info[:, :, 1]
         self.stats["n_fg_rows"] += int(nfev.sum())
         self.stats["n_rounds"] += int(nfev.max())
@@ -254,11 +294,22 @@ class ReplicaEngine:
         # re-reads its theta (streaming model)
         self.stats["argmax_bytes"].append(int(nfev.sum()) * 4 * (2 * D + 1)
                                           + int(nfev.max(axis=1).sum()) * 4 * self.P)
-        ok = (info[:, :, 2] == 0) | (info[:, :, 2] == 1)          # success or status == 1
-        f = np.where(ok, fun, np.inf)
-        best = np.argmin(f, axis=1)                                # ties keep the earliest
-        x_next = x[np.arange(g.b - g.a), best].copy()
-        none = ~ok.any(axis=1)
+        if self.select == "device":
+            x_next = g.x_best_pin.numpy().copy()
+            none = g.best_pin.numpy() < 0
+        else:
+            x, fun = g.x_pin.numpy(), g.fun_pin.numpy()
+            ok = (info[:, :, 2] == 0) | (info[:, :, 2] == 1)      # success or status == 1
+            if self.deduplicate:                                   # Record.is_duplicate as filter_fn
+                for l in range(g.b - g.a):
+                    for r in range(x.shape[1]):
+                        if ok[l, r] and any(np.allclose(xp, x[l, r], rtol=1e-5, atol=1e-8)
+                                            for xp in g.X[l]):
+                            ok[l, r] = False
+            f = np.where(ok, fun, np.inf)
+            best = np.argmin(f, axis=1)                            # ties keep the earliest
+            x_next = x[np.arange(g.b - g.a), best].copy()
+            none = ~ok.any(axis=1)
         if none.any():                                             # reference: random fallback
             self.stats["none_results"] += int(none.sum())
             for l in np.nonzero(none)[0]:
@@ -349,7 +400,22 @@ class _Group:
             self.fun = torch.empty((Lg, R), dtype=torch.float64, device=dev)
             self.info = torch.empty((Lg, R, 5), dtype=torch.int32, device=dev)
             self.cap = 0
-            self.alloc_inputs(eng, max(256, 2 * self.X.shape[1]))
+            if eng.select == "device":
+                n0 = self.X.shape[1]
+                self.store = ops.ObservationStore(Lg, D, max(256, 2 * n0), device=dev)
+                self.store.load(self.X, self.y)
+                self.new_x_pin = torch.empty((Lg, D), dtype=torch.float64).pin_memory()
+                self.new_y_pin = torch.empty(Lg, dtype=torch.float64).pin_memory()
+                self.new_x_pin_np, self.new_y_pin_np = self.new_x_pin.numpy(), self.new_y_pin.numpy()
+                self.new_x = torch.empty((Lg, D), dtype=torch.float64, device=dev)
+                self.new_y = torch.empty(Lg, dtype=torch.float64, device=dev)
+                self.x_best = torch.empty((Lg, D), dtype=torch.float64, device=dev)
+                self.best = torch.empty(Lg, dtype=torch.int32, device=dev)
+                self.x_best_pin = torch.empty((Lg, D), dtype=torch.float64).pin_memory()
+                self.best_pin = torch.empty(Lg, dtype=torch.int32).pin_memory()
+                self.z_dev = torch.empty(Lg * self.store.cap, dtype=torch.float32, device=dev)
+            else:
+                self.alloc_inputs(eng, max(256, 2 * self.X.shape[1]))
 
     def alloc_inputs(self, eng, cap):
         """(Re)allocate the observation buffers for up to `cap` points per loop."""

@@ -223,3 +223,82 @@ def lbfgsb_minimize(desc, theta, x0, low, high, transform="identity", negate=Tru
         _lib.ptr(x0), R, lo_p, hi_p, C.byref(opts), _lib.ptr(x), _lib.ptr(fun), _lib.ptr(jac),
         _lib.ptr(info), _lib.stream_ptr()))
     return x, fun, jac, info
+
+
+class ObservationStore:
+    """Device-resident ``Record`` of n_models BO loops (bore/data.py:4-29): fp64 features and
+    targets with room for ``cap`` rows per loop, appended to on the device
+    (``bore_append_observations``), plus the dense views the label step and the fit read."""
+
+    def __init__(self, n_models, D, cap, device=None):
+        device = device or _lib.require_gpu()
+        self.L, self.D, self.cap, self.n = int(n_models), int(D), int(cap), 0
+        self.X = torch.empty((self.L, self.cap, self.D), dtype=torch.float64, device=device)
+        self.y = torch.empty((self.L, self.cap), dtype=torch.float64, device=device)
+        self.X32 = torch.empty(self.L * self.cap * self.D, dtype=torch.float32, device=device)
+        self.y_dense = torch.empty(self.L * self.cap, dtype=torch.float64, device=device)
+
+    def load(self, X, y):
+        """Replace the contents with X [L, n, D], y [L, n] (host arrays or tensors)."""
+        X = torch.as_tensor(X, dtype=torch.float64)
+        y = torch.as_tensor(y, dtype=torch.float64)
+        n = X.shape[1]
+        if tuple(X.shape) != (self.L, n, self.D) or tuple(y.shape) != (self.L, n) or n > self.cap:
+            raise ValueError("ObservationStore.load: expected X [L, n <= cap, D] and y [L, n]")
+        self.X[:, :n].copy_(X)
+        self.y[:, :n].copy_(y)
+        self.n = n
+        self.append(None, None)
+
+    def grow(self, cap):
+        """Reallocate for ``cap`` rows per loop, keeping the contents (synchronises)."""
+        old = self
+        new = ObservationStore(self.L, self.D, cap, device=self.X.device)
+        new.X[:, :old.n].copy_(old.X[:, :old.n])
+        new.y[:, :old.n].copy_(old.y[:, :old.n])
+        new.n = old.n
+        torch.cuda.synchronize()
+        self.__dict__.update(new.__dict__)
+        if self.n:
+            self.append(None, None)      # the dense views live in the new buffers
+
+    def append(self, x_new, y_new):
+        """Append one row per loop (x_new [L, D], y_new [L], device fp64; None = just refresh the
+        dense views) on the current stream."""
+        if x_new is not None:
+            _chk(x_new, torch.float64, (self.L, self.D), "x_new")
+            _chk(y_new, torch.float64, (self.L,), "y_new")
+            if self.n + 1 > self.cap:
+                raise ValueError("ObservationStore is full: grow() it first")
+        _lib.check(_lib.lib().bore_append_observations(
+            self.L, self.D, _lib.ptr(self.X), _lib.ptr(self.y), self.n, self.cap,
+            _lib.ptr(x_new), _lib.ptr(y_new), _lib.ptr(self.X32), _lib.ptr(self.y_dense),
+            _lib.stream_ptr()))
+        if x_new is not None:
+            self.n += 1
+
+    def views(self):
+        """(X32 [L, n, D] fp32, y [L, n] fp64): dense, as bore_labels / bore_mlp_fit take them."""
+        n = self.n
+        return (self.X32[:self.L * n * self.D].view(self.L, n, self.D),
+                self.y_dense[:self.L * n].view(self.L, n))
+
+
+def select_best(x, fun, info, store=None, rtol=1e-5, atol=1e-8):
+    """``MaximizableMixin.argmax``'s pick over device L-BFGS-B results (bore/mixins.py:74-89), with
+    ``Record.is_duplicate`` as filter_fn when ``store`` (an ObservationStore) is given.
+    Returns (x_best [L, D] f64, best [L] int32: restart index or -1 = None)."""
+    L, R, D = x.shape
+    _chk(x, torch.float64, (L, R, D), "x")
+    _chk(fun, torch.float64, (L, R), "fun")
+    _chk(info, torch.int32, (L, R, 5), "info")
+    x_best = torch.zeros((L, D), dtype=torch.float64, device=x.device)
+    best = torch.empty(L, dtype=torch.int32, device=x.device)
+    if store is not None and (store.L, store.D) != (L, D):
+        raise ValueError("select_best: store does not match the results")
+    _lib.check(_lib.lib().bore_select_best(
+        L, R, D, _lib.ptr(x), _lib.ptr(fun), _lib.ptr(info),
+        _lib.ptr(store.X) if store is not None else _lib.ptr(None),
+        store.n if store is not None else 0, store.cap if store is not None else 0,
+        float(rtol), float(atol), _lib.ptr(x_best), _lib.ptr(best), _lib.stream_ptr()))
+    return x_best, best

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define BORE_ABI_VERSION 2
+#define BORE_ABI_VERSION 3
 #define BORE_MAX_LAYERS 8
 #define BORE_BATCH_MAX 64 /* rows per tile == wavefront width */
 #define BORE_DIM_MAX 64   /* largest input dimension for the by-value bound arrays */
@@ -216,6 +216,36 @@ int bore_lbfgsb_minimize(const bore_mlp_desc *desc, int n_models, const float *t
                          int transform, int negate, const double *x0, int num_starts,
                          const double *lb, const double *ub, const bore_lbfgsb_opts *opts,
                          double *x, double *fun, double *jac, int32_t *info, void *stream);
+
+/*
+ * Record.append + Record.load_regression_data for replica runs (bore/data.py:14-29): the
+ * device keeps every loop's observations in fp64, X_seen [n_models][cap][D] and y_seen
+ * [n_models][cap] (the first n_seen rows valid).  This call appends row n_seen = (x_new, y_new)
+ * of every model (skipped when x_new == NULL) and writes the DENSE training views the label
+ * step and the fit consume: X32 fp32 [n_models][n][D] (Keras casts the float64 features to
+ * float32) and y_dense fp64 [n_models][n], n = n_seen + (x_new != NULL).
+ *   x_new device fp64 [n_models][D], y_new device fp64 [n_models]   (or both NULL)
+ */
+int bore_append_observations(int n_models, int D, double *X_seen, double *y_seen, int64_t n_seen,
+                             int64_t cap, const double *x_new, const double *y_new, float *X32,
+                             double *y_dense, void *stream);
+
+/*
+ * The selection of MaximizableMixin.argmax (bore/mixins.py:74-89) over the results
+ * bore_lbfgsb_minimize wrote, with the duplicate filter the plugin passes as filter_fn
+ * (bore/plugins/hpbandster/base.py:210-214 -> Record.is_duplicate, bore/data.py:43-48):
+ * per model, among the restarts with status 0 or 1 (`res.success or res.status == 1`) that
+ * are not np.allclose(x_prev, x, rtol, atol) to any stored x_prev -- i.e. not
+ * all_d |x_prev[d] - x[d]| <= atol + rtol*|x[d]| -- the one with the smallest fun, the
+ * earliest on ties (the reference compares with a strict <).  fun is assumed not NaN.
+ *   x, fun, info  device, as bore_lbfgsb_minimize wrote them
+ *   X_seen        device fp64 [n_models][cap][D], first n_seen rows valid; NULL = no filter
+ *   x_best        device fp64 [n_models][D]   (left untouched for a model without a result)
+ *   best          device int32 [n_models]     restart index, or -1 where the reference returns None
+ */
+int bore_select_best(int n_models, int num_starts, int D, const double *x, const double *fun,
+                     const int32_t *info, const double *X_seen, int64_t n_seen, int64_t cap,
+                     double rtol, double atol, double *x_best, int32_t *best, void *stream);
 
 /* The in-kernel shuffle stream of bore_mlp_fit, written out:
  * perm device int32 [n_models][epochs][N]. */

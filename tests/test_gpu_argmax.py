@@ -237,6 +237,30 @@ def test_replica_engine_device_mode_runs_bo(gpu):
     assert [g.b - g.a for g in eng3.groups] == [2, 3, 3] and len(eng3.stats["fit_ms"]) == 24
     assert np.array_equal(eng3.X, eng.X) and np.array_equal(eng3.y, eng.y)
     assert torch.equal(eng3.theta, eng.theta) and torch.equal(eng3.adam_t, eng.adam_t)
+    # the device-resident record + device selection (the default) against the host statement
+    eng4 = ReplicaEngine(np.arange(4, 12), epochs=50, mode="device", groups=2, select="host")
+    eng4.run(8)
+    assert np.array_equal(eng4.X, eng.X) and np.array_equal(eng4.y, eng.y)
+    assert torch.equal(eng4.theta, eng.theta)
+    assert eng4.stats["none_results"] == eng.stats["none_results"]
+
+
+def test_replica_engine_duplicate_filter_device_equals_host(gpu):
+    """Record.is_duplicate as filter_fn (the plugin's rule) inside the engine: device selection
+    and its numpy statement walk the same trajectories; the record grows past its first
+    capacity on the way."""
+    from bore_amd.engine import ReplicaEngine
+    kw = dict(epochs=20, mode="device", deduplicate=True, num_samples=64)
+    a = ReplicaEngine(np.arange(6), select="device", groups=2, **kw)
+    b = ReplicaEngine(np.arange(6), select="host", **kw)
+    for g in a.groups:                       # force a grow() during the run
+        g.store.grow(g.store.n + 2)
+    a.run(12)
+    b.run(12)
+    assert np.array_equal(a.X, b.X) and np.array_equal(a.y, b.y)
+    assert a.stats["none_results"] == b.stats["none_results"]
+    for g in a.groups:
+        assert g.store.n == 21 and np.array_equal(g.store.X[:, :21].cpu().numpy(), g.X[:, :21])
 
 
 def test_bf16_argmax_kernels_equal_their_host_build(gpu):
@@ -273,3 +297,84 @@ def test_bf16_argmax_kernels_equal_their_host_build(gpu):
         ops.lbfgsb_minimize(small, ths, dev(rs.uniform(size=(1, 3, 2))), np.zeros(2), np.ones(2))
     with pytest.raises(RuntimeError, match="wide static shapes"):
         ops.mlp_forward(small, ths, dev(rs.uniform(size=(1, 4, 2)).astype(np.float32)))
+
+
+def _reference_pick(results, features=None, rtol=1e-5, atol=1e-8):
+    """MaximizableMixin.argmax's loop (bore/mixins.py:80-89) with Record.is_duplicate as the
+    filter (bore/data.py:43-48, bore/plugins/hpbandster/base.py:210-214).  results: (x, fun, status)."""
+    best = None
+    for i, (x, fun, status) in enumerate(results):
+        unique = features is None or not any(np.allclose(xp, x, rtol=rtol, atol=atol) for xp in features)
+        if (status == 0 or status == 1) and unique:
+            if best is None or fun < results[best][1]:
+                best = i
+    return -1 if best is None else best
+
+
+def test_duplicate_filter_matches_reference_vectors(gpu, golden_labels, golden_misc):
+    """Record.is_duplicate of the reference (goldens recorded from bore.data.Record) through the
+    device selection: one model per probe, one restart each -> chosen iff not a duplicate."""
+    g = golden_labels
+    for k, case in enumerate(golden_misc["label_cases"]):
+        X, probes, dup = g[f"X{k}"], g[f"probe{k}"], g[f"dup{k}"]
+        n, D, L = X.shape[0], X.shape[1], len(probes)
+        store = ops.ObservationStore(L, D, cap=n + 3)
+        store.load(np.broadcast_to(X, (L, n, D)).copy(), np.zeros((L, n)))
+        x = dev(probes[:, None, :])
+        fun = dev(np.zeros((L, 1)))
+        info = torch.zeros((L, 1, 5), dtype=torch.int32, device=gpu)
+        xb, best = ops.select_best(x, fun, info, store)
+        assert np.array_equal(best.cpu().numpy() == -1, dup), case
+        assert np.array_equal(xb.cpu().numpy()[~dup], probes[~dup])
+        _, best = ops.select_best(x, fun, info, None)            # no filter: everything passes
+        assert np.array_equal(best.cpu().numpy(), np.zeros(L, dtype=np.int32))
+
+
+@pytest.mark.parametrize("R,D,n", [(3, 2, 40), (5, 6, 17), (256, 6, 64), (70, 3, 1)])
+def test_select_best_equals_the_reference_loop(gpu, R, D, n):
+    rs = np.random.RandomState(R + D)
+    L = 24
+    Xs = rs.uniform(size=(L, n, D))
+    x = rs.uniform(size=(L, R, D))
+    fun = np.round(rs.normal(size=(L, R)), 1)                    # many ties
+    status = rs.randint(0, 3, size=(L, R))
+    status[0] = 2                                                # a model where every restart failed
+    status[1] = 0
+    for l in range(2, L):                                        # plant duplicates of stored rows
+        for r in rs.choice(R, size=max(1, R // 3), replace=False):
+            x[l, r] = Xs[l, rs.randint(n)] * (1 + rs.choice([0.0, 5e-6, 2e-5, -8e-6]))
+    x[2] = Xs[2, 0]                                              # every result a duplicate
+    store = ops.ObservationStore(L, D, cap=n + 7)
+    store.load(Xs, rs.normal(size=(L, n)))
+    info = np.zeros((L, R, 5), dtype=np.int32)
+    info[:, :, 2] = status
+    for st in (store, None):
+        xb, best = ops.select_best(dev(x), dev(fun), torch.from_numpy(info).to(gpu), st)
+        best, xb = best.cpu().numpy(), xb.cpu().numpy()
+        for l in range(L):
+            want = _reference_pick([(x[l, r], fun[l, r], status[l, r]) for r in range(R)],
+                                   None if st is None else Xs[l])
+            assert best[l] == want, (l, st is None)
+            if want >= 0:
+                assert np.array_equal(xb[l], x[l, want])
+    assert best[0] == -1
+
+
+def test_observation_store_appends_and_packs(gpu):
+    rs = np.random.RandomState(3)
+    L, D = 5, 3
+    X0, y0 = rs.uniform(size=(L, 4, D)), rs.normal(size=(L, 4))
+    store = ops.ObservationStore(L, D, cap=6)
+    store.load(X0, y0)
+    Xh, yh = X0.copy(), y0.copy()
+    for step in range(5):
+        if store.n + 1 > store.cap:
+            store.grow(2 * store.cap)
+        xn, yn = rs.uniform(size=(L, D)), rs.normal(size=L)
+        store.append(dev(xn), dev(yn))
+        Xh, yh = np.concatenate([Xh, xn[:, None]], axis=1), np.concatenate([yh, yn[:, None]], axis=1)
+        X32, yd = store.views()
+        assert np.array_equal(X32.cpu().numpy(), Xh.astype(np.float32))      # Keras' float32 cast
+        assert np.array_equal(yd.cpu().numpy(), yh)
+        assert np.array_equal(store.X[:, :store.n].cpu().numpy(), Xh)        # fp64 kept for the filter
+    assert store.n == 9 and store.cap == 12
