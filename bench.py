@@ -127,13 +127,16 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for N > 1 (nccl = RCCL; gloo only to rehearse the "
                          "multi-rank flow on a one-GPU box together with BORE_BENCH_ONE_DEVICE=1)")
+    ap.add_argument("--engine", default="native", choices=["native", "python"],
+                    help="host loop of the replica engine: native = bore_engine_* (C++), python = "
+                         "bore_amd.engine.ReplicaEngine (the same trajectories, bit for bit)")
     ap.add_argument("--mode", default="device", choices=["device", "lockstep"],
                     help="device: L-BFGS-B restarts inside one kernel; lockstep: scipy on the host")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
-    from bore_amd.engine import ReplicaEngine, gather_results, shard_loop_ids
+    from bore_amd.engine import NativeEngine, ReplicaEngine, gather_results, shard_loop_ids
 
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
@@ -149,7 +152,11 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     loop_ids = shard_loop_ids(rank, world, args.loops)     # contiguous shard per rank
-    eng = ReplicaEngine(loop_ids, mode=args.mode, groups=args.groups)
+    native = args.engine == "native" and args.mode == "device"
+    if native:
+        eng = NativeEngine(loop_ids, groups=args.groups)
+    else:
+        eng = ReplicaEngine(loop_ids, mode=args.mode, groups=args.groups)
 
     def barrier():
         torch.cuda.synchronize()
@@ -158,10 +165,15 @@ def main():
         torch.cuda.synchronize()
 
     eng.run(args.warmup)
-    eng.finish_timing()
-    for k in ("fit_ms", "fit_bytes", "argmax_ms", "argmax_bytes"):
-        eng.stats[k] = []
-    eng.stats["n_fg_rows"] = eng.stats["n_rounds"] = 0
+    if native:
+        eng.take_stats(reset=True)
+    else:
+        eng.finish_timing()
+        for k in ("fit_ms", "fit_bytes", "argmax_ms", "argmax_bytes"):
+            eng.stats[k] = []
+        eng.stats["n_fg_rows"] = eng.stats["n_rounds"] = 0
+        eng.stats["host_enqueue_s"] = eng.stats["host_finalize_s"] = 0.0
+        eng.stats["none_results"] = 0
     n_start = eng.N
 
     barrier()
@@ -169,7 +181,21 @@ def main():
     eng.run(args.steps)
     barrier()
     dt = time.perf_counter() - t0
-    eng.finish_timing()
+    if native:
+        st = eng.take_stats()
+        n_groups = eng.n_groups
+    else:
+        eng.finish_timing()
+        n_groups = len(eng.groups)
+        st = dict(fit_ms=float(np.sum(eng.stats["fit_ms"])), fit_launches=len(eng.stats["fit_ms"]),
+                  fit_bytes=float(np.sum(eng.stats["fit_bytes"], dtype=np.float64)),
+                  argmax_ms=float(np.sum(eng.stats["argmax_ms"])),
+                  argmax_launches=len(eng.stats["argmax_ms"]),
+                  argmax_bytes=float(np.sum(eng.stats["argmax_bytes"], dtype=np.float64)),
+                  n_fg_rows=eng.stats["n_fg_rows"], n_rounds=eng.stats["n_rounds"],
+                  none_results=eng.stats["none_results"],
+                  host_enqueue_s=eng.stats.get("host_enqueue_s", 0.0),
+                  host_finalize_s=eng.stats.get("host_finalize_s", 0.0))
 
     tmax = torch.tensor([dt], dtype=torch.float64,
                         device="cuda" if args.backend == "nccl" else "cpu")
@@ -180,8 +206,6 @@ def main():
 
     if rank == 0:
         total_iters = args.loops * world * args.steps
-        fit_ms = np.array(eng.stats["fit_ms"])
-        fit_bytes = np.array(eng.stats["fit_bytes"], dtype=np.float64)
 
         # HBM traffic per launch from the committed PMC pass (FETCH_SIZE / WRITE_SIZE, gfx950
         # correction applied): it is per model, launches here carry loops/groups models
@@ -190,24 +214,25 @@ def main():
                 pmc = json.load(f)
         except Exception:
             pmc = {}
-        models_per_launch = args.loops / len(eng.groups)
+        models_per_launch = args.loops / n_groups
 
-        def roof(name, ms, nbytes):
-            ach = nbytes.sum() / (ms.sum() * 1e-3) / 1e9
+        def roof(name, ms_sum, bytes_sum, launches):
+            # HIP-event durations (recorded on the launching stream) summed over the timed region
+            ach = bytes_sum / (ms_sum * 1e-3) / 1e9
             per_model = pmc.get(name, {}).get("hbm_bytes_per_model")
             return {"bound": "hbm", "kernel": name, "achieved": ach, "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                     "traffic": None if per_model is None else per_model * models_per_launch,
-                    "avg_launch_ms": float(ms.mean()),
-                    "algorithmic_bytes_per_launch": float(nbytes.mean()),
-                    "launches": int(len(ms)),
+                    "avg_launch_ms": float(ms_sum / launches),
+                    "algorithmic_bytes_per_launch": float(bytes_sum / launches),
+                    "launches": int(launches),
                     # kernel-busy time / wall time; groups overlap, so shares can add up to > 1
-                    "share_of_step": float(ms.sum() / (1e3 * dt))}
+                    "share_of_step": float(ms_sum / (1e3 * dt))}
 
-        kernels = [roof("fit_kernel", fit_ms, fit_bytes)]
-        if eng.stats["argmax_ms"]:
-            kernels.append(roof("lbfgsb_kernel", np.array(eng.stats["argmax_ms"]),
-                                np.array(eng.stats["argmax_bytes"], dtype=np.float64)))
+        kernels = [roof("fit_kernel", st["fit_ms"], st["fit_bytes"], st["fit_launches"])]
+        if st["argmax_launches"]:
+            kernels.append(roof("lbfgsb_kernel", st["argmax_ms"], st["argmax_bytes"],
+                                st["argmax_launches"]))
         dominant = max(kernels, key=lambda k: k["share_of_step"])
         out = {
             "metric": "BO-iterations/sec (fit+argmax), 16-16-1 MLP",
@@ -219,16 +244,17 @@ def main():
                                    "16-16-1 MLP, q=0.25, 200 epochs, batch 64, 3 L-BFGS-B "
                                    "restarts from 1024 samples",
                        "loops_per_gpu": args.loops, "restarts": args.mode,
-                       "stream_groups": len(eng.groups), "N_start": int(n_start),
+                       "host_loop": "native" if native else "python",
+                       "stream_groups": n_groups, "N_start": int(n_start),
                        "N_end": int(eng.N), "parallelism": f"replica-shard x{world}"},
             "roofline": dominant,
             "kernels": kernels,
-            "phases": {"fit_ms_per_step": float(fit_ms.mean()),
-                       "fg_rows_per_step": eng.stats["n_fg_rows"] / args.steps,
-                       "fg_rounds_per_step": eng.stats["n_rounds"] / args.steps,
-                       "none_results": eng.stats["none_results"],
-                       "host_enqueue_ms_per_step": 1e3 * eng.stats.get("host_enqueue_s", 0.0) / (args.steps + args.warmup),
-                       "host_finalize_ms_per_step": 1e3 * eng.stats.get("host_finalize_s", 0.0) / (args.steps + args.warmup)},
+            "phases": {"fit_ms_per_launch": float(st["fit_ms"] / st["fit_launches"]),
+                       "fg_rows_per_step": st["n_fg_rows"] / args.steps,
+                       "fg_rounds_per_step": st["n_rounds"] / args.steps,
+                       "none_results": int(st["none_results"]),
+                       "host_enqueue_ms_per_step": 1e3 * st["host_enqueue_s"] / args.steps,
+                       "host_finalize_ms_per_step": 1e3 * st["host_finalize_s"] / args.steps},
             "best_y_median": float(np.median(results[:, -1])),
         }
         out["cpu_baseline"] = None

@@ -15,7 +15,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libbore_hip.so")
-SOURCES = ["bore_hip.hip", "bore_argmax.hip"]
+SOURCES = ["bore_hip.hip", "bore_argmax.hip", "bore_engine.hip"]
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "bore_hip.h")
 
 MAX_LAYERS = 8
@@ -30,6 +30,8 @@ EXPORTS = [
     "bore_mlp_value_and_input_grad", "bore_mlp_fit", "bore_mlp_evaluate",
     "bore_shuffle_perm", "bore_labels", "bore_uniform_candidates", "bore_screen_topk",
     "bore_lbfgsb_minimize", "bore_append_observations", "bore_select_best",
+    "bore_engine_create", "bore_engine_run", "bore_engine_size", "bore_engine_observations",
+    "bore_engine_state", "bore_engine_get_stats", "bore_engine_destroy",
 ]
 
 
@@ -48,6 +50,27 @@ class LbfgsbOpts(C.Structure):
 class AdamCfg(C.Structure):
     _fields_ = [("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float),
                 ("eps", C.c_float)]
+
+
+class EngineCfg(C.Structure):
+    _fields_ = [("n_loops", C.c_int32), ("groups", C.c_int32), ("loop_id0", C.c_int64),
+                ("n_init", C.c_int32), ("epochs", C.c_int32), ("batch_size", C.c_int32),
+                ("num_starts", C.c_int32), ("num_samples", C.c_int32), ("transform", C.c_int32),
+                ("deduplicate", C.c_int32), ("reserved", C.c_int32), ("seed", C.c_uint64),
+                ("gamma", C.c_double), ("adam", AdamCfg), ("lbfgsb", LbfgsbOpts),
+                ("low", C.POINTER(C.c_double)), ("high", C.POINTER(C.c_double))]
+
+
+class EngineStats(C.Structure):
+    _fields_ = [("fit_ms", C.c_double), ("fit_bytes", C.c_double), ("argmax_ms", C.c_double),
+                ("argmax_bytes", C.c_double), ("host_enqueue_s", C.c_double),
+                ("host_finalize_s", C.c_double), ("fit_launches", C.c_int64),
+                ("argmax_launches", C.c_int64), ("n_fg_rows", C.c_int64), ("n_rounds", C.c_int64),
+                ("none_results", C.c_int64)]
+
+
+OBJECTIVE_FN = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_double), C.c_int64, C.c_int32,
+                           C.POINTER(C.c_double), C.c_void_p)
 
 
 def hipcc_path():
@@ -116,9 +139,20 @@ def lib():
     L.bore_append_observations.argtypes = [i32, i32, vp, vp, i64, i64, vp, vp, vp, vp, vp]
     L.bore_select_best.argtypes = [i32, i32, i32, vp, vp, vp, vp, i64, i64, C.c_double,
                                    C.c_double, vp, vp, vp]
+    L.bore_engine_create.argtypes = [dp, C.POINTER(EngineCfg), vp, vp, vp, vp, OBJECTIVE_FN, vp,
+                                     C.POINTER(vp)]
+    L.bore_engine_run.argtypes = [vp, i32]
+    L.bore_engine_size.argtypes = [vp]
+    L.bore_engine_observations.argtypes = [vp, vp, vp]
+    L.bore_engine_state.argtypes = [vp, vp, vp, vp, vp]
+    L.bore_engine_get_stats.argtypes = [vp, C.POINTER(EngineStats), i32]
+    L.bore_engine_destroy.argtypes = [vp]
     for name in EXPORTS:
-        if name not in ("bore_last_error", "bore_param_count"):
+        if name not in ("bore_last_error", "bore_param_count", "bore_engine_size",
+                        "bore_engine_destroy"):
             getattr(L, name).restype = i32
+    L.bore_engine_size.restype = i64
+    L.bore_engine_destroy.restype = None
     _lib = L
     return L
 

@@ -1,0 +1,442 @@
+// bore_engine.hip -- native replica engine: many independent BO loops on one GPU
+// (BASELINE.json config 4).  Host-side C++ over the library's own C-ABI.
+//
+// One BO iteration of a loop is  label -> fit -> sample + screen -> L-BFGS-B restarts -> pick
+// (README.rst:83-103; bore/plugins/hpbandster/base.py:216-262) and only the objective value of
+// the suggestion comes from the host.  The loops of a GPU are split into GROUPS, each stepping on
+// its own HIP stream; per iteration a group costs
+//     H2D  (x_new, y_new)  [Lg][D+1] fp64        -- the record itself lives on the device
+//     7 launches: append, labels, fit, candidates, screen, lbfgsb, select
+//     D2H  x_best [Lg][D], best [Lg], info [Lg][R][5]
+// and one host turnaround (objective callback).  What this file replaces is the Python statement
+// of the same loop (bore_amd/engine.py ReplicaEngine, kept as its check: trajectories are
+// bit-identical, tested): per group and iteration the interpreter spent ~260 us between the
+// result's arrival and the next fit's launch -- on the critical path of a ~2.3 ms iteration.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/bore_hip.h"
+#include "host_common.h"
+
+namespace {
+
+// numpy.random.RandomState (MT19937) continued from an exported state: the fallback point of a
+// loop whose argmax returned None comes from that loop's own stream (engine.py: rs[l].uniform).
+struct Mt19937 {
+  uint32_t key[624];
+  int pos;
+  uint32_t next32() {
+    if (pos >= 624) {
+      int i;
+      for (i = 0; i < 624 - 397; ++i) {
+        const uint32_t y = (key[i] & 0x80000000u) | (key[i + 1] & 0x7fffffffu);
+        key[i] = key[i + 397] ^ (y >> 1) ^ (-(int32_t)(y & 1) & 0x9908b0dfu);
+      }
+      for (; i < 623; ++i) {
+        const uint32_t y = (key[i] & 0x80000000u) | (key[i + 1] & 0x7fffffffu);
+        key[i] = key[i + (397 - 624)] ^ (y >> 1) ^ (-(int32_t)(y & 1) & 0x9908b0dfu);
+      }
+      const uint32_t y = (key[623] & 0x80000000u) | (key[0] & 0x7fffffffu);
+      key[623] = key[396] ^ (y >> 1) ^ (-(int32_t)(y & 1) & 0x9908b0dfu);
+      pos = 0;
+    }
+    uint32_t y = key[pos++];
+    y ^= (y >> 11);
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= (y >> 18);
+    return y;
+  }
+  double next_double() {  // numpy's random_sample: 53 bits from two draws
+    const uint32_t a = next32() >> 5, b = next32() >> 6;
+    return (a * 67108864.0 + b) / 9007199254740992.0;
+  }
+};
+
+struct Group {
+  int a = 0, b = 0;  // loops [a, b) of the engine
+  hipStream_t stream = nullptr;
+  hipEvent_t done = nullptr, ev[4] = {nullptr, nullptr, nullptr, nullptr};  // fit / lbfgsb brackets
+  int64_t n = 0, cap = 0;          // rows in the device record / its capacity
+  int64_t epochs_seen = 0, draws = 0, steps = 0;
+  bool inflight = false, has_new = false;
+  // device
+  double *X_seen = nullptr, *y_seen = nullptr, *y_dense = nullptr;
+  float *X32 = nullptr, *z = nullptr;
+  double *new_x = nullptr, *new_y = nullptr;
+  double *Xc = nullptr, *x0 = nullptr, *x = nullptr, *jac = nullptr, *fun = nullptr, *x_best = nullptr;
+  int32_t *idx = nullptr, *info = nullptr, *best = nullptr;
+  // pinned host
+  double *new_x_pin = nullptr, *new_y_pin = nullptr, *x_best_pin = nullptr;
+  int32_t *best_pin = nullptr, *info_pin = nullptr;
+};
+
+}  // namespace
+
+struct bore_engine {
+  bore_mlp_desc desc;
+  bore_engine_cfg cfg;
+  int D = 0, P = 0;
+  std::vector<double> low, high;
+  bore_objective_fn objective = nullptr;
+  void *user = nullptr;
+  float *theta = nullptr, *adam_m = nullptr, *adam_v = nullptr;
+  int64_t *adam_t = nullptr;
+  std::vector<Mt19937> rs;
+  std::vector<Group> groups;
+  bore_engine_stats st;
+  std::vector<double> y_tmp;
+};
+
+namespace {
+
+double now_s() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+template <typename T>
+int dev_alloc(T **p, size_t count) {
+  HIP_TRY(hipMalloc(reinterpret_cast<void **>(p), count * sizeof(T)));
+  return 0;
+}
+template <typename T>
+int pin_alloc(T **p, size_t count) {
+  HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(p), count * sizeof(T), hipHostMallocDefault));
+  return 0;
+}
+
+// (Re)allocate the record of group g for `cap` rows per loop, keeping its rows.
+int alloc_record(bore_engine *e, Group &g, int64_t cap) {
+  const size_t Lg = g.b - g.a, D = e->D;
+  double *X = nullptr, *y = nullptr, *yd = nullptr;
+  float *X32 = nullptr, *z = nullptr;
+  int rc;
+  if ((rc = dev_alloc(&X, Lg * cap * D)) || (rc = dev_alloc(&y, Lg * cap)) ||
+      (rc = dev_alloc(&yd, Lg * cap)) || (rc = dev_alloc(&X32, Lg * cap * D)) ||
+      (rc = dev_alloc(&z, Lg * cap)))
+    return rc;
+  if (g.X_seen) {
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    HIP_TRY(hipMemcpy2D(X, cap * D * 8, g.X_seen, g.cap * D * 8, g.n * D * 8, Lg,
+                        hipMemcpyDeviceToDevice));
+    HIP_TRY(hipMemcpy2D(y, cap * 8, g.y_seen, g.cap * 8, g.n * 8, Lg, hipMemcpyDeviceToDevice));
+    (void)hipFree(g.X_seen); (void)hipFree(g.y_seen); (void)hipFree(g.y_dense);
+    (void)hipFree(g.X32); (void)hipFree(g.z);
+  }
+  g.X_seen = X; g.y_seen = y; g.y_dense = yd; g.X32 = X32; g.z = z;
+  g.cap = cap;
+  return 0;
+}
+
+// Queue one BO iteration of group g on its stream.
+int enqueue(bore_engine *e, Group &g) {
+  const double t0 = now_s();
+  const int Lg = g.b - g.a, D = e->D, R = e->cfg.num_starts;
+  const bore_engine_cfg &c = e->cfg;
+  int rc;
+  if (g.has_new && g.n + 1 > g.cap && (rc = alloc_record(e, g, 2 * g.cap))) return rc;
+  void *sp = g.stream;
+  if (g.has_new) {
+    HIP_TRY(hipMemcpyAsync(g.new_x, g.new_x_pin, (size_t)Lg * D * 8, hipMemcpyHostToDevice, g.stream));
+    HIP_TRY(hipMemcpyAsync(g.new_y, g.new_y_pin, (size_t)Lg * 8, hipMemcpyHostToDevice, g.stream));
+  }
+  if ((rc = bore_append_observations(Lg, D, g.X_seen, g.y_seen, g.n, g.cap,
+                                     g.has_new ? g.new_x : nullptr, g.has_new ? g.new_y : nullptr,
+                                     g.X32, g.y_dense, sp)))
+    return rc;
+  if (g.has_new) ++g.n;
+  g.has_new = false;
+  const int64_t N = g.n;
+  if ((rc = bore_labels(Lg, g.y_dense, N, c.gamma, g.z, nullptr, sp))) return rc;
+  float *th = e->theta + (size_t)g.a * e->P, *m = e->adam_m + (size_t)g.a * e->P,
+        *v = e->adam_v + (size_t)g.a * e->P;
+  HIP_TRY(hipEventRecord(g.ev[0], g.stream));
+  if ((rc = bore_mlp_fit(&e->desc, Lg, th, m, v, e->adam_t + g.a, g.X32, g.z, N, c.epochs,
+                         c.batch_size, nullptr, c.seed, c.loop_id0 + g.a, g.epochs_seen, &c.adam,
+                         nullptr, sp)))
+    return rc;
+  HIP_TRY(hipEventRecord(g.ev[1], g.stream));
+  const int64_t steps = (N + c.batch_size - 1) / c.batch_size;
+  e->st.fit_bytes += (double)Lg * c.epochs * (4.0 * N * (D + 1) + steps * 24.0 * e->P);
+  g.epochs_seen += c.epochs;
+  if ((rc = bore_uniform_candidates(c.seed, c.loop_id0 + g.a, Lg, g.draws, c.num_samples, D,
+                                    e->low.data(), e->high.data(), g.Xc, sp)))
+    return rc;
+  ++g.draws;
+  if ((rc = bore_screen_topk(&e->desc, Lg, th, g.Xc, c.num_samples, 0, R, g.x0, g.idx, nullptr, sp)))
+    return rc;
+  HIP_TRY(hipEventRecord(g.ev[2], g.stream));
+  if ((rc = bore_lbfgsb_minimize(&e->desc, Lg, th, c.transform, 1, g.x0, R, e->low.data(),
+                                 e->high.data(), &c.lbfgsb, g.x, g.fun, g.jac, g.info, sp)))
+    return rc;
+  HIP_TRY(hipEventRecord(g.ev[3], g.stream));
+  if ((rc = bore_select_best(Lg, R, D, g.x, g.fun, g.info, c.deduplicate ? g.X_seen : nullptr, g.n,
+                             g.cap, 1e-5, 1e-8, g.x_best, g.best, sp)))
+    return rc;
+  HIP_TRY(hipMemcpyAsync(g.x_best_pin, g.x_best, (size_t)Lg * D * 8, hipMemcpyDeviceToHost, g.stream));
+  HIP_TRY(hipMemcpyAsync(g.best_pin, g.best, (size_t)Lg * 4, hipMemcpyDeviceToHost, g.stream));
+  HIP_TRY(hipMemcpyAsync(g.info_pin, g.info, (size_t)Lg * R * 5 * 4, hipMemcpyDeviceToHost, g.stream));
+  HIP_TRY(hipEventRecord(g.done, g.stream));
+  g.inflight = true;
+  e->st.host_enqueue_s += now_s() - t0;
+  return 0;
+}
+
+// Host side of a finished iteration: fallback points, objective, stage the new row.
+int finalize(bore_engine *e, Group &g) {
+  const double t0 = now_s();
+  const int Lg = g.b - g.a, D = e->D, R = e->cfg.num_starts;
+  float ms = 0.f;
+  HIP_TRY(hipEventElapsedTime(&ms, g.ev[0], g.ev[1]));
+  e->st.fit_ms += ms;
+  e->st.fit_launches += 1;
+  HIP_TRY(hipEventElapsedTime(&ms, g.ev[2], g.ev[3]));
+  e->st.argmax_ms += ms;
+  e->st.argmax_launches += 1;
+  // every f/g row reads x and writes value + gradient; every round of a loop
+  // re-reads its theta (streaming model)
+  int64_t rows = 0, rounds_sum = 0, rounds_max = 0;
+  for (int l = 0; l < Lg; ++l) {
+    int64_t mx = 0;
+    for (int r = 0; r < R; ++r) {
+      const int64_t nfev = g.info_pin[((size_t)l * R + r) * 5 + 1];
+      rows += nfev;
+      mx = nfev > mx ? nfev : mx;
+    }
+    rounds_sum += mx;
+    rounds_max = mx > rounds_max ? mx : rounds_max;
+  }
+  e->st.n_fg_rows += rows;
+  e->st.n_rounds += rounds_max;
+  e->st.argmax_bytes += rows * 4.0 * (2 * D + 1) + rounds_sum * 4.0 * e->P;
+  for (int l = 0; l < Lg; ++l) {
+    double *xn = g.new_x_pin + (size_t)l * D;
+    if (g.best_pin[l] < 0) {  // reference: fall back to a random point of this loop's stream
+      ++e->st.none_results;
+      Mt19937 &rs = e->rs[g.a + l];
+      for (int d = 0; d < D; ++d) xn[d] = e->low[d] + (e->high[d] - e->low[d]) * rs.next_double();
+    } else {
+      std::memcpy(xn, g.x_best_pin + (size_t)l * D, (size_t)D * 8);
+    }
+  }
+  g.inflight = false;
+  if (e->objective(g.new_x_pin, Lg, D, g.new_y_pin, e->user))
+    return fail(BORE_E_CALLBACK, "engine_run: the objective callback failed");
+  g.has_new = true;
+  ++g.steps;
+  e->st.host_finalize_s += now_s() - t0;
+  return 0;
+}
+
+void free_group(Group &g) {
+  void *dev[] = {g.X_seen, g.y_seen, g.y_dense, g.X32, g.z, g.new_x, g.new_y, g.Xc, g.x0,
+                 g.x, g.jac, g.fun, g.x_best, g.idx, g.info, g.best};
+  for (void *p : dev)
+    if (p) (void)hipFree(p);
+  void *pin[] = {g.new_x_pin, g.new_y_pin, g.x_best_pin, g.best_pin, g.info_pin};
+  for (void *p : pin)
+    if (p) (void)hipHostFree(p);
+  if (g.done) (void)hipEventDestroy(g.done);
+  for (hipEvent_t ev : g.ev)
+    if (ev) (void)hipEventDestroy(ev);
+  if (g.stream) (void)hipStreamDestroy(g.stream);
+}
+
+}  // namespace
+
+extern "C" void bore_engine_destroy(bore_engine *e) {
+  if (!e) return;
+  (void)hipDeviceSynchronize();
+  for (Group &g : e->groups) free_group(g);
+  void *dev[] = {e->theta, e->adam_m, e->adam_v, e->adam_t};
+  for (void *p : dev)
+    if (p) (void)hipFree(p);
+  delete e;
+}
+
+extern "C" int bore_engine_create(const bore_mlp_desc *desc, const bore_engine_cfg *cfg,
+                                  const float *theta0, const double *X0, const double *y0,
+                                  const uint32_t *mt_state, bore_objective_fn objective, void *user,
+                                  bore_engine **out) {
+  if (!desc || !cfg || !theta0 || !X0 || !y0 || !mt_state || !objective || !out)
+    return fail(BORE_E_INVALID, "engine_create: NULL argument");
+  const int64_t P = bore_param_count(desc);
+  if (P < 0) return fail(BORE_E_INVALID, "engine_create: bad bore_mlp_desc");
+  const int D = desc->input_dim, L = cfg->n_loops;
+  if (L < 1 || cfg->groups < 1 || cfg->n_init < 1 || cfg->epochs < 1 || cfg->num_starts < 1 ||
+      cfg->num_samples < cfg->num_starts || !cfg->low || !cfg->high || D < 1 || D > BORE_DIM_MAX)
+    return fail(BORE_E_INVALID, "engine_create: bad configuration");
+  bore_engine *e = new (std::nothrow) bore_engine();
+  if (!e) return fail(BORE_E_HIP, "engine_create: out of memory");
+  e->desc = *desc;
+  e->cfg = *cfg;
+  e->D = D;
+  e->P = (int)P;
+  e->low.assign(cfg->low, cfg->low + D);
+  e->high.assign(cfg->high, cfg->high + D);
+  e->cfg.low = e->low.data();
+  e->cfg.high = e->high.data();
+  e->objective = objective;
+  e->user = user;
+  std::memset(&e->st, 0, sizeof(e->st));
+  e->rs.resize(L);
+  for (int l = 0; l < L; ++l) {
+    std::memcpy(e->rs[l].key, mt_state + (size_t)l * 625, 624 * 4);
+    e->rs[l].pos = (int)mt_state[(size_t)l * 625 + 624];
+  }
+  int rc = 0;
+#define ENG_TRY(expr)                \
+  do {                               \
+    if ((rc = (expr))) {             \
+      bore_engine_destroy(e);        \
+      return rc;                     \
+    }                                \
+  } while (0)
+#define ENG_HIP(expr)                                                          \
+  do {                                                                         \
+    hipError_t e_ = (expr);                                                    \
+    if (e_ != hipSuccess) {                                                    \
+      bore_engine_destroy(e);                                                  \
+      return fail(BORE_E_HIP, "%s: %s", #expr, hipGetErrorString(e_));         \
+    }                                                                          \
+  } while (0)
+  ENG_TRY(dev_alloc(&e->theta, (size_t)L * P));
+  ENG_TRY(dev_alloc(&e->adam_m, (size_t)L * P));
+  ENG_TRY(dev_alloc(&e->adam_v, (size_t)L * P));
+  ENG_TRY(dev_alloc(&e->adam_t, (size_t)L));
+  ENG_HIP(hipMemcpy(e->theta, theta0, (size_t)L * P * 4, hipMemcpyHostToDevice));
+  ENG_HIP(hipMemset(e->adam_m, 0, (size_t)L * P * 4));
+  ENG_HIP(hipMemset(e->adam_v, 0, (size_t)L * P * 4));
+  ENG_HIP(hipMemset(e->adam_t, 0, (size_t)L * 8));
+  const int G = cfg->groups < L ? cfg->groups : L;
+  e->groups.resize(G);
+  const int R = cfg->num_starts, n0 = cfg->n_init;
+  for (int k = 0; k < G; ++k) {
+    Group &g = e->groups[k];
+    // the same split as numpy.linspace(0, L, G + 1).astype(int) (engine.py)
+    const double step = (double)L / G;
+    g.a = (int)(k * step);
+    g.b = k + 1 == G ? L : (int)((k + 1) * step);
+    const size_t Lg = g.b - g.a;
+    ENG_HIP(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
+    ENG_HIP(hipEventCreateWithFlags(&g.done, hipEventDisableTiming));
+    for (hipEvent_t &ev : g.ev) ENG_HIP(hipEventCreate(&ev));
+    ENG_TRY(alloc_record(e, g, n0 * 2 > 256 ? n0 * 2 : 256));
+    ENG_HIP(hipMemcpy2D(g.X_seen, g.cap * D * 8, X0 + (size_t)g.a * n0 * D, (size_t)n0 * D * 8,
+                        (size_t)n0 * D * 8, Lg, hipMemcpyHostToDevice));
+    ENG_HIP(hipMemcpy2D(g.y_seen, g.cap * 8, y0 + (size_t)g.a * n0, (size_t)n0 * 8, (size_t)n0 * 8, Lg,
+                        hipMemcpyHostToDevice));
+    g.n = n0;
+    ENG_TRY(dev_alloc(&g.new_x, Lg * D));
+    ENG_TRY(dev_alloc(&g.new_y, Lg));
+    ENG_TRY(dev_alloc(&g.Xc, Lg * (size_t)cfg->num_samples * D));
+    ENG_TRY(dev_alloc(&g.x0, Lg * R * D));
+    ENG_TRY(dev_alloc(&g.x, Lg * R * D));
+    ENG_TRY(dev_alloc(&g.jac, Lg * R * D));
+    ENG_TRY(dev_alloc(&g.fun, Lg * R));
+    ENG_TRY(dev_alloc(&g.x_best, Lg * D));
+    ENG_TRY(dev_alloc(&g.idx, Lg * R));
+    ENG_TRY(dev_alloc(&g.info, Lg * R * 5));
+    ENG_TRY(dev_alloc(&g.best, Lg));
+    ENG_TRY(pin_alloc(&g.new_x_pin, Lg * D));
+    ENG_TRY(pin_alloc(&g.new_y_pin, Lg));
+    ENG_TRY(pin_alloc(&g.x_best_pin, Lg * D));
+    ENG_TRY(pin_alloc(&g.best_pin, Lg));
+    ENG_TRY(pin_alloc(&g.info_pin, Lg * R * 5));
+  }
+#undef ENG_TRY
+#undef ENG_HIP
+  *out = e;
+  return 0;
+}
+
+// Advance every loop by n_steps BO iterations.  Groups proceed independently; the host only
+// reacts to completion events.
+extern "C" int bore_engine_run(bore_engine *e, int n_steps) {
+  if (!e || n_steps < 0) return fail(BORE_E_INVALID, "engine_run: bad argument");
+  if (n_steps == 0) return 0;
+  std::vector<int64_t> target(e->groups.size());
+  int rc;
+  for (size_t k = 0; k < e->groups.size(); ++k) target[k] = e->groups[k].steps + n_steps;
+  for (size_t k = 0; k < e->groups.size(); ++k)
+    if ((rc = enqueue(e, e->groups[k]))) {
+      for (Group &o : e->groups) {
+        (void)hipStreamSynchronize(o.stream);
+        o.inflight = false;
+      }
+      return rc;
+    }
+  size_t remaining = e->groups.size();
+  while (remaining) {
+    for (size_t k = 0; k < e->groups.size(); ++k) {
+      Group &g = e->groups[k];
+      if (!g.inflight) continue;
+      const hipError_t q = hipEventQuery(g.done);
+      if (q == hipErrorNotReady) continue;
+      if (q != hipSuccess) return fail(BORE_E_HIP, "engine_run: %s", hipGetErrorString(q));
+      if ((rc = finalize(e, g)) || (g.steps < target[k] && (rc = enqueue(e, g)))) {
+        // stop: let the other groups' launches finish, keep their iterations out of the record
+        for (Group &o : e->groups) {
+          (void)hipStreamSynchronize(o.stream);
+          o.inflight = false;
+        }
+        return rc;
+      }
+      if (g.steps >= target[k]) --remaining;
+    }
+  }
+  return 0;
+}
+
+extern "C" int64_t bore_engine_size(const bore_engine *e) {
+  if (!e || e->groups.empty()) return -1;
+  const Group &g = e->groups[0];
+  return g.n + (g.has_new ? 1 : 0);
+}
+
+// The record of every loop: X host [n_loops][N][D], y host [n_loops][N], N = bore_engine_size().
+extern "C" int bore_engine_observations(bore_engine *e, double *X, double *y) {
+  if (!e || !X || !y) return fail(BORE_E_INVALID, "engine_observations: NULL argument");
+  const int D = e->D;
+  const int64_t N = bore_engine_size(e);
+  for (Group &g : e->groups) {
+    const size_t Lg = g.b - g.a;
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    HIP_TRY(hipMemcpy2D(X + (size_t)g.a * N * D, (size_t)N * D * 8, g.X_seen, g.cap * D * 8,
+                        (size_t)g.n * D * 8, Lg, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy2D(y + (size_t)g.a * N, (size_t)N * 8, g.y_seen, g.cap * 8, (size_t)g.n * 8, Lg,
+                        hipMemcpyDeviceToHost));
+    if (g.has_new)  // the newest row is still staged on the host
+      for (size_t l = 0; l < Lg; ++l) {
+        std::memcpy(X + ((size_t)(g.a + l) * N + g.n) * D, g.new_x_pin + l * D, (size_t)D * 8);
+        y[(size_t)(g.a + l) * N + g.n] = g.new_y_pin[l];
+      }
+  }
+  return 0;
+}
+
+// Classifier state of every loop (host buffers; any may be NULL).
+extern "C" int bore_engine_state(bore_engine *e, float *theta, float *adam_m, float *adam_v,
+                                 int64_t *adam_t) {
+  if (!e) return fail(BORE_E_INVALID, "engine_state: NULL engine");
+  HIP_TRY(hipDeviceSynchronize());
+  const size_t n = (size_t)e->cfg.n_loops * e->P;
+  if (theta) HIP_TRY(hipMemcpy(theta, e->theta, n * 4, hipMemcpyDeviceToHost));
+  if (adam_m) HIP_TRY(hipMemcpy(adam_m, e->adam_m, n * 4, hipMemcpyDeviceToHost));
+  if (adam_v) HIP_TRY(hipMemcpy(adam_v, e->adam_v, n * 4, hipMemcpyDeviceToHost));
+  if (adam_t) HIP_TRY(hipMemcpy(adam_t, e->adam_t, (size_t)e->cfg.n_loops * 8, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+extern "C" int bore_engine_get_stats(bore_engine *e, bore_engine_stats *out, int reset) {
+  if (!e || !out) return fail(BORE_E_INVALID, "engine_get_stats: NULL argument");
+  *out = e->st;
+  if (reset) std::memset(&e->st, 0, sizeof(e->st));
+  return 0;
+}

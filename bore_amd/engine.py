@@ -36,6 +36,149 @@ def branin01(X):
             + 10 * (1 - 1 / (8 * np.pi)) * np.cos(x1) + 10)
 
 
+def initial_state(loop_ids, D, units, P, n_init, objective, low, high):
+    """What every loop starts from: its numpy RandomState(loop id) -- the stream the reference
+    would consume --, Keras-default weights (glorot_uniform kernels, zero biases) and n_init
+    uniform observations, drawn from that stream in this order."""
+    rss = [np.random.RandomState(int(s)) for s in loop_ids]
+    th = np.empty((len(rss), P), dtype=np.float32)
+    for i, rs in enumerate(rss):
+        off, fan_in = 0, D
+        for u in units:
+            lim = np.sqrt(6.0 / (fan_in + u))
+            th[i, off:off + fan_in * u] = rs.uniform(-lim, lim, size=fan_in * u)
+            off += fan_in * u
+            th[i, off:off + u] = 0.0
+            off += u
+            fan_in = u
+    X0 = np.stack([rs.uniform(low, high, size=(n_init, D)) for rs in rss])
+    return rss, th, X0, objective(X0)
+
+
+LBFGSB_DEFAULTS = dict(maxcor=10, ftol=2.2204460492503131e-09, gtol=1e-5, maxfun=15000,
+                       maxiter=15000, maxls=20)
+
+
+def lbfgsb_opts(options):
+    o = dict(LBFGSB_DEFAULTS)
+    unknown = set(options) - set(o)
+    if unknown:
+        raise TypeError(f"unknown L-BFGS-B options: {sorted(unknown)}")
+    o.update(options)
+    return _lib.LbfgsbOpts(int(o["maxcor"]), int(o["maxiter"]), int(o["maxfun"]), int(o["maxls"]),
+                           float(o["ftol"]), float(o["gtol"]))
+
+
+class NativeEngine:
+    """The replica engine with its host loop in C++ (``bore_engine_*``, bore_amd/csrc/
+    bore_engine.hip): same loops, same streams of random numbers, same kernels and the same
+    trajectories as ``ReplicaEngine(mode="device", select="device")`` -- bit for bit, tested --
+    without the interpreter between a group's results and its next launch.  ``objective`` is called
+    with [n, D] points (one group's suggestions) and returns n values."""
+
+    def __init__(self, loop_ids, input_dim=2, units=(16, 16, 1), acts=("relu", "relu", "sigmoid"),
+                 transform="identity", gamma=0.25, epochs=200, batch_size=64, num_starts=3,
+                 num_samples=1024, n_init=10, objective=branin01, options=None, device=None,
+                 seed=0, groups=4, deduplicate=False):
+        self.device = device or _lib.require_gpu()
+        self.loop_ids = np.asarray(loop_ids, dtype=np.int64)
+        self.L = L = len(self.loop_ids)
+        assert L >= 1 and np.array_equal(self.loop_ids, self.loop_ids[0] + np.arange(L)), \
+            "loop ids must be consecutive (the device streams are keyed by first id + offset)"
+        self.D = D = int(input_dim)
+        self.units, self.acts = list(units), list(acts)
+        self.desc = _lib.make_desc(D, self.units, self.acts)
+        self.P = ops.param_count(self.desc)
+        tr = resolve(transform).negated()
+        assert tr.negate, "the engine minimises transform(-f(x)) (bore/mixins.py:20)"
+        self.objective = objective
+        self.low, self.high = np.zeros(D), np.ones(D)
+        rss, th, X0, y0 = initial_state(self.loop_ids, D, self.units, self.P, n_init, objective,
+                                        self.low, self.high)
+        mt = np.empty((L, 625), dtype=np.uint32)
+        for i, rs in enumerate(rss):
+            _, key, pos, _, _ = rs.get_state()
+            mt[i, :624], mt[i, 624] = key, pos
+        self._error = None
+
+        def _objective(xp, n, d, yp, _user):
+            try:
+                X = np.ctypeslib.as_array(xp, shape=(n, d))
+                np.ctypeslib.as_array(yp, shape=(n,))[:] = self.objective(X)
+                return 0
+            except BaseException as e:          # never unwind through the C frames
+                self._error = e
+                return 1
+
+        self._cb = _lib.OBJECTIVE_FN(_objective)
+        self._lo, lo_p = ops._host_f64(self.low, D, "low")
+        self._hi, hi_p = ops._host_f64(self.high, D, "high")
+        cfg = _lib.EngineCfg(L, max(1, min(int(groups), L)), int(self.loop_ids[0]), int(n_init),
+                             int(epochs), int(batch_size), int(num_starts), int(num_samples),
+                             _lib.TRANSFORM[tr.name], int(bool(deduplicate)), 0,
+                             int(seed) & (2 ** 64 - 1), float(gamma),
+                             _lib.AdamCfg(1e-3, 0.9, 0.999, 1e-7),
+                             lbfgsb_opts(dict(options or dict(maxiter=1000, ftol=1e-9))), lo_p, hi_p)
+        self.n_groups = cfg.groups
+        th = np.ascontiguousarray(th)
+        X0, y0 = np.ascontiguousarray(X0, dtype=np.float64), np.ascontiguousarray(y0, dtype=np.float64)
+        self._h = _lib_ctypes.c_void_p()
+        vp = lambda a: a.ctypes.data_as(_lib_ctypes.c_void_p)
+        torch.cuda.set_device(self.device)
+        _lib.check(_lib.lib().bore_engine_create(_lib_ctypes.byref(self.desc), _lib_ctypes.byref(cfg),
+                                                 vp(th), vp(X0), vp(y0), vp(mt), self._cb, None,
+                                                 _lib_ctypes.byref(self._h)))
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            _lib.lib().bore_engine_destroy(h)
+
+    def run(self, n_steps):
+        rc = _lib.lib().bore_engine_run(self._h, int(n_steps))
+        if self._error is not None:             # the objective raised: the engine stopped
+            e, self._error = self._error, None
+            raise e
+        _lib.check(rc)
+
+    @property
+    def N(self):
+        return int(_lib.lib().bore_engine_size(self._h))
+
+    def observations(self):
+        N = self.N
+        X, y = np.empty((self.L, N, self.D)), np.empty((self.L, N))
+        vp = lambda a: a.ctypes.data_as(_lib_ctypes.c_void_p)
+        _lib.check(_lib.lib().bore_engine_observations(self._h, vp(X), vp(y)))
+        return X, y
+
+    @property
+    def X(self):
+        return self.observations()[0]
+
+    @property
+    def y(self):
+        return self.observations()[1]
+
+    def state(self):
+        """(theta, adam_m, adam_v [L, P] float32, adam_t [L] int64) as host arrays."""
+        th, m, v = (np.empty((self.L, self.P), dtype=np.float32) for _ in range(3))
+        t = np.empty(self.L, dtype=np.int64)
+        vp = lambda a: a.ctypes.data_as(_lib_ctypes.c_void_p)
+        _lib.check(_lib.lib().bore_engine_state(self._h, vp(th), vp(m), vp(v), vp(t)))
+        return th, m, v, t
+
+    def take_stats(self, reset=True):
+        st = _lib.EngineStats()
+        _lib.check(_lib.lib().bore_engine_get_stats(self._h, _lib_ctypes.byref(st), int(reset)))
+        return {k: getattr(st, k) for k, _ in st._fields_}
+
+    def best(self):
+        X, y = self.observations()
+        i = np.argmin(y, axis=1)
+        return X[np.arange(self.L), i], y[np.arange(self.L), i]
+
+
 class ReplicaEngine:
     def __init__(self, loop_ids, input_dim=2, units=(16, 16, 1), acts=("relu", "relu", "sigmoid"),
                  transform="identity", gamma=0.25, epochs=200, batch_size=64, num_starts=3,
@@ -78,37 +221,16 @@ class ReplicaEngine:
         self.objective = objective
         self.options = dict(options or dict(maxiter=1000, ftol=1e-9))
         self.low, self.high = np.zeros(D), np.ones(D)
-        # per-loop host RNG: the stream the reference would consume (RandomState(seed))
-        self.rs = [np.random.RandomState(int(s)) for s in self.loop_ids]
-        # Keras-default initial weights, one model per loop
-        th = np.empty((L, self.P), dtype=np.float32)
-        for i, rs in enumerate(self.rs):
-            off, fan_in = 0, D
-            for u in self.units:
-                lim = np.sqrt(6.0 / (fan_in + u))
-                th[i, off:off + fan_in * u] = rs.uniform(-lim, lim, size=fan_in * u)
-                off += fan_in * u
-                th[i, off:off + u] = 0.0
-                off += u
-                fan_in = u
+        self.rs, th, X0, y0 = initial_state(self.loop_ids, D, self.units, self.P, n_init,
+                                            self.objective, self.low, self.high)
         self.theta = torch.from_numpy(th).to(self.device)
         self.adam_m = torch.zeros_like(self.theta)
         self.adam_v = torch.zeros_like(self.theta)
         self.adam_t = torch.zeros(L, dtype=torch.int64, device=self.device)
-        # observations
-        X0 = np.stack([rs.uniform(self.low, self.high, size=(n_init, D)) for rs in self.rs])
-        y0 = self.objective(X0)
         self._lo, self._lo_p = ops._host_f64(self.low, D, "low")
         self._hi, self._hi_p = ops._host_f64(self.high, D, "high")
         self._adam = _lib.AdamCfg(1e-3, 0.9, 0.999, 1e-7)
-        o = dict(maxcor=10, ftol=2.2204460492503131e-09, gtol=1e-5, maxfun=15000, maxiter=15000,
-                 maxls=20)
-        unknown = set(self.options) - set(o)
-        if unknown:
-            raise TypeError(f"unknown L-BFGS-B options: {sorted(unknown)}")
-        o.update(self.options)
-        self._lopts = _lib.LbfgsbOpts(int(o["maxcor"]), int(o["maxiter"]), int(o["maxfun"]),
-                                      int(o["maxls"]), float(o["ftol"]), float(o["gtol"]))
+        self._lopts = lbfgsb_opts(self.options)
         G = max(1, min(int(groups), L)) if mode == "device" else 1
         bounds = np.linspace(0, L, G + 1).astype(int)
         self.groups = [_Group(int(a), int(b), X0[a:b], y0[a:b], self)

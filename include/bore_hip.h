@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define BORE_ABI_VERSION 3
+#define BORE_ABI_VERSION 4
 #define BORE_MAX_LAYERS 8
 #define BORE_BATCH_MAX 64 /* rows per tile == wavefront width */
 #define BORE_DIM_MAX 64   /* largest input dimension for the by-value bound arrays */
@@ -40,7 +40,8 @@ enum bore_status {
   BORE_OK = 0,
   BORE_E_INVALID = -1,   /* bad argument */
   BORE_E_UNSUPPORTED = -2, /* shape does not fit this build's kernels (e.g. LDS budget) */
-  BORE_E_HIP = -3        /* HIP runtime error (message has hipGetErrorString) */
+  BORE_E_HIP = -3,       /* HIP runtime error (message has hipGetErrorString) */
+  BORE_E_CALLBACK = -4   /* a host callback asked to stop (bore_engine_run) */
 };
 
 /* Keras activation names accepted by Dense(activation=...) on this path
@@ -252,6 +253,71 @@ int bore_select_best(int n_models, int num_starts, int D, const double *x, const
 int bore_shuffle_perm(uint64_t seed, int64_t model_index0, int n_models,
                       int64_t epoch0, int epochs, int64_t N, int32_t *perm,
                       void *stream);
+
+/* ---------------------------------------------------------------------------
+ * Replica engine: n_loops independent BO loops on one GPU (BASELINE.json config 4), each
+ * iteration being label -> fit -> sample + screen -> L-BFGS-B restarts -> pick as in the
+ * reference's loop (README.rst:83-103; bore/plugins/hpbandster/base.py:216-262), driven by a
+ * native host loop: the loops are split into `groups`, each stepping on its own HIP stream;
+ * per iteration a group uploads one row per loop, makes seven launches and downloads the
+ * suggestions.  Only the objective is evaluated on the host, through the callback.
+ * Not thread-safe per engine; engines are independent of each other.
+ * ------------------------------------------------------------------------- */
+
+/* y[i] = objective(x[i]) for n points: x host fp64 [n][D], y host fp64 [n].  Returns 0, or
+ * non-zero to stop: bore_engine_run then drains the work in flight and returns BORE_E_CALLBACK. */
+typedef int (*bore_objective_fn)(const double *x, int64_t n, int32_t D, double *y, void *user);
+
+typedef struct bore_engine_cfg {
+  int32_t n_loops;      /* loops on this GPU */
+  int32_t groups;       /* stream groups (clamped to n_loops) */
+  int64_t loop_id0;     /* global id of the first loop: keys the device shuffle/candidate streams */
+  int32_t n_init;       /* observations per loop at the start */
+  int32_t epochs;       /* fit(epochs=..) per iteration */
+  int32_t batch_size;   /* <= BORE_BATCH_MAX */
+  int32_t num_starts;   /* argmax(num_starts=..) */
+  int32_t num_samples;  /* argmax(num_samples=..) */
+  int32_t transform;    /* enum bore_transform */
+  int32_t deduplicate;  /* != 0: Record.is_duplicate as filter_fn (the plugin's rule) */
+  int32_t reserved;
+  uint64_t seed;
+  double gamma;
+  bore_adam_cfg adam;
+  bore_lbfgsb_opts lbfgsb;
+  const double *low, *high; /* HOST fp64 [D]: the search box (copied) */
+} bore_engine_cfg;
+
+/* Sums since creation / the last reset (HIP-event durations of the two big kernels, the
+ * algorithmic bytes of SURVEY.md 8d, counts). */
+typedef struct bore_engine_stats {
+  double fit_ms, fit_bytes, argmax_ms, argmax_bytes;
+  double host_enqueue_s, host_finalize_s;
+  int64_t fit_launches, argmax_launches, n_fg_rows, n_rounds, none_results;
+} bore_engine_stats;
+
+typedef struct bore_engine bore_engine;
+
+/*
+ *   theta0    HOST fp32 [n_loops][P]              initial weights (Keras defaults drawn by the caller)
+ *   X0, y0    HOST fp64 [n_loops][n_init][D], [n_loops][n_init]
+ *   mt_state  HOST uint32 [n_loops][625]          each loop's numpy RandomState (624 key words + pos):
+ *             the fallback point of a loop whose argmax returns None is drawn from it
+ *             (rs.uniform(low, high), bore/plugins/hpbandster/base.py:255-262)
+ */
+int bore_engine_create(const bore_mlp_desc *desc, const bore_engine_cfg *cfg, const float *theta0,
+                       const double *X0, const double *y0, const uint32_t *mt_state,
+                       bore_objective_fn objective, void *user, bore_engine **out);
+/* Advance every loop by n_steps BO iterations (returns when all have finished). */
+int bore_engine_run(bore_engine *engine, int n_steps);
+/* Observations per loop so far (<0: bad engine). */
+int64_t bore_engine_size(const bore_engine *engine);
+/* X host fp64 [n_loops][N][D], y host fp64 [n_loops][N], N = bore_engine_size(). */
+int bore_engine_observations(bore_engine *engine, double *X, double *y);
+/* Classifier state, host buffers [n_loops][P] / [n_loops]; any may be NULL. */
+int bore_engine_state(bore_engine *engine, float *theta, float *adam_m, float *adam_v,
+                      int64_t *adam_t);
+int bore_engine_get_stats(bore_engine *engine, bore_engine_stats *out, int reset);
+void bore_engine_destroy(bore_engine *engine);
 
 #ifdef __cplusplus
 }

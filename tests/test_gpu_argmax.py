@@ -263,6 +263,54 @@ def test_replica_engine_duplicate_filter_device_equals_host(gpu):
         assert g.store.n == 21 and np.array_equal(g.store.X[:, :21].cpu().numpy(), g.X[:, :21])
 
 
+@pytest.mark.parametrize("dedup", [False, True])
+def test_native_engine_equals_python_engine(gpu, dedup):
+    """bore_engine_* (C++ host loop) against ReplicaEngine: same observations, classifier state and
+    fallback draws, bit for bit; a hard problem set (few samples, short fits) so that None results,
+    duplicates and a growing record all occur."""
+    from bore_amd.engine import NativeEngine, ReplicaEngine
+    kw = dict(epochs=20, num_samples=64, deduplicate=dedup)
+    a = NativeEngine(np.arange(3, 14), groups=3, **kw)
+    b = ReplicaEngine(np.arange(3, 14), mode="device", groups=2, **kw)
+    assert a.N == b.N == 10 and np.array_equal(a.X, b.X)
+    a.run(7)
+    a.run(5)
+    b.run(12)
+    Xa, ya = a.observations()
+    assert Xa.shape == (11, 22, 2)
+    assert np.array_equal(Xa, b.X) and np.array_equal(ya, b.y)
+    th, m, v, t = a.state()
+    assert np.array_equal(th, b.theta.cpu().numpy()) and np.array_equal(t, b.adam_t.cpu().numpy())
+    assert np.array_equal(v, b.adam_v.cpu().numpy())
+    st = a.take_stats()
+    assert st["none_results"] == b.stats["none_results"]
+    assert st["fit_launches"] == 3 * 12 and st["n_fg_rows"] == b.stats["n_fg_rows"]
+    assert st["fit_ms"] > 0 and st["argmax_ms"] > 0
+    assert a.take_stats()["fit_launches"] == 0                       # reset
+
+
+def test_native_engine_grows_its_record_and_reports_objective_errors(gpu):
+    from bore_amd.engine import NativeEngine, ReplicaEngine, branin01
+    a = NativeEngine(np.arange(4), groups=1, epochs=5, num_samples=16, n_init=120)
+    b = ReplicaEngine(np.arange(4), mode="device", groups=1, epochs=5, num_samples=16, n_init=120)
+    a.run(140)                                   # capacity 256 -> 512 on the way
+    b.run(140)
+    assert a.N == 260 and np.array_equal(a.X, b.X) and np.array_equal(a.y, b.y)
+
+    calls = []
+
+    def bad(X):
+        calls.append(len(X))
+        if len(calls) > 2:
+            raise ValueError("objective failed")
+        return branin01(X)
+
+    c = NativeEngine(np.arange(2), groups=1, epochs=5, num_samples=16, objective=bad)
+    c.run(1)
+    with pytest.raises(ValueError, match="objective failed"):
+        c.run(3)
+
+
 def test_bf16_argmax_kernels_equal_their_host_build(gpu):
     """desc.compute = bfloat16: screening and the in-kernel L-BFGS-B evaluate the network with
     bf16 rounding -- bit for bit the f/g that mlp_value_and_input_grad returns for that
