@@ -426,3 +426,48 @@ def test_observation_store_appends_and_packs(gpu):
         assert np.array_equal(yd.cpu().numpy(), yh)
         assert np.array_equal(store.X[:, :store.n].cpu().numpy(), Xh)        # fp64 kept for the filter
     assert store.n == 9 and store.cap == 12
+
+
+@pytest.mark.parametrize("name,D,units,compute,R,Ns", [
+    ("config2", 6, [32, 32, 1], "float32", 256, 1024),
+    ("config3", 16, [64, 64, 64, 1], "float32", 1024, 1024),
+    ("config5", 32, [128, 128, 1], "bfloat16", 4096, 4096)])
+def test_argmax_properties_at_baseline_sizes(gpu, name, D, units, compute, R, Ns):
+    """BASELINE.json configs 2, 3 and 5 at their full restart counts, through properties that do
+    not need the (slow) CPU oracle: results stay in the box, the reported value/gradient ARE the
+    f/g operator at the reported point, no restart ends above its start, and a restart's result does
+    not depend on its position in the batch or on the batch's size (row independence)."""
+    rs = np.random.RandomState(len(name))
+    acts = ["relu"] * (len(units) - 1) + ["sigmoid"]
+    desc = _lib.make_desc(D, units, acts, compute=compute)
+    th = dev(pack(rand_model(rs, D, units))[None])
+    lo, hi = np.zeros(D), np.ones(D)
+    Xc = ops.uniform_candidates(11, 1, Ns, lo, hi)
+    x0, idx = ops.screen_topk(desc, th, Xc, R)
+    assert len(set(idx.cpu().numpy()[0].tolist())) == R
+    opts = dict(maxiter=1000, ftol=1e-9)
+    x, fun, jac, info = ops.lbfgsb_minimize(desc, th, x0, lo, hi, "identity", True, **opts)
+    xh, fh, ih = x.cpu().numpy()[0], fun.cpu().numpy()[0], info.cpu().numpy()[0]
+    assert ((xh >= -1e-12) & (xh <= 1 + 1e-12)).all()
+    assert np.isin(ih[:, 2], (0, 1, 2)).all() and (ih[:, 1] >= 1).all() and (ih[:, 0] <= 1000).all()
+    v, g = ops.mlp_value_and_input_grad(desc, th, x, "identity", True)
+    assert np.array_equal(v.cpu().numpy()[0].astype(np.float64), fh)
+    assert np.array_equal(g.cpu().numpy()[0], jac.cpu().numpy()[0])
+    v0, _ = ops.mlp_value_and_input_grad(desc, th, x0, "identity", True)
+    assert (fh <= v0.cpu().numpy()[0].astype(np.float64)).all()
+    # converged by the projected-gradient test => that gradient is small
+    pg = np.where(jac.cpu().numpy()[0] < 0, np.maximum(xh - hi, jac.cpu().numpy()[0]),
+                  np.minimum(xh - lo, jac.cpu().numpy()[0]))
+    pgtol = ih[:, 4] == 401
+    assert (np.abs(pg[pgtol]).max(axis=1) <= 1e-5).all() if pgtol.any() else True
+    # position / batch-size independence, bit for bit
+    perm = rs.permutation(R)
+    xp, fp, _, ip = ops.lbfgsb_minimize(desc, th, x0[:, torch.from_numpy(perm).to(gpu)].contiguous(),
+                                        lo, hi, "identity", True, **opts)
+    assert np.array_equal(xp.cpu().numpy()[0], xh[perm]) and np.array_equal(ip.cpu().numpy()[0], ih[perm])
+    xs, fs, _, is_ = ops.lbfgsb_minimize(desc, th, x0[:, :7].contiguous(), lo, hi, "identity", True, **opts)
+    assert np.array_equal(xs.cpu().numpy()[0], xh[:7]) and np.array_equal(is_.cpu().numpy()[0], ih[:7])
+    # the device pick equals the reference loop over these results
+    xb, best = ops.select_best(x, fun, info)
+    want = _reference_pick([(xh[r], fh[r], ih[r, 2]) for r in range(R)])
+    assert int(best[0]) == want

@@ -403,3 +403,53 @@ def test_bf16_forward_and_input_grad_match_the_bf16_oracle(gpu, D, units, acts, 
     desc32 = _lib.make_desc(D, units, acts)
     p32 = ops.mlp_forward(desc32, th, dev(X[None].astype(np.float32)))[0].cpu().numpy()
     assert not np.array_equal(p32, pred) and np.abs(p32 - pred).max() < 0.05 * (1 + np.abs(p32).max())
+
+
+@pytest.mark.parametrize("name,D,units,compute,L,N", [
+    ("config4", 2, [16, 16, 1], "float32", 512, 110),          # 512 replicas of config 1
+    ("config2", 6, [32, 32, 1], "float32", 3, 256),
+    ("config3", 16, [64, 64, 64, 1], "float32", 3, 256),
+    ("config5", 32, [128, 128, 1], "bfloat16", 2, 256)])
+def test_fit_properties_at_baseline_sizes(gpu, name, D, units, compute, L, N):
+    """BASELINE.json configs at full size (200 epochs, batch 64) through properties instead of the
+    CPU oracle: the Adam counter, a falling loss that Keras' evaluate() reproduces, replicas that do
+    not depend on their neighbours (any model alone == the same model inside the launch, bit for
+    bit) and warm start (two fits of 100 epochs continue the shuffle stream of one of 200)."""
+    rs = np.random.RandomState(len(name) + D)
+    acts = ["relu"] * (len(units) - 1) + ["sigmoid"]
+    desc = _lib.make_desc(D, units, acts, compute=compute)
+    th0 = np.stack([pack(rand_model(rs, D, units)) for _ in range(L)])
+    X = rs.uniform(size=(L, N, D)).astype(np.float32)
+    z = (np.sum((X - 0.4) ** 2, axis=2) < np.quantile(np.sum((X - 0.4) ** 2, axis=2), 0.25, axis=1)[:, None])
+    z = z.astype(np.float32)
+    E, steps = 200, -(-N // 64)
+
+    def run(sel, splits):
+        th = dev(th0[sel]); m = torch.zeros_like(th); v = torch.zeros_like(th)
+        t = torch.zeros(len(sel), dtype=torch.int64, device="cuda")
+        losses, e0 = [], 0
+        for e in splits:      # consecutive models share (seed, model_index0 + i): pass the first id
+            losses.append(ops.mlp_fit(desc, th, m, v, t, dev(X[sel]), dev(z[sel]), e, 64, seed=5,
+                                      model_index0=int(sel[0]), epoch0=e0))
+            e0 += e
+        return th, m, v, t, torch.cat(losses, dim=1)
+
+    allm = np.arange(L)
+    th, m, v, t, loss = run(allm, [E])
+    assert (t.cpu().numpy() == E * steps).all()
+    lh = loss.cpu().numpy()
+    first, last = lh[:, :5].mean(axis=1), lh[:, -20:].mean(axis=1)
+    assert np.isfinite(lh).all() and (last < first).all() and np.median(last / first) < 0.8
+    ev_loss, ev_acc = ops.mlp_evaluate(desc, th, dev(X), dev(z))
+    assert (ev_acc.cpu().numpy() >= 0.6).all() and np.median(ev_acc.cpu().numpy()) >= 0.74
+    if compute == "float32":                                    # evaluate's accuracy == predict's
+        pred = ops.mlp_forward(desc, th, dev(X)).cpu().numpy()
+        np.testing.assert_allclose(ev_acc.cpu().numpy(), ((pred > 0.5) == (z > 0.5)).mean(axis=1), atol=1e-6)
+    assert np.all(np.abs(ev_loss.cpu().numpy() - lh[:, -1]) < 0.2)
+    for l in sorted({0, L // 2, L - 1}):                        # alone == inside the launch
+        th1, m1, v1, t1, loss1 = run(np.array([l]), [E])
+        assert torch.equal(th1[0], th[l]) and torch.equal(v1[0], v[l]) and torch.equal(loss1[0], loss[l])
+    th2, m2, v2, t2, loss2 = run(allm[:2], [100, 100])          # warm start
+    assert torch.equal(t2, t[:2])
+    tol = dict(rtol=2e-2, atol=2e-3) if compute == "bfloat16" else dict(rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(th2.cpu().numpy(), th[:2].cpu().numpy(), **tol)
