@@ -15,7 +15,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libbore_hip.so")
-SOURCES = ["bore_hip.hip", "bore_argmax.hip", "bore_engine.hip"]
+SOURCES = ["bore_hip.hip", "bore_argmax.hip", "bore_svgd.hip", "bore_engine.hip"]
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "bore_hip.h")
 
 MAX_LAYERS = 8
@@ -30,7 +30,7 @@ EXPORTS = [
     "bore_mlp_value_and_input_grad", "bore_mlp_fit", "bore_mlp_evaluate",
     "bore_shuffle_perm", "bore_labels", "bore_uniform_candidates", "bore_screen_topk",
     "bore_lbfgsb_minimize", "bore_append_observations", "bore_select_best",
-    "bore_engine_create", "bore_engine_run", "bore_engine_size", "bore_engine_observations",
+    "bore_svgd_optimize", "bore_engine_create", "bore_engine_run", "bore_engine_size", "bore_engine_observations",
     "bore_engine_state", "bore_engine_get_stats", "bore_engine_destroy",
 ]
 
@@ -50,6 +50,12 @@ class LbfgsbOpts(C.Structure):
 class AdamCfg(C.Structure):
     _fields_ = [("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float),
                 ("eps", C.c_float)]
+
+
+class SvgdOpts(C.Structure):
+    _fields_ = [("n_iter", C.c_int32), ("distortion", C.c_int32), ("step_size", C.c_double),
+                ("alpha", C.c_double), ("eps", C.c_double), ("tau", C.c_double),
+                ("length_scale", C.c_double), ("distortion_param", C.c_double)]
 
 
 class EngineCfg(C.Structure):
@@ -139,6 +145,7 @@ def lib():
     L.bore_append_observations.argtypes = [i32, i32, vp, vp, i64, i64, vp, vp, vp, vp, vp]
     L.bore_select_best.argtypes = [i32, i32, i32, vp, vp, vp, vp, i64, i64, C.c_double,
                                    C.c_double, vp, vp, vp]
+    L.bore_svgd_optimize.argtypes = [dp, i32, vp, i32, vp, i32, dpp, dpp, C.POINTER(SvgdOpts), vp, vp]
     L.bore_engine_create.argtypes = [dp, C.POINTER(EngineCfg), vp, vp, vp, vp, OBJECTIVE_FN, vp,
                                      C.POINTER(vp)]
     L.bore_engine_run.argtypes = [vp, i32]

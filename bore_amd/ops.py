@@ -302,3 +302,34 @@ def select_best(x, fun, info, store=None, rtol=1e-5, atol=1e-8):
         store.n if store is not None else 0, store.cap if store is not None else 0,
         float(rtol), float(atol), _lib.ptr(x_best), _lib.ptr(best), _lib.stream_ptr()))
     return x_best, best
+
+
+def svgd_optimize(desc, theta, x_init, low=None, high=None, transform="identity", length_scale=None,
+                  n_iter=1000, step_size=1e-3, alpha=.9, eps=1e-6, tau=1., c=1., lambd=None):
+    """SVGD on transform(f(x)) for L models x n particles, all iterations in one launch
+    (``bore_svgd_optimize``).  x_init [L, n, D] f64 -> particles [L, n, D] f64.  ``lambd`` selects
+    DistortionExpDecay, otherwise DistortionConstant(c); low/high None = no clipping."""
+    L = theta.shape[0]
+    D = desc.input_dim
+    _chk(theta, torch.float32, (L, param_count(desc)), "theta")
+    if x_init.dim() != 3:
+        raise ValueError("x_init: expected [n_models, n_particles, D]")
+    n = x_init.shape[1]
+    _chk(x_init, torch.float64, (L, n, D), "x_init")
+    if transform not in _lib.TRANSFORM:
+        raise ValueError(f"unknown transform {transform!r}")
+    if (low is None) != (high is None):
+        raise ValueError("low and high go together")
+    null = C.POINTER(C.c_double)()
+    lo_p = hi_p = null
+    if low is not None:
+        lo, lo_p = _host_f64(low, D, "low")
+        hi, hi_p = _host_f64(high, D, "high")
+    opts = _lib.SvgdOpts(int(n_iter), 0 if lambd is None else 1, float(step_size), float(alpha),
+                         float(eps), float(tau), -1.0 if length_scale is None else float(length_scale),
+                         float(c) if lambd is None else float(lambd))
+    out = torch.empty_like(x_init)
+    _lib.check(_lib.lib().bore_svgd_optimize(C.byref(desc), L, _lib.ptr(theta),
+                                             _lib.TRANSFORM[transform], _lib.ptr(x_init), n, lo_p, hi_p,
+                                             C.byref(opts), _lib.ptr(out), _lib.stream_ptr()))
+    return out

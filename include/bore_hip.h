@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define BORE_ABI_VERSION 4
+#define BORE_ABI_VERSION 5
 #define BORE_MAX_LAYERS 8
 #define BORE_BATCH_MAX 64 /* rows per tile == wavefront width */
 #define BORE_DIM_MAX 64   /* largest input dimension for the by-value bound arrays */
@@ -247,6 +247,30 @@ int bore_append_observations(int n_models, int D, double *X_seen, double *y_seen
 int bore_select_best(int n_models, int num_starts, int D, const double *x, const double *fun,
                      const int32_t *info, const double *X_seen, int64_t n_seen, int64_t cap,
                      double rtol, double atol, double *x_best, int32_t *best, void *stream);
+
+/* SVGD hyper-parameters as BatchMaximizableMixin.argmax_batch passes them (bore/mixins.py:100-116;
+ * defaults n_iter 1000, step_size 1e-3, alpha 0.9, eps 1e-6, tau 1.0, length_scale None). */
+typedef struct bore_svgd_opts {
+  int32_t n_iter;
+  int32_t distortion;       /* 0: omega = distortion_param (DistortionConstant c);
+                               1: omega = rank^-distortion_param (DistortionExpDecay lambd) */
+  double step_size, alpha, eps, tau;
+  double length_scale;      /* RadialBasis length scale; < 0: the median heuristic (None) */
+  double distortion_param;
+} bore_svgd_opts;
+
+/*
+ * SVGD.optimize_from_init (bore/optimizers/svgd/base.py:79-119) with the RadialBasis kernel
+ * (bore/optimizers/svgd/kernels.py:4-28) on the objective transform(f(x)) -- every iteration of
+ * every particle inside ONE launch per model (particles, kernel matrix and Adagrad history in LDS).
+ *   x_init, x_out  device fp64 [n_models][n_particles][D]   (n_particles <= BORE_BATCH_MAX)
+ *   lb, ub         HOST fp64 [D]: particles are clipped into the box after every update;
+ *                  both NULL = no clipping
+ * BORE_E_UNSUPPORTED when particles x dimension do not fit the LDS beside the network.
+ */
+int bore_svgd_optimize(const bore_mlp_desc *desc, int n_models, const float *theta, int transform,
+                       const double *x_init, int n_particles, const double *lb, const double *ub,
+                       const bore_svgd_opts *opts, double *x_out, void *stream);
 
 /* The in-kernel shuffle stream of bore_mlp_fit, written out:
  * perm device int32 [n_models][epochs][N]. */

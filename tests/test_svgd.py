@@ -85,3 +85,76 @@ def test_argmax_batch_on_the_gpu(gpu):
     # _func_max is transform(f), no negation
     v, grad = model._func_max(xa)
     assert v.shape == (8,) and grad.shape == (8, 2) and ((v > 0) & (v < 1)).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,D,units,ls,lambd,tr", [
+    (8, 2, [16, 16, 1], None, None, "sigmoid"),
+    (5, 3, [32, 32, 1], 0.3, None, "identity"),
+    (16, 6, [32, 32, 1], None, 0.5, "sigmoid"),
+    (33, 2, [16, 16, 1], None, None, "exp"),
+    (64, 6, [32, 32, 1], 0.7, None, "sigmoid"),
+    (24, 16, [64, 64, 64, 1], None, None, "sigmoid"),
+    (1, 2, [16, 16, 1], None, None, "identity")])
+def test_device_svgd_tracks_the_host_statement(gpu, n, D, units, ls, lambd, tr):
+    """bore_svgd_optimize (all iterations in one launch) against SVGD.optimize_from_init of
+    bore_amd/optimizers/svgd.py (bit-equal to the reference, test above) driven by the same
+    device f/g operator: same particles to rounding -- sums run in another order and exp() is
+    the device's -- after 200 iterations, with clipping active on some coordinates."""
+    import torch
+    from bore_amd import _lib, ops
+    from test_gpu_parity import dev, pack, rand_model
+    rs = np.random.RandomState(n + D)
+    acts = ["tanh"] + ["relu"] * (len(units) - 2) + ["linear"]
+    desc = _lib.make_desc(D, units, acts)
+    L = 2
+    th = dev(np.stack([pack(rand_model(rs, D, units)) for _ in range(L)]))
+    x0 = rs.uniform(size=(L, n, D))
+    kw = dict(n_iter=200, step_size=1e-2, alpha=.9, eps=1e-6, tau=1.)
+    out = ops.svgd_optimize(desc, th, dev(x0), np.zeros(D), np.ones(D), tr, length_scale=ls,
+                            lambd=lambd, **kw).cpu().numpy()
+    assert ((out >= 0) & (out <= 1)).all()
+    for l in range(L):
+        def func(X):
+            v, g = ops.mlp_value_and_input_grad(desc, th[l:l + 1], dev(X[None]), tr, False)
+            return v.cpu().numpy()[0].astype(np.float64), g.cpu().numpy()[0]
+        dist = DistortionConstant() if lambd is None else DistortionExpDecay(lambd=lambd)
+        ref = SVGD(kernel=RadialBasis(length_scale=ls), distortion=dist, **kw).optimize_from_init(
+            func, x0[l], bounds=[(0.0, 1.0)] * D)
+        # rank ties/near-ties under DistortionExpDecay can flip a weight: looser there
+        np.testing.assert_allclose(out[l], ref, rtol=0, atol=1e-9 if lambd is None else 1e-6)
+    assert (np.abs(out - x0) > 1e-4).any()          # the particles moved
+    # no box: same arithmetic without the clip
+    free = ops.svgd_optimize(desc, th, dev(x0), None, None, tr, length_scale=ls, lambd=lambd,
+                             n_iter=3, step_size=1e-2).cpu().numpy()
+    assert np.isfinite(free).all()
+    # what does not fit the LDS beside the network is refused, loudly
+    big = _lib.make_desc(16, [64, 64, 64, 1], ["relu"] * 3 + ["linear"])
+    thb = dev(pack(rand_model(rs, 16, [64, 64, 64, 1]))[None])
+    with pytest.raises(RuntimeError, match="LDS"):
+        ops.svgd_optimize(big, thb, dev(rs.uniform(size=(1, 64, 16))), n_iter=1)
+    with pytest.raises(RuntimeError, match="particles"):
+        ops.svgd_optimize(desc, th, dev(rs.uniform(size=(L, 65, D))), n_iter=1)
+
+
+@pytest.mark.gpu
+def test_argmax_batch_device_mode(gpu):
+    from scipy.optimize import Bounds
+    from bore_amd.layers import Dense
+    from bore_amd.models import BatchMaximizableSequential
+    rs = np.random.RandomState(0)
+    model = BatchMaximizableSequential("sigmoid", seed=2)
+    model.add(Dense(16, activation="relu", input_dim=2))
+    model.add(Dense(16, activation="relu"))
+    model.add(Dense(1))
+    model.compile(optimizer="adam", loss=__import__("bore_amd").BinaryCrossentropy(from_logits=True))
+    X = rs.uniform(size=(64, 2))
+    y = np.sum((X - 0.3) ** 2, 1)
+    model.fit(X, y < np.quantile(y, 0.25), epochs=300, batch_size=64)
+    bounds = Bounds(np.zeros(2), np.ones(2))
+    host = model.argmax_batch(8, bounds, n_iter=100, step_size=1e-2, random_state=5)
+    model.svgd_mode = "device"
+    devp = model.argmax_batch(8, bounds, n_iter=100, step_size=1e-2, random_state=5)
+    np.testing.assert_allclose(devp, host, rtol=0, atol=1e-9)
+    full = model.argmax_batch(8, bounds, random_state=5)          # the reference's 1000 iterations
+    assert full.shape == (8, 2) and ((full >= 0) & (full <= 1)).all()
