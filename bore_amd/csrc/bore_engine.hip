@@ -142,10 +142,9 @@ int enqueue(bore_engine *e, Group &g) {
   int rc;
   if (g.has_new && g.n + 1 > g.cap && (rc = alloc_record(e, g, 2 * g.cap))) return rc;
   void *sp = g.stream;
-  if (g.has_new) {
-    HIP_TRY(hipMemcpyAsync(g.new_x, g.new_x_pin, (size_t)Lg * D * 8, hipMemcpyHostToDevice, g.stream));
-    HIP_TRY(hipMemcpyAsync(g.new_y, g.new_y_pin, (size_t)Lg * 8, hipMemcpyHostToDevice, g.stream));
-  }
+  if (g.has_new)  // new_x | new_y are one block on both sides: one copy
+    HIP_TRY(hipMemcpyAsync(g.new_x, g.new_x_pin, (size_t)Lg * (D + 1) * 8, hipMemcpyHostToDevice,
+                           g.stream));
   if ((rc = bore_append_observations(Lg, D, g.X_seen, g.y_seen, g.n, g.cap,
                                      g.has_new ? g.new_x : nullptr, g.has_new ? g.new_y : nullptr,
                                      g.X32, g.y_dense, sp)))
@@ -179,9 +178,9 @@ int enqueue(bore_engine *e, Group &g) {
   if ((rc = bore_select_best(Lg, R, D, g.x, g.fun, g.info, c.deduplicate ? g.X_seen : nullptr, g.n,
                              g.cap, 1e-5, 1e-8, g.x_best, g.best, sp)))
     return rc;
-  HIP_TRY(hipMemcpyAsync(g.x_best_pin, g.x_best, (size_t)Lg * D * 8, hipMemcpyDeviceToHost, g.stream));
-  HIP_TRY(hipMemcpyAsync(g.best_pin, g.best, (size_t)Lg * 4, hipMemcpyDeviceToHost, g.stream));
-  HIP_TRY(hipMemcpyAsync(g.info_pin, g.info, (size_t)Lg * R * 5 * 4, hipMemcpyDeviceToHost, g.stream));
+  // x_best | info | best are one block on both sides: one copy
+  HIP_TRY(hipMemcpyAsync(g.x_best_pin, g.x_best, (size_t)Lg * (D * 8 + R * 5 * 4 + 4),
+                         hipMemcpyDeviceToHost, g.stream));
   HIP_TRY(hipEventRecord(g.done, g.stream));
   g.inflight = true;
   e->st.host_enqueue_s += now_s() - t0;
@@ -235,11 +234,11 @@ int finalize(bore_engine *e, Group &g) {
 }
 
 void free_group(Group &g) {
-  void *dev[] = {g.X_seen, g.y_seen, g.y_dense, g.X32, g.z, g.new_x, g.new_y, g.Xc, g.x0,
-                 g.x, g.jac, g.fun, g.x_best, g.idx, g.info, g.best};
+  void *dev[] = {g.X_seen, g.y_seen, g.y_dense, g.X32, g.z, g.new_x, g.Xc, g.x0,
+                 g.x, g.jac, g.fun, g.x_best, g.idx};
   for (void *p : dev)
     if (p) (void)hipFree(p);
-  void *pin[] = {g.new_x_pin, g.new_y_pin, g.x_best_pin, g.best_pin, g.info_pin};
+  void *pin[] = {g.new_x_pin, g.x_best_pin};
   for (void *p : pin)
     if (p) (void)hipHostFree(p);
   if (g.done) (void)hipEventDestroy(g.done);
@@ -333,22 +332,23 @@ extern "C" int bore_engine_create(const bore_mlp_desc *desc, const bore_engine_c
     ENG_HIP(hipMemcpy2D(g.y_seen, g.cap * 8, y0 + (size_t)g.a * n0, (size_t)n0 * 8, (size_t)n0 * 8, Lg,
                         hipMemcpyHostToDevice));
     g.n = n0;
-    ENG_TRY(dev_alloc(&g.new_x, Lg * D));
-    ENG_TRY(dev_alloc(&g.new_y, Lg));
+    ENG_TRY(dev_alloc(&g.new_x, Lg * (D + 1)));  // new_x [Lg][D] | new_y [Lg]
+    g.new_y = g.new_x + Lg * D;
     ENG_TRY(dev_alloc(&g.Xc, Lg * (size_t)cfg->num_samples * D));
     ENG_TRY(dev_alloc(&g.x0, Lg * R * D));
     ENG_TRY(dev_alloc(&g.x, Lg * R * D));
     ENG_TRY(dev_alloc(&g.jac, Lg * R * D));
     ENG_TRY(dev_alloc(&g.fun, Lg * R));
-    ENG_TRY(dev_alloc(&g.x_best, Lg * D));
+    // x_best [Lg][D] fp64 | info [Lg][R][5] int32 | best [Lg] int32
+    ENG_TRY(dev_alloc(&g.x_best, Lg * D + (Lg * R * 5 + Lg + 1) / 2));
+    g.info = reinterpret_cast<int32_t *>(g.x_best + Lg * D);
+    g.best = g.info + Lg * R * 5;
     ENG_TRY(dev_alloc(&g.idx, Lg * R));
-    ENG_TRY(dev_alloc(&g.info, Lg * R * 5));
-    ENG_TRY(dev_alloc(&g.best, Lg));
-    ENG_TRY(pin_alloc(&g.new_x_pin, Lg * D));
-    ENG_TRY(pin_alloc(&g.new_y_pin, Lg));
-    ENG_TRY(pin_alloc(&g.x_best_pin, Lg * D));
-    ENG_TRY(pin_alloc(&g.best_pin, Lg));
-    ENG_TRY(pin_alloc(&g.info_pin, Lg * R * 5));
+    ENG_TRY(pin_alloc(&g.new_x_pin, Lg * (D + 1)));
+    g.new_y_pin = g.new_x_pin + Lg * D;
+    ENG_TRY(pin_alloc(&g.x_best_pin, Lg * D + (Lg * R * 5 + Lg + 1) / 2));
+    g.info_pin = reinterpret_cast<int32_t *>(g.x_best_pin + Lg * D);
+    g.best_pin = g.info_pin + Lg * R * 5;
   }
 #undef ENG_TRY
 #undef ENG_HIP
