@@ -180,6 +180,9 @@ class NativeEngine:
 
 
 class ReplicaEngine:
+    """The Python statement of the replica engine (``NativeEngine`` runs the same loop in C++ and
+    is what ``bench.py`` uses): kept as the readable reference and as the check of the native one."""
+
     def __init__(self, loop_ids, input_dim=2, units=(16, 16, 1), acts=("relu", "relu", "sigmoid"),
                  transform="identity", gamma=0.25, epochs=200, batch_size=64, num_starts=3,
                  num_samples=1024, n_init=10, objective=branin01, max_points=None,
@@ -189,13 +192,15 @@ class ReplicaEngine:
         as five launches per BO iteration with ONE host sync (candidates from the device
         counter stream).  mode "lockstep": candidates from each loop's numpy RandomState and
         SciPy's L-BFGS-B on the host around the batched f/g kernel (the reference's streams
-        and optimiser code; slow -- one launch + L*R host state machines per round)."""
-        """groups > 1 (device mode): the loops are split into that many contiguous groups, each
+        and optimiser code; slow -- one launch + L*R host state machines per round).
+
+        groups > 1 (device mode): the loops are split into that many contiguous groups, each
         stepping on its own HIP stream.  A BO iteration of a group ends when its SLOWEST
         L-BFGS-B restart does; with several groups in flight one group's tail overlaps the
         others' fit/argmax instead of idling the GPU (loops never interact, so grouping only
-        changes scheduling -- every loop's trajectory is the same; tested)."""
-        """select "device" (device mode): the observations live on the device in fp64
+        changes scheduling -- every loop's trajectory is the same; tested).
+
+        select "device" (device mode): the observations live on the device in fp64
         (``ops.ObservationStore``: one [L, D+1] upload per iteration instead of the whole data
         set) and ``bore_select_best`` picks each loop's suggestion there; "host": the numpy
         statement of the same rule on downloaded results (kept as the check of the device path).
@@ -317,7 +322,7 @@ class ReplicaEngine:
         return x_next
 
     def _enqueue(self, g):
-        """Queue one BO iteration of group g on its stream: 5 launches + async copies.  Every
+        """Queue one BO iteration of group g on its stream: 5-7 launches + async copies.  Every
         buffer is preallocated (an allocation or a pageable copy here would serialise the
         streams) and the C-ABI is called directly (shapes were validated when the group's
         buffers were made)."""
