@@ -5,7 +5,7 @@ import numpy as np, torch
 from bore_amd import _lib
 so = os.path.abspath('scratch/libbore_stamp.so')
 subprocess.run(['hipcc', '-O3', '--offload-arch=gfx950', '-std=c++17', '-shared', '-fPIC', '-ffp-contract=off',
-                '-DBORE_STAMPS', 'bore_amd/csrc/bore_hip.hip', 'bore_amd/csrc/bore_argmax.hip', '-o', so],
+                '-DBORE_STAMPS', *['bore_amd/csrc/' + f for f in _lib.SOURCES], '-o', so],
                check=True, stderr=subprocess.DEVNULL)
 _lib.LIB_PATH = so
 from bore_amd.engine import ReplicaEngine
