@@ -119,3 +119,28 @@ def test_fp32_classifier_objective_statistics_match_scipy(D, units, acts, tr):
     na = np.mean([a.nfev for a, _ in res])
     nb = np.mean([b.nfev for _, b in res])
     assert abs(na - nb) <= 0.25 * na
+
+
+def test_host_build_is_clean_under_asan_and_ubsan(tmp_path):
+    """The optimiser header compiled with -fsanitize=address,undefined (GPU sanitizers are not
+    available on the pool; the host build shares every line of the state machine): 256 runs over
+    n = 1..31, maxcor = 1..17, all bound patterns, plus the fp32 classifier objective."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    so = str(tmp_path / "liblbfgsb_host_san.so")
+    cc = subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-shared", "-fPIC", "-ffp-contract=off",
+                         "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+                         os.path.join(here, "native", "lbfgsb_host.cpp"), "-o", so],
+                        capture_output=True, text=True)
+    if cc.returncode != 0:
+        pytest.skip("no sanitizer runtime in this toolchain: " + cc.stderr[-200:])
+    pre = [subprocess.run(["g++", f"-print-file-name={n}"], capture_output=True, text=True).stdout.strip()
+           for n in ("libasan.so", "libubsan.so")]
+    if not all(os.path.isabs(p) for p in pre):
+        pytest.skip("sanitizer runtimes not found")
+    env = dict(os.environ, LD_PRELOAD=":".join(pre), ASAN_OPTIONS="detect_leaks=0")
+    run = subprocess.run([sys.executable, os.path.join(here, "native", "sanitized_run.py"), so],
+                         capture_output=True, text=True, env=env, timeout=600)
+    assert run.returncode == 0 and "sanitized runs ok: 256" in run.stdout, run.stderr[-2000:]
