@@ -28,7 +28,7 @@ TRANSFORM = dict(identity=0, sigmoid=1, exp=2)
 EXPORTS = [
     "bore_abi_version", "bore_last_error", "bore_param_count", "bore_mlp_forward",
     "bore_mlp_value_and_input_grad", "bore_mlp_fit", "bore_mlp_evaluate",
-    "bore_shuffle_perm", "bore_labels", "bore_uniform_candidates", "bore_screen_topk",
+    "bore_shuffle_perm", "bore_labels", "bore_uniform_candidates", "bore_screen_topk", "bore_sample_screen_topk",
     "bore_lbfgsb_minimize", "bore_append_observations", "bore_select_best",
     "bore_svgd_optimize", "bore_engine_create", "bore_engine_run", "bore_engine_size", "bore_engine_observations",
     "bore_engine_state", "bore_engine_get_stats", "bore_engine_destroy",
@@ -140,6 +140,7 @@ def lib():
     dpp = C.POINTER(C.c_double)
     L.bore_uniform_candidates.argtypes = [u64, i64, i32, i64, i64, i32, dpp, dpp, vp, vp]
     L.bore_screen_topk.argtypes = [dp, i32, vp, vp, i64, i32, i32, vp, vp, vp, vp]
+    L.bore_sample_screen_topk.argtypes = [dp, i32, vp, u64, i64, i64, i64, dpp, dpp, i32, vp, vp, vp, vp]
     L.bore_lbfgsb_minimize.argtypes = [dp, i32, vp, i32, i32, vp, i32, dpp, dpp,
                                        C.POINTER(LbfgsbOpts), vp, vp, vp, vp, vp]
     L.bore_append_observations.argtypes = [i32, i32, vp, vp, i64, i64, vp, vp, vp, vp, vp]

@@ -139,6 +139,12 @@ struct ScreenArgs {
   long long n_samples;
   int x_shared, R, n_pad;
   int o_tile, o_keys, o_layout, total;  // float offsets (o_keys is 8-byte aligned)
+  // sampled != 0: no X in memory -- row i of model m IS row i of bore_uniform_candidates(seed,
+  // model0 + m, draw), recomputed from the counter stream where it is needed
+  int sampled, o_box;
+  unsigned long long seed;
+  long long model0, draw;
+  BoxArgs box;
 };
 
 // float -> unsigned that sorts like the float
@@ -169,7 +175,22 @@ __global__ __launch_bounds__(BORE_THREADS) void screen_topk_kernel(const ScreenA
   unsigned long long *keys = reinterpret_cast<unsigned long long *>(smem + a.o_keys);
   const int wv = tid >> 6, lane = tid & 63, m16 = lane & 15, q4 = lane >> 4;
   stage_theta<BF16>(L, n, a.theta + model * L.P, smem);
-  const double *X = a.X + (a.x_shared ? 0 : model * a.n_samples * D);
+  const double *X = a.sampled ? nullptr : a.X + (a.x_shared ? 0 : model * a.n_samples * D);
+  double *blo = reinterpret_cast<double *>(smem + a.o_box), *bhi = blo + D;
+  if (a.sampled && tid < D) {  // the box is indexed per lane: LDS copy
+    blo[tid] = a.box.lo[tid];
+    bhi[tid] = a.box.hi[tid];
+  }
+  const unsigned long long cbase = a.sampled ? candidate_base(a.seed, a.model0 + model, a.draw) : 0ULL;
+  auto xval = [&](long long row, int d) -> double {
+    if (a.sampled) {
+      const long long i = row * D + d;
+      const unsigned long long r = mix64(cbase + 0x8CB92BA72F3D8DD7ULL * (unsigned long long)(i + 1));
+      const double u = (double)(r >> 11) * (1.0 / 9007199254740992.0);
+      return blo[d] + (bhi[d] - blo[d]) * u;
+    }
+    return X[row * D + d];
+  };
   __syncthreads();
   // predictions -> sort keys: ascending key == descending prediction, ties to the lower row.
   // Every wave walks its own 16-row blocks of the candidates.
@@ -191,13 +212,13 @@ __global__ __launch_bounds__(BORE_THREADS) void screen_topk_kernel(const ScreenA
 #pragma unroll
         for (int kc = 0; kc < Net::KC0; ++kc) {
           const int d = 4 * kc + q4;
-          xin[kc] = (d < D && row < Ns) ? Net::rnd((float)X[(long long)row * D + d]) : 0.f;
+          xin[kc] = (d < D && row < Ns) ? Net::rnd((float)xval(row, d)) : 0.f;
         }
         net.forward(thw, xin, false);
         p = net.h[Net::n][0][0];
       } else {
         float *A0 = tile + L.aoff[0] + (wv * 16 + m16) * L.lda[0];
-        for (int d = q4; d < D; d += 4) A0[d] = row < Ns ? (float)X[(long long)row * D + d] : 0.f;
+        for (int d = q4; d < D; d += 4) A0[d] = row < Ns ? (float)xval(row, d) : 0.f;
         wave_lds_sync();
         fwd_all(L, n, th, tile, wv, false);
         p = tile[L.aoff[n] + (wv * 16 + (lane & 15)) * L.lda[n]];
@@ -261,14 +282,20 @@ __global__ __launch_bounds__(BORE_THREADS) void screen_topk_kernel(const ScreenA
   double *x0 = a.x0 + model * (long long)a.R * D;
   for (int i = tid; i < a.R * D; i += nthr) {
     const int r = i / D, d = i - r * D;
-    x0[i] = X[(long long)(unsigned)(picks[r] & 0xFFFFFFFFu) * D + d];
+    x0[i] = xval((long long)(unsigned)(picks[r] & 0xFFFFFFFFu), d);
   }
 }
 
-extern "C" int bore_screen_topk(const bore_mlp_desc *desc, int n_models, const float *theta,
-                                const double *X_init, int64_t n_samples, int x_shared,
-                                int num_starts, double *x0, int32_t *idx, float *pred,
-                                void *stream) {
+struct SampleSpec {
+  uint64_t seed;
+  int64_t model_index0, draw_index;
+  const double *low, *high;
+};
+
+static int screen_launch(const bore_mlp_desc *desc, int n_models, const float *theta,
+                         const double *X_init, const SampleSpec *spec, int64_t n_samples,
+                         int x_shared, int num_starts, double *x0, int32_t *idx, float *pred,
+                         void *stream) {
   ScreenArgs a;
   if (n_samples < 1 || n_samples > (1 << 20))
     return fail(BORE_E_INVALID, "screen_topk: n_samples out of range");
@@ -276,16 +303,30 @@ extern "C" int bore_screen_topk(const bore_mlp_desc *desc, int n_models, const f
     return fail(BORE_E_INVALID, "screen_topk: need 1 <= num_starts <= n_samples");
   int n_pad = 1;
   while (n_pad < n_samples) n_pad <<= 1;
-  const size_t key_floats = 2 * ((size_t)n_pad + 32) + 1 + BORE_LAYOUT_FLOATS + 4;
+  const size_t key_floats = 2 * ((size_t)n_pad + 32) + 1 + BORE_LAYOUT_FLOATS + 4 + 4 * BORE_DIM_MAX + 4;
   int rc = check_common(desc, n_models, 0, BORE_BATCH_MAX, true, key_floats, &a.L);
   if (rc) return rc;
   if (a.L.w[a.L.n_layers] != 1)
     return fail(BORE_E_INVALID, "screen_topk: the last Dense layer must have 1 unit");
-  if (!theta || !X_init || !x0 || !idx) return fail(BORE_E_INVALID, "screen_topk: null pointer");
+  if (!theta || (!X_init && !spec) || !x0 || !idx) return fail(BORE_E_INVALID, "screen_topk: null pointer");
   a.theta = theta; a.X = X_init; a.x0 = x0; a.idx = idx; a.pred = pred;
   a.n_samples = n_samples; a.x_shared = x_shared; a.R = num_starts; a.n_pad = n_pad;
+  a.sampled = spec != nullptr;
+  a.seed = 0; a.model0 = 0; a.draw = 0;
+  if (spec) {
+    const int D = desc->input_dim;
+    if (D > BORE_DIM_MAX) return fail(BORE_E_UNSUPPORTED, "sample_screen_topk: D must be 1..%d", BORE_DIM_MAX);
+    if (!spec->low || !spec->high) return fail(BORE_E_INVALID, "sample_screen_topk: null bounds");
+    a.seed = spec->seed; a.model0 = spec->model_index0; a.draw = spec->draw_index;
+    for (int d = 0; d < D; ++d) {
+      a.box.lo[d] = spec->low[d];
+      a.box.hi[d] = spec->high[d];
+    }
+  }
   size_t off = a.L.P_lds;
   a.o_tile = (int)off; off += a.L.tile_floats;
+  off = (off + 3) & ~(size_t)3;
+  a.o_box = (int)off; off += 4 * (size_t)desc->input_dim;
   off = (off + 1) & ~(size_t)1;
   a.o_keys = (int)off; off += 2 * ((size_t)n_pad + 32);
   a.total = (int)off;
@@ -330,6 +371,25 @@ extern "C" int bore_screen_topk(const bore_mlp_desc *desc, int n_models, const f
 #undef BORE_LAUNCH_SCREEN
   HIP_TRY(hipGetLastError());
   return 0;
+}
+
+extern "C" int bore_screen_topk(const bore_mlp_desc *desc, int n_models, const float *theta,
+                                const double *X_init, int64_t n_samples, int x_shared,
+                                int num_starts, double *x0, int32_t *idx, float *pred,
+                                void *stream) {
+  if (!X_init) return fail(BORE_E_INVALID, "screen_topk: null pointer");
+  return screen_launch(desc, n_models, theta, X_init, nullptr, n_samples, x_shared, num_starts, x0,
+                       idx, pred, stream);
+}
+
+extern "C" int bore_sample_screen_topk(const bore_mlp_desc *desc, int n_models, const float *theta,
+                                       uint64_t seed, int64_t model_index0, int64_t draw_index,
+                                       int64_t n_samples, const double *low, const double *high,
+                                       int num_starts, double *x0, int32_t *idx, float *pred,
+                                       void *stream) {
+  const SampleSpec spec{seed, model_index0, draw_index, low, high};
+  return screen_launch(desc, n_models, theta, nullptr, &spec, n_samples, 0, num_starts, x0, idx,
+                       pred, stream);
 }
 
 // ---------------------------------------------------------------------------

@@ -6,7 +6,7 @@
 // the suggestion comes from the host.  The loops of a GPU are split into GROUPS, each stepping on
 // its own HIP stream; per iteration a group costs
 //     H2D  (x_new, y_new)  [Lg][D+1] fp64        -- the record itself lives on the device
-//     7 launches: append, labels, fit, candidates, screen, lbfgsb, select
+//     6 launches: append, labels, fit, sample + screen, lbfgsb, select
 //     D2H  x_best [Lg][D], best [Lg], info [Lg][R][5]
 // and one host turnaround (objective callback).  What this file replaces is the Python statement
 // of the same loop (bore_amd/engine.py ReplicaEngine, kept as its check: trajectories are
@@ -70,7 +70,7 @@ struct Group {
   double *X_seen = nullptr, *y_seen = nullptr, *y_dense = nullptr;
   float *X32 = nullptr, *z = nullptr;
   double *new_x = nullptr, *new_y = nullptr;
-  double *Xc = nullptr, *x0 = nullptr, *x = nullptr, *jac = nullptr, *fun = nullptr, *x_best = nullptr;
+  double *x0 = nullptr, *x = nullptr, *jac = nullptr, *fun = nullptr, *x_best = nullptr;
   int32_t *idx = nullptr, *info = nullptr, *best = nullptr;
   // pinned host
   double *new_x_pin = nullptr, *new_y_pin = nullptr, *x_best_pin = nullptr;
@@ -164,12 +164,10 @@ int enqueue(bore_engine *e, Group &g) {
   const int64_t steps = (N + c.batch_size - 1) / c.batch_size;
   e->st.fit_bytes += (double)Lg * c.epochs * (4.0 * N * (D + 1) + steps * 24.0 * e->P);
   g.epochs_seen += c.epochs;
-  if ((rc = bore_uniform_candidates(c.seed, c.loop_id0 + g.a, Lg, g.draws, c.num_samples, D,
-                                    e->low.data(), e->high.data(), g.Xc, sp)))
+  if ((rc = bore_sample_screen_topk(&e->desc, Lg, th, c.seed, c.loop_id0 + g.a, g.draws, c.num_samples,
+                                    e->low.data(), e->high.data(), R, g.x0, g.idx, nullptr, sp)))
     return rc;
   ++g.draws;
-  if ((rc = bore_screen_topk(&e->desc, Lg, th, g.Xc, c.num_samples, 0, R, g.x0, g.idx, nullptr, sp)))
-    return rc;
   HIP_TRY(hipEventRecord(g.ev[2], g.stream));
   if ((rc = bore_lbfgsb_minimize(&e->desc, Lg, th, c.transform, 1, g.x0, R, e->low.data(),
                                  e->high.data(), &c.lbfgsb, g.x, g.fun, g.jac, g.info, sp)))
@@ -234,7 +232,7 @@ int finalize(bore_engine *e, Group &g) {
 }
 
 void free_group(Group &g) {
-  void *dev[] = {g.X_seen, g.y_seen, g.y_dense, g.X32, g.z, g.new_x, g.Xc, g.x0,
+  void *dev[] = {g.X_seen, g.y_seen, g.y_dense, g.X32, g.z, g.new_x, g.x0,
                  g.x, g.jac, g.fun, g.x_best, g.idx};
   for (void *p : dev)
     if (p) (void)hipFree(p);
@@ -334,7 +332,6 @@ extern "C" int bore_engine_create(const bore_mlp_desc *desc, const bore_engine_c
     g.n = n0;
     ENG_TRY(dev_alloc(&g.new_x, Lg * (D + 1)));  // new_x [Lg][D] | new_y [Lg]
     g.new_y = g.new_x + Lg * D;
-    ENG_TRY(dev_alloc(&g.Xc, Lg * (size_t)cfg->num_samples * D));
     ENG_TRY(dev_alloc(&g.x0, Lg * R * D));
     ENG_TRY(dev_alloc(&g.x, Lg * R * D));
     ENG_TRY(dev_alloc(&g.jac, Lg * R * D));

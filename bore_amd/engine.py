@@ -376,13 +376,20 @@ class ReplicaEngine:
             self.stats["fit_bytes"].append(Lg * self.epochs * (4 * N * (D + 1)
                                                                + steps * 24 * self.P))
             g.epochs_seen += self.epochs
-            _lib.check(lib.bore_uniform_candidates(C.c_uint64(self.seed), int(self.loop_ids[g.a]),
-                                                   Lg, g.draws, self.num_samples, D, self._lo_p,
-                                                   self._hi_p, ptr(g.Xc), sp))
+            if self.select == "device":     # candidates recomputed in the screening kernel
+                _lib.check(lib.bore_sample_screen_topk(
+                    C.byref(self.desc), Lg, ptr(th), C.c_uint64(self.seed), int(self.loop_ids[g.a]),
+                    g.draws, self.num_samples, self._lo_p, self._hi_p, R, ptr(g.x0), ptr(g.idx),
+                    None, sp))
+            else:                           # the two-launch statement of the same step
+                _lib.check(lib.bore_uniform_candidates(C.c_uint64(self.seed),
+                                                       int(self.loop_ids[g.a]), Lg, g.draws,
+                                                       self.num_samples, D, self._lo_p, self._hi_p,
+                                                       ptr(g.Xc), sp))
+                _lib.check(lib.bore_screen_topk(C.byref(self.desc), Lg, ptr(th), ptr(g.Xc),
+                                                self.num_samples, 0, R, ptr(g.x0), ptr(g.idx),
+                                                None, sp))
             g.draws += 1
-            _lib.check(lib.bore_screen_topk(C.byref(self.desc), Lg, ptr(th), ptr(g.Xc),
-                                            self.num_samples, 0, R, ptr(g.x0), ptr(g.idx), None,
-                                            sp))
             e2, e3 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e2.record()
             _lib.check(lib.bore_lbfgsb_minimize(C.byref(self.desc), Lg, ptr(th),

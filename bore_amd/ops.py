@@ -191,6 +191,26 @@ def screen_topk(desc, theta, X_init, num_starts, want_pred=False):
     return (x0, idx, pred) if want_pred else (x0, idx)
 
 
+def sample_screen_topk(desc, theta, seed, n_samples, low, high, num_starts, model_index0=0,
+                       draw_index=0, want_pred=False):
+    """``uniform_candidates`` + ``screen_topk`` in one launch; the candidates are never written to
+    memory (``bore_sample_screen_topk``).  Returns (x0 [L,R,D] f64, idx [L,R] int32[, pred])."""
+    L = theta.shape[0]
+    D = desc.input_dim
+    _chk(theta, torch.float32, (L, param_count(desc)), "theta")
+    lo, lo_p = _host_f64(low, D, "low")
+    hi, hi_p = _host_f64(high, D, "high")
+    R, Ns = int(num_starts), int(n_samples)
+    x0 = torch.empty((L, R, D), dtype=torch.float64, device=theta.device)
+    idx = torch.empty((L, R), dtype=torch.int32, device=theta.device)
+    pred = torch.empty((L, Ns), dtype=torch.float32, device=theta.device) if want_pred else None
+    _lib.check(_lib.lib().bore_sample_screen_topk(
+        C.byref(desc), L, _lib.ptr(theta), C.c_uint64(seed & (2**64 - 1)), int(model_index0),
+        int(draw_index), Ns, lo_p, hi_p, R, _lib.ptr(x0), _lib.ptr(idx), _lib.ptr(pred),
+        _lib.stream_ptr()))
+    return (x0, idx, pred) if want_pred else (x0, idx)
+
+
 def lbfgsb_minimize(desc, theta, x0, low, high, transform="identity", negate=True, maxcor=10,
                     ftol=2.2204460492503131e-09, gtol=1e-5, maxfun=15000, maxiter=15000,
                     maxls=20):

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define BORE_ABI_VERSION 5
+#define BORE_ABI_VERSION 6
 #define BORE_MAX_LAYERS 8
 #define BORE_BATCH_MAX 64 /* rows per tile == wavefront width */
 #define BORE_DIM_MAX 64   /* largest input dimension for the by-value bound arrays */
@@ -187,6 +187,18 @@ int bore_uniform_candidates(uint64_t seed, int64_t model_index0, int n_models, i
 int bore_screen_topk(const bore_mlp_desc *desc, int n_models, const float *theta,
                      const double *X_init, int64_t n_samples, int x_shared, int num_starts,
                      double *x0, int32_t *idx, float *pred, void *stream);
+
+/*
+ * bore_uniform_candidates + bore_screen_topk in one launch, without the candidates ever being
+ * written to memory: row i of model m is recomputed from the counter stream (seed,
+ * model_index0 + m, draw_index) where the forward pass and the final gather need it.  Same
+ * picks, bit for bit, as the two calls (tested); saves the [n_models][n_samples][D] fp64
+ * round trip through HBM (16 KB per model at 1024 x 2).
+ */
+int bore_sample_screen_topk(const bore_mlp_desc *desc, int n_models, const float *theta,
+                            uint64_t seed, int64_t model_index0, int64_t draw_index,
+                            int64_t n_samples, const double *low, const double *high,
+                            int num_starts, double *x0, int32_t *idx, float *pred, void *stream);
 
 /* scipy.optimize.minimize(method="L-BFGS-B") options as the reference passes them
  * (bore/mixins.py:23: maxiter=1000, ftol=1e-9; SciPy defaults for the rest). */

@@ -72,6 +72,24 @@ def test_screen_topk_selects_the_best_rows(gpu, Ns, R):
     assert np.array_equal(idxs.cpu().numpy()[0], idx[0])
 
 
+@pytest.mark.parametrize("D,units,Ns,R", [(2, [16, 16, 1], 1024, 3), (6, [32, 32, 1], 1000, 40),
+                                          (16, [64, 64, 64, 1], 1024, 1024), (3, [8, 24, 1], 77, 5)])
+def test_sample_screen_topk_equals_the_two_launches(gpu, D, units, Ns, R):
+    """bore_sample_screen_topk never writes the candidates: same picks and rows, bit for bit, as
+    bore_uniform_candidates followed by bore_screen_topk."""
+    rs = np.random.RandomState(D)
+    acts = ["relu"] * (len(units) - 1) + ["sigmoid"]
+    desc = _lib.make_desc(D, units, acts)
+    L = 3
+    th = dev(np.stack([pack(rand_model(rs, D, units)) for _ in range(L)]))
+    lo, hi = rs.uniform(-2, 0, size=D), rs.uniform(0.5, 3, size=D)
+    Xc = ops.uniform_candidates(91, L, Ns, lo, hi, model_index0=7, draw_index=4)
+    x0a, idxa, preda = ops.screen_topk(desc, th, Xc, R, want_pred=True)
+    x0b, idxb, predb = ops.sample_screen_topk(desc, th, 91, Ns, lo, hi, R, model_index0=7,
+                                              draw_index=4, want_pred=True)
+    assert torch.equal(idxa, idxb) and torch.equal(x0a, x0b) and torch.equal(preda, predb)
+
+
 CASES = [(2, [16, 16, 1], ["relu", "relu", "sigmoid"], "identity", 3),
          (6, [32, 32, 1], ["relu", "relu", "linear"], "sigmoid", 40),
          (3, [32, 32, 32, 1], ["elu"] * 3 + ["linear"], "exp", 9),
