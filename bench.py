@@ -130,6 +130,10 @@ def main():
     ap.add_argument("--engine", default="native", choices=["native", "python"],
                     help="host loop of the replica engine: native = bore_engine_* (C++), python = "
                          "bore_amd.engine.ReplicaEngine (the same trajectories, bit for bit)")
+    ap.add_argument("--schedule", default="groups", choices=["groups", "async"],
+                    help="native engine: groups = loop groups in lock-step on their own streams; "
+                         "async = every loop re-enters the next launch as soon as its own restarts "
+                         "are done (same trajectories)")
     ap.add_argument("--mode", default="device", choices=["device", "lockstep"],
                     help="device: L-BFGS-B restarts inside one kernel; lockstep: scipy on the host")
     args = ap.parse_args()
@@ -154,7 +158,7 @@ def main():
     loop_ids = shard_loop_ids(rank, world, args.loops)     # contiguous shard per rank
     native = args.engine == "native" and args.mode == "device"
     if native:
-        eng = NativeEngine(loop_ids, groups=args.groups)
+        eng = NativeEngine(loop_ids, groups=args.groups, async_loops=args.schedule == "async")
     else:
         eng = ReplicaEngine(loop_ids, mode=args.mode, groups=args.groups)
 
@@ -245,6 +249,7 @@ def main():
                                    "restarts from 1024 samples",
                        "loops_per_gpu": args.loops, "restarts": args.mode,
                        "host_loop": "native" if native else "python",
+                       "schedule": args.schedule if native else "groups",
                        "stream_groups": n_groups, "N_start": int(n_start),
                        "N_end": int(eng.N), "parallelism": f"replica-shard x{world}"},
             "roofline": dominant,

@@ -30,7 +30,7 @@ EXPORTS = [
     "bore_mlp_value_and_input_grad", "bore_mlp_fit", "bore_mlp_evaluate",
     "bore_shuffle_perm", "bore_labels", "bore_uniform_candidates", "bore_screen_topk", "bore_sample_screen_topk",
     "bore_lbfgsb_minimize", "bore_append_observations", "bore_select_best",
-    "bore_svgd_optimize", "bore_engine_create", "bore_engine_run", "bore_engine_size", "bore_engine_observations",
+    "bore_svgd_optimize", "bore_set_batch", "bore_engine_create", "bore_engine_run", "bore_engine_size", "bore_engine_observations",
     "bore_engine_state", "bore_engine_get_stats", "bore_engine_destroy",
 ]
 
@@ -62,7 +62,7 @@ class EngineCfg(C.Structure):
     _fields_ = [("n_loops", C.c_int32), ("groups", C.c_int32), ("loop_id0", C.c_int64),
                 ("n_init", C.c_int32), ("epochs", C.c_int32), ("batch_size", C.c_int32),
                 ("num_starts", C.c_int32), ("num_samples", C.c_int32), ("transform", C.c_int32),
-                ("deduplicate", C.c_int32), ("reserved", C.c_int32), ("seed", C.c_uint64),
+                ("deduplicate", C.c_int32), ("async_loops", C.c_int32), ("seed", C.c_uint64),
                 ("gamma", C.c_double), ("adam", AdamCfg), ("lbfgsb", LbfgsbOpts),
                 ("low", C.POINTER(C.c_double)), ("high", C.POINTER(C.c_double))]
 
@@ -157,10 +157,12 @@ def lib():
     L.bore_engine_destroy.argtypes = [vp]
     for name in EXPORTS:
         if name not in ("bore_last_error", "bore_param_count", "bore_engine_size",
-                        "bore_engine_destroy"):
+                        "bore_engine_destroy", "bore_set_batch"):
             getattr(L, name).restype = i32
     L.bore_engine_size.restype = i64
     L.bore_engine_destroy.restype = None
+    L.bore_set_batch.restype = None
+    L.bore_set_batch.argtypes = [vp]
     _lib = L
     return L
 

@@ -16,12 +16,23 @@ using namespace bore;
 // ---------------------------------------------------------------------------
 // labels: tau = np.quantile(y, gamma) (linear interpolation), z = y < tau
 // ---------------------------------------------------------------------------
+// (batch mode: slot -> loop ids[slot] with its own N = n_init + its[slot]; y and z `cap`-strided)
 __global__ __launch_bounds__(BORE_THREADS) void labels_kernel(const double *y, int N, double vi,
-                                                              float *z, double *tau_out) {
+                                                              float *z, double *tau_out,
+                                                              const int *ids, const int *its,
+                                                              int n_init, long long cap,
+                                                              double gamma) {
   extern __shared__ float smem[];
   double *ys = reinterpret_cast<double *>(smem);  // [N] + 2 (a, b)
-  const long long model = blockIdx.x;
-  const double *ym = y + model * (long long)N;
+  long long model = blockIdx.x;
+  long long stride = N;
+  if (ids) {
+    N = n_init + its[model];
+    model = ids[model];
+    stride = cap;
+    vi = (double)(N - 1) * gamma;  // numpy's virtual index for this slot's N
+  }
+  const double *ym = y + model * stride;
   for (int i = threadIdx.x; i < N; i += blockDim.x) ys[i] = ym[i];
   // numpy's _get_indexes: floor/ceil neighbours of the virtual index, clamped to the ends
   int lo, hi;
@@ -51,7 +62,7 @@ __global__ __launch_bounds__(BORE_THREADS) void labels_kernel(const double *y, i
   const double diff = b - a;
   double tau = a + diff * gam;
   if (gam >= 0.5) tau = b - diff * (1.0 - gam);
-  for (int i = threadIdx.x; i < N; i += blockDim.x) z[model * (long long)N + i] = ys[i] < tau ? 1.f : 0.f;
+  for (int i = threadIdx.x; i < N; i += blockDim.x) z[model * stride + i] = ys[i] < tau ? 1.f : 0.f;
   if (threadIdx.x == 0 && tau_out) tau_out[model] = tau;
 }
 
@@ -65,8 +76,11 @@ extern "C" int bore_labels(int n_models, const double *y, int64_t N, double gamm
   const size_t bytes = ((size_t)N + 2) * 8;
   int rc = allow_lds(labels_kernel, bytes);
   if (rc) return rc;
+  if (g_batch && tau) return fail(BORE_E_INVALID, "labels: no tau output in batch mode");
   hipLaunchKernelGGL(labels_kernel, dim3(n_models), dim3(BORE_THREADS), bytes, (hipStream_t)stream,
-                     y, (int)N, vi, z, tau);
+                     y, (int)N, vi, z, tau, g_batch ? g_batch->ids : nullptr,
+                     g_batch ? g_batch->its : nullptr, g_batch ? g_batch->n_init : 0,
+                     g_batch ? (long long)g_batch->cap : 0LL, gamma);
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -144,6 +158,7 @@ struct ScreenArgs {
   int sampled, o_box;
   unsigned long long seed;
   long long model0, draw;
+  const int *ids, *its;  // batch mode: theta and the stream of loop ids[slot], draw its[slot]
   BoxArgs box;
 };
 
@@ -168,20 +183,22 @@ __global__ __launch_bounds__(BORE_THREADS) void screen_topk_kernel(const ScreenA
   constexpr MlpLayout Lc = bore_static_layout(SHAPE > 0 ? SHAPE : 0, 0, BORE_BATCH_MAX);
   const MlpLayout &L = begin_kernel<SHAPE>(Lc, a.L, smem, a.total, a.o_layout);
   const int tid = threadIdx.x, nthr = blockDim.x;
-  const long long model = blockIdx.x;
+  const long long model = blockIdx.x;                        // output slot
+  const long long lid = a.ids ? a.ids[model] : model;        // whose weights and stream
   const int n = layer_count<SHAPE>(L), D = L.w[0];
   const int Ns = (int)a.n_samples;
   float *th = smem, *tile = smem + a.o_tile;
   unsigned long long *keys = reinterpret_cast<unsigned long long *>(smem + a.o_keys);
   const int wv = tid >> 6, lane = tid & 63, m16 = lane & 15, q4 = lane >> 4;
-  stage_theta<BF16>(L, n, a.theta + model * L.P, smem);
+  stage_theta<BF16>(L, n, a.theta + lid * L.P, smem);
   const double *X = a.sampled ? nullptr : a.X + (a.x_shared ? 0 : model * a.n_samples * D);
   double *blo = reinterpret_cast<double *>(smem + a.o_box), *bhi = blo + D;
   if (a.sampled && tid < D) {  // the box is indexed per lane: LDS copy
     blo[tid] = a.box.lo[tid];
     bhi[tid] = a.box.hi[tid];
   }
-  const unsigned long long cbase = a.sampled ? candidate_base(a.seed, a.model0 + model, a.draw) : 0ULL;
+  const unsigned long long cbase =
+      a.sampled ? candidate_base(a.seed, a.model0 + lid, a.ids ? (long long)a.its[model] : a.draw) : 0ULL;
   auto xval = [&](long long row, int d) -> double {
     if (a.sampled) {
       const long long i = row * D + d;
@@ -313,6 +330,11 @@ static int screen_launch(const bore_mlp_desc *desc, int n_models, const float *t
   a.n_samples = n_samples; a.x_shared = x_shared; a.R = num_starts; a.n_pad = n_pad;
   a.sampled = spec != nullptr;
   a.seed = 0; a.model0 = 0; a.draw = 0;
+  a.ids = a.its = nullptr;
+  if (g_batch) {
+    if (!spec) return fail(BORE_E_INVALID, "screen_topk: batch mode needs the sampled form");
+    a.ids = g_batch->ids; a.its = g_batch->its;
+  }
   if (spec) {
     const int D = desc->input_dim;
     if (D > BORE_DIM_MAX) return fail(BORE_E_UNSUPPORTED, "sample_screen_topk: D must be 1..%d", BORE_DIM_MAX);
@@ -414,6 +436,14 @@ struct LbfgsbArgs {
   float sign;
   // LDS carve (float offsets; the fp64 regions are 8-byte aligned)
   int o_tile, o_vals, o_box, o_prob, prob_floats, o_state, o_dw, o_iw, o_layout, total;
+  // batch mode (bore_set_batch): weights of loop ids[slot]; each loop's pick is published to the
+  // host as soon as ITS restarts are done (one workgroup per loop: R <= 4)
+  const int *ids, *its;
+  int n_init, dedup, o_res;
+  long long cap;
+  const double *X_seen;
+  double *result;
+  int *flag;
 };
 
 // -DBORE_STAMPS: cycles spent in the optimiser / in f-g evaluation by wave 0 of workgroup 0
@@ -447,7 +477,8 @@ __global__ __launch_bounds__(BORE_THREADS) void lbfgsb_kernel(const LbfgsbArgs a
   const MlpLayout &L = begin_kernel<SHAPE>(Lc, a.L, smem, a.total, a.o_layout);
   const int tid = threadIdx.x;
   const int wv = tid >> 6, lane = tid & 63;
-  const long long model = blockIdx.x;
+  const long long model = blockIdx.x;               // slot: indexes x0 / x / fun / jac / info
+  const long long lid = a.ids ? a.ids[model] : model;  // whose weights (and record, and result)
   const int n_lay = layer_count<SHAPE>(L), D = L.w[0];
   const int p0 = blockIdx.y * a.PB;               // first problem of this workgroup
   const int np = min(a.PB, a.R - p0);             // problems here (>= 1 by grid construction)
@@ -460,7 +491,7 @@ __global__ __launch_bounds__(BORE_THREADS) void lbfgsb_kernel(const LbfgsbArgs a
     bhi[tid] = a.box.hi[tid];
     bnbd[tid] = a.nbd[tid];
   }
-  stage_theta<BF16>(L, n_lay, a.theta + model * L.P, smem);
+  stage_theta<BF16>(L, n_lay, a.theta + lid * L.P, smem);
   __syncthreads();
 
   // Which problem this thread works on.  With at most one problem per wave (np <= 4: the
@@ -577,14 +608,13 @@ __global__ __launch_bounds__(BORE_THREADS) void lbfgsb_kernel(const LbfgsbArgs a
   }
 #endif
 
-  if (coop && lane != 0) return;  // one lane reports the shared problem
-  if (myp >= 0) {
+  if (myp >= 0 && st.stage != lbfgsb::S_FINISHED) {  // round cap hit (cannot happen with a sane cap)
+    st.status = 2;
+    st.task = lbfgsb::T_STOP;
+    st.msg = lbfgsb::M_MAXFUN;
+  }
+  if (myp >= 0 && (!coop || lane == 0)) {  // (coop: one lane reports the shared problem)
     const long long q = model * a.R + p0 + myp;
-    if (st.stage != lbfgsb::S_FINISHED) {  // round cap hit (cannot happen with a sane cap)
-      st.status = 2;
-      st.task = lbfgsb::T_STOP;
-      st.msg = lbfgsb::M_MAXFUN;
-    }
     for (int d = 0; d < D; ++d) {
       a.x[q * D + d] = wk.x[d];
       a.jac[q * D + d] = wk.g[d];
@@ -592,6 +622,62 @@ __global__ __launch_bounds__(BORE_THREADS) void lbfgsb_kernel(const LbfgsbArgs a
     a.fun[q] = st.f;
     int *inf = a.info + q * 5;
     inf[0] = st.nit; inf[1] = st.nfev; inf[2] = st.status; inf[3] = st.task; inf[4] = st.msg;
+  }
+  if (!a.result) return;
+  // ---- batch mode: the loop's pick (bore_select_best's rule), published by whichever of its
+  // waves finishes last, while other loops of the launch are still optimising ----
+  double *res = reinterpret_cast<double *>(smem + a.o_res);  // [np][D + 3]: fun, status, nfev, x
+  int *cnt = reinterpret_cast<int *>(res + 4 * (D + 3));
+  if (lane == 0) {
+    double *r = res + wv * (D + 3);
+    r[0] = st.f;
+    r[1] = (double)st.status;
+    r[2] = (double)st.nfev;
+    for (int d = 0; d < D; ++d) r[3 + d] = wk.x[d];
+  }
+  wave_lds_sync();
+  int last = 0;
+  if (lane == 0) last = atomicAdd(cnt, 1) == np - 1;
+  last = __shfl(last, 0, 64);
+  if (!last) return;
+  wave_lds_sync();
+  const int N = a.n_init + a.its[model];
+  const double *Xs = a.dedup ? a.X_seen + lid * a.cap * D : nullptr;
+  int best = -1;
+  double best_fun = 0.0, nfev_sum = 0.0, nfev_max = 0.0;
+  for (int r = 0; r < np; ++r) {
+    const double *rr = res + r * (D + 3);
+    nfev_sum += rr[2];
+    nfev_max = fmax(nfev_max, rr[2]);
+    const int status = (int)rr[1];
+    if (status != 0 && status != 1) continue;  // res.success or res.status == 1
+    bool dup = false;
+    if (a.dedup) {  // any(np.allclose(x_prev, x) for x_prev in record): rows dealt to lanes
+      bool mine = false;
+      for (int i = lane; i < N && !mine; i += 64) {
+        bool close = true;
+        for (int d = 0; d < D && close; ++d) {
+          const double b = rr[3 + d];
+          close = fabs(Xs[(long long)i * D + d] - b) <= 1e-8 + 1e-5 * fabs(b);
+        }
+        mine = close;
+      }
+      dup = __any(mine) != 0;
+    }
+    if (dup) continue;
+    if (best < 0 || rr[0] < best_fun) {
+      best = r;
+      best_fun = rr[0];
+    }
+  }
+  if (lane == 0) {
+    double *out = a.result + lid * (D + 3);
+    for (int d = 0; d < D; ++d) out[d] = best >= 0 ? res[best * (D + 3) + 3 + d] : 0.0;
+    out[D] = (double)best;
+    out[D + 1] = nfev_sum;
+    out[D + 2] = nfev_max;
+    __threadfence_system();
+    __hip_atomic_store(a.flag + lid, a.its[model] + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 
@@ -664,6 +750,8 @@ extern "C" int bore_lbfgsb_minimize(const bore_mlp_desc *desc, int n_models, con
     a.o_box = (int)off; off += 4 * (size_t)D + (((size_t)D + 3) & ~(size_t)3) + (D & 1 ? 2 : 0);
     off = (off + 3) & ~(size_t)3;
     a.o_prob = (int)off; off += (size_t)a.prob_floats * PB;
+    off = (off + 3) & ~(size_t)3;
+    a.o_res = (int)off; off += g_batch ? 2 * 4 * ((size_t)D + 3) + 4 : 0;
     a.total = (int)off;
     off = (off + 3) & ~(size_t)3;
     a.o_layout = (int)off; off += BORE_LAYOUT_FLOATS;
@@ -674,6 +762,18 @@ extern "C" int bore_lbfgsb_minimize(const bore_mlp_desc *desc, int n_models, con
     return fail(BORE_E_INVALID, "lbfgsb_minimize: the last Dense layer must have 1 unit");
   a.theta = theta; a.x0 = x0; a.x = x; a.fun = fun; a.jac = jac; a.info = info;
   a.R = num_starts; a.transform = transform; a.sign = negate ? -1.f : 1.f;
+  a.ids = a.its = nullptr; a.n_init = a.dedup = 0; a.cap = 0;
+  a.X_seen = nullptr; a.result = nullptr; a.flag = nullptr;
+  if (g_batch) {
+    if (num_starts > 4 || PB < num_starts)
+      return fail(BORE_E_UNSUPPORTED, "lbfgsb_minimize: batch mode needs num_starts <= 4 in one workgroup");
+    if (!g_batch->ids || !g_batch->its || !g_batch->result || !g_batch->flag ||
+        (g_batch->deduplicate && !g_batch->X_seen))
+      return fail(BORE_E_INVALID, "lbfgsb_minimize: incomplete bore_batch");
+    a.ids = g_batch->ids; a.its = g_batch->its; a.n_init = g_batch->n_init;
+    a.dedup = g_batch->deduplicate; a.cap = g_batch->cap; a.X_seen = g_batch->X_seen;
+    a.result = g_batch->result; a.flag = g_batch->flag;
+  }
   long long cap = (long long)opts->maxfun + opts->maxls + 64;
   a.max_rounds = (int)(cap > (1 << 24) ? (1 << 24) : cap);
   int rc = 0;
@@ -727,8 +827,21 @@ __global__ __launch_bounds__(BORE_THREADS) void append_kernel(int D, double *X_s
                                                               long long n_seen, long long cap,
                                                               const double *x_new,
                                                               const double *y_new, float *X32,
-                                                              double *y_dense) {
+                                                              double *y_dense, const int *ids,
+                                                              const int *its, int n_init) {
   const long long model = blockIdx.x;
+  if (ids) {  // batch mode: row N - 1 of loop ids[slot] into the three cap-strided buffers
+    const int it = its[model];
+    if (it <= 0) return;  // nothing new before the first iteration
+    const long long lid = ids[model], row = n_init + it - 1;
+    for (int d = threadIdx.x; d < D; d += blockDim.x) {
+      const double v = x_new[model * D + d];
+      X_seen[(lid * cap + row) * D + d] = v;
+      X32[(lid * cap + row) * D + d] = (float)v;
+    }
+    if (threadIdx.x == 0) y_seen[lid * cap + row] = y_new[model];
+    return;
+  }
   double *Xs = X_seen + model * cap * D, *ys = y_seen + model * cap;
   if (x_new) {  // row n_seen of the store; the same threads read it back below
     for (int d = threadIdx.x; d < D; d += blockDim.x) Xs[n_seen * D + d] = x_new[model * D + d];
@@ -746,6 +859,15 @@ extern "C" int bore_append_observations(int n_models, int D, double *X_seen, dou
                                         int64_t n_seen, int64_t cap, const double *x_new,
                                         const double *y_new, float *X32, double *y_dense,
                                         void *stream) {
+  if (g_batch) {
+    if (n_models < 1 || D < 1 || !X_seen || !y_seen || !X32 || !x_new || !y_new)
+      return fail(BORE_E_INVALID, "append_observations: bad argument");
+    hipLaunchKernelGGL(append_kernel, dim3(n_models), dim3(64), 0, (hipStream_t)stream, D, X_seen,
+                       y_seen, 0LL, (long long)g_batch->cap, x_new, y_new, X32, y_dense,
+                       g_batch->ids, g_batch->its, g_batch->n_init);
+    HIP_TRY(hipGetLastError());
+    return 0;
+  }
   if (n_models < 1 || D < 1 || !X_seen || !y_seen || !X32 || !y_dense)
     return fail(BORE_E_INVALID, "append_observations: bad argument");
   if ((x_new == nullptr) != (y_new == nullptr))
@@ -754,7 +876,8 @@ extern "C" int bore_append_observations(int n_models, int D, double *X_seen, dou
     return fail(BORE_E_INVALID, "append_observations: %lld rows (+%d) do not fit cap %lld",
                 (long long)n_seen, x_new ? 1 : 0, (long long)cap);
   hipLaunchKernelGGL(append_kernel, dim3(n_models), dim3(BORE_THREADS), 0, (hipStream_t)stream, D,
-                     X_seen, y_seen, (long long)n_seen, (long long)cap, x_new, y_new, X32, y_dense);
+                     X_seen, y_seen, (long long)n_seen, (long long)cap, x_new, y_new, X32, y_dense,
+                     (const int *)nullptr, (const int *)nullptr, 0);
   HIP_TRY(hipGetLastError());
   return 0;
 }

@@ -17,6 +17,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -77,6 +78,42 @@ struct Group {
   int32_t *best_pin = nullptr, *info_pin = nullptr;
 };
 
+// ---- asynchronous mode: loops advance individually (include/bore_hip.h: bore_batch) --------------
+// A WORKER is a stream that runs one launch chain (append, labels, fit, sample + screen, restarts
+// + pick) over whatever loops are ready when it becomes free.  A loop's result reaches the host
+// through its flag the moment ITS restarts are done -- the chain may still be busy with slower
+// loops -- so the loop joins the next free worker's batch instead of waiting for them.
+struct Worker {
+  hipStream_t stream = nullptr;
+  hipEvent_t done = nullptr, ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  bool busy = false;
+  int n = 0;  // slots of the launch in flight
+  // staging: ids [L] | its [L] (int32) then x_new [L][D] | y_new [L] (fp64), host and device
+  int32_t *h_int = nullptr, *d_int = nullptr;
+  double *h_dbl = nullptr, *d_dbl = nullptr;
+  // per-slot outputs of the launch (device)
+  double *x0 = nullptr, *x = nullptr, *jac = nullptr, *fun = nullptr;
+  int32_t *idx = nullptr, *info = nullptr;
+  double fit_bytes = 0;
+};
+
+struct Async {
+  int64_t cap = 0;
+  double *X_seen = nullptr, *y_seen = nullptr;   // device [L][cap][D], [L][cap]
+  float *X32 = nullptr, *z = nullptr;            // device [L][cap][D], [L][cap]
+  double *result = nullptr;                      // pinned [L][D + 3]
+  int32_t *flag = nullptr;                       // pinned [L]
+  std::vector<int32_t> it, target, state;        // per loop: iterations done; 0 ready 1 in flight 2 done
+  std::vector<double> x_new, y_new, ready_since; // per loop: the row to append at its next launch
+  std::vector<Worker> workers;
+  std::vector<int> scratch_ids;
+  std::vector<double> cb_x, cb_y;
+  // diagnostics (BORE_ASYNC_DEBUG): waits between a loop's states
+  std::vector<double> launched_at;
+  double sum_wait = 0, sum_flight = 0;
+  long long n_wait = 0, n_batches = 0, n_slots = 0;
+};
+
 }  // namespace
 
 struct bore_engine {
@@ -92,6 +129,7 @@ struct bore_engine {
   std::vector<Group> groups;
   bore_engine_stats st;
   std::vector<double> y_tmp;
+  Async *as = nullptr;  // asynchronous mode (cfg.async_loops)
 };
 
 namespace {
@@ -245,11 +283,295 @@ void free_group(Group &g) {
   if (g.stream) (void)hipStreamDestroy(g.stream);
 }
 
+// (Re)allocate the per-loop record buffers of the asynchronous mode for `cap` rows.
+int async_alloc(bore_engine *e, int64_t cap) {
+  Async &A = *e->as;
+  const size_t L = e->cfg.n_loops, D = e->D;
+  double *X = nullptr, *y = nullptr;
+  float *X32 = nullptr, *z = nullptr;
+  int rc;
+  if ((rc = dev_alloc(&X, L * cap * D)) || (rc = dev_alloc(&y, L * cap)) ||
+      (rc = dev_alloc(&X32, L * cap * D)) || (rc = dev_alloc(&z, L * cap)))
+    return rc;
+  if (A.X_seen) {
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy2D(X, cap * D * 8, A.X_seen, A.cap * D * 8, A.cap * D * 8, L, hipMemcpyDeviceToDevice));
+    HIP_TRY(hipMemcpy2D(y, cap * 8, A.y_seen, A.cap * 8, A.cap * 8, L, hipMemcpyDeviceToDevice));
+    HIP_TRY(hipMemcpy2D(X32, cap * D * 4, A.X32, A.cap * D * 4, A.cap * D * 4, L, hipMemcpyDeviceToDevice));
+    (void)hipFree(A.X_seen); (void)hipFree(A.y_seen); (void)hipFree(A.X32); (void)hipFree(A.z);
+  }
+  A.X_seen = X; A.y_seen = y; A.X32 = X32; A.z = z;
+  A.cap = cap;
+  return 0;
+}
+
+int async_create(bore_engine *e, const double *X0, const double *y0) {
+  const size_t L = e->cfg.n_loops, D = e->D, R = e->cfg.num_starts, n0 = e->cfg.n_init;
+  if (R > 4) return fail(BORE_E_UNSUPPORTED, "engine_create: async_loops needs num_starts <= 4");
+  e->as = new (std::nothrow) Async();
+  if (!e->as) return fail(BORE_E_HIP, "engine_create: out of memory");
+  Async &A = *e->as;
+  int rc;
+  if ((rc = async_alloc(e, n0 * 2 > 256 ? n0 * 2 : 256))) return rc;
+  std::vector<float> x32(L * n0 * D);
+  for (size_t i = 0; i < x32.size(); ++i) x32[i] = (float)X0[i];
+  HIP_TRY(hipMemcpy2D(A.X_seen, A.cap * D * 8, X0, n0 * D * 8, n0 * D * 8, L, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy2D(A.y_seen, A.cap * 8, y0, n0 * 8, n0 * 8, L, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy2D(A.X32, A.cap * D * 4, x32.data(), n0 * D * 4, n0 * D * 4, L, hipMemcpyHostToDevice));
+  if ((rc = pin_alloc(&A.result, L * (D + 3))) || (rc = pin_alloc(&A.flag, L))) return rc;
+  std::memset(A.flag, 0, L * 4);
+  A.it.assign(L, 0); A.target.assign(L, 0); A.state.assign(L, 2);
+  A.x_new.assign(L * D, 0.0); A.y_new.assign(L, 0.0); A.ready_since.assign(L, 0.0);
+  A.scratch_ids.reserve(L); A.cb_x.resize(L * D); A.cb_y.resize(L);
+  A.launched_at.assign(L, 0.0);
+  A.workers.resize(getenv("BORE_ASYNC_WORKERS") ? atoi(getenv("BORE_ASYNC_WORKERS")) : 4);
+  for (Worker &w : A.workers) {
+    HIP_TRY(hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&w.done, hipEventDisableTiming));
+    for (hipEvent_t &ev : w.ev) HIP_TRY(hipEventCreate(&ev));
+    if ((rc = pin_alloc(&w.h_int, 2 * L)) || (rc = dev_alloc(&w.d_int, 2 * L)) ||
+        (rc = pin_alloc(&w.h_dbl, L * (D + 1))) || (rc = dev_alloc(&w.d_dbl, L * (D + 1))) ||
+        (rc = dev_alloc(&w.x0, L * R * D)) || (rc = dev_alloc(&w.x, L * R * D)) ||
+        (rc = dev_alloc(&w.jac, L * R * D)) || (rc = dev_alloc(&w.fun, L * R)) ||
+        (rc = dev_alloc(&w.idx, L * R)) || (rc = dev_alloc(&w.info, L * R * 5)))
+      return rc;
+  }
+  return 0;
+}
+
+void async_destroy(bore_engine *e) {
+  if (!e->as) return;
+  Async &A = *e->as;
+  for (Worker &w : A.workers) {
+    void *dev[] = {w.d_int, w.d_dbl, w.x0, w.x, w.jac, w.fun, w.idx, w.info};
+    for (void *p : dev)
+      if (p) (void)hipFree(p);
+    if (w.h_int) (void)hipHostFree(w.h_int);
+    if (w.h_dbl) (void)hipHostFree(w.h_dbl);
+    if (w.done) (void)hipEventDestroy(w.done);
+    for (hipEvent_t ev : w.ev)
+      if (ev) (void)hipEventDestroy(ev);
+    if (w.stream) (void)hipStreamDestroy(w.stream);
+  }
+  void *dev[] = {A.X_seen, A.y_seen, A.X32, A.z};
+  for (void *p : dev)
+    if (p) (void)hipFree(p);
+  if (A.result) (void)hipHostFree(A.result);
+  if (A.flag) (void)hipHostFree(A.flag);
+  delete e->as;
+  e->as = nullptr;
+}
+
+// One launch chain of worker w over the loops listed in A.scratch_ids.
+int async_launch(bore_engine *e, Worker &w) {
+  const double t0 = now_s();
+  Async &A = *e->as;
+  const bore_engine_cfg &c = e->cfg;
+  const int L = c.n_loops, D = e->D, R = c.num_starts, B = (int)A.scratch_ids.size();
+  int max_it = 0;
+  double *hx = w.h_dbl, *hy = w.h_dbl + (size_t)L * D;
+  w.fit_bytes = 0;
+  for (int b = 0; b < B; ++b) {
+    const int l = A.scratch_ids[b], it = A.it[l];
+    w.h_int[b] = l;
+    w.h_int[L + b] = it;
+    std::memcpy(hx + (size_t)b * D, &A.x_new[(size_t)l * D], (size_t)D * 8);
+    hy[b] = A.y_new[l];
+    max_it = it > max_it ? it : max_it;
+    A.state[l] = 1;
+    A.launched_at[l] = t0;
+    A.sum_wait += t0 - A.ready_since[l];
+    ++A.n_wait;
+    const double N = c.n_init + it, steps = std::ceil(N / c.batch_size);
+    w.fit_bytes += c.epochs * (4.0 * N * (D + 1) + steps * 24.0 * e->P);
+  }
+  HIP_TRY(hipMemcpyAsync(w.d_int, w.h_int, (size_t)2 * L * 4, hipMemcpyHostToDevice, w.stream));
+  HIP_TRY(hipMemcpyAsync(w.d_dbl, w.h_dbl, (size_t)L * (D + 1) * 8, hipMemcpyHostToDevice, w.stream));
+  const int64_t N_max = c.n_init + max_it;
+  bore_batch bt;
+  bt.ids = w.d_int; bt.its = w.d_int + L; bt.n_init = c.n_init; bt.deduplicate = c.deduplicate;
+  bt.cap = A.cap; bt.X_seen = A.X_seen; bt.result = A.result; bt.flag = A.flag;
+  bore_set_batch(&bt);
+  void *sp = w.stream;
+  int rc = bore_append_observations(B, D, A.X_seen, A.y_seen, 0, A.cap, w.d_dbl,
+                                    w.d_dbl + (size_t)L * D, A.X32, nullptr, sp);
+  if (!rc) rc = bore_labels(B, A.y_seen, N_max, c.gamma, A.z, nullptr, sp);
+  if (!rc && hipEventRecord(w.ev[0], w.stream) != hipSuccess) rc = fail(BORE_E_HIP, "hipEventRecord");
+  if (!rc)
+    rc = bore_mlp_fit(&e->desc, B, e->theta, e->adam_m, e->adam_v, e->adam_t, A.X32, A.z, N_max,
+                      c.epochs, c.batch_size, nullptr, c.seed, c.loop_id0, 0, &c.adam, nullptr, sp);
+  if (!rc && hipEventRecord(w.ev[1], w.stream) != hipSuccess) rc = fail(BORE_E_HIP, "hipEventRecord");
+  if (!rc)
+    rc = bore_sample_screen_topk(&e->desc, B, e->theta, c.seed, c.loop_id0, 0, c.num_samples,
+                                 e->low.data(), e->high.data(), R, w.x0, w.idx, nullptr, sp);
+  if (!rc && hipEventRecord(w.ev[2], w.stream) != hipSuccess) rc = fail(BORE_E_HIP, "hipEventRecord");
+  if (!rc)
+    rc = bore_lbfgsb_minimize(&e->desc, B, e->theta, c.transform, 1, w.x0, R, e->low.data(),
+                              e->high.data(), &c.lbfgsb, w.x, w.fun, w.jac, w.info, sp);
+  if (!rc && hipEventRecord(w.ev[3], w.stream) != hipSuccess) rc = fail(BORE_E_HIP, "hipEventRecord");
+  if (!rc && hipEventRecord(w.done, w.stream) != hipSuccess) rc = fail(BORE_E_HIP, "hipEventRecord");
+  bore_set_batch(nullptr);
+  if (rc) return rc;
+  w.busy = true;
+  w.n = B;
+  ++A.n_batches;
+  A.n_slots += B;
+  e->st.host_enqueue_s += now_s() - t0;
+  return 0;
+}
+
+int async_drain(bore_engine *e) {
+  for (Worker &w : e->as->workers) {
+    (void)hipStreamSynchronize(w.stream);
+    w.busy = false;
+  }
+  return 0;
+}
+
+int async_run(bore_engine *e, int n_steps) {
+  Async &A = *e->as;
+  const bore_engine_cfg &c = e->cfg;
+  const int L = c.n_loops, D = e->D;
+  int max_it = 0;
+  for (int l = 0; l < L; ++l) max_it = A.it[l] > max_it ? A.it[l] : max_it;
+  int rc;
+  if (c.n_init + max_it + n_steps > A.cap) {
+    int64_t cap = A.cap;
+    while (cap < c.n_init + max_it + n_steps) cap *= 2;
+    if ((rc = async_alloc(e, cap))) return rc;
+  }
+  const double start = now_s();
+  int remaining = L;
+  for (int l = 0; l < L; ++l) {
+    A.target[l] = A.it[l] + n_steps;
+    A.state[l] = 0;
+    A.ready_since[l] = start;
+  }
+  // launch policy: a free worker takes the ready loops once there are `min_batch` of them or the
+  // oldest has waited `max_wait` (or nothing else is running)
+  const int min_batch = getenv("BORE_ASYNC_MIN") ? atoi(getenv("BORE_ASYNC_MIN")) : (L >= 16 ? L / 8 : 1);
+  const double max_wait = getenv("BORE_ASYNC_WAIT_US") ? 1e-6 * atof(getenv("BORE_ASYNC_WAIT_US")) : 150e-6;
+  double last_progress = start;
+  while (remaining) {
+    // 1. loops whose result has arrived
+    const double t0 = now_s();
+    int n_done = 0;
+    for (int l = 0; l < L; ++l) {
+      if (A.state[l] != 1) continue;
+      if (__atomic_load_n(&A.flag[l], __ATOMIC_ACQUIRE) != A.it[l] + 1) continue;
+      const double *r = A.result + (size_t)l * (D + 3);
+      double *xn = &A.cb_x[(size_t)n_done * D];
+      A.sum_flight += t0 - A.launched_at[l];
+      if (r[D] < 0.0) {  // reference: fall back to a random point of this loop's stream
+        ++e->st.none_results;
+        Mt19937 &rs = e->rs[l];
+        for (int d = 0; d < D; ++d) xn[d] = e->low[d] + (e->high[d] - e->low[d]) * rs.next_double();
+      } else {
+        std::memcpy(xn, r, (size_t)D * 8);
+      }
+      e->st.n_fg_rows += (int64_t)r[D + 1];
+      e->st.n_rounds += (int64_t)r[D + 2];
+      e->st.argmax_bytes += r[D + 1] * 4.0 * (2 * D + 1) + r[D + 2] * 4.0 * e->P;
+      A.scratch_ids.resize(n_done + 1);
+      A.scratch_ids[n_done++] = l;
+    }
+    if (n_done) {
+      if (e->objective(A.cb_x.data(), n_done, D, A.cb_y.data(), e->user)) {
+        async_drain(e);
+        for (int l = 0; l < L; ++l) A.state[l] = 2;
+        return fail(BORE_E_CALLBACK, "engine_run: the objective callback failed");
+      }
+      const double now = now_s();
+      for (int k = 0; k < n_done; ++k) {
+        const int l = A.scratch_ids[k];
+        std::memcpy(&A.x_new[(size_t)l * D], &A.cb_x[(size_t)k * D], (size_t)D * 8);
+        A.y_new[l] = A.cb_y[k];
+        ++A.it[l];
+        if (A.it[l] >= A.target[l]) {
+          A.state[l] = 2;
+          --remaining;
+        } else {
+          A.state[l] = 0;
+          A.ready_since[l] = now;
+        }
+      }
+      last_progress = now;
+      e->st.host_finalize_s += now - t0;
+    }
+    // 2. workers that have finished their chain
+    int busy = 0;
+    for (Worker &w : A.workers) {
+      if (!w.busy) continue;
+      const hipError_t q = hipEventQuery(w.done);
+      if (q == hipErrorNotReady) {
+        ++busy;
+        continue;
+      }
+      if (q != hipSuccess) return fail(BORE_E_HIP, "engine_run: %s", hipGetErrorString(q));
+      float ms = 0.f;
+      HIP_TRY(hipEventElapsedTime(&ms, w.ev[0], w.ev[1]));
+      e->st.fit_ms += ms;
+      e->st.fit_launches += 1;
+      e->st.fit_bytes += w.fit_bytes;
+      HIP_TRY(hipEventElapsedTime(&ms, w.ev[2], w.ev[3]));
+      e->st.argmax_ms += ms;
+      e->st.argmax_launches += 1;
+      w.busy = false;
+    }
+    // 3. a free worker takes the ready loops
+    if (busy < (int)A.workers.size()) {
+      A.scratch_ids.clear();
+      double oldest = 1e300;
+      for (int l = 0; l < L; ++l)
+        if (A.state[l] == 0) {
+          A.scratch_ids.push_back(l);
+          oldest = A.ready_since[l] < oldest ? A.ready_since[l] : oldest;
+        }
+      const int nr = (int)A.scratch_ids.size();
+      if (nr && (nr >= min_batch || busy == 0 || now_s() - oldest >= max_wait)) {
+        for (Worker &w : A.workers)
+          if (!w.busy) {
+            if ((rc = async_launch(e, w))) {
+              async_drain(e);
+              return rc;
+            }
+            break;
+          }
+        last_progress = now_s();
+      }
+    }
+    if (now_s() - last_progress > 30.0) {
+      async_drain(e);
+      return fail(BORE_E_HIP, "engine_run: no loop finished for 30 s");
+    }
+  }
+  if (getenv("BORE_ASYNC_DEBUG"))
+    fprintf(stderr, "[async] %lld batches, %.1f loops/batch; ready->launch %.0f us, launch->result %.0f us (means)\n",
+            A.n_batches, (double)A.n_slots / (double)(A.n_batches ? A.n_batches : 1),
+            1e6 * A.sum_wait / (double)(A.n_wait ? A.n_wait : 1), 1e6 * A.sum_flight / (double)(A.n_wait ? A.n_wait : 1));
+  // let the chains run out (their loops are done; the streams may still hold the slowest ones)
+  for (Worker &w : A.workers)
+    if (w.busy) {
+      HIP_TRY(hipStreamSynchronize(w.stream));
+      float ms = 0.f;
+      HIP_TRY(hipEventElapsedTime(&ms, w.ev[0], w.ev[1]));
+      e->st.fit_ms += ms;
+      e->st.fit_launches += 1;
+      e->st.fit_bytes += w.fit_bytes;
+      HIP_TRY(hipEventElapsedTime(&ms, w.ev[2], w.ev[3]));
+      e->st.argmax_ms += ms;
+      e->st.argmax_launches += 1;
+      w.busy = false;
+    }
+  return 0;
+}
+
 }  // namespace
 
 extern "C" void bore_engine_destroy(bore_engine *e) {
   if (!e) return;
   (void)hipDeviceSynchronize();
+  async_destroy(e);
   for (Group &g : e->groups) free_group(g);
   void *dev[] = {e->theta, e->adam_m, e->adam_v, e->adam_t};
   for (void *p : dev)
@@ -311,6 +633,11 @@ extern "C" int bore_engine_create(const bore_mlp_desc *desc, const bore_engine_c
   ENG_HIP(hipMemset(e->adam_m, 0, (size_t)L * P * 4));
   ENG_HIP(hipMemset(e->adam_v, 0, (size_t)L * P * 4));
   ENG_HIP(hipMemset(e->adam_t, 0, (size_t)L * 8));
+  if (cfg->async_loops) {
+    ENG_TRY(async_create(e, X0, y0));
+    *out = e;
+    return 0;
+  }
   const int G = cfg->groups < L ? cfg->groups : L;
   e->groups.resize(G);
   const int R = cfg->num_starts, n0 = cfg->n_init;
@@ -358,6 +685,7 @@ extern "C" int bore_engine_create(const bore_mlp_desc *desc, const bore_engine_c
 extern "C" int bore_engine_run(bore_engine *e, int n_steps) {
   if (!e || n_steps < 0) return fail(BORE_E_INVALID, "engine_run: bad argument");
   if (n_steps == 0) return 0;
+  if (e->as) return async_run(e, n_steps);
   std::vector<int64_t> target(e->groups.size());
   int rc;
   for (size_t k = 0; k < e->groups.size(); ++k) target[k] = e->groups[k].steps + n_steps;
@@ -392,6 +720,7 @@ extern "C" int bore_engine_run(bore_engine *e, int n_steps) {
 }
 
 extern "C" int64_t bore_engine_size(const bore_engine *e) {
+  if (e && e->as) return e->cfg.n_init + e->as->it[0];
   if (!e || e->groups.empty()) return -1;
   const Group &g = e->groups[0];
   return g.n + (g.has_new ? 1 : 0);
@@ -402,6 +731,21 @@ extern "C" int bore_engine_observations(bore_engine *e, double *X, double *y) {
   if (!e || !X || !y) return fail(BORE_E_INVALID, "engine_observations: NULL argument");
   const int D = e->D;
   const int64_t N = bore_engine_size(e);
+  if (e->as) {  // rows on the device: all but the newest, which waits on the host for its launch
+    Async &A = *e->as;
+    const size_t L = e->cfg.n_loops;
+    HIP_TRY(hipDeviceSynchronize());
+    const int64_t nd = A.it[0] > 0 ? N - 1 : N;
+    HIP_TRY(hipMemcpy2D(X, (size_t)N * D * 8, A.X_seen, A.cap * D * 8, (size_t)nd * D * 8, L,
+                        hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy2D(y, (size_t)N * 8, A.y_seen, A.cap * 8, (size_t)nd * 8, L, hipMemcpyDeviceToHost));
+    if (A.it[0] > 0)
+      for (size_t l = 0; l < L; ++l) {
+        std::memcpy(X + (l * N + nd) * D, &A.x_new[l * D], (size_t)D * 8);
+        y[l * N + nd] = A.y_new[l];
+      }
+    return 0;
+  }
   for (Group &g : e->groups) {
     const size_t Lg = g.b - g.a;
     HIP_TRY(hipStreamSynchronize(g.stream));

@@ -33,6 +33,15 @@ __device__ int g_stamp_on;
 #endif
 
 extern "C" int bore_abi_version(void) { return BORE_ABI_VERSION; }
+
+extern "C" void bore_set_batch(const bore_batch *batch) {
+  if (batch) {
+    g_batch_store = *batch;
+    g_batch = &g_batch_store;
+  } else {
+    g_batch = nullptr;
+  }
+}
 extern "C" const char *bore_last_error(void) { return g_bore_err; }
 
 extern "C" int64_t bore_param_count(const bore_mlp_desc *desc) {
@@ -58,6 +67,11 @@ struct FitArgs {
   int state_in_lds, data_in_lds;
   // LDS carve (float offsets)
   int o_tile, o_zt, o_misc, o_m, o_v, o_perm, o_keys, o_X, o_z, o_layout, total;
+  // batch mode (bore_set_batch): slot -> loop ids[slot] at iteration its[slot]; N above is the
+  // largest of the batch and the data buffers are `cap`-strided per loop
+  const int *ids, *its;
+  int n_init;
+  long long cap;
 };
 
 // Adam update of one parameter (ResourceApplyAdam, non-nesterov); returns the new weight.
@@ -358,8 +372,11 @@ __global__ __launch_bounds__(BORE_THREADS) void fit_kernel(const FitArgs a) {
   const MlpLayout &L = begin_kernel<SHAPE>(Lc, a.L, smem, a.total, a.o_layout);
   const int tid = threadIdx.x, nthr = blockDim.x;
   const int wv = tid >> 6, lane = tid & 63, m16 = lane & 15, q4 = lane >> 4;
-  const long long model = blockIdx.x;
-  const int P = L.P, n = layer_count<SHAPE>(L), D = L.w[0], N = a.N;
+  const long long slot = blockIdx.x;
+  const long long model = a.ids ? a.ids[slot] : slot;  // the loop this workgroup fits
+  const int P = L.P, n = layer_count<SHAPE>(L), D = L.w[0];
+  const int N = a.ids ? a.n_init + a.its[slot] : a.N;
+  const long long epoch0 = a.ids ? (long long)a.its[slot] * a.epochs : a.epoch0;
 
   float *th = smem;
   float *tile = smem + a.o_tile;
@@ -368,13 +385,13 @@ __global__ __launch_bounds__(BORE_THREADS) void fit_kernel(const FitArgs a) {
   int *perm_all = reinterpret_cast<int *>(smem + a.o_perm);
   int *perm_s = perm_all;  // the current epoch's permutation
   unsigned *keys = reinterpret_cast<unsigned *>(smem + a.o_keys);
-  const int PG = a.perm ? 1 : perm_group(a.N, BORE_THREADS);
+  const int PG = a.perm ? 1 : perm_group(N, BORE_THREADS);
 
   float *theta_g = a.theta + model * P;
   float *m_g = a.am + model * P;
   float *v_g = a.av + model * P;
-  const float *X_g = a.X + model * (long long)N * D;
-  const float *z_g = a.z + model * (long long)N;
+  const float *X_g = a.X + model * (a.ids ? a.cap : (long long)N) * D;
+  const float *z_g = a.z + model * (a.ids ? a.cap : (long long)N);
   float *sm = smem + a.o_m, *sv = smem + a.o_v;  // padded images (when state_in_lds)
 
   load_theta(L, n, theta_g, th);
@@ -423,11 +440,11 @@ __global__ __launch_bounds__(BORE_THREADS) void fit_kernel(const FitArgs a) {
     } else if (PG > 1) {  // small data set: the shuffles of PG consecutive epochs at once
       const int eg = e & (PG - 1);  // PG is 2 or 4
       if (eg == 0)
-        make_perm_group(a.seed, a.model0 + model, a.epoch0 + e, min(PG, a.epochs - e), N, keys,
+        make_perm_group(a.seed, a.model0 + model, epoch0 + e, min(PG, a.epochs - e), N, keys,
                         perm_all);
       perm_s = perm_all + eg * N;
     } else {
-      make_perm(shuffle_base(a.seed, a.model0 + model, a.epoch0 + e), N, keys, perm_s);
+      make_perm(shuffle_base(a.seed, a.model0 + model, epoch0 + e), N, keys, perm_s);
     }
     float eloss = 0.f;  // per lane: sum over the epoch of the losses of its row slot
 
@@ -1104,9 +1121,11 @@ extern "C" int bore_mlp_fit(const bore_mlp_desc *desc, int n_models, float *thet
                             int64_t N, int epochs, int batch_size, const int32_t *perm,
                             uint64_t seed, int64_t model_index0, int64_t epoch0,
                             const bore_adam_cfg *adam, float *epoch_loss, void *stream) {
-  if (desc && desc->compute == BORE_COMPUTE_BF16)
+  if (desc && desc->compute == BORE_COMPUTE_BF16) {
+    if (g_batch) return fail(BORE_E_UNSUPPORTED, "fit: batch mode is float32 only");
     return fit_bf16_impl(desc, n_models, theta, adam_m, adam_v, adam_t, X, z, N, epochs, batch_size,
                          perm, seed, model_index0, epoch0, adam, epoch_loss, stream);
+  }
   FitArgs a;
   if (batch_size < 1 || batch_size > BORE_BATCH_MAX)
     return fail(BORE_E_UNSUPPORTED, "fit: batch_size must be 1..%d (got %d)", BORE_BATCH_MAX,
@@ -1132,6 +1151,11 @@ extern "C" int bore_mlp_fit(const bore_mlp_desc *desc, int n_models, float *thet
   a.seed = seed; a.model0 = model_index0; a.epoch0 = epoch0;
   a.N = (int)N; a.epochs = epochs; a.B = batch_size;
   a.lr = adam->lr; a.beta1 = adam->beta1; a.beta2 = adam->beta2; a.eps = adam->eps;
+  a.ids = a.its = nullptr; a.n_init = 0; a.cap = 0;
+  if (g_batch) {
+    if (perm || epoch_loss) return fail(BORE_E_INVALID, "fit: no perm / epoch_loss in batch mode");
+    a.ids = g_batch->ids; a.its = g_batch->its; a.n_init = g_batch->n_init; a.cap = g_batch->cap;
+  }
 
   // LDS carve: theta | tile | zt | misc | perm | keys | [m v] | [X z]
   size_t off = 0;
@@ -1140,9 +1164,17 @@ extern "C" int bore_mlp_fit(const bore_mlp_desc *desc, int n_models, float *thet
   a.o_zt = (int)off; off += BORE_BATCH_MAX;
   a.o_misc = (int)off; off += 8;
   const int PG = perm ? 1 : perm_group(N, BORE_THREADS);  // epochs shuffled together (N <= 128)
-  a.o_perm = (int)off; off += (size_t)PG * N;
+  size_t perm_f = (size_t)PG * N, keys_f = perm ? 0 : (size_t)perm_group_scratch_floats(N, PG);
+  if (g_batch)  // a slot's own N (<= this N) may shuffle more epochs together: room for each case
+    for (long long nn : {(long long)(N < 64 ? N : 64), (long long)(N < 128 ? N : 128)}) {
+      const int pg = perm_group(nn, BORE_THREADS);
+      if ((size_t)pg * nn > perm_f) perm_f = (size_t)pg * nn;
+      if ((size_t)perm_group_scratch_floats(nn, pg) > keys_f)
+        keys_f = (size_t)perm_group_scratch_floats(nn, pg);
+    }
+  a.o_perm = (int)off; off += perm_f;
   off = (off + 3) & ~(size_t)3;  // keys: 64-bit words fetched two at a time
-  a.o_keys = (int)off; off += perm ? 0 : (size_t)perm_group_scratch_floats(N, PG);
+  a.o_keys = (int)off; off += keys_f;
   if ((off + BORE_LAYOUT_FLOATS + 4) * 4 > BORE_LDS_BYTES)
     return fail(BORE_E_UNSUPPORTED, "fit: theta+tile+perm need %zu B of LDS (> %d)", off * 4,
                 BORE_LDS_BYTES);

@@ -9,6 +9,10 @@
 
 inline thread_local char g_bore_err[512] = "";
 
+// batch mode (include/bore_hip.h: bore_set_batch): the calling thread's current batch, if any
+inline thread_local bore_batch g_batch_store;
+inline thread_local const bore_batch *g_batch = nullptr;
+
 inline int fail(int code, const char *fmt, ...) {
   va_list ap;
   va_start(ap, fmt);

@@ -79,7 +79,10 @@ class NativeEngine:
     def __init__(self, loop_ids, input_dim=2, units=(16, 16, 1), acts=("relu", "relu", "sigmoid"),
                  transform="identity", gamma=0.25, epochs=200, batch_size=64, num_starts=3,
                  num_samples=1024, n_init=10, objective=branin01, options=None, device=None,
-                 seed=0, groups=4, deduplicate=False):
+                 seed=0, groups=4, deduplicate=False, async_loops=False):
+        """async_loops: every loop advances on its own (a loop re-enters the next launch as soon
+        as ITS restarts are done instead of waiting for the slowest loop of its group); same
+        trajectories, tested.  Needs num_starts <= 4."""
         self.device = device or _lib.require_gpu()
         self.loop_ids = np.asarray(loop_ids, dtype=np.int64)
         self.L = L = len(self.loop_ids)
@@ -115,7 +118,7 @@ class NativeEngine:
         self._hi, hi_p = ops._host_f64(self.high, D, "high")
         cfg = _lib.EngineCfg(L, max(1, min(int(groups), L)), int(self.loop_ids[0]), int(n_init),
                              int(epochs), int(batch_size), int(num_starts), int(num_samples),
-                             _lib.TRANSFORM[tr.name], int(bool(deduplicate)), 0,
+                             _lib.TRANSFORM[tr.name], int(bool(deduplicate)), int(bool(async_loops)),
                              int(seed) & (2 ** 64 - 1), float(gamma),
                              _lib.AdamCfg(1e-3, 0.9, 0.999, 1e-7),
                              lbfgsb_opts(dict(options or dict(maxiter=1000, ftol=1e-9))), lo_p, hi_p)

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define BORE_ABI_VERSION 6
+#define BORE_ABI_VERSION 7
 #define BORE_MAX_LAYERS 8
 #define BORE_BATCH_MAX 64 /* rows per tile == wavefront width */
 #define BORE_DIM_MAX 64   /* largest input dimension for the by-value bound arrays */
@@ -290,6 +290,40 @@ int bore_shuffle_perm(uint64_t seed, int64_t model_index0, int n_models,
                       int64_t epoch0, int epochs, int64_t N, int32_t *perm,
                       void *stream);
 
+/*
+ * Batch mode (plumbing of the asynchronous replica engine; off by default).  While a batch is set
+ * for the calling thread, the leading dimension of bore_append_observations, bore_labels,
+ * bore_mlp_fit, bore_sample_screen_topk and bore_lbfgsb_minimize is a BATCH of arbitrary loops at
+ * different iteration counts instead of consecutive models of one size: slot b works on loop
+ * ids[b] with N = n_init + its[b] observations.
+ *   - per-LOOP arrays are indexed by ids[b]: theta/adam_m/adam_v [n_loops][P], adam_t, and the
+ *     record buffers, all with `cap` rows per loop: X_seen fp64 [n_loops][cap][D], y_seen
+ *     [n_loops][cap], the float32 training view X (fit) [n_loops][cap][D], z [n_loops][cap];
+ *   - per-SLOT arrays are indexed by b: x_new, y_new, x0, idx, x, fun, jac, info;
+ *   - the N / n_seen / epoch0 / draw_index arguments give the LARGEST value in the batch (they
+ *     size the LDS); each slot uses its own: epoch0 = its[b] * epochs, draw_index = its[b];
+ *     stream keys use model_index0 + ids[b];
+ *   - bore_append_observations writes row N - 1 of loop ids[b] (its[b] > 0) into X_seen, y_seen
+ *     and X32 (all `cap`-strided; y_dense unused);
+ *   - bore_lbfgsb_minimize (num_starts <= 4) ends each loop with the pick of bore_select_best
+ *     (filter over X_seen when deduplicate != 0) and publishes it as soon as THAT loop's restarts
+ *     are done: result[ids[b]] = {x_best[D], best, sum nfev, max nfev} (doubles), then, after a
+ *     system-scope fence, flag[ids[b]] = its[b] + 1.  result and flag must be host-visible
+ *     (pinned) memory.
+ * bore_set_batch(NULL) returns to the plain meaning.  The struct is copied.
+ */
+typedef struct bore_batch {
+  const int32_t *ids;    /* device [n_models] */
+  const int32_t *its;    /* device [n_models] */
+  int32_t n_init;
+  int32_t deduplicate;
+  int64_t cap;
+  const double *X_seen;  /* device fp64 [n_loops][cap][D] */
+  double *result;        /* pinned [n_loops][D + 3] */
+  int32_t *flag;         /* pinned [n_loops] */
+} bore_batch;
+void bore_set_batch(const bore_batch *batch);
+
 /* ---------------------------------------------------------------------------
  * Replica engine: n_loops independent BO loops on one GPU (BASELINE.json config 4), each
  * iteration being label -> fit -> sample + screen -> L-BFGS-B restarts -> pick as in the
@@ -315,7 +349,8 @@ typedef struct bore_engine_cfg {
   int32_t num_samples;  /* argmax(num_samples=..) */
   int32_t transform;    /* enum bore_transform */
   int32_t deduplicate;  /* != 0: Record.is_duplicate as filter_fn (the plugin's rule) */
-  int32_t reserved;
+  int32_t async_loops;  /* != 0: loops advance individually (batch mode above; num_starts <= 4):
+                           a loop re-enters the next launch as soon as ITS restarts are done */
   uint64_t seed;
   double gamma;
   bore_adam_cfg adam;

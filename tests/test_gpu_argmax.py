@@ -307,6 +307,40 @@ def test_native_engine_equals_python_engine(gpu, dedup):
     assert a.take_stats()["fit_launches"] == 0                       # reset
 
 
+@pytest.mark.parametrize("dedup", [False, True])
+def test_async_engine_equals_lockstep_engine(gpu, dedup):
+    """async_loops: loops advance individually through batches of arbitrary composition (batch
+    mode of the kernels: index lists, per-slot N, per-loop completion flags).  A loop's trajectory
+    does not depend on who it shares a launch with: identical to the lock-step engine."""
+    from bore_amd.engine import NativeEngine
+    kw = dict(epochs=20, num_samples=64, deduplicate=dedup)
+    a = NativeEngine(np.arange(3, 40), async_loops=True, **kw)
+    b = NativeEngine(np.arange(3, 40), groups=3, **kw)
+    a.run(9)
+    a.run(6)
+    b.run(15)
+    Xa, ya = a.observations()
+    Xb, yb = b.observations()
+    assert Xa.shape == (37, 25, 2) and np.array_equal(Xa, Xb) and np.array_equal(ya, yb)
+    for u, v in zip(a.state(), b.state()):
+        assert np.array_equal(u, v)
+    sa, sb = a.take_stats(), b.take_stats()
+    assert sa["none_results"] == sb["none_results"] and sa["n_fg_rows"] == sb["n_fg_rows"]
+    assert sa["fit_bytes"] == sb["fit_bytes"] and sa["argmax_bytes"] == sb["argmax_bytes"]
+    assert sa["fit_launches"] >= 15 and sa["fit_ms"] > 0
+
+
+def test_async_engine_long_run_past_64_points_and_capacity(gpu):
+    from bore_amd.engine import NativeEngine
+    kw = dict(epochs=5, num_samples=16, n_init=50)
+    a = NativeEngine(np.arange(6), async_loops=True, **kw)
+    b = NativeEngine(np.arange(6), groups=2, **kw)
+    a.run(230)                               # N: 50 -> 280 (two batches per epoch, record 256 -> 512)
+    b.run(230)
+    assert a.N == 280 and np.array_equal(a.X, b.X) and np.array_equal(a.y, b.y)
+    assert np.array_equal(a.state()[0], b.state()[0])
+
+
 def test_native_engine_grows_its_record_and_reports_objective_errors(gpu):
     from bore_amd.engine import NativeEngine, ReplicaEngine, branin01
     a = NativeEngine(np.arange(4), groups=1, epochs=5, num_samples=16, n_init=120)
