@@ -15,8 +15,13 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libbore_hip.so")
-SOURCES = ["bore_hip.hip", "bore_argmax.hip", "bore_svgd.hip", "bore_engine.hip"]
+SOURCES = ["bore_all.hip"]   # a unity build of bore_{hip,argmax,svgd,iter,engine}.hip
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "bore_hip.h")
+
+# The replica engine runs up to a dozen independent launches on as many HIP streams; ROCm gives a
+# process GPU_MAX_HW_QUEUES hardware queues (default 4) and streams sharing one serialise.  Read at
+# HIP initialisation, so it has to be in the environment before the first GPU call.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 MAX_LAYERS = 8
 BATCH_MAX = 64
@@ -89,7 +94,7 @@ def hipcc_path():
 def build_native(force=False, verbose=False):
     """Compile libbore_hip.so for gfx950.  Cross-compiles without a GPU."""
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [HEADER]
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hip"))] + [HEADER]
     if (not force and os.path.exists(LIB_PATH)
             and os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(d) for d in deps)):
         return LIB_PATH

@@ -17,14 +17,12 @@ using namespace bore;
 // labels: tau = np.quantile(y, gamma) (linear interpolation), z = y < tau
 // ---------------------------------------------------------------------------
 // (batch mode: slot -> loop ids[slot] with its own N = n_init + its[slot]; y and z `cap`-strided)
-__global__ __launch_bounds__(BORE_THREADS) void labels_kernel(const double *y, int N, double vi,
-                                                              float *z, double *tau_out,
-                                                              const int *ids, const int *its,
-                                                              int n_init, long long cap,
-                                                              double gamma) {
+__device__ __forceinline__ void labels_body(const double *y, int N, double vi, float *z,
+                                            double *tau_out, const int *ids, const int *its,
+                                            int n_init, long long cap, double gamma,
+                                            long long model) {
   extern __shared__ float smem[];
   double *ys = reinterpret_cast<double *>(smem);  // [N] + 2 (a, b)
-  long long model = blockIdx.x;
   long long stride = N;
   if (ids) {
     N = n_init + its[model];
@@ -64,6 +62,14 @@ __global__ __launch_bounds__(BORE_THREADS) void labels_kernel(const double *y, i
   if (gam >= 0.5) tau = b - diff * (1.0 - gam);
   for (int i = threadIdx.x; i < N; i += blockDim.x) z[model * stride + i] = ys[i] < tau ? 1.f : 0.f;
   if (threadIdx.x == 0 && tau_out) tau_out[model] = tau;
+}
+
+__global__ __launch_bounds__(BORE_THREADS) void labels_kernel(const double *y, int N, double vi,
+                                                              float *z, double *tau_out,
+                                                              const int *ids, const int *its,
+                                                              int n_init, long long cap,
+                                                              double gamma) {
+  labels_body(y, N, vi, z, tau_out, ids, its, n_init, cap, gamma, blockIdx.x);
 }
 
 extern "C" int bore_labels(int n_models, const double *y, int64_t N, double gamma, float *z,
@@ -178,12 +184,12 @@ __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
 }
 
 template <int SHAPE, bool BF16 = false>
-__global__ __launch_bounds__(BORE_THREADS) void screen_topk_kernel(const ScreenArgs a) {
+__device__ __forceinline__ void screen_body(const ScreenArgs &a, const long long model) {
   extern __shared__ float smem[];
   constexpr MlpLayout Lc = bore_static_layout(SHAPE > 0 ? SHAPE : 0, 0, BORE_BATCH_MAX);
   const MlpLayout &L = begin_kernel<SHAPE>(Lc, a.L, smem, a.total, a.o_layout);
   const int tid = threadIdx.x, nthr = blockDim.x;
-  const long long model = blockIdx.x;                        // output slot
+  // `model` is the output slot
   const long long lid = a.ids ? a.ids[model] : model;        // whose weights and stream
   const int n = layer_count<SHAPE>(L), D = L.w[0];
   const int Ns = (int)a.n_samples;
@@ -303,17 +309,21 @@ __global__ __launch_bounds__(BORE_THREADS) void screen_topk_kernel(const ScreenA
   }
 }
 
+template <int SHAPE, bool BF16 = false>
+__global__ __launch_bounds__(BORE_THREADS) void screen_topk_kernel(const ScreenArgs a) {
+  screen_body<SHAPE, BF16>(a, blockIdx.x);
+}
+
 struct SampleSpec {
   uint64_t seed;
   int64_t model_index0, draw_index;
   const double *low, *high;
 };
 
-static int screen_launch(const bore_mlp_desc *desc, int n_models, const float *theta,
-                         const double *X_init, const SampleSpec *spec, int64_t n_samples,
-                         int x_shared, int num_starts, double *x0, int32_t *idx, float *pred,
-                         void *stream) {
-  ScreenArgs a;
+static int screen_build(const bore_mlp_desc *desc, int n_models, const float *theta,
+                        const double *X_init, const SampleSpec *spec, int64_t n_samples,
+                        int x_shared, int num_starts, double *x0, int32_t *idx, float *pred,
+                        ScreenArgs &a, size_t &lds_floats, int &shape_out) {
   if (n_samples < 1 || n_samples > (1 << 20))
     return fail(BORE_E_INVALID, "screen_topk: n_samples out of range");
   if (num_starts < 1 || num_starts > n_samples)
@@ -354,7 +364,21 @@ static int screen_launch(const bore_mlp_desc *desc, int n_models, const float *t
   a.total = (int)off;
   off = (off + 3) & ~(size_t)3;
   a.o_layout = (int)off; off += BORE_LAYOUT_FLOATS;
-  const int shape = bore_kernel_flavour(desc, true);  // (static flavours do not use the tile)
+  lds_floats = off;
+  shape_out = bore_kernel_flavour(desc, true);  // (static flavours do not use the tile)
+  return 0;
+}
+
+static int screen_launch(const bore_mlp_desc *desc, int n_models, const float *theta,
+                         const double *X_init, const SampleSpec *spec, int64_t n_samples,
+                         int x_shared, int num_starts, double *x0, int32_t *idx, float *pred,
+                         void *stream) {
+  ScreenArgs a;
+  size_t off = 0;
+  int shape = 0;
+  int rc = screen_build(desc, n_models, theta, X_init, spec, n_samples, x_shared, num_starts, x0, idx,
+                        pred, a, off, shape);
+  if (rc) return rc;
   if (desc->compute == BORE_COMPUTE_BF16) {
     if (!bore_shape_is_wide(shape)) return fail(BORE_E_UNSUPPORTED, kBf16Shapes);
     if (shape == 3) {
@@ -471,16 +495,17 @@ extern "C" int bore_debug_lpp(unsigned long long *out) {  // [LB_PP_MAX][16]
 #endif
 
 template <int SHAPE, bool BF16 = false>
-__global__ __launch_bounds__(BORE_THREADS) void lbfgsb_kernel(const LbfgsbArgs a) {
+__device__ __forceinline__ void lbfgsb_body(const LbfgsbArgs &a, const long long model,
+                                            const int block_y) {
   extern __shared__ float smem[];
   constexpr MlpLayout Lc = bore_static_layout(SHAPE > 0 ? SHAPE : 0, 2, BORE_BATCH_MAX);
   const MlpLayout &L = begin_kernel<SHAPE>(Lc, a.L, smem, a.total, a.o_layout);
   const int tid = threadIdx.x;
   const int wv = tid >> 6, lane = tid & 63;
-  const long long model = blockIdx.x;               // slot: indexes x0 / x / fun / jac / info
+  // `model` is the slot: it indexes x0 / x / fun / jac / info
   const long long lid = a.ids ? a.ids[model] : model;  // whose weights (and record, and result)
   const int n_lay = layer_count<SHAPE>(L), D = L.w[0];
-  const int p0 = blockIdx.y * a.PB;               // first problem of this workgroup
+  const int p0 = block_y * a.PB;                  // first problem of this workgroup
   const int np = min(a.PB, a.R - p0);             // problems here (>= 1 by grid construction)
   float *th = smem, *tile = smem + a.o_tile, *vals = smem + a.o_vals;
   // the box, too, is indexed at run time by the optimiser: LDS copy (see stage_layout)
@@ -681,12 +706,16 @@ __global__ __launch_bounds__(BORE_THREADS) void lbfgsb_kernel(const LbfgsbArgs a
   }
 }
 
-extern "C" int bore_lbfgsb_minimize(const bore_mlp_desc *desc, int n_models, const float *theta,
-                                    int transform, int negate, const double *x0, int num_starts,
-                                    const double *lb, const double *ub,
-                                    const bore_lbfgsb_opts *opts, double *x, double *fun,
-                                    double *jac, int32_t *info, void *stream) {
-  LbfgsbArgs a;
+template <int SHAPE, bool BF16 = false>
+__global__ __launch_bounds__(BORE_THREADS) void lbfgsb_kernel(const LbfgsbArgs a) {
+  lbfgsb_body<SHAPE, BF16>(a, blockIdx.x, blockIdx.y);
+}
+
+static int lbfgsb_build(const bore_mlp_desc *desc, int n_models, const float *theta,
+                        int transform, int negate, const double *x0, int num_starts,
+                        const double *lb, const double *ub, const bore_lbfgsb_opts *opts, double *x,
+                        double *fun, double *jac, int32_t *info, LbfgsbArgs &a, size_t &lds_floats,
+                        int &flavour_out, int &blocks_out) {
   if (!desc || !theta || !x0 || !lb || !ub || !opts || !x || !fun || !jac || !info)
     return fail(BORE_E_INVALID, "lbfgsb_minimize: null pointer");
   if (n_models < 1) return fail(BORE_E_INVALID, "n_models must be >= 1 (got %d)", n_models);
@@ -776,9 +805,25 @@ extern "C" int bore_lbfgsb_minimize(const bore_mlp_desc *desc, int n_models, con
   }
   long long cap = (long long)opts->maxfun + opts->maxls + 64;
   a.max_rounds = (int)(cap > (1 << 24) ? (1 << 24) : cap);
-  int rc = 0;
   const int blocks = (num_starts + PB - 1) / PB;
   if (blocks > 65535) return fail(BORE_E_UNSUPPORTED, "lbfgsb_minimize: too many restarts");
+  lds_floats = off;
+  flavour_out = flavour;
+  blocks_out = blocks;
+  return 0;
+}
+
+extern "C" int bore_lbfgsb_minimize(const bore_mlp_desc *desc, int n_models, const float *theta,
+                                    int transform, int negate, const double *x0, int num_starts,
+                                    const double *lb, const double *ub,
+                                    const bore_lbfgsb_opts *opts, double *x, double *fun,
+                                    double *jac, int32_t *info, void *stream) {
+  LbfgsbArgs a;
+  size_t off = 0;
+  int flavour = 0, blocks = 0;
+  int rc = lbfgsb_build(desc, n_models, theta, transform, negate, x0, num_starts, lb, ub, opts, x, fun,
+                        jac, info, a, off, flavour, blocks);
+  if (rc) return rc;
   if (desc->compute == BORE_COMPUTE_BF16) {
     if (!bore_shape_is_wide(flavour)) return fail(BORE_E_UNSUPPORTED, kBf16Shapes);
     if (flavour == 3) {

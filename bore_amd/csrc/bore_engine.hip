@@ -95,6 +95,7 @@ struct Worker {
   double *x0 = nullptr, *x = nullptr, *jac = nullptr, *fun = nullptr;
   int32_t *idx = nullptr, *info = nullptr;
   double fit_bytes = 0;
+  IterArgs *h_args = nullptr, *d_args = nullptr;  // fused iteration kernel: pinned / device copy
 };
 
 struct Async {
@@ -106,8 +107,9 @@ struct Async {
   std::vector<int32_t> it, target, state;        // per loop: iterations done; 0 ready 1 in flight 2 done
   std::vector<double> x_new, y_new, ready_since; // per loop: the row to append at its next launch
   std::vector<Worker> workers;
-  std::vector<int> scratch_ids;
+  std::vector<int> scratch_ids, done_ids;
   std::vector<double> cb_x, cb_y;
+  bool fused = false;  // one kernel per launch (bore_iter.hip) instead of the five-launch chain
   // diagnostics (BORE_ASYNC_DEBUG): waits between a loop's states
   std::vector<double> launched_at;
   double sum_wait = 0, sum_flight = 0;
@@ -324,7 +326,9 @@ int async_create(bore_engine *e, const double *X0, const double *y0) {
   A.x_new.assign(L * D, 0.0); A.y_new.assign(L, 0.0); A.ready_since.assign(L, 0.0);
   A.scratch_ids.reserve(L); A.cb_x.resize(L * D); A.cb_y.resize(L);
   A.launched_at.assign(L, 0.0);
-  A.workers.resize(getenv("BORE_ASYNC_WORKERS") ? atoi(getenv("BORE_ASYNC_WORKERS")) : 4);
+  A.done_ids.assign(L, 0);
+  A.fused = iteration_supported(&e->desc) && !(getenv("BORE_ASYNC_CHAIN") && atoi(getenv("BORE_ASYNC_CHAIN")));
+  A.workers.resize(getenv("BORE_ASYNC_WORKERS") ? atoi(getenv("BORE_ASYNC_WORKERS")) : (A.fused ? 12 : 4));
   for (Worker &w : A.workers) {
     HIP_TRY(hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&w.done, hipEventDisableTiming));
@@ -333,7 +337,8 @@ int async_create(bore_engine *e, const double *X0, const double *y0) {
         (rc = pin_alloc(&w.h_dbl, L * (D + 1))) || (rc = dev_alloc(&w.d_dbl, L * (D + 1))) ||
         (rc = dev_alloc(&w.x0, L * R * D)) || (rc = dev_alloc(&w.x, L * R * D)) ||
         (rc = dev_alloc(&w.jac, L * R * D)) || (rc = dev_alloc(&w.fun, L * R)) ||
-        (rc = dev_alloc(&w.idx, L * R)) || (rc = dev_alloc(&w.info, L * R * 5)))
+        (rc = dev_alloc(&w.idx, L * R)) || (rc = dev_alloc(&w.info, L * R * 5)) ||
+        (rc = pin_alloc(&w.h_args, 1)) || (rc = dev_alloc(&w.d_args, 1)))
       return rc;
   }
   return 0;
@@ -343,7 +348,8 @@ void async_destroy(bore_engine *e) {
   if (!e->as) return;
   Async &A = *e->as;
   for (Worker &w : A.workers) {
-    void *dev[] = {w.d_int, w.d_dbl, w.x0, w.x, w.jac, w.fun, w.idx, w.info};
+    void *dev[] = {w.d_int, w.d_dbl, w.x0, w.x, w.jac, w.fun, w.idx, w.info, w.d_args};
+    if (w.h_args) (void)hipHostFree(w.h_args);
     for (void *p : dev)
       if (p) (void)hipFree(p);
     if (w.h_int) (void)hipHostFree(w.h_int);
@@ -393,6 +399,25 @@ int async_launch(bore_engine *e, Worker &w) {
   bt.cap = A.cap; bt.X_seen = A.X_seen; bt.result = A.result; bt.flag = A.flag;
   bore_set_batch(&bt);
   void *sp = w.stream;
+  if (A.fused) {
+    int rc = hipEventRecord(w.ev[2], w.stream) == hipSuccess ? 0 : fail(BORE_E_HIP, "hipEventRecord");
+    if (!rc)
+      rc = iteration_launch(&e->desc, B, e->theta, e->adam_m, e->adam_v, e->adam_t, A.X_seen, A.y_seen,
+                            A.X32, A.z, w.d_dbl, w.d_dbl + (size_t)L * D, c.gamma, c.epochs,
+                            c.batch_size, c.seed, c.loop_id0, &c.adam, c.num_samples, e->low.data(),
+                            e->high.data(), R, c.transform, &c.lbfgsb, w.x0, w.idx, w.x, w.fun,
+                            w.jac, w.info, w.h_args, w.d_args, sp);
+    if (!rc && hipEventRecord(w.ev[3], w.stream) != hipSuccess) rc = fail(BORE_E_HIP, "hipEventRecord");
+    if (!rc && hipEventRecord(w.done, w.stream) != hipSuccess) rc = fail(BORE_E_HIP, "hipEventRecord");
+    bore_set_batch(nullptr);
+    if (rc) return rc;
+    w.busy = true;
+    w.n = B;
+    ++A.n_batches;
+    A.n_slots += B;
+    e->st.host_enqueue_s += now_s() - t0;
+    return 0;
+  }
   int rc = bore_append_observations(B, D, A.X_seen, A.y_seen, 0, A.cap, w.d_dbl,
                                     w.d_dbl + (size_t)L * D, A.X32, nullptr, sp);
   if (!rc) rc = bore_labels(B, A.y_seen, N_max, c.gamma, A.z, nullptr, sp);
@@ -451,14 +476,19 @@ int async_run(bore_engine *e, int n_steps) {
   // oldest has waited `max_wait` (or nothing else is running)
   const int min_batch = getenv("BORE_ASYNC_MIN") ? atoi(getenv("BORE_ASYNC_MIN")) : (L >= 16 ? L / 8 : 1);
   const double max_wait = getenv("BORE_ASYNC_WAIT_US") ? 1e-6 * atof(getenv("BORE_ASYNC_WAIT_US")) : 150e-6;
-  double last_progress = start;
+  double last_progress = start, first_done = start;
+  int n_done = 0;
+  const int cb_min = getenv("BORE_ASYNC_CB_MIN") ? atoi(getenv("BORE_ASYNC_CB_MIN")) : (L >= 64 ? L / 16 : 1);
+  const double cb_wait = getenv("BORE_ASYNC_CB_WAIT_US") ? 1e-6 * atof(getenv("BORE_ASYNC_CB_WAIT_US")) : 40e-6;
   while (remaining) {
-    // 1. loops whose result has arrived
+    // 1. loops whose result has arrived: collected over polling passes, handed to the objective
+    // callback in bunches (a call into the interpreter costs tens of microseconds)
     const double t0 = now_s();
-    int n_done = 0;
     for (int l = 0; l < L; ++l) {
       if (A.state[l] != 1) continue;
       if (__atomic_load_n(&A.flag[l], __ATOMIC_ACQUIRE) != A.it[l] + 1) continue;
+      A.state[l] = 3;  // result taken, objective pending
+      if (n_done == 0) first_done = t0;
       const double *r = A.result + (size_t)l * (D + 3);
       double *xn = &A.cb_x[(size_t)n_done * D];
       A.sum_flight += t0 - A.launched_at[l];
@@ -472,10 +502,9 @@ int async_run(bore_engine *e, int n_steps) {
       e->st.n_fg_rows += (int64_t)r[D + 1];
       e->st.n_rounds += (int64_t)r[D + 2];
       e->st.argmax_bytes += r[D + 1] * 4.0 * (2 * D + 1) + r[D + 2] * 4.0 * e->P;
-      A.scratch_ids.resize(n_done + 1);
-      A.scratch_ids[n_done++] = l;
+      A.done_ids[n_done++] = l;
     }
-    if (n_done) {
+    if (n_done && (n_done >= cb_min || t0 - first_done >= cb_wait)) {
       if (e->objective(A.cb_x.data(), n_done, D, A.cb_y.data(), e->user)) {
         async_drain(e);
         for (int l = 0; l < L; ++l) A.state[l] = 2;
@@ -483,7 +512,7 @@ int async_run(bore_engine *e, int n_steps) {
       }
       const double now = now_s();
       for (int k = 0; k < n_done; ++k) {
-        const int l = A.scratch_ids[k];
+        const int l = A.done_ids[k];
         std::memcpy(&A.x_new[(size_t)l * D], &A.cb_x[(size_t)k * D], (size_t)D * 8);
         A.y_new[l] = A.cb_y[k];
         ++A.it[l];
@@ -497,6 +526,7 @@ int async_run(bore_engine *e, int n_steps) {
       }
       last_progress = now;
       e->st.host_finalize_s += now - t0;
+      n_done = 0;
     }
     // 2. workers that have finished their chain
     int busy = 0;
@@ -509,8 +539,10 @@ int async_run(bore_engine *e, int n_steps) {
       }
       if (q != hipSuccess) return fail(BORE_E_HIP, "engine_run: %s", hipGetErrorString(q));
       float ms = 0.f;
-      HIP_TRY(hipEventElapsedTime(&ms, w.ev[0], w.ev[1]));
-      e->st.fit_ms += ms;
+      if (!A.fused) {
+        HIP_TRY(hipEventElapsedTime(&ms, w.ev[0], w.ev[1]));
+        e->st.fit_ms += ms;
+      }
       e->st.fit_launches += 1;
       e->st.fit_bytes += w.fit_bytes;
       HIP_TRY(hipEventElapsedTime(&ms, w.ev[2], w.ev[3]));
@@ -554,8 +586,10 @@ int async_run(bore_engine *e, int n_steps) {
     if (w.busy) {
       HIP_TRY(hipStreamSynchronize(w.stream));
       float ms = 0.f;
-      HIP_TRY(hipEventElapsedTime(&ms, w.ev[0], w.ev[1]));
-      e->st.fit_ms += ms;
+      if (!A.fused) {
+        HIP_TRY(hipEventElapsedTime(&ms, w.ev[0], w.ev[1]));
+        e->st.fit_ms += ms;
+      }
       e->st.fit_launches += 1;
       e->st.fit_bytes += w.fit_bytes;
       HIP_TRY(hipEventElapsedTime(&ms, w.ev[2], w.ev[3]));

@@ -365,14 +365,14 @@ __device__ __forceinline__ void dw_adam_wide(const FitArgs &a, float *smem, floa
   }
 }
 
+// (the body is a device function so that the fused iteration kernel of bore_iter.hip can run it)
 template <int SHAPE>
-__global__ __launch_bounds__(BORE_THREADS) void fit_kernel(const FitArgs a) {
+__device__ __forceinline__ void fit_body(const FitArgs &a, const long long slot) {
   extern __shared__ float smem[];
   constexpr MlpLayout Lc = bore_static_layout(SHAPE > 0 ? SHAPE : 0, 1, BORE_BATCH_MAX);
   const MlpLayout &L = begin_kernel<SHAPE>(Lc, a.L, smem, a.total, a.o_layout);
   const int tid = threadIdx.x, nthr = blockDim.x;
   const int wv = tid >> 6, lane = tid & 63, m16 = lane & 15, q4 = lane >> 4;
-  const long long slot = blockIdx.x;
   const long long model = a.ids ? a.ids[slot] : slot;  // the loop this workgroup fits
   const int P = L.P, n = layer_count<SHAPE>(L), D = L.w[0];
   const int N = a.ids ? a.n_init + a.its[slot] : a.N;
@@ -711,6 +711,11 @@ __global__ __launch_bounds__(BORE_THREADS) void fit_kernel(const FitArgs a) {
     store_theta(L, n, sv, v_g);
   }
   if (tid == 0) a.at[model] = t0 + (long long)a.epochs * steps;
+}
+
+template <int SHAPE>
+__global__ __launch_bounds__(BORE_THREADS) void fit_kernel(const FitArgs a) {
+  fit_body<SHAPE>(a, blockIdx.x);
 }
 
 // ---------------------------------------------------------------------------
@@ -1116,17 +1121,14 @@ static int fit_bf16_impl(const bore_mlp_desc *, int, float *, float *, float *, 
                          const float *, const float *, int64_t, int, int, const int32_t *, uint64_t,
                          int64_t, int64_t, const bore_adam_cfg *, float *, void *);
 
-extern "C" int bore_mlp_fit(const bore_mlp_desc *desc, int n_models, float *theta, float *adam_m,
-                            float *adam_v, int64_t *adam_t, const float *X, const float *z,
-                            int64_t N, int epochs, int batch_size, const int32_t *perm,
-                            uint64_t seed, int64_t model_index0, int64_t epoch0,
-                            const bore_adam_cfg *adam, float *epoch_loss, void *stream) {
-  if (desc && desc->compute == BORE_COMPUTE_BF16) {
-    if (g_batch) return fail(BORE_E_UNSUPPORTED, "fit: batch mode is float32 only");
-    return fit_bf16_impl(desc, n_models, theta, adam_m, adam_v, adam_t, X, z, N, epochs, batch_size,
-                         perm, seed, model_index0, epoch0, adam, epoch_loss, stream);
-  }
-  FitArgs a;
+// Arguments, LDS bytes and kernel flavour of a float32 fit launch (what bore_mlp_fit launches;
+// the fused iteration kernel of bore_iter.hip builds its fit phase with it).  Returns 1 when
+// there is nothing to do (epochs == 0).
+static int fit_build(const bore_mlp_desc *desc, int n_models, float *theta, float *adam_m,
+                     float *adam_v, int64_t *adam_t, const float *X, const float *z, int64_t N,
+                     int epochs, int batch_size, const int32_t *perm, uint64_t seed,
+                     int64_t model_index0, int64_t epoch0, const bore_adam_cfg *adam,
+                     float *epoch_loss, FitArgs &a, size_t &lds_floats, int &shape_out) {
   if (batch_size < 1 || batch_size > BORE_BATCH_MAX)
     return fail(BORE_E_UNSUPPORTED, "fit: batch_size must be 1..%d (got %d)", BORE_BATCH_MAX,
                 batch_size);
@@ -1144,7 +1146,7 @@ extern "C" int bore_mlp_fit(const bore_mlp_desc *desc, int n_models, float *thet
   if (!theta || !adam_m || !adam_v || !adam_t || !X || !z || !adam)
     return fail(BORE_E_INVALID, "fit: null pointer");
   if (epochs < 0) return fail(BORE_E_INVALID, "fit: epochs < 0");
-  if (epochs == 0) return 0;
+  if (epochs == 0) return 1;
 
   a.theta = theta; a.am = adam_m; a.av = adam_v; a.at = (long long *)adam_t;
   a.X = X; a.z = z; a.perm = perm; a.epoch_loss = epoch_loss;
@@ -1200,6 +1202,27 @@ extern "C" int bore_mlp_fit(const bore_mlp_desc *desc, int n_models, float *thet
   int shape = bore_kernel_flavour(desc, batch_size == BORE_BATCH_MAX);
   if (shape > 0 && (!bore_shape_has_static_fit(shape) || (!a.state_in_lds && !bore_shape_is_wide(shape))))
     shape = -desc->n_layers;
+  lds_floats = off;
+  shape_out = shape;
+  return 0;
+}
+
+extern "C" int bore_mlp_fit(const bore_mlp_desc *desc, int n_models, float *theta, float *adam_m,
+                            float *adam_v, int64_t *adam_t, const float *X, const float *z,
+                            int64_t N, int epochs, int batch_size, const int32_t *perm,
+                            uint64_t seed, int64_t model_index0, int64_t epoch0,
+                            const bore_adam_cfg *adam, float *epoch_loss, void *stream) {
+  if (desc && desc->compute == BORE_COMPUTE_BF16) {
+    if (g_batch) return fail(BORE_E_UNSUPPORTED, "fit: batch mode is float32 only");
+    return fit_bf16_impl(desc, n_models, theta, adam_m, adam_v, adam_t, X, z, N, epochs, batch_size,
+                         perm, seed, model_index0, epoch0, adam, epoch_loss, stream);
+  }
+  FitArgs a;
+  size_t off = 0;
+  int shape = 0;
+  int rc = fit_build(desc, n_models, theta, adam_m, adam_v, adam_t, X, z, N, epochs, batch_size, perm,
+                     seed, model_index0, epoch0, adam, epoch_loss, a, off, shape);
+  if (rc) return rc < 0 ? rc : 0;
 #define BORE_LAUNCH_FIT(S)                                                              \
   case S:                                                                               \
     rc = allow_lds(fit_kernel<S>, off * 4);                                             \

@@ -1,0 +1,104 @@
+// bore_iter.hip -- one BO iteration of a loop as ONE kernel (asynchronous replica schedule).
+//
+// append -> labels -> fit -> sample + screen -> L-BFGS-B restarts -> pick, the bodies of the
+// kernels of bore_hip.hip / bore_argmax.hip run back to back by the same workgroup, one workgroup
+// per loop of the batch (bore_set_batch).  With separate launches a loop waits for the slowest
+// fit of its batch before its restarts start, and a launch chain holds its stream until the
+// slowest restart of the batch is done; as one kernel a loop-iteration takes its OWN fit plus its
+// OWN restarts, and batches are independent single-kernel packets (more than four concurrently
+// running dependent chains do not scale on this GPU).  The phases hand data to each
+// other through global memory (labels z, the fitted theta, the screened x0): a workgroup-wide
+// barrier plus an agent-scope fence separates them (the fit re-reads nothing it wrote, but the
+// screening phase loads theta lines the fit's prologue may have left in the vector L1).
+// Static shape 1 (2 -> 16-16-1, the BASELINE config) only; anything else keeps the launch chain.
+// Included by bore_all.hip after bore_hip.hip and bore_argmax.hip.
+
+struct IterArgs {
+  FitArgs f;
+  ScreenArgs s;
+  LbfgsbArgs b;
+  double *X_seen, *y_seen;  // records, cap-strided per loop
+  float *X32, *z;
+  const double *x_new, *y_new;  // per slot: the row to append
+  double gamma;
+  int D;
+};
+
+template <int SHAPE>
+__global__ __launch_bounds__(BORE_THREADS, 2) void iteration_kernel(const IterArgs *__restrict__ pa) {
+  const IterArgs &a = *pa;
+  const long long slot = blockIdx.x;
+  const int it = a.f.its[slot];
+  const long long lid = a.f.ids[slot], cap = a.f.cap;
+  if (it > 0) {  // append (append_kernel's batch branch)
+    const long long row = a.f.n_init + it - 1;
+    for (int d = threadIdx.x; d < a.D; d += blockDim.x) {
+      const double v = a.x_new[slot * a.D + d];
+      a.X_seen[(lid * cap + row) * a.D + d] = v;
+      a.X32[(lid * cap + row) * a.D + d] = (float)v;
+    }
+    if (threadIdx.x == 0) a.y_seen[lid * cap + row] = a.y_new[slot];
+  }
+  __threadfence();
+  __syncthreads();
+  labels_body(a.y_seen, 0, 0.0, a.z, nullptr, a.f.ids, a.f.its, a.f.n_init, cap, a.gamma, slot);
+  __threadfence();
+  __syncthreads();
+  fit_body<SHAPE>(a.f, slot);
+  __threadfence();
+  __syncthreads();
+  screen_body<SHAPE, false>(a.s, slot);
+  __threadfence();
+  __syncthreads();
+  lbfgsb_body<SHAPE, false>(a.b, slot, 0);
+}
+
+// What one fused launch needs, for the batch currently set (bore_set_batch); fills *h (host copy of
+// the arguments, to be uploaded to d_args by the caller BEFORE the launch on `stream`) and launches.
+// Returns BORE_E_UNSUPPORTED when the model is not static shape 1: the caller falls back to the
+// launch chain.
+static int iteration_supported(const bore_mlp_desc *desc) {
+  return desc->compute == BORE_COMPUTE_F32 && bore_kernel_flavour(desc, true) == 1;
+}
+
+static int iteration_launch(const bore_mlp_desc *desc, int n_slots, float *theta, float *adam_m,
+                            float *adam_v, int64_t *adam_t, double *X_seen, double *y_seen,
+                            float *X32, float *z, const double *x_new, const double *y_new,
+                            double gamma, int epochs, int batch_size, uint64_t seed,
+                            int64_t loop_id0, const bore_adam_cfg *adam, int64_t num_samples,
+                            const double *low, const double *high, int num_starts, int transform,
+                            const bore_lbfgsb_opts *opts, double *x0, int32_t *idx, double *x,
+                            double *fun, double *jac, int32_t *info, IterArgs *h,
+                            const IterArgs *d_args, void *stream) {
+  if (!g_batch) return fail(BORE_E_INVALID, "iteration_launch: no batch set");
+  const int64_t cap = g_batch->cap;
+  size_t lf = 0, ls = 0, lb = 0;
+  int sf = 0, ss = 0, sb = 0, blocks = 0;
+  int rc = fit_build(desc, n_slots, theta, adam_m, adam_v, adam_t, X32, z, cap, epochs, batch_size,
+                     nullptr, seed, loop_id0, 0, adam, nullptr, h->f, lf, sf);
+  if (rc) return rc < 0 ? rc : fail(BORE_E_INVALID, "iteration_launch: epochs must be positive");
+  const SampleSpec spec{seed, loop_id0, 0, low, high};
+  if ((rc = screen_build(desc, n_slots, theta, nullptr, &spec, num_samples, 0, num_starts, x0, idx,
+                         nullptr, h->s, ls, ss)))
+    return rc;
+  if ((rc = lbfgsb_build(desc, n_slots, theta, transform, 1, x0, num_starts, low, high, opts, x, fun,
+                         jac, info, h->b, lb, sb, blocks)))
+    return rc;
+  if (sf != 1 || ss != 1 || sb != 1 || blocks != 1)
+    return fail(BORE_E_UNSUPPORTED, "iteration_launch: static shape 1 only");
+  h->X_seen = X_seen; h->y_seen = y_seen; h->X32 = X32; h->z = z;
+  h->x_new = x_new; h->y_new = y_new;
+  h->gamma = gamma;
+  h->D = desc->input_dim;
+  size_t floats = lf > ls ? lf : ls;
+  floats = floats > lb ? floats : lb;
+  const size_t labels_floats = 2 * ((size_t)cap + 2);
+  floats = floats > labels_floats ? floats : labels_floats;
+  if ((rc = allow_lds(iteration_kernel<1>, floats * 4))) return rc;
+  HIP_TRY(hipMemcpyAsync(const_cast<IterArgs *>(d_args), h, sizeof(IterArgs), hipMemcpyHostToDevice,
+                         (hipStream_t)stream));
+  hipLaunchKernelGGL(iteration_kernel<1>, dim3(n_slots), dim3(BORE_THREADS), floats * 4,
+                     (hipStream_t)stream, d_args);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}

@@ -327,7 +327,7 @@ def test_async_engine_equals_lockstep_engine(gpu, dedup):
     sa, sb = a.take_stats(), b.take_stats()
     assert sa["none_results"] == sb["none_results"] and sa["n_fg_rows"] == sb["n_fg_rows"]
     assert sa["fit_bytes"] == sb["fit_bytes"] and sa["argmax_bytes"] == sb["argmax_bytes"]
-    assert sa["fit_launches"] >= 15 and sa["fit_ms"] > 0
+    assert sa["fit_launches"] >= 15 and sa["argmax_ms"] > 0     # (fused kernel: one timing)
 
 
 def test_async_engine_long_run_past_64_points_and_capacity(gpu):
