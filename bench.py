@@ -261,7 +261,10 @@ def main():
                        "loops_per_gpu": args.loops, "restarts": args.mode,
                        "host_loop": "native" if native else "python",
                        "schedule": args.schedule if native else "groups",
-                       "stream_groups": n_groups, "N_start": int(n_start),
+                       "stream_groups": None if (native and args.schedule == "async") else n_groups,
+                       "worker_streams": (int(os.environ.get("BORE_ASYNC_WORKERS", 12))
+                                          if (native and args.schedule == "async") else None),
+                       "N_start": int(n_start),
                        "N_end": int(eng.N), "parallelism": f"replica-shard x{world}"},
             "roofline": dominant,
             "kernels": kernels,

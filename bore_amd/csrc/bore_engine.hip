@@ -96,6 +96,7 @@ struct Worker {
   int32_t *idx = nullptr, *info = nullptr;
   double fit_bytes = 0;
   IterArgs *h_args = nullptr, *d_args = nullptr;  // fused iteration kernel: pinned / device copy
+  size_t stage_bytes = 0;                          // (start of the worker's staging block)
 };
 
 struct Async {
@@ -333,12 +334,18 @@ int async_create(bore_engine *e, const double *X0, const double *y0) {
     HIP_TRY(hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&w.done, hipEventDisableTiming));
     for (hipEvent_t &ev : w.ev) HIP_TRY(hipEventCreate(&ev));
-    if ((rc = pin_alloc(&w.h_int, 2 * L)) || (rc = dev_alloc(&w.d_int, 2 * L)) ||
-        (rc = pin_alloc(&w.h_dbl, L * (D + 1))) || (rc = dev_alloc(&w.d_dbl, L * (D + 1))) ||
-        (rc = dev_alloc(&w.x0, L * R * D)) || (rc = dev_alloc(&w.x, L * R * D)) ||
+    // ONE staging block per side -- IterArgs | x_new [L][D] | y_new [L] | ids [L] | its [L] -- so
+    // that a launch is preceded by one upload (each small copy is its own ~30 us blit packet)
+    w.stage_bytes = ((sizeof(IterArgs) + 15) & ~(size_t)15) + L * (D + 1) * 8 + 2 * L * 4;
+    char *hb = nullptr, *db = nullptr;
+    if ((rc = pin_alloc(&hb, w.stage_bytes)) || (rc = dev_alloc(&db, w.stage_bytes))) return rc;
+    const size_t o_dbl = (sizeof(IterArgs) + 15) & ~(size_t)15, o_int = o_dbl + L * (D + 1) * 8;
+    w.h_args = reinterpret_cast<IterArgs *>(hb); w.d_args = reinterpret_cast<IterArgs *>(db);
+    w.h_dbl = reinterpret_cast<double *>(hb + o_dbl); w.d_dbl = reinterpret_cast<double *>(db + o_dbl);
+    w.h_int = reinterpret_cast<int32_t *>(hb + o_int); w.d_int = reinterpret_cast<int32_t *>(db + o_int);
+    if ((rc = dev_alloc(&w.x0, L * R * D)) || (rc = dev_alloc(&w.x, L * R * D)) ||
         (rc = dev_alloc(&w.jac, L * R * D)) || (rc = dev_alloc(&w.fun, L * R)) ||
-        (rc = dev_alloc(&w.idx, L * R)) || (rc = dev_alloc(&w.info, L * R * 5)) ||
-        (rc = pin_alloc(&w.h_args, 1)) || (rc = dev_alloc(&w.d_args, 1)))
+        (rc = dev_alloc(&w.idx, L * R)) || (rc = dev_alloc(&w.info, L * R * 5)))
       return rc;
   }
   return 0;
@@ -348,12 +355,10 @@ void async_destroy(bore_engine *e) {
   if (!e->as) return;
   Async &A = *e->as;
   for (Worker &w : A.workers) {
-    void *dev[] = {w.d_int, w.d_dbl, w.x0, w.x, w.jac, w.fun, w.idx, w.info, w.d_args};
+    void *dev[] = {w.d_args, w.x0, w.x, w.jac, w.fun, w.idx, w.info};
     if (w.h_args) (void)hipHostFree(w.h_args);
     for (void *p : dev)
       if (p) (void)hipFree(p);
-    if (w.h_int) (void)hipHostFree(w.h_int);
-    if (w.h_dbl) (void)hipHostFree(w.h_dbl);
     if (w.done) (void)hipEventDestroy(w.done);
     for (hipEvent_t ev : w.ev)
       if (ev) (void)hipEventDestroy(ev);
@@ -391,8 +396,9 @@ int async_launch(bore_engine *e, Worker &w) {
     const double N = c.n_init + it, steps = std::ceil(N / c.batch_size);
     w.fit_bytes += c.epochs * (4.0 * N * (D + 1) + steps * 24.0 * e->P);
   }
-  HIP_TRY(hipMemcpyAsync(w.d_int, w.h_int, (size_t)2 * L * 4, hipMemcpyHostToDevice, w.stream));
-  HIP_TRY(hipMemcpyAsync(w.d_dbl, w.h_dbl, (size_t)L * (D + 1) * 8, hipMemcpyHostToDevice, w.stream));
+  if (!A.fused)  // (the fused launch uploads the whole block together with its arguments)
+    HIP_TRY(hipMemcpyAsync(w.d_dbl, w.h_dbl, w.stage_bytes - ((sizeof(IterArgs) + 15) & ~(size_t)15),
+                           hipMemcpyHostToDevice, w.stream));
   const int64_t N_max = c.n_init + max_it;
   bore_batch bt;
   bt.ids = w.d_int; bt.its = w.d_int + L; bt.n_init = c.n_init; bt.deduplicate = c.deduplicate;
@@ -406,7 +412,7 @@ int async_launch(bore_engine *e, Worker &w) {
                             A.X32, A.z, w.d_dbl, w.d_dbl + (size_t)L * D, c.gamma, c.epochs,
                             c.batch_size, c.seed, c.loop_id0, &c.adam, c.num_samples, e->low.data(),
                             e->high.data(), R, c.transform, &c.lbfgsb, w.x0, w.idx, w.x, w.fun,
-                            w.jac, w.info, w.h_args, w.d_args, sp);
+                            w.jac, w.info, w.h_args, w.d_args, w.stage_bytes, sp);
     if (!rc && hipEventRecord(w.ev[3], w.stream) != hipSuccess) rc = fail(BORE_E_HIP, "hipEventRecord");
     if (!rc && hipEventRecord(w.done, w.stream) != hipSuccess) rc = fail(BORE_E_HIP, "hipEventRecord");
     bore_set_batch(nullptr);

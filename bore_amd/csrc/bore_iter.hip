@@ -53,8 +53,9 @@ __global__ __launch_bounds__(BORE_THREADS, 2) void iteration_kernel(const IterAr
   lbfgsb_body<SHAPE, false>(a.b, slot, 0);
 }
 
-// What one fused launch needs, for the batch currently set (bore_set_batch); fills *h (host copy of
-// the arguments, to be uploaded to d_args by the caller BEFORE the launch on `stream`) and launches.
+// One fused launch for the batch currently set (bore_set_batch): fills *h (pinned host copy of the
+// arguments, at the head of a staging block of upload_bytes that also holds x_new / y_new / ids /
+// its), uploads the block to d_args and launches.
 // Returns BORE_E_UNSUPPORTED when the model is not static shape 1: the caller falls back to the
 // launch chain.
 static int iteration_supported(const bore_mlp_desc *desc) {
@@ -69,7 +70,7 @@ static int iteration_launch(const bore_mlp_desc *desc, int n_slots, float *theta
                             const double *low, const double *high, int num_starts, int transform,
                             const bore_lbfgsb_opts *opts, double *x0, int32_t *idx, double *x,
                             double *fun, double *jac, int32_t *info, IterArgs *h,
-                            const IterArgs *d_args, void *stream) {
+                            const IterArgs *d_args, size_t upload_bytes, void *stream) {
   if (!g_batch) return fail(BORE_E_INVALID, "iteration_launch: no batch set");
   const int64_t cap = g_batch->cap;
   size_t lf = 0, ls = 0, lb = 0;
@@ -95,7 +96,8 @@ static int iteration_launch(const bore_mlp_desc *desc, int n_slots, float *theta
   const size_t labels_floats = 2 * ((size_t)cap + 2);
   floats = floats > labels_floats ? floats : labels_floats;
   if ((rc = allow_lds(iteration_kernel<1>, floats * 4))) return rc;
-  HIP_TRY(hipMemcpyAsync(const_cast<IterArgs *>(d_args), h, sizeof(IterArgs), hipMemcpyHostToDevice,
+  // h heads the caller's staging block (arguments | per-slot inputs | index lists): one upload
+  HIP_TRY(hipMemcpyAsync(const_cast<IterArgs *>(d_args), h, upload_bytes, hipMemcpyHostToDevice,
                          (hipStream_t)stream));
   hipLaunchKernelGGL(iteration_kernel<1>, dim3(n_slots), dim3(BORE_THREADS), floats * 4,
                      (hipStream_t)stream, d_args);

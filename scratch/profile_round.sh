@@ -17,13 +17,14 @@ python3 scratch/prof_summary.py $O/prof_${tag}_kt $O/${tag} > $O/${tag}_kt_summa
 for pmc in FETCH_SIZE WRITE_SIZE; do
   echo "== rocprofv3 --pmc $pmc"
   rm -rf $O/prof_${tag}_$pmc
-  timeout -k 10 400 rocprofv3 --pmc $pmc -d $O/prof_${tag}_$pmc --output-format csv -- python3 bench.py --steps 4 --warmup 1 --cpu-seconds 0 --loops 512 --groups 1 > /dev/null 2> $O/${tag}_rocprof_$pmc.err || exit 1
+  timeout -k 10 400 rocprofv3 --pmc $pmc -d $O/prof_${tag}_$pmc --output-format csv -- python3 bench.py --steps 4 --warmup 1 --cpu-seconds 0 --loops 512 > /dev/null 2> $O/${tag}_rocprof_$pmc.err || exit 1
   python3 scratch/prof_summary.py $O/prof_${tag}_$pmc $O/${tag}_$pmc | tail -12
 done
 echo "== rocprofv3 --pmc SQ"
 rm -rf $O/prof_${tag}_sq
-timeout -k 10 400 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_ACTIVE_INST_ANY -d $O/prof_${tag}_sq --output-format csv -- python3 bench.py --steps 4 --warmup 1 --cpu-seconds 0 --loops 512 --groups 1 > /dev/null 2> $O/${tag}_rocprof_sq.err || exit 1
+timeout -k 10 400 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_ACTIVE_INST_ANY -d $O/prof_${tag}_sq --output-format csv -- python3 bench.py --steps 4 --warmup 1 --cpu-seconds 0 --loops 512 > /dev/null 2> $O/${tag}_rocprof_sq.err || exit 1
 python3 scratch/prof_summary.py $O/prof_${tag}_sq $O/${tag}_sq | tail -12
+echo "== lock-step groups schedule"; timeout -k 10 300 python3 bench.py --cpu-seconds 0 --schedule groups > $O/${tag}_bench_groups.json 2>/dev/null; tail -c 300 $O/${tag}_bench_groups.json | head -c 10; python3 -c "import json;d=json.loads(open('$O/${tag}_bench_groups.json').read().strip().splitlines()[-1]);print('groups schedule: %.0f it/s'%d['value'])"
 echo "== configs 2/3/5, one model"; timeout -k 10 300 python3 scratch/cfg_time.py > $O/${tag}_cfg_time.txt 2>&1; cat $O/${tag}_cfg_time.txt
 echo "== loops per GPU"
 for L in 64 128 256 512 1024 2048 4096; do
@@ -32,7 +33,8 @@ for L in 64 128 256 512 1024 2048 4096; do
 import json
 d=json.loads(open("$O/${tag}_loops_$L.json").read().strip().splitlines()[-1])
 k={x["kernel"]:x for x in d["kernels"]}
-print("loops $L: %.0f it/s  ms/step %.3f  fit %.3f ms (%.1f GB/s alg)  lbfgsb %.3f ms"%(d["value"],d["ms_per_step"],k["fit_kernel"]["avg_launch_ms"],k["fit_kernel"]["achieved"],k["lbfgsb_kernel"]["avg_launch_ms"]))
+x=d["kernels"][0]
+print("loops $L: %.0f it/s  ms/step %.3f  %s %.3f ms x %d launches (%.1f in flight, %.0f GB/s algorithmic in aggregate)"%(d["value"],d["ms_per_step"],x["kernel"],x["avg_launch_ms"],x["launches"],x["share_of_step"],x["aggregate_GBs"]))
 PY
 done
 rm -rf $O/prof_${tag}_*/*/*.db 2>/dev/null
