@@ -13,7 +13,8 @@
 //     x = clip(x, low, high)
 // The host statement of the same arithmetic (bore_amd/optimizers/svgd.py, bit-equal to the
 // reference) needs a launch, a download and an upload per iteration; here the particles, the
-// kernel matrix and the Adagrad history stay in LDS for all n_iter iterations.  Sums run in plain
+// kernel matrix and the Adagrad history stay in LDS for all n_iter iterations; the median of the
+// n^2 distances is a radix select.  Sums run in plain
 // index order and exp() is the device's, so particles agree with the host statement to rounding
 // (tests: 1e-9 after 200 iterations), not bit for bit.
 #include <hip/hip_runtime.h>
@@ -75,7 +76,7 @@ __global__ __launch_bounds__(BORE_THREADS) void svgd_kernel(const SvgdArgs a) {
       tile[L.aoff[0] + i * L.lda[0] + d] = (float)x[e];
     }
     double h = a.length_scale;
-    if (a.length_scale < 0.0) {  // np.median over all n^2 entries: bitonic sort in LDS
+    if (a.length_scale < 0.0 && a.n_sort <= 1024) {  // np.median, few entries: bitonic sort in LDS
       for (int e = nn + tid; e < a.n_sort; e += BORE_THREADS) srt[e] = INFINITY;
       __syncthreads();
       for (int k = 2; k <= a.n_sort; k <<= 1)
@@ -93,6 +94,74 @@ __global__ __launch_bounds__(BORE_THREADS) void svgd_kernel(const SvgdArgs a) {
           __syncthreads();
         }
       const double med = (nn & 1) ? srt[nn >> 1] : (srt[(nn >> 1) - 1] + srt[nn >> 1]) / 2.0;
+      h = sqrt(.5 * med / log((double)(n + 1)));
+    } else if (a.length_scale < 0.0) {
+      // np.median over all n^2 entries = the order statistics k1 = (nn - 1) / 2 and k2 = nn / 2.
+      // Radix select on the bit patterns (squared distances are >= 0: their bits order like the
+      // values), 8 bits per pass from the top: a 256-bin histogram of the entries that share the
+      // prefix found so far, then the bin holding rank k1 (thread b owns bin b: a scan over the
+      // 256 counts finds it).  (A full bitonic sort of 4096 entries costs 78 barrier stages.)
+      const unsigned long long *sb = reinterpret_cast<const unsigned long long *>(srt);
+      unsigned *hist_s = reinterpret_cast<unsigned *>(srt + a.n_sort);  // [256] bins + [8] scratch
+      int *scan_s = reinterpret_cast<int *>(hist_s + 256);  // [0..3] wave totals, [4] bin, [5] below
+      const int k1 = (nn - 1) >> 1, k2 = nn >> 1;
+      unsigned long long prefix = 0;
+      int rank = k1;  // rank of the wanted entry among those sharing `prefix`
+      for (int shift = 56; shift >= 0; shift -= 8) {
+        hist_s[tid] = 0u;
+        __syncthreads();
+        const unsigned long long hi_mask = shift == 56 ? 0ULL : ~0ULL << (shift + 8);
+        for (int e = tid; e < nn; e += BORE_THREADS) {
+          const unsigned long long v = sb[e];
+          if ((v & hi_mask) == prefix) atomicAdd(&hist_s[(unsigned)(v >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        // inclusive scan of the 256 counts: within each wave by shuffles, then the wave totals
+        const int cnt = (int)hist_s[tid];
+        int incl = cnt;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+          const int up = __shfl_up(incl, off, 64);
+          if ((tid & 63) >= off) incl += up;
+        }
+        if ((tid & 63) == 63) scan_s[tid >> 6] = incl;
+        __syncthreads();
+        int base = 0;
+        for (int w = 0; w < (tid >> 6); ++w) base += scan_s[w];
+        incl += base;
+        if (incl - cnt <= rank && rank < incl) {  // exactly one bin holds the rank
+          scan_s[4] = tid;
+          scan_s[5] = incl - cnt;
+        }
+        __syncthreads();
+        rank -= scan_s[5];
+        prefix |= (unsigned long long)scan_s[4] << shift;
+        __syncthreads();
+      }
+      const double v1 = __longlong_as_double((long long)prefix);
+      double med = v1;
+      if (k2 != k1) {  // even count: the next entry in order = v1 again if it repeats, else min above
+        unsigned *cnt_le = hist_s;                                       // #entries <= v1
+        unsigned long long *min_gt = reinterpret_cast<unsigned long long *>(hist_s + 2);
+        if (tid == 0) {
+          *cnt_le = 0u;
+          *min_gt = ~0ULL;
+        }
+        __syncthreads();
+        unsigned c = 0;
+        unsigned long long mg = ~0ULL;
+        for (int e = tid; e < nn; e += BORE_THREADS) {
+          const unsigned long long v = sb[e];
+          if (v <= prefix) ++c;
+          else if (v < mg) mg = v;
+        }
+        atomicAdd(cnt_le, c);
+        atomicMin(min_gt, mg);
+        __syncthreads();
+        const double v2 = (int)*cnt_le > k2 ? v1 : __longlong_as_double((long long)*min_gt);
+        med = (v1 + v2) / 2.0;
+        __syncthreads();
+      }
       h = sqrt(.5 * med / log((double)(n + 1)));
     } else {
       __syncthreads();
@@ -187,7 +256,7 @@ extern "C" int bore_svgd_optimize(const bore_mlp_desc *desc, int n_models, const
   a.o_hist = (int)off; off += nD2;
   a.o_K = (int)off; off += 2 * (size_t)n * n + 2;
   off = (off + 3) & ~(size_t)3;
-  a.o_sort = (int)off; off += opts->length_scale < 0.0 ? 2 * (size_t)ns : 0;
+  a.o_sort = (int)off; off += opts->length_scale < 0.0 ? 2 * (size_t)ns + 256 + 8 : 0;
   a.o_f = (int)off; off += 4 * (size_t)n + 4;
   a.total = (int)off;
   off = (off + 3) & ~(size_t)3;
