@@ -330,6 +330,24 @@ def test_async_engine_equals_lockstep_engine(gpu, dedup):
     assert sa["fit_launches"] >= 15 and sa["argmax_ms"] > 0     # (fused kernel: one timing)
 
 
+def test_async_engine_launch_chain_for_other_models(gpu):
+    """Models other than static shape 1 have no fused iteration kernel: the asynchronous schedule
+    then runs the five-launch chain in batch mode.  Same trajectories as lock-step."""
+    from bore_amd.engine import NativeEngine
+    obj = lambda X: np.sum((X - 0.3) ** 2, axis=-1)
+    kw = dict(input_dim=3, units=(8, 24, 1), acts=("elu", "tanh", "sigmoid"), epochs=15,
+              num_samples=64, num_starts=4, objective=obj, deduplicate=True)
+    a = NativeEngine(np.arange(20, 33), async_loops=True, **kw)
+    b = NativeEngine(np.arange(20, 33), groups=2, **kw)
+    a.run(10)
+    b.run(10)
+    assert np.array_equal(a.X, b.X) and np.array_equal(a.y, b.y)
+    for u, v in zip(a.state(), b.state()):
+        assert np.array_equal(u, v)
+    st = a.take_stats()
+    assert st["fit_ms"] > 0 and st["argmax_ms"] > 0          # separate kernels were timed
+
+
 def test_async_engine_long_run_past_64_points_and_capacity(gpu):
     from bore_amd.engine import NativeEngine
     kw = dict(epochs=5, num_samples=16, n_init=50)
