@@ -328,9 +328,16 @@ void bore_set_batch(const bore_batch *batch);
  * Replica engine: n_loops independent BO loops on one GPU (BASELINE.json config 4), each
  * iteration being label -> fit -> sample + screen -> L-BFGS-B restarts -> pick as in the
  * reference's loop (README.rst:83-103; bore/plugins/hpbandster/base.py:216-262), driven by a
- * native host loop: the loops are split into `groups`, each stepping on its own HIP stream;
- * per iteration a group uploads one row per loop, makes seven launches and downloads the
- * suggestions.  Only the objective is evaluated on the host, through the callback.
+ * native host loop.  Two schedules (bore_engine_cfg.async_loops):
+ *   0  the loops are split into `groups`, each stepping in lock-step on its own HIP stream; per
+ *      iteration a group uploads one row per loop, makes six launches (append, labels, fit,
+ *      sample + screen, restarts, pick) and downloads the suggestions;
+ *   1  every loop advances on its own: ready loops are launched in batches (batch mode above; for
+ *      the 2 -> 16-16-1 BASELINE model ONE fused kernel per loop-iteration, otherwise the launch
+ *      chain), a loop's suggestion reaches the host through a flag the moment ITS restarts are
+ *      done, and the loop joins the next launch without waiting for the slowest loop of a group.
+ *      Needs num_starts <= 4 and ~14 hardware queues (GPU_MAX_HW_QUEUES, read at HIP start-up).
+ * Same trajectories either way.  Only the objective is evaluated on the host, through the callback.
  * Not thread-safe per engine; engines are independent of each other.
  * ------------------------------------------------------------------------- */
 
