@@ -329,7 +329,16 @@ int async_create(bore_engine *e, const double *X0, const double *y0) {
   A.launched_at.assign(L, 0.0);
   A.done_ids.assign(L, 0);
   A.fused = iteration_supported(&e->desc) && !(getenv("BORE_ASYNC_CHAIN") && atoi(getenv("BORE_ASYNC_CHAIN")));
-  A.workers.resize(getenv("BORE_ASYNC_WORKERS") ? atoi(getenv("BORE_ASYNC_WORKERS")) : (A.fused ? 12 : 4));
+  // Worker streams: a dozen independent single-kernel launches in flight when fused (each stream
+  // needs its own hardware queue -- streams sharing one serialise, which halves the throughput --
+  // so no more than GPU_MAX_HW_QUEUES - 2 of them); four dependent launch chains otherwise.
+  int n_workers = A.fused ? 12 : 4;
+  if (A.fused) {
+    const int queues = getenv("GPU_MAX_HW_QUEUES") ? atoi(getenv("GPU_MAX_HW_QUEUES")) : 4;
+    if (n_workers > queues - 2) n_workers = queues - 2 > 2 ? queues - 2 : 2;
+  }
+  if (getenv("BORE_ASYNC_WORKERS")) n_workers = atoi(getenv("BORE_ASYNC_WORKERS"));
+  A.workers.resize(n_workers > 0 ? n_workers : 1);
   for (Worker &w : A.workers) {
     HIP_TRY(hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&w.done, hipEventDisableTiming));
