@@ -1,2 +1,4 @@
 """Callers of the hot path (bore/plugins)."""
 from .classifier import ClassifierSuggester  # noqa: F401
+from .types import (Categorical, DenseSpace, UniformFloat, UniformInteger,  # noqa: F401
+                    array_from_dict, dict_from_array)

@@ -1,9 +1,10 @@
 """The plugin's BO driver without HpBandSter / ConfigSpace.
 
 ``ClassifierSuggester`` is ``ClassifierConfigGenerator`` (bore/plugins/hpbandster/base.py:84-288)
-with the two framework-specific ends cut off: candidates are plain arrays in a box instead
-of ``ConfigSpace`` configurations (the one-hot encode/decode of ``types.py`` needs ConfigSpace,
-which this image does not have), and there is no HyperBand around it.  Everything between --
+without HyperBand around it.  Candidates are plain arrays in a box, or -- with ``space=`` a
+``bore_amd.plugins.types.DenseSpace`` (the ConfigSpace-free statement of the reference's dense
+one-hot encoding, types.py) -- configuration dictionaries, encoded and decoded as
+``array_from_dict`` / ``dict_from_array`` do in the reference (:250-265, :274-278).  Everything between --
 what is fitted when, with which defaults, how a suggestion is chosen, when a random point is
 returned instead -- follows the reference:
 
@@ -27,11 +28,17 @@ from ..transforms import TRANSFORMS
 
 
 class ClassifierSuggester:
-    def __init__(self, bounds, gamma=1 / 3, num_random_init=10, random_rate=0.1, retrain=False,
+    def __init__(self, bounds=None, gamma=1 / 3, num_random_init=10, random_rate=0.1, retrain=False,
                  num_starts=5, num_samples=1024, batch_size=64, num_steps_per_iter=1000,
                  num_epochs_per_iter=None, optimizer="adam", num_layers=2, num_units=32,
                  activation="elu", l2_factor=None, transform="sigmoid", method="L-BFGS-B",
-                 max_iter=1000, ftol=1e-9, distortion=None, seed=None, logger=None):
+                 max_iter=1000, ftol=1e-9, distortion=None, seed=None, logger=None, space=None):
+        """space: a ``DenseSpace``; then ``bounds`` is its unit box, ``suggest()`` returns a
+        configuration dictionary and ``observe()`` takes one."""
+        assert (bounds is None) != (space is None), "give either `bounds` or `space`"
+        self.space = space
+        if space is not None:
+            bounds = space.get_bounds()
         assert 0. < gamma < 1., "`gamma` must be in (0, 1)"
         assert num_random_init > 0, "number of initial random designs must be non-zero!"
         assert random_rate is None or 0. <= random_rate < 1., "`random_rate` must be in [0, 1)"
@@ -106,8 +113,18 @@ class ClassifierSuggester:
     # -- the two entry points ------------------------------------------------------------------
     def suggest(self):
         """One candidate, as ``get_config`` (:216-265) picks it; returns ``(x, info)`` with
-        ``info["source"]`` in {"random:rate", "random:init", "random:failed", "model"}."""
-        x_random = self._space_rng.uniform(self.low, self.high)
+        ``info["source"]`` in {"random:rate", "random:init", "random:failed", "model"}.  With a
+        ``space`` the candidate is a configuration dictionary (dict_from_array, :264)."""
+        x, info = self._suggest_array()
+        if self.space is not None:
+            return (x if isinstance(x, dict) else self.space.from_array(x)), info
+        return x, info
+
+    def _suggest_array(self):
+        if self.space is not None:   # config_space.sample_configuration() (:220-221)
+            x_random = self.space.sample_configuration()
+        else:
+            x_random = self._space_rng.uniform(self.low, self.high)
         if self.random_rate is not None and self.random_state.binomial(p=self.random_rate, n=1):
             return x_random, dict(source="random:rate")
         if self.record.size() < self.num_random_init:
@@ -131,5 +148,9 @@ class ClassifierSuggester:
         return np.asarray(x, dtype=np.float64), dict(source="model", value=-opt.fun)
 
     def observe(self, x, loss, budget=None):
-        """``new_result`` (:267-288): log the evaluated candidate."""
+        """``new_result`` (:267-288): log the evaluated candidate (a dictionary is encoded with
+        array_from_dict, :276)."""
+        if isinstance(x, dict):
+            assert self.space is not None, "a configuration dictionary needs `space`"
+            x = self.space.to_array(x)
         self.record.append(x=np.asarray(x, dtype=np.float64), y=loss, b=budget)

@@ -107,3 +107,88 @@ def test_suggester_runs_the_plugin_loop(gpu):
             s3.observe(x, float(branin01(x)))
         runs.append(np.array(xs))
     assert np.array_equal(runs[0], runs[1])
+
+
+def _reference_space(seed=8888):
+    """The search space of the reference's tests/test_types.py:17-33."""
+    from bore_amd.plugins.types import Categorical, DenseSpace, UniformFloat, UniformInteger
+    return DenseSpace([
+        UniformInteger("n_units_1", lower=0, upper=5), UniformInteger("n_units_2", lower=0, upper=5),
+        UniformFloat("dropout_1", lower=0, upper=0.9), UniformFloat("dropout_2", lower=0, upper=0.9),
+        Categorical("activation_fn_1", ["tanh", "relu"]), Categorical("activation_fn_2", ["tanh", "relu"]),
+        UniformInteger("init_lr", lower=0, upper=5), Categorical("lr_schedule", ["cosine", "const"]),
+        UniformInteger("batch_size", lower=0, upper=3)], seed=seed)
+
+
+def test_dense_encoding_reproduces_the_reference_test_vector():
+    """tests/test_types.py:36-104 of the reference, values and all: shapes, bounds, the dense
+    array of a given configuration, exact round trip, argmax decoding of soft one-hots."""
+    cs = _reference_space()
+    assert cs.get_dimensions(sparse=True) == 9 and cs.get_dimensions(sparse=False) == 12
+    b = cs.get_bounds()
+    np.testing.assert_array_equal(b.lb, np.zeros(12))
+    np.testing.assert_array_equal(b.ub, np.ones(12))
+    assert cs.get_hyperparameter_by_idx(0) == "activation_fn_1"
+    dct = {'activation_fn_1': 'relu', 'activation_fn_2': 'tanh', 'batch_size': 2,
+           'dropout_1': 0.39803953082292726, 'dropout_2': 0.022039062686389176, 'init_lr': 0,
+           'lr_schedule': 'cosine', 'n_units_1': 5, 'n_units_2': 1}
+    array = cs.to_array(dct)
+    assert np.less_equal(0., array).all() and np.less_equal(array, 1.).all()
+    np.testing.assert_array_almost_equal(array, [0., 1., 1., 0., 0.62500063, 0.44226615, 0.02448785,
+                                                 0.08333194, 1., 0., 0.91666806, 0.24999917])
+    assert cs.from_array(array) == dct                      # "recover original dictionary exactly"
+    array[0], array[1] = 0.8, 0.6                           # soft one-hot: argmax
+    assert cs.from_array(array)["activation_fn_1"] == "tanh"
+    for cfg in cs.sample_configuration(size=5):
+        a = cs.to_array(cfg)
+        assert a.shape == (12,) and cs.from_array(a) == cfg
+    assert isinstance(cs.sample_configuration(), dict)
+
+
+def test_dense_encoding_log_scales_and_integer_edges():
+    from bore_amd.plugins.types import DenseSpace, UniformFloat, UniformInteger, array_from_dict, dict_from_array
+    cs = DenseSpace([UniformFloat("lr", 1e-5, 1e-1, log=True), UniformInteger("width", 16, 1024, log=True),
+                     UniformInteger("depth", 1, 4)])
+    for cfg in [dict(lr=1e-5, width=16, depth=1), dict(lr=1e-1, width=1024, depth=4),
+                dict(lr=3e-3, width=100, depth=2)]:
+        a = array_from_dict(cs, cfg)
+        assert ((a >= 0) & (a <= 1)).all()
+        back = dict_from_array(cs, a)
+        assert back["width"] == cfg["width"] and back["depth"] == cfg["depth"]
+        assert back["lr"] == pytest.approx(cfg["lr"], rel=1e-12)
+    # every integer owns an equal share of [0, 1]
+    u = np.linspace(0, 1, 4001)
+    assert cs.get_hyperparameter_by_idx(0) == "depth"       # (sorted by name, like ConfigSpace)
+    counts = np.bincount([dict_from_array(cs, np.array([t, 0.5, 0.5]))["depth"] for t in u])[1:]
+    assert counts.min() >= 999 and counts.max() <= 1002
+
+
+@pytest.mark.gpu
+def test_suggester_over_a_mixed_space(gpu):
+    """get_config / new_result with configuration dictionaries (bore/plugins/hpbandster/base.py:
+    250-265, 274-278): a categorical + integer + float space through the dense encoding."""
+    from bore_amd.plugins.types import Categorical, DenseSpace, UniformFloat, UniformInteger
+    space = DenseSpace([Categorical("act", ["tanh", "relu", "elu"]), UniformInteger("units", 1, 8),
+                        UniformFloat("lr", 1e-4, 1e-1, log=True)], seed=3)
+    good = dict(act="relu", units=6, lr=1e-2)
+
+    def loss(cfg):      # a made-up validation loss with a known best configuration
+        return (0.0 if cfg["act"] == good["act"] else 1.0) + 0.1 * abs(cfg["units"] - good["units"]) \
+            + abs(np.log10(cfg["lr"]) - np.log10(good["lr"]))
+
+    s = ClassifierSuggester(space=space, seed=0, random_rate=None, num_random_init=10,
+                            num_steps_per_iter=200)
+    assert s.input_dim == 5
+    sources = []
+    for i in range(30):
+        cfg, info = s.suggest()
+        assert set(cfg) == {"act", "units", "lr"} and cfg["act"] in ("tanh", "relu", "elu")
+        assert isinstance(cfg["units"], int) and 1 <= cfg["units"] <= 8 and 1e-4 <= cfg["lr"] <= 1e-1
+        sources.append(info["source"])
+        s.observe(cfg, loss(cfg))
+    assert sources.count("model") >= 15
+    X = np.vstack(s.record.features)
+    assert X.shape == (30, 5) and ((X >= 0) & (X <= 1)).all()
+    assert np.all(np.sort(X[:, :3], axis=1)[:, :2] == 0) and np.all(X[:, :3].max(axis=1) == 1)   # one-hot
+    y = np.array(s.record.targets)
+    assert y[10:].min() <= y[:10].min()                  # the classifier finds at least as good a config
