@@ -249,6 +249,20 @@ def main():
                 kernels.append(roof("lbfgsb_kernel", st["argmax_ms"], st["argmax_bytes"],
                                     st["argmax_launches"]))
         dominant = max(kernels, key=lambda k: k["share_of_step"])
+        # secondary figure: algorithmic FLOPs of the timed region against the fp32
+        # vector/MFMA peak -- with theta in LDS the path is arithmetic/latency bound, not HBM bound
+        D_, units_ = 2, [16, 16, 1]
+        M_ = sum(a * b for a, b in zip([D_] + units_[:-1], units_))            # MACs per row
+        P_ = M_ + sum(units_)
+        Ns_ = np.arange(n_start, n_start + args.steps)
+        rows = float(args.loops * world * 200 * Ns_.sum())                     # S_rows = E * N per fit
+        adam = float(args.loops * world * 200 * np.ceil(Ns_ / 64).sum())       # S = E * ceil(N / B)
+        flops = (rows * (6 * M_ - 2 * D_ * units_[0]) + adam * 12 * P_
+                 + 2.0 * M_ * 1024 * total_iters + 4.0 * M_ * st["n_fg_rows"] * world)
+        flop_roof = {"bound": "mfma", "what": "whole timed region, all kernels (secondary; SURVEY 8d)",
+                     "achieved": flops / dt / 1e12, "peak": 157.3, "unit": "TFLOP/s",
+                     "frac": flops / dt / 1e12 / 157.3,
+                     "algorithmic_flops_per_iteration": flops / total_iters}
         out = {
             "metric": "BO-iterations/sec (fit+argmax), 16-16-1 MLP",
             "value": total_iters / dt, "unit": "BO-iterations/s", "n_gpus": world,
@@ -267,6 +281,7 @@ def main():
                        "N_start": int(n_start),
                        "N_end": int(eng.N), "parallelism": f"replica-shard x{world}"},
             "roofline": dominant,
+            "roofline_flops": flop_roof,
             "kernels": kernels,
             "phases": {"fit_ms_per_launch": float(st["fit_ms"] / max(st["fit_launches"], 1)),
                        "fg_rows_per_step": st["n_fg_rows"] / args.steps,
