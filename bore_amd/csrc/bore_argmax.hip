@@ -494,7 +494,9 @@ extern "C" int bore_debug_lpp(unsigned long long *out) {  // [LB_PP_MAX][16]
 #define BORE_LCLOCK() 0LL
 #endif
 
-template <int SHAPE, bool BF16 = false>
+// LEAN: the network's weight operands are re-requested from LDS for every evaluation instead of
+// living in registers across the optimiser (the fused iteration kernel is held to 256 VGPRs).
+template <int SHAPE, bool BF16 = false, bool LEAN = false>
 __device__ __forceinline__ void lbfgsb_body(const LbfgsbArgs &a, const long long model,
                                             const int block_y) {
   extern __shared__ float smem[];
@@ -548,8 +550,10 @@ __device__ __forceinline__ void lbfgsb_body(const LbfgsbArgs &a, const long long
   Net net;
   if constexpr (SHAPE > 0) {
     if constexpr (Net::RT_ACT) net.set_acts(a.L);
-    net.load_fwd(thw);
-    net.template load_bwd<Net::n, 1>(thw);
+    if constexpr (!LEAN) {
+      net.load_fwd(thw);
+      net.template load_bwd<Net::n, 1>(thw);
+    }
   }
   bool done = (myp < 0);
   long long t_adv = 0, t_fg = 0, n_rounds = 0;
@@ -575,6 +579,10 @@ __device__ __forceinline__ void lbfgsb_body(const LbfgsbArgs &a, const long long
       // static shape: the 16-row block goes through the network in registers (mlp_regs.h)
       const int m16 = lane & 15, q4 = lane >> 4;
       float xin[Net::KC0];
+      if constexpr (LEAN) {
+        net.load_fwd(thw);
+        net.template load_bwd<Net::n, 1>(thw);
+      }
       if (coop) {
         // one point per wave: every row of the block evaluates it, read straight from the
         // optimiser's fp64 x (Keras autocast fp64 -> fp32)

@@ -50,7 +50,7 @@ __global__ __launch_bounds__(BORE_THREADS, 2) void iteration_kernel(const IterAr
   screen_body<SHAPE, false>(a.s, slot);
   __threadfence();
   __syncthreads();
-  lbfgsb_body<SHAPE, false>(a.b, slot, 0);
+  lbfgsb_body<SHAPE, false, true>(a.b, slot, 0);
 }
 
 // One fused launch for the batch currently set (bore_set_batch): fills *h (pinned host copy of the
