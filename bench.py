@@ -1,28 +1,45 @@
 #!/usr/bin/env python
 """bench.py -- BO-iterations/sec (fit + argmax) for the 16-16-1 classifier on MI355X.
 
-Workload (BASELINE.json config 4 = config 1 replicated): `--loops` independent Branin BO
-loops per GPU (default 512, the whole of config 4 on one GPU), 16-16-1 MLP, gamma 0.25,
-fit(epochs=200, batch_size=64) warm-started every iteration, argmax with 3 L-BFGS-B
-restarts from 1024 uniform samples (maxiter 1000, ftol 1e-9), 10 initial points.  One
-"step" is one BO iteration of EVERY loop on the GPU; the data set grows by one point per
-step.  Loops are sharded over ranks (weak scaling, no data-path collective; one gather of
-the results at the end, outside the timed region).  `--schedule async` (default): every loop
-advances on its own, one fused kernel (labels -> fit -> screen -> restarts -> pick) per
-loop-iteration, launched in batches of whatever loops are ready; `--schedule groups`: four
-groups of loops in lock-step, five launches per group-iteration.  Same trajectories.
+Workload (BASELINE.json config 4 = config 1 replicated): independent Branin BO loops, 16-16-1
+MLP, gamma 0.25, fit(epochs=200, batch_size=64) warm-started every iteration, argmax with 3
+L-BFGS-B restarts from 1024 uniform samples (maxiter 1000, ftol 1e-9), 10 initial points.  One
+"step" is one BO iteration of EVERY loop of the job; the data set grows by one point per step.
 
-Prints ONE JSON line on rank 0 (see the driver contract in the task statement) with the
-`roofline` of the dominant kernel (async: iteration_kernel, the only big one; groups: the one
-with the largest share of the step, lbfgsb_kernel, `kernels` lists fit_kernel too;
-algorithmic bytes per SURVEY.md §8d divided by the HIP-event duration measured on the
-launching stream) and a `cpu_baseline` (the numpy/scipy oracle, which
-mirrors the reference's per-step structure, timed on this host's cores -- one single-threaded
-process per core -- for a bounded sample; `cpu_baseline_1core` is the one-core figure).
+Loops and GPUs.  Loops are sharded over ranks in contiguous blocks, no data-path collective; one
+gather of the results at the end (RCCL), outside the timed region.
+  --gpus 1                     512 loops on the GPU (all of config 4 on one GPU).
+  --gpus N (N > 1), default    BASELINE config 4 AS WRITTEN: 512 loops in total, 512/N per GPU
+                               ("scaling": "strong"; --total-loops T changes the total).
+  --gpus N --loops L           L loops PER GPU ("scaling": "weak").
+With N > 1 rank 0 afterwards times the single-GPU reference points alone (the other ranks wait)
+and the line carries both efficiencies of SURVEY.md 8e:
+  eff_w = T(N, total) / (N * T(1, total/N))   same per-GPU load   (what the >= 0.9 target uses)
+  eff_s = T(N, total) / (N * T(1, total))     same total problem
+`python bench.py --gpus N` from a plain shell starts its own N ranks (one process per GPU,
+before anything in the parent touches HIP) and relays rank 0's line; under torchrun (RANK set)
+it runs as the rank it is given.
+
+Schedules: `--schedule async` (default): every loop advances on its own, one fused kernel
+(labels -> fit -> screen -> restarts -> pick) per loop-iteration, launched in batches of whatever
+loops are ready; `--schedule groups`: four groups of loops in lock-step, five launches per
+group-iteration.  Same trajectories.
+
+Prints ONE JSON line on rank 0 (driver contract) with the `roofline` of the dominant kernel
+(algorithmic bytes per SURVEY.md 8d divided by the HIP-event duration measured on the launching
+stream), `roofline_flops` (secondary), `runs` (N = 1: the timed region is repeated on fresh
+engines while it is shorter than a second; `value` is the median run), `configs` (N = 1: one
+driver-visible figure per BASELINE config -- single-loop config 1, configs 2, 3 and 5 -- with
+per-phase times, algorithmic bytes / FLOPs, both roofline fractions and a bounded CPU-oracle
+timing) and `cpu_baseline` (the numpy/scipy oracle, which mirrors the reference's per-step
+structure, on this host's cores -- one single-threaded process per core -- for a bounded sample;
+`cpu_baseline_1core` is the one-core figure).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -30,12 +47,17 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-# The replica engine steps groups of loops on separate HIP streams.  ROCm multiplexes streams
+# The replica engine runs independent launches on a dozen HIP streams.  ROCm multiplexes streams
 # onto GPU_MAX_HW_QUEUES hardware queues (default 4, one of them taken by the null stream);
-# streams sharing a queue serialise.  Must be set before the HIP runtime initialises.
+# streams sharing a queue serialise.  Must be set before the HIP runtime initialises (the engine
+# checks what it got and says so in the line: config.hw_queues).
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
-HBM_PEAK_GBS = 8000.0   # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0    # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
+FP32_PEAK_TF = 157.3     # fp32 vector / MFMA peak, same guide
+BF16_PEAK_TF = 2500.0    # dense bf16 MFMA peak
+TOTAL_LOOPS = 512        # BASELINE.json config 4
+TRAFFIC_FILE = os.path.join("profiles", "r2", "pmc_traffic.json")
 
 
 def _branin01(X):
@@ -46,6 +68,67 @@ def _branin01(X):
             + 10 * (1 - 1 / (8 * np.pi)) * np.cos(x1) + 10)
 
 
+# ------------------------------------------------------------------------------------------
+# self-spawn: `python bench.py --gpus N` from a plain shell
+# ------------------------------------------------------------------------------------------
+def _free_port():
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(n, argv):
+    """Start n ranks of this script (children, NOT exec: this process never touches the GPU, the
+    children initialise HIP themselves), wait for all, relay rank 0's stdout.  Returns the exit
+    code: 0 only when every rank exited 0."""
+    env = dict(os.environ)
+    env.update(WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", LOCAL_WORLD_SIZE=str(n),
+               MASTER_PORT=env.get("BORE_BENCH_PORT") or str(_free_port()),
+               HSA_ENABLE_IPC_MODE_LEGACY=env.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    procs = []
+    for r in range(n):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv),
+                                      env=e, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0 = b""
+    rc = 0
+    try:
+        out0, _ = procs[0].communicate()
+        deadline = time.time() + 120
+        for p in procs:
+            try:
+                p.wait(timeout=max(1.0, deadline - time.time()))
+            except subprocess.TimeoutExpired:
+                rc = rc or 124
+    finally:
+        for p in procs:                      # a failed rank must not leave the others waiting
+            if p.poll() is None:
+                p.kill()
+                p.wait()
+    for r, p in enumerate(procs):
+        if p.returncode != 0:
+            print(f"bench.py: rank {r} exited with code {p.returncode}", file=sys.stderr)
+            rc = rc or (p.returncode if p.returncode and p.returncode > 0 else 1)
+    sys.stdout.write(out0.decode())
+    sys.stdout.flush()
+    return rc
+
+
+def resolve_loops(args, world):
+    """(loops per GPU, total, scaling).  See the module docstring."""
+    if args.loops is not None and args.total_loops is not None:
+        raise SystemExit("bench.py: give --loops (per GPU) or --total-loops, not both")
+    if args.loops is not None:
+        return args.loops, args.loops * world, "weak"
+    total = args.total_loops if args.total_loops is not None else TOTAL_LOOPS
+    if total % world:
+        raise SystemExit(f"bench.py: --total-loops {total} does not divide over {world} GPUs")
+    return total // world, total, "weak" if world == 1 else "strong"
+
+
+# ------------------------------------------------------------------------------------------
+# CPU baseline (the oracle = the checker, timed beside the GPU path; never part of it)
+# ------------------------------------------------------------------------------------------
 def _cpu_worker(job):
     """Oracle BO loops (config 1) on ONE host core for `seconds`: label -> per-step eager fit ->
     predict -> sequential scipy L-BFGS-B with one single-point f/g call per evaluation.
@@ -86,13 +169,28 @@ def _cpu_worker(job):
         return it, time.perf_counter() - t0
 
 
+def _cpu_quota():
+    """What the container lets this process use: (hardware threads in the affinity mask, cgroup
+    cpu.max as 'quota period' or None)."""
+    quota = None
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                quota = f.read().strip()
+            break
+        except OSError:
+            pass
+    return len(os.sched_getaffinity(0)), quota
+
+
 def cpu_baseline(seconds, iters_per_loop=100, max_workers=64):
     """The CPU restatement of the reference's loop on the host cores of this box: independent
     BO loops, one single-threaded process per core (all cores, count stated), plus
     the one-core figure.  Bounded: `seconds` of wall time for the all-core run, a third of it
     for the one-core run."""
     import multiprocessing as mp
-    cores = min(len(os.sched_getaffinity(0)), max_workers)
+    threads, quota = _cpu_quota()
+    cores = min(threads, max_workers)
     it1, dt1 = _cpu_worker((seconds / 3.0, iters_per_loop, 0))
     what = ("numpy fp32 oracle + scipy L-BFGS-B (sequential restarts, single-point f/g), "
             f"loops of <= {iters_per_loop} iterations (N 10->{10 + iters_per_loop})")
@@ -112,68 +210,68 @@ def cpu_baseline(seconds, iters_per_loop=100, max_workers=64):
     its = sum(r[0] for r in res)
     rate = sum(r[0] / r[1] for r in res)          # steady state: process start-up not counted
     allc = dict(value=rate, unit="BO-iterations/s", cores=cores, kind="port",
-                sample=f"{its} BO iterations by {cores} single-threaded processes (of "
-                       f"{len(os.sched_getaffinity(0))} hardware threads available; one per core, "
-                       f"independent loops) running {seconds:.0f} s each ({wall:.1f} s wall with "
-                       f"start-up); {what}")
+                scaling_vs_1core=rate / (it1 / dt1),
+                sample=f"{its} BO iterations by {cores} single-threaded processes (of {threads} "
+                       f"hardware threads in the affinity mask; cgroup cpu.max = {quota!r}; one "
+                       f"per core, independent loops) running {seconds:.0f} s each ({wall:.1f} s "
+                       f"wall with start-up); {what}")
     return allc, one
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--loops", type=int, default=512, help="BO loops per GPU")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0)
-    ap.add_argument("--groups", type=int, default=4,
-                    help="loop groups stepping on separate streams (overlaps L-BFGS-B tails)")
-    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
-                    help="process-group backend for N > 1 (nccl = RCCL; gloo only to rehearse the "
-                         "multi-rank flow on a one-GPU box together with BORE_BENCH_ONE_DEVICE=1)")
-    ap.add_argument("--engine", default="native", choices=["native", "python"],
-                    help="host loop of the replica engine: native = bore_engine_* (C++), python = "
-                         "bore_amd.engine.ReplicaEngine (the same trajectories, bit for bit)")
-    ap.add_argument("--schedule", default="async", choices=["groups", "async"],
-                    help="native engine: groups = loop groups in lock-step on their own streams; "
-                         "async = every loop re-enters the next launch as soon as its own restarts "
-                         "are done (same trajectories)")
-    ap.add_argument("--mode", default="device", choices=["device", "lockstep"],
-                    help="device: L-BFGS-B restarts inside one kernel; lockstep: scipy on the host")
-    args = ap.parse_args()
+def tf_keras_probe():
+    """the tf.keras CPU row exists only where TensorFlow imports."""
+    import importlib.util
+    try:
+        found = importlib.util.find_spec("tensorflow") is not None
+    except Exception:       # pragma: no cover
+        found = False
+    return "importable (row not implemented: never seen on this image)" if found else "unavailable"
 
-    import torch
-    import torch.distributed as dist
-    from bore_amd.engine import NativeEngine, ReplicaEngine, gather_results, shard_loop_ids
 
-    rank = int(os.environ.get("RANK", 0))
-    world = int(os.environ.get("WORLD_SIZE", 1))
-    local = int(os.environ.get("LOCAL_RANK", 0))
-    if os.environ.get("BORE_BENCH_ONE_DEVICE") == "1":     # rehearsal: every rank on cuda:0
-        local = 0
-    torch.cuda.set_device(local)
-    if world > 1:
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-        else:
-            dist.init_process_group("gloo")
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+# ------------------------------------------------------------------------------------------
+# one timed region on one engine
+# ------------------------------------------------------------------------------------------
+class _DryEngine:
+    """--dry-run: stands in for the replica engine so that the multi-rank flow of this script (rank
+    spawning, rendezvous, barriers, max-over-ranks time, the gather) runs on a box without a GPU
+    (tests/test_bench_spawn.py).  It computes nothing and its line says so."""
 
-    loop_ids = shard_loop_ids(rank, world, args.loops)     # contiguous shard per rank
+    def __init__(self, loop_ids):
+        import torch
+        self.loop_ids, self.N, self.n_groups = np.asarray(loop_ids, dtype=np.int64), 10, 1
+        self.device = torch.device("cpu")
+
+    def run(self, n):
+        time.sleep(0.002 * n)
+        self.N += n
+
+    def take_stats(self, reset=True):
+        z = dict.fromkeys(("fit_ms", "fit_bytes", "host_enqueue_s", "host_finalize_s"), 0.0)
+        z.update(dict.fromkeys(("fit_launches", "n_fg_rows", "n_rounds", "none_results"), 0))
+        z.update(argmax_ms=1.0, argmax_bytes=1.0, argmax_launches=1)
+        return z
+
+    def best(self):
+        L = len(self.loop_ids)
+        return np.zeros((L, 2)), self.loop_ids.astype(np.float64)
+
+
+def timed_run(args, loop_ids, barrier, steps=None, warmup=None):
+    """W untimed warm-up steps, then EXACTLY K steps between barriers.  Returns a dict with the
+    wall time, the engine's statistics of the timed region and the engine."""
+    steps = args.steps if steps is None else steps
+    warmup = args.warmup if warmup is None else warmup
     native = args.engine == "native" and args.mode == "device"
-    if native:
+    if args.dry_run:
+        eng = _DryEngine(loop_ids)
+    elif native:
+        from bore_amd.engine import NativeEngine
         eng = NativeEngine(loop_ids, groups=args.groups, async_loops=args.schedule == "async")
     else:
+        from bore_amd.engine import ReplicaEngine
         eng = ReplicaEngine(loop_ids, mode=args.mode, groups=args.groups)
-
-    def barrier():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    eng.run(args.warmup)
-    if native:
+    eng.run(warmup)
+    if native or args.dry_run:
         eng.take_stats(reset=True)
     else:
         eng.finish_timing()
@@ -183,13 +281,12 @@ def main():
         eng.stats["host_enqueue_s"] = eng.stats["host_finalize_s"] = 0.0
         eng.stats["none_results"] = 0
     n_start = eng.N
-
     barrier()
     t0 = time.perf_counter()
-    eng.run(args.steps)
+    eng.run(steps)
     barrier()
     dt = time.perf_counter() - t0
-    if native:
+    if native or args.dry_run:
         st = eng.take_stats()
         n_groups = eng.n_groups
     else:
@@ -204,25 +301,264 @@ def main():
                   none_results=eng.stats["none_results"],
                   host_enqueue_s=eng.stats.get("host_enqueue_s", 0.0),
                   host_finalize_s=eng.stats.get("host_finalize_s", 0.0))
+    return dict(dt=dt, st=st, eng=eng, n_start=n_start, n_end=eng.N, n_groups=n_groups,
+                native=native, loops=len(loop_ids), steps=steps)
 
-    tmax = torch.tensor([dt], dtype=torch.float64,
+
+# ------------------------------------------------------------------------------------------
+# BASELINE configs 2 / 3 / 5 and single-loop config 1 (N = 1 only; `configs` in the line)
+# ------------------------------------------------------------------------------------------
+WIDE_CONFIGS = {
+    # name: D, units, restarts R, screening samples Ns, data-set size N, arithmetic
+    "cfg2_hartmann6_32-32-1_R256": dict(D=6, units=[32, 32, 1], R=256, Ns=1024, N=256,
+                                        compute="float32"),
+    "cfg3_hpo16_64-64-64-1_R1024": dict(D=16, units=[64, 64, 64, 1], R=1024, Ns=1024, N=256,
+                                        compute="float32"),
+    "cfg5_nas32_128-128-1_bf16_R4096": dict(D=32, units=[128, 128, 1], R=4096, Ns=4096, N=256,
+                                            compute="bfloat16"),
+}
+
+
+def _synthetic(rs, L, N, D):
+    """Seeded smooth synthetic objective on [0,1]^D (value distribution irrelevant to cost)."""
+    X = rs.uniform(size=(L, N, D))
+    c = rs.uniform(0.2, 0.8, size=D)
+    y = np.sum((X - c) ** 2, axis=2) + 0.1 * np.sin(5.0 * X.sum(axis=2))
+    return X, y
+
+
+def _counts(D, units):
+    M = sum(a * b for a, b in zip([D] + units[:-1], units))
+    return M, M + sum(units)
+
+
+def config_gpu(name, c, loops, epochs=200, batch=64, reps=3):
+    """`loops` independent models of config `c`: fit -> sample + screen -> R L-BFGS-B restarts ->
+    pick, per phase HIP events on the launching stream.  One BO iteration of a loop = the
+    sequence; loops are grid-parallel inside each launch."""
+    import torch
+    from bore_amd import _lib, ops
+    D, units, R, Ns, N = c["D"], c["units"], c["R"], c["Ns"], c["N"]
+    acts = ["relu"] * (len(units) - 1) + ["sigmoid"]
+    desc = _lib.make_desc(D, units, acts, compute=c["compute"])
+    M, P = _counts(D, units)
+    rs = np.random.RandomState(0)
+    th = np.zeros((loops, P), dtype=np.float32)
+    for l in range(loops):
+        off, fan = 0, D
+        for u in units:
+            lim = np.sqrt(6.0 / (fan + u))
+            th[l, off:off + fan * u] = rs.uniform(-lim, lim, size=fan * u)
+            off += fan * u + u
+            fan = u
+    X, y = _synthetic(rs, loops, N, D)
+    z = (y < np.quantile(y, 0.25, axis=1)[:, None]).astype(np.float32)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    theta = torch.from_numpy(th).to(dev)
+    m, v = torch.zeros_like(theta), torch.zeros_like(theta)
+    t = torch.zeros(loops, dtype=torch.int64, device=dev)
+    Xd, zd = torch.from_numpy(X.astype(np.float32)).to(dev), torch.from_numpy(z).to(dev)
+    lo, hi = np.zeros(D), np.ones(D)
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(reps + 1)]
+    infos = []
+    for k in range(reps + 1):                       # k = 0 warms up (first-launch set-up)
+        e = ev[k]
+        e[0].record()
+        ops.mlp_fit(desc, theta, m, v, t, Xd, zd, epochs, batch, seed=0, epoch0=k * epochs,
+                    want_loss=False)
+        e[1].record()
+        x0, _ = ops.sample_screen_topk(desc, theta, 0, Ns, lo, hi, R, draw_index=k)
+        e[2].record()
+        x, fun, jac, info = ops.lbfgsb_minimize(desc, theta, x0, lo, hi, "identity", True,
+                                                maxiter=1000, ftol=1e-9)
+        e[3].record()
+        ops.select_best(x, fun, info)
+        e[4].record()
+        infos.append(info)
+    torch.cuda.synchronize()
+    ph = np.array([[ev[k][i].elapsed_time(ev[k][i + 1]) for i in range(4)]
+                   for k in range(1, reps + 1)]).mean(axis=0)             # ms per phase
+    nfev = np.stack([i.cpu().numpy()[:, :, 1] for i in infos[1:]]).astype(np.float64)
+    rows = float(nfev.sum() / reps)                                      # f/g rows per iteration
+    rounds = float(nfev.max(axis=2).sum() / reps)                        # rounds, summed over loops
+    status = np.stack([i.cpu().numpy()[:, :, 2] for i in infos[1:]])
+    S = epochs * -(-N // batch)
+    by = dict(fit=loops * epochs * (4.0 * N * (D + 1) + -(-N // batch) * 24.0 * P),
+              screen=loops * (4.0 * Ns * (D + 1) + 4.0 * P),
+              fg=rows * 4.0 * (2 * D + 1) + rounds * 4.0 * P)
+    fl = dict(fit=loops * (epochs * N * (6.0 * M - 2.0 * D * units[0]) + S * 12.0 * P),
+              screen=loops * 2.0 * M * Ns, fg=4.0 * M * rows)
+    total_ms = float(ph.sum())
+    peak_tf = BF16_PEAK_TF if c["compute"] == "bfloat16" else FP32_PEAK_TF
+    kern = {"fit": ph[0], "screen": ph[1], "fg": ph[2]}
+    return {
+        "loops": loops, "it_per_s": loops / (total_ms * 1e-3),
+        "ms": {"fit": float(ph[0]), "screen": float(ph[1]), "lbfgsb": float(ph[2]),
+               "pick": float(ph[3]), "iteration": total_ms},
+        "us_per_adam_step": 1e3 * float(ph[0]) / S,
+        "fg_rows_per_iteration": rows, "restarts_ok_frac": float(np.mean(status <= 1)),
+        "algorithmic_bytes": {k: float(x) for k, x in by.items()},
+        "algorithmic_flops": {k: float(x) for k, x in fl.items()},
+        "roofline_hbm": {k: {"achieved_GBs": by[k] / (kern[k] * 1e-3) / 1e9,
+                             "frac": by[k] / (kern[k] * 1e-3) / 1e9 / HBM_PEAK_GBS} for k in by},
+        "roofline_fma": {k: {"achieved_TFs": fl[k] / (kern[k] * 1e-3) / 1e12,
+                             "frac": fl[k] / (kern[k] * 1e-3) / 1e12 / peak_tf,
+                             "peak_TFs": peak_tf} for k in fl},
+    }
+
+
+def config_cpu(c, epochs_sample=4, restarts_sample=6, batch=64, epochs=200):
+    """The oracle on ONE host core for a bounded sample of config `c`: a few epochs of the fit, the
+    screening forward and a few sequential scipy restarts, scaled to 200 epochs / R restarts."""
+    from scipy.optimize import Bounds
+    from oracle import bore_oracle as O
+    try:
+        from threadpoolctl import threadpool_limits
+        ctx = threadpool_limits(limits=1)
+    except Exception:          # pragma: no cover
+        import contextlib
+        ctx = contextlib.nullcontext()
+    D, units, R, Ns, N = c["D"], c["units"], c["R"], c["Ns"], c["N"]
+    acts = ["relu"] * (len(units) - 1) + ["sigmoid"]
+    rs = np.random.RandomState(0)
+    with ctx:
+        p = O.glorot_uniform_params(D, units, rs)
+        st = O.AdamState(p)
+        X, y = _synthetic(rs, 1, N, D)
+        z, _ = O.labels(y[0], 0.25)
+        perms = np.stack([rs.permutation(N) for _ in range(epochs_sample)])
+        bf16 = c["compute"] == "bfloat16"
+        t0 = time.perf_counter()
+        (O.fit_bf16 if bf16 else O.fit)(p, acts, st, X[0], z, perms, batch_size=batch)
+        t_fit = (time.perf_counter() - t0) * epochs / epochs_sample
+        t0 = time.perf_counter()
+        res = O.maxima(p, acts, Bounds(np.zeros(D), np.ones(D)), num_starts=restarts_sample,
+                       num_samples=Ns, random_state=rs)
+        t_arg = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        O.predict(p, acts, rs.uniform(size=(Ns, D)))
+        t_scr = time.perf_counter() - t0
+    t_restart = max(t_arg - t_scr, 0.0) / restarts_sample
+    total = t_fit + t_scr + t_restart * R
+    return dict(value=1.0 / total, unit="BO-iterations/s", cores=1, kind="port",
+                ms=dict(fit=1e3 * t_fit, screen=1e3 * t_scr, lbfgsb=1e3 * t_restart * R),
+                sample=f"{epochs_sample} of {epochs} epochs of the fit and {restarts_sample} of {R} "
+                       f"sequential scipy restarts (fp32 numpy arithmetic"
+                       f"{'; the fit in the bf16 statement' if bf16 else ''}), scaled; mean nit "
+                       f"{np.mean([r.nit for r in res]):.1f}, nfev {np.mean([r.nfev for r in res]):.1f}")
+
+
+def all_configs(args, barrier, cpu):
+    out = {}
+    # config 1 as ONE loop (the literal "Branin-2D ... 3 restarts" configuration)
+    r = timed_run(args, np.arange(1, dtype=np.int64), barrier, steps=max(args.steps, 20), warmup=3)
+    out["cfg1_branin2_16-16-1_single_loop"] = {
+        "loops": 1, "it_per_s": r["steps"] / r["dt"], "ms": {"iteration": 1e3 * r["dt"] / r["steps"]},
+        "N_start": int(r["n_start"]), "N_end": int(r["n_end"]),
+        "note": "chain latency of one loop: own fit + own restarts + host hand-over"}
+    del r
+    for name, c in WIDE_CONFIGS.items():
+        try:
+            one = config_gpu(name, c, loops=1)
+            many = config_gpu(name, c, loops=64 if c["R"] >= 4096 else 256, reps=2)
+            out[name] = dict(one, many_loops=many)
+            if cpu:
+                out[name]["cpu_baseline"] = config_cpu(c)
+        except Exception as e:                     # a config that cannot run says so in the line
+            out[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
+    return out
+
+
+# ------------------------------------------------------------------------------------------
+def run_rank(args):
+    import torch
+    import torch.distributed as dist
+    from bore_amd.engine import gather_results, shard_loop_ids
+
+    dry = args.dry_run
+    if dry:
+        args.backend = "gloo"
+    sync = (lambda: None) if dry else torch.cuda.synchronize
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+    if os.environ.get("BORE_BENCH_ONE_DEVICE") == "1":     # rehearsal: every rank on cuda:0
+        local = 0
+    if not dry:
+        torch.cuda.set_device(local)
+    if world > 1:
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group("gloo")
+    loops, total, scaling = resolve_loops(args, world)
+
+    def barrier():
+        sync()
+        if world > 1:
+            dist.barrier()
+        sync()
+
+    def solo_barrier():
+        sync()
+
+    loop_ids = shard_loop_ids(rank, world, loops)          # contiguous shard per rank
+    r = timed_run(args, loop_ids, barrier)
+    tmax = torch.tensor([r["dt"]], dtype=torch.float64,
                         device="cuda" if args.backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax[0])
-    results = gather_results(eng, world)            # the path's only collective (RCCL gather)
+    runs = [dict(value=total * args.steps / float(tmax[0]), dt=float(tmax[0]), r=r)]
+    results = gather_results(r["eng"], world)       # the path's only collective (RCCL gather)
+    r["eng"] = None
+
+    # N = 1: a timed region shorter than a second is one sample of a noisy quantity -- repeat it on
+    # fresh engines and report the median run (each run times exactly K steps after W warm-up)
+    if world == 1 and args.repeats != 1:
+        n_rep = args.repeats if args.repeats > 0 else (5 if runs[0]["dt"] < 1.0 else 1)
+        for _ in range(n_rep - 1):
+            rr = timed_run(args, loop_ids, barrier)
+            rr["eng"] = None
+            runs.append(dict(value=total * args.steps / rr["dt"], dt=rr["dt"], r=rr))
+    order = sorted(range(len(runs)), key=lambda i: runs[i]["value"])
+    med = runs[order[(len(runs) - 1) // 2]]         # (lower median for an even count)
+    r, dt = med["r"], med["dt"]
+    st = r["st"]
+
+    # N > 1: the single-GPU reference points of the two efficiencies, timed by rank 0 ALONE
+    eff = None
+    if world > 1 and not args.no_efficiency:
+        if rank == 0:
+            t_share = timed_run(args, shard_loop_ids(0, 1, loops), solo_barrier)
+            v_share = loops * args.steps / t_share["dt"]
+            del t_share
+            t_all = timed_run(args, shard_loop_ids(0, 1, total), solo_barrier)
+            v_all = total * args.steps / t_all["dt"]
+            del t_all
+            v = med["value"]
+            eff = {"T_N_total": v, "T_1_share": v_share, "T_1_total": v_all,
+                   "share_loops": loops, "total_loops": total,
+                   "eff_w": v / (world * v_share), "eff_s": v / (world * v_all),
+                   "definitions": "eff_w = T(N,total)/(N*T(1,total/N)); eff_s = T(N,total)/(N*T(1,total)) "
+                                  "(SURVEY.md 8e); reference points timed by rank 0 alone in this "
+                                  "invocation, same steps/warm-up",
+                   "target_0.9_uses": "eff_w (same per-GPU load; the path has no collective, so what "
+                                      "it measures is host contention between the ranks). eff_s is "
+                                      "bounded by one loop's dependency chain: a GPU with total/N "
+                                      "loops runs each of them no faster than with all of them"}
+        barrier()
 
     if rank == 0:
-        total_iters = args.loops * world * args.steps
-
-        # HBM traffic per launch from the committed PMC pass (FETCH_SIZE / WRITE_SIZE, gfx950
-        # correction applied): it is per model, launches here carry loops/groups models
+        total_iters = total * args.steps
         try:
-            with open(os.path.join(ROOT, "profiles", "r1", "pmc_traffic.json")) as f:
+            with open(os.path.join(ROOT, TRAFFIC_FILE)) as f:
                 pmc = json.load(f)
         except Exception:
             pmc = {}
-        models_per_launch = args.loops / n_groups if st["fit_ms"] else args.loops * args.steps / max(st["argmax_launches"], 1)
+        models_per_launch = (loops / r["n_groups"] if st["fit_ms"]
+                             else loops * args.steps / max(st["argmax_launches"], 1))
 
         def roof(name, ms_sum, bytes_sum, launches):
             # HIP-event durations (recorded on the launching stream) summed over the timed region
@@ -230,7 +566,11 @@ def main():
             per_model = pmc.get(name, {}).get("hbm_bytes_per_model")
             return {"bound": "hbm", "kernel": name, "achieved": ach, "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                    # (not measured in this run: the committed PMC pass, per model x models per launch)
                     "traffic": None if per_model is None else per_model * models_per_launch,
+                    "traffic_source": None if per_model is None else
+                    f"{TRAFFIC_FILE} ({pmc.get('build', '?')}; rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                    "passes, committed; NOT collected in this run)",
                     "avg_launch_ms": float(ms_sum / launches),
                     "algorithmic_bytes_per_launch": float(bytes_sum / launches),
                     "launches": int(launches),
@@ -238,7 +578,8 @@ def main():
                     # (stream groups / asynchronous batches overlap, so shares add up to > 1)
                     "share_of_step": float(ms_sum / (1e3 * dt)),
                     # all launches together: algorithmic bytes of the timed region / wall time
-                    "aggregate_GBs": float(bytes_sum / dt / 1e9)}
+                    "aggregate_GBs": float(bytes_sum / dt / 1e9),
+                    "aggregate_frac": float(bytes_sum / dt / 1e9 / HBM_PEAK_GBS)}
 
         if st["fit_ms"] == 0.0:        # asynchronous schedule: fit + argmax are ONE kernel per launch
             kernels = [roof("iteration_kernel", st["argmax_ms"], st["fit_bytes"] + st["argmax_bytes"],
@@ -252,55 +593,123 @@ def main():
         # secondary figure: algorithmic FLOPs of the timed region against the fp32
         # vector/MFMA peak -- with theta in LDS the path is arithmetic/latency bound, not HBM bound
         D_, units_ = 2, [16, 16, 1]
-        M_ = sum(a * b for a, b in zip([D_] + units_[:-1], units_))            # MACs per row
-        P_ = M_ + sum(units_)
-        Ns_ = np.arange(n_start, n_start + args.steps)
-        rows = float(args.loops * world * 200 * Ns_.sum())                     # S_rows = E * N per fit
-        adam = float(args.loops * world * 200 * np.ceil(Ns_ / 64).sum())       # S = E * ceil(N / B)
+        M_, P_ = _counts(D_, units_)
+        Ns_ = np.arange(r["n_start"], r["n_start"] + args.steps)
+        rows = float(loops * 200 * Ns_.sum())                        # S_rows = E * N per fit
+        adam = float(loops * 200 * np.ceil(Ns_ / 64).sum())          # S = E * ceil(N / B)
         flops = (rows * (6 * M_ - 2 * D_ * units_[0]) + adam * 12 * P_
-                 + 2.0 * M_ * 1024 * total_iters + 4.0 * M_ * st["n_fg_rows"] * world)
-        flop_roof = {"bound": "mfma", "what": "whole timed region, all kernels (secondary; SURVEY 8d)",
-                     "achieved": flops / dt / 1e12, "peak": 157.3, "unit": "TFLOP/s",
-                     "frac": flops / dt / 1e12 / 157.3,
-                     "algorithmic_flops_per_iteration": flops / total_iters}
+                 + 2.0 * M_ * 1024 * loops * args.steps + 4.0 * M_ * st["n_fg_rows"])   # rank 0's
+        flop_roof = {"bound": "mfma", "what": "whole timed region of one GPU, all kernels (secondary; SURVEY 8d)",
+                     "achieved": flops / dt / 1e12, "peak": FP32_PEAK_TF, "unit": "TFLOP/s",
+                     "frac": flops / dt / 1e12 / FP32_PEAK_TF,
+                     "algorithmic_flops_per_iteration": flops / (loops * args.steps)}
+        phases = {"fg_rows_per_step": st["n_fg_rows"] / args.steps,
+                  "fg_rounds_per_step": st["n_rounds"] / args.steps,
+                  "none_results": int(st["none_results"]),
+                  "host_enqueue_ms_per_step": 1e3 * st["host_enqueue_s"] / args.steps,
+                  "host_finalize_ms_per_step": 1e3 * st["host_finalize_s"] / args.steps}
+        if st["fit_ms"]:
+            phases["fit_ms_per_launch"] = float(st["fit_ms"] / max(st["fit_launches"], 1))
+        if st.get("phase_iterations"):     # fused kernel: in-kernel clock stamps, mean per loop-iteration
+            n_it = st["phase_iterations"]
+            phases["per_loop_iteration_us"] = {k: 1e-3 * st["phase_ns_" + k] / n_it
+                                               for k in ("labels", "fit", "screen", "lbfgsb")}
         out = {
             "metric": "BO-iterations/sec (fit+argmax), 16-16-1 MLP",
-            "value": total_iters / dt, "unit": "BO-iterations/s", "n_gpus": world,
+            "value": med["value"], "unit": "BO-iterations/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": "BASELINE config 4 (= config 1 x independent loops): Branin-2D, "
                                    "16-16-1 MLP, q=0.25, 200 epochs, batch 64, 3 L-BFGS-B "
                                    "restarts from 1024 samples",
-                       "loops_per_gpu": args.loops, "restarts": args.mode,
-                       "host_loop": "native" if native else "python",
-                       "schedule": args.schedule if native else "groups",
-                       "stream_groups": None if (native and args.schedule == "async") else n_groups,
+                       "loops_per_gpu": loops, "total_loops": total, "restarts": args.mode,
+                       "host_loop": "native" if r["native"] else "python",
+                       "schedule": args.schedule if r["native"] else "groups",
+                       "stream_groups": None if (r["native"] and args.schedule == "async") else r["n_groups"],
                        "worker_streams": (int(os.environ.get("BORE_ASYNC_WORKERS", 12))
-                                          if (native and args.schedule == "async") else None),
-                       "N_start": int(n_start),
-                       "N_end": int(eng.N), "parallelism": f"replica-shard x{world}"},
+                                          if (r["native"] and args.schedule == "async") else None),
+                       "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
+                       "N_start": int(r["n_start"]),
+                       "N_end": int(r["n_end"]), "parallelism": f"replica-shard x{world}"},
             "roofline": dominant,
             "roofline_flops": flop_roof,
             "kernels": kernels,
-            "phases": {"fit_ms_per_launch": float(st["fit_ms"] / max(st["fit_launches"], 1)),
-                       "fg_rows_per_step": st["n_fg_rows"] / args.steps,
-                       "fg_rounds_per_step": st["n_rounds"] / args.steps,
-                       "none_results": int(st["none_results"]),
-                       "host_enqueue_ms_per_step": 1e3 * st["host_enqueue_s"] / args.steps,
-                       "host_finalize_ms_per_step": 1e3 * st["host_finalize_s"] / args.steps},
+            "phases": phases,
+            "runs": {"values": [q["value"] for q in runs], "n": len(runs),
+                     "min": min(q["value"] for q in runs), "max": max(q["value"] for q in runs),
+                     "value_is": "the median run" if len(runs) > 1 else "the only run",
+                     "timed_region_s": dt},
             "best_y_median": float(np.median(results[:, -1])),
+            "tf_keras": tf_keras_probe(),
         }
+        if eff is not None:
+            out["efficiency"] = eff
         out["cpu_baseline"] = None
-        if args.cpu_seconds > 0 and world == 1:              # (rank 0 at N = 1 only)
-            allc, one = cpu_baseline(args.cpu_seconds, iters_per_loop=args.steps + args.warmup)
-            out["cpu_baseline"] = allc
-            if one is not None:
-                out["cpu_baseline_1core"] = one
+        if dry:
+            out["dry_run"] = ("no GPU work was done: this line only shows that the multi-rank flow "
+                              "of bench.py ran; every figure in it is meaningless")
+            out["value"] = None
+        if world == 1 and not dry:
+            if not args.no_configs:
+                out["configs"] = all_configs(args, solo_barrier, cpu=args.cpu_seconds > 0)
+            if args.cpu_seconds > 0:                             # (rank 0 at N = 1 only)
+                allc, one = cpu_baseline(args.cpu_seconds, iters_per_loop=args.steps + args.warmup)
+                out["cpu_baseline"] = allc
+                if one is not None:
+                    out["cpu_baseline_1core"] = one
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
 
 
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--loops", type=int, default=None,
+                    help="BO loops PER GPU (weak scaling); default: see --total-loops")
+    ap.add_argument("--total-loops", type=int, default=None,
+                    help=f"BO loops of the whole job, sharded over the GPUs (default {TOTAL_LOOPS} = "
+                         "BASELINE config 4)")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--repeats", type=int, default=0,
+                    help="N = 1: timed regions on fresh engines (0 = 5 when a region is < 1 s, else 1)")
+    ap.add_argument("--no-configs", action="store_true",
+                    help="skip the per-config figures (configs 1-single-loop, 2, 3, 5)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no GPU: run the multi-rank flow (spawn, rendezvous over gloo, barriers, "
+                         "gather) around an engine stand-in; the line carries \"dry_run\" and no value")
+    ap.add_argument("--no-efficiency", action="store_true",
+                    help="N > 1: skip rank 0's single-GPU reference runs (eff_w / eff_s)")
+    ap.add_argument("--groups", type=int, default=4,
+                    help="loop groups stepping on separate streams (overlaps L-BFGS-B tails)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend for N > 1 (nccl = RCCL; gloo only to rehearse the "
+                         "multi-rank flow on a one-GPU box together with BORE_BENCH_ONE_DEVICE=1)")
+    ap.add_argument("--engine", default="native", choices=["native", "python"],
+                    help="host loop of the replica engine: native = bore_engine_* (C++), python = "
+                         "bore_amd.engine.ReplicaEngine (the same trajectories, bit for bit)")
+    ap.add_argument("--schedule", default="async", choices=["groups", "async"],
+                    help="native engine: groups = loop groups in lock-step on their own streams; "
+                         "async = every loop re-enters the next launch as soon as its own restarts "
+                         "are done (same trajectories)")
+    ap.add_argument("--mode", default="device", choices=["device", "lockstep"],
+                    help="device: L-BFGS-B restarts inside one kernel; lockstep: scipy on the host")
+    return ap.parse_args(argv)
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else list(argv)
+    args = parse_args(argv)
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # a plain shell: start the ranks ourselves.  Nothing above imported torch or touched HIP.
+        resolve_loops(args, args.gpus)          # (argument errors before any process starts)
+        return spawn_ranks(args.gpus, argv)
+    run_rank(args)
+    return 0
+
+
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -280,7 +280,11 @@ class ObservationStore:
         torch.cuda.synchronize()
         self.__dict__.update(new.__dict__)
         if self.n:
-            self.append(None, None)      # the dense views live in the new buffers
+            # the dense views live in the new buffers.  The refresh runs on the CURRENT stream and
+            # the caller may go on to use another one (ReplicaEngine appends on its group's
+            # non-blocking stream): finish it before returning, as the docstring promises.
+            self.append(None, None)
+            torch.cuda.synchronize()
 
     def append(self, x_new, y_new):
         """Append one row per loop (x_new [L, D], y_new [L], device fp64; None = just refresh the

@@ -1,0 +1,73 @@
+"""bench.py as the driver starts it: `python bench.py --gpus N` from a plain shell must start its
+own N ranks.  Runs here without a GPU through --dry-run
+(an engine stand-in; rank spawning, rendezvous over gloo, barriers, max-over-ranks time and the
+gather are the real code)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _plain_env():
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    return env
+
+
+def _run(*argv, timeout=240):
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], env=_plain_env(),
+                          capture_output=True, text=True, timeout=timeout, cwd=ROOT)
+
+
+def test_spawns_its_own_ranks_config4_as_written():
+    p = _run("--gpus", "2", "--dry-run", "--steps", "3", "--warmup", "1")
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout          # ONE JSON line, from rank 0
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1
+    assert d["scaling"] == "strong"            # 512 loops in total, whatever N
+    assert d["config"]["total_loops"] == 512 and d["config"]["loops_per_gpu"] == 256
+    assert "dry_run" in d and d["value"] is None
+    eff = d["efficiency"]
+    assert eff["share_loops"] == 256 and eff["total_loops"] == 512
+    assert set(("eff_w", "eff_s", "T_1_share", "T_1_total", "T_N_total")) <= set(eff)
+
+
+def test_per_gpu_loops_is_weak_scaling():
+    p = _run("--gpus", "2", "--dry-run", "--steps", "2", "--warmup", "0", "--loops", "8",
+             "--no-efficiency")
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
+    assert d["scaling"] == "weak" and d["config"]["loops_per_gpu"] == 8
+    assert d["config"]["total_loops"] == 16 and "efficiency" not in d
+
+
+def test_torchrun_style_launch_still_works():
+    """Under a launcher (RANK / WORLD_SIZE set) the script is the rank it is told to be."""
+    env = _plain_env()
+    env.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29617")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--dry-run",
+                        "--steps", "2", "--warmup", "0"], env=env, capture_output=True, text=True,
+                       timeout=120, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
+    assert d["n_gpus"] == 1 and d["config"]["loops_per_gpu"] == 512 and d["scaling"] == "weak"
+
+
+def test_bad_split_is_refused_before_any_rank_starts():
+    p = _run("--gpus", "3", "--dry-run")
+    assert p.returncode != 0 and "does not divide" in p.stderr
+
+
+def test_failed_rank_fails_the_run():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("needs a box without a GPU: the ranks fail at torch.cuda.set_device")
+    p = _run("--gpus", "2", "--steps", "1", "--warmup", "0", "--cpu-seconds", "0")
+    assert p.returncode != 0
+    assert "rank 0 exited" in p.stderr or "rank 1 exited" in p.stderr
