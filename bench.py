@@ -191,6 +191,12 @@ def cpu_baseline(seconds, iters_per_loop=100, max_workers=64):
     import multiprocessing as mp
     threads, quota = _cpu_quota()
     cores = min(threads, max_workers)
+    try:        # cgroup v2 "quota period": more processes than the quota allows only throttle
+        q, per = quota.split()
+        if q != "max":
+            cores = max(1, min(cores, int(-(-int(q) // int(per)))))
+    except Exception:
+        pass
     it1, dt1 = _cpu_worker((seconds / 3.0, iters_per_loop, 0))
     what = ("numpy fp32 oracle + scipy L-BFGS-B (sequential restarts, single-point f/g), "
             f"loops of <= {iters_per_loop} iterations (N 10->{10 + iters_per_loop})")
@@ -212,8 +218,8 @@ def cpu_baseline(seconds, iters_per_loop=100, max_workers=64):
     allc = dict(value=rate, unit="BO-iterations/s", cores=cores, kind="port",
                 scaling_vs_1core=rate / (it1 / dt1),
                 sample=f"{its} BO iterations by {cores} single-threaded processes (of {threads} "
-                       f"hardware threads in the affinity mask; cgroup cpu.max = {quota!r}; one "
-                       f"per core, independent loops) running {seconds:.0f} s each ({wall:.1f} s "
+                       f"hardware threads in the affinity mask; cgroup cpu.max = {quota!r} bounds the "
+                       f"usable cores; one process per usable core, independent loops) running {seconds:.0f} s each ({wall:.1f} s "
                        f"wall with start-up); {what}")
     return allc, one
 
@@ -614,6 +620,13 @@ def run_rank(args):
             n_it = st["phase_iterations"]
             phases["per_loop_iteration_us"] = {k: 1e-3 * st["phase_ns_" + k] / n_it
                                                for k in ("labels", "fit", "screen", "lbfgsb")}
+            # the host's view of the same loop-iterations (means): a loop is ready (its new row
+            # is known) -> its launch is enqueued -> the host sees its result -> objective done
+            phases["per_loop_iteration_us"].update(
+                host_ready_to_launch=1e6 * st["ready_to_launch_s"] / n_it,
+                host_launch_to_result=1e6 * st["launch_to_result_s"] / n_it,
+                host_result_to_ready=1e6 * st["result_to_ready_s"] / n_it)
+            phases["loops_per_launch"] = n_it / max(st["batches"], 1)
         out = {
             "metric": "BO-iterations/sec (fit+argmax), 16-16-1 MLP",
             "value": med["value"], "unit": "BO-iterations/s", "n_gpus": world,

@@ -77,7 +77,12 @@ class EngineStats(C.Structure):
                 ("argmax_bytes", C.c_double), ("host_enqueue_s", C.c_double),
                 ("host_finalize_s", C.c_double), ("fit_launches", C.c_int64),
                 ("argmax_launches", C.c_int64), ("n_fg_rows", C.c_int64), ("n_rounds", C.c_int64),
-                ("none_results", C.c_int64)]
+                ("none_results", C.c_int64),
+                ("phase_ns_labels", C.c_double), ("phase_ns_fit", C.c_double),
+                ("phase_ns_screen", C.c_double), ("phase_ns_lbfgsb", C.c_double),
+                ("ready_to_launch_s", C.c_double), ("launch_to_result_s", C.c_double),
+                ("result_to_ready_s", C.c_double), ("phase_iterations", C.c_int64),
+                ("batches", C.c_int64)]
 
 
 OBJECTIVE_FN = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_double), C.c_int64, C.c_int32,

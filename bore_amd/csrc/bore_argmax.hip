@@ -468,6 +468,7 @@ struct LbfgsbArgs {
   const double *X_seen;
   double *result;
   int *flag;
+  const long long *stamps;  // [n_loops][4] clock stamps of the fused kernel's earlier phases, or NULL
 };
 
 // -DBORE_STAMPS: cycles spent in the optimiser / in f-g evaluation by wave 0 of workgroup 0
@@ -704,11 +705,22 @@ __device__ __forceinline__ void lbfgsb_body(const LbfgsbArgs &a, const long long
     }
   }
   if (lane == 0) {
-    double *out = a.result + lid * (D + 3);
+    double *out = a.result + lid * (D + 8);
     for (int d = 0; d < D; ++d) out[d] = best >= 0 ? res[best * (D + 3) + 3 + d] : 0.0;
     out[D] = (double)best;
     out[D + 1] = nfev_sum;
     out[D + 2] = nfev_max;
+    if (a.stamps) {  // device-clock ticks per phase of this loop-iteration (fused kernel)
+      const long long *s = a.stamps + lid * 4;
+      const long long now = wall_clock64();
+      out[D + 3] = (double)(s[1] - s[0]);
+      out[D + 4] = (double)(s[2] - s[1]);
+      out[D + 5] = (double)(s[3] - s[2]);
+      out[D + 6] = (double)(now - s[3]);
+    } else {
+      out[D + 3] = out[D + 4] = out[D + 5] = out[D + 6] = 0.0;
+    }
+    out[D + 7] = 0.0;
     __threadfence_system();
     __hip_atomic_store(a.flag + lid, a.its[model] + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
@@ -800,7 +812,7 @@ static int lbfgsb_build(const bore_mlp_desc *desc, int n_models, const float *th
   a.theta = theta; a.x0 = x0; a.x = x; a.fun = fun; a.jac = jac; a.info = info;
   a.R = num_starts; a.transform = transform; a.sign = negate ? -1.f : 1.f;
   a.ids = a.its = nullptr; a.n_init = a.dedup = 0; a.cap = 0;
-  a.X_seen = nullptr; a.result = nullptr; a.flag = nullptr;
+  a.X_seen = nullptr; a.result = nullptr; a.flag = nullptr; a.stamps = nullptr;
   if (g_batch) {
     if (num_starts > 4 || PB < num_starts)
       return fail(BORE_E_UNSUPPORTED, "lbfgsb_minimize: batch mode needs num_starts <= 4 in one workgroup");

@@ -103,10 +103,13 @@ struct Async {
   int64_t cap = 0;
   double *X_seen = nullptr, *y_seen = nullptr;   // device [L][cap][D], [L][cap]
   float *X32 = nullptr, *z = nullptr;            // device [L][cap][D], [L][cap]
-  double *result = nullptr;                      // pinned [L][D + 3]
+  double *result = nullptr;                      // pinned [L][D + 8]
   int32_t *flag = nullptr;                       // pinned [L]
+  int64_t *stamps = nullptr;                     // device [L][4]: phase clock stamps (fused kernel)
+  double ns_per_tick = 10.0;                     // of the device wall clock (100 MHz on gfx950)
   std::vector<int32_t> it, target, state;        // per loop: iterations done; 0 ready 1 in flight 2 done
   std::vector<double> x_new, y_new, ready_since; // per loop: the row to append at its next launch
+  std::vector<double> seen_at;                   // per loop: when the host took its result
   std::vector<Worker> workers;
   std::vector<int> scratch_ids, done_ids;
   std::vector<double> cb_x, cb_y;
@@ -321,8 +324,18 @@ int async_create(bore_engine *e, const double *X0, const double *y0) {
   HIP_TRY(hipMemcpy2D(A.X_seen, A.cap * D * 8, X0, n0 * D * 8, n0 * D * 8, L, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy2D(A.y_seen, A.cap * 8, y0, n0 * 8, n0 * 8, L, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy2D(A.X32, A.cap * D * 4, x32.data(), n0 * D * 4, n0 * D * 4, L, hipMemcpyHostToDevice));
-  if ((rc = pin_alloc(&A.result, L * (D + 3))) || (rc = pin_alloc(&A.flag, L))) return rc;
+  if ((rc = pin_alloc(&A.result, L * (D + 8))) || (rc = pin_alloc(&A.flag, L)) ||
+      (rc = dev_alloc(&A.stamps, L * 4)))
+    return rc;
   std::memset(A.flag, 0, L * 4);
+  HIP_TRY(hipMemset(A.stamps, 0, L * 4 * 8));
+  {
+    int dev = 0, khz = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) == hipSuccess && khz > 0)
+      A.ns_per_tick = 1e6 / khz;
+  }
+  A.seen_at.assign(L, 0.0);
   A.it.assign(L, 0); A.target.assign(L, 0); A.state.assign(L, 2);
   A.x_new.assign(L * D, 0.0); A.y_new.assign(L, 0.0); A.ready_since.assign(L, 0.0);
   A.scratch_ids.reserve(L); A.cb_x.resize(L * D); A.cb_y.resize(L);
@@ -373,7 +386,7 @@ void async_destroy(bore_engine *e) {
       if (ev) (void)hipEventDestroy(ev);
     if (w.stream) (void)hipStreamDestroy(w.stream);
   }
-  void *dev[] = {A.X_seen, A.y_seen, A.X32, A.z};
+  void *dev[] = {A.X_seen, A.y_seen, A.X32, A.z, A.stamps};
   for (void *p : dev)
     if (p) (void)hipFree(p);
   if (A.result) (void)hipHostFree(A.result);
@@ -401,6 +414,7 @@ int async_launch(bore_engine *e, Worker &w) {
     A.state[l] = 1;
     A.launched_at[l] = t0;
     A.sum_wait += t0 - A.ready_since[l];
+    e->st.ready_to_launch_s += t0 - A.ready_since[l];
     ++A.n_wait;
     const double N = c.n_init + it, steps = std::ceil(N / c.batch_size);
     w.fit_bytes += c.epochs * (4.0 * N * (D + 1) + steps * 24.0 * e->P);
@@ -412,6 +426,7 @@ int async_launch(bore_engine *e, Worker &w) {
   bore_batch bt;
   bt.ids = w.d_int; bt.its = w.d_int + L; bt.n_init = c.n_init; bt.deduplicate = c.deduplicate;
   bt.cap = A.cap; bt.X_seen = A.X_seen; bt.result = A.result; bt.flag = A.flag;
+  bt.stamps = A.stamps;
   bore_set_batch(&bt);
   void *sp = w.stream;
   if (A.fused) {
@@ -429,6 +444,7 @@ int async_launch(bore_engine *e, Worker &w) {
     w.busy = true;
     w.n = B;
     ++A.n_batches;
+    ++e->st.batches;
     A.n_slots += B;
     e->st.host_enqueue_s += now_s() - t0;
     return 0;
@@ -455,6 +471,7 @@ int async_launch(bore_engine *e, Worker &w) {
   w.busy = true;
   w.n = B;
   ++A.n_batches;
+  ++e->st.batches;
   A.n_slots += B;
   e->st.host_enqueue_s += now_s() - t0;
   return 0;
@@ -504,9 +521,16 @@ int async_run(bore_engine *e, int n_steps) {
       if (__atomic_load_n(&A.flag[l], __ATOMIC_ACQUIRE) != A.it[l] + 1) continue;
       A.state[l] = 3;  // result taken, objective pending
       if (n_done == 0) first_done = t0;
-      const double *r = A.result + (size_t)l * (D + 3);
+      const double *r = A.result + (size_t)l * (D + 8);
       double *xn = &A.cb_x[(size_t)n_done * D];
       A.sum_flight += t0 - A.launched_at[l];
+      A.seen_at[l] = t0;
+      e->st.launch_to_result_s += t0 - A.launched_at[l];
+      e->st.phase_ns_labels += r[D + 3] * A.ns_per_tick;
+      e->st.phase_ns_fit += r[D + 4] * A.ns_per_tick;
+      e->st.phase_ns_screen += r[D + 5] * A.ns_per_tick;
+      e->st.phase_ns_lbfgsb += r[D + 6] * A.ns_per_tick;
+      ++e->st.phase_iterations;
       if (r[D] < 0.0) {  // reference: fall back to a random point of this loop's stream
         ++e->st.none_results;
         Mt19937 &rs = e->rs[l];
@@ -530,6 +554,7 @@ int async_run(bore_engine *e, int n_steps) {
         const int l = A.done_ids[k];
         std::memcpy(&A.x_new[(size_t)l * D], &A.cb_x[(size_t)k * D], (size_t)D * 8);
         A.y_new[l] = A.cb_y[k];
+        e->st.result_to_ready_s += now - A.seen_at[l];
         ++A.it[l];
         if (A.it[l] >= A.target[l]) {
           A.state[l] = 2;

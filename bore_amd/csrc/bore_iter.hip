@@ -20,6 +20,7 @@ struct IterArgs {
   double *X_seen, *y_seen;  // records, cap-strided per loop
   float *X32, *z;
   const double *x_new, *y_new;  // per slot: the row to append
+  long long *stamps;            // [n_loops][4] device-clock stamps of the phase boundaries, or NULL
   double gamma;
   int D;
 };
@@ -30,6 +31,8 @@ __global__ __launch_bounds__(BORE_THREADS, 2) void iteration_kernel(const IterAr
   const long long slot = blockIdx.x;
   const int it = a.f.its[slot];
   const long long lid = a.f.ids[slot], cap = a.f.cap;
+  long long *stp = a.stamps ? a.stamps + lid * 4 : nullptr;  // read back by the restart phase's epilogue
+  if (stp && threadIdx.x == 0) stp[0] = wall_clock64();
   if (it > 0) {  // append (append_kernel's batch branch)
     const long long row = a.f.n_init + it - 1;
     for (int d = threadIdx.x; d < a.D; d += blockDim.x) {
@@ -42,12 +45,15 @@ __global__ __launch_bounds__(BORE_THREADS, 2) void iteration_kernel(const IterAr
   __threadfence();
   __syncthreads();
   labels_body(a.y_seen, 0, 0.0, a.z, nullptr, a.f.ids, a.f.its, a.f.n_init, cap, a.gamma, slot);
+  if (stp && threadIdx.x == 0) stp[1] = wall_clock64();
   __threadfence();
   __syncthreads();
   fit_body<SHAPE>(a.f, slot);
+  if (stp && threadIdx.x == 0) stp[2] = wall_clock64();
   __threadfence();
   __syncthreads();
   screen_body<SHAPE, false>(a.s, slot);
+  if (stp && threadIdx.x == 0) stp[3] = wall_clock64();
   __threadfence();
   __syncthreads();
   lbfgsb_body<SHAPE, false, true>(a.b, slot, 0);
@@ -89,6 +95,8 @@ static int iteration_launch(const bore_mlp_desc *desc, int n_slots, float *theta
     return fail(BORE_E_UNSUPPORTED, "iteration_launch: static shape 1 only");
   h->X_seen = X_seen; h->y_seen = y_seen; h->X32 = X32; h->z = z;
   h->x_new = x_new; h->y_new = y_new;
+  h->stamps = reinterpret_cast<long long *>(g_batch->stamps);
+  h->b.stamps = h->stamps;
   h->gamma = gamma;
   h->D = desc->input_dim;
   size_t floats = lf > ls ? lf : ls;

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define BORE_ABI_VERSION 7
+#define BORE_ABI_VERSION 8
 #define BORE_MAX_LAYERS 8
 #define BORE_BATCH_MAX 64 /* rows per tile == wavefront width */
 #define BORE_DIM_MAX 64   /* largest input dimension for the by-value bound arrays */
@@ -307,9 +307,11 @@ int bore_shuffle_perm(uint64_t seed, int64_t model_index0, int n_models,
  *     and X32 (all `cap`-strided; y_dense unused);
  *   - bore_lbfgsb_minimize (num_starts <= 4) ends each loop with the pick of bore_select_best
  *     (filter over X_seen when deduplicate != 0) and publishes it as soon as THAT loop's restarts
- *     are done: result[ids[b]] = {x_best[D], best, sum nfev, max nfev} (doubles), then, after a
- *     system-scope fence, flag[ids[b]] = its[b] + 1.  result and flag must be host-visible
- *     (pinned) memory.
+ *     are done: result[ids[b]] = {x_best[D], best, sum nfev, max nfev, then the device-clock
+ *     ticks (hipDeviceAttributeWallClockRate) the loop-iteration spent in labels, fit, sample +
+ *     screen and restarts + pick -- zeros unless `stamps` is given and the launch is the fused
+ *     iteration kernel --, one spare} (D + 8 doubles), then, after a system-scope fence,
+ *     flag[ids[b]] = its[b] + 1.  result and flag must be host-visible (pinned) memory.
  * bore_set_batch(NULL) returns to the plain meaning.  The struct is copied.
  */
 typedef struct bore_batch {
@@ -319,8 +321,9 @@ typedef struct bore_batch {
   int32_t deduplicate;
   int64_t cap;
   const double *X_seen;  /* device fp64 [n_loops][cap][D] */
-  double *result;        /* pinned [n_loops][D + 3] */
+  double *result;        /* pinned [n_loops][D + 8] */
   int32_t *flag;         /* pinned [n_loops] */
+  int64_t *stamps;       /* device [n_loops][4] scratch for the phase clock stamps, or NULL */
 } bore_batch;
 void bore_set_batch(const bore_batch *batch);
 
@@ -371,6 +374,12 @@ typedef struct bore_engine_stats {
   double fit_ms, fit_bytes, argmax_ms, argmax_bytes;
   double host_enqueue_s, host_finalize_s;
   int64_t fit_launches, argmax_launches, n_fg_rows, n_rounds, none_results;
+  /* asynchronous schedule, fused iteration kernel: device-clock time of the phases of a
+   * loop-iteration summed over `phase_iterations` of them (ns), and the host's view of the same
+   * iterations: ready -> launched, launched -> result seen, result seen -> ready again (s) */
+  double phase_ns_labels, phase_ns_fit, phase_ns_screen, phase_ns_lbfgsb;
+  double ready_to_launch_s, launch_to_result_s, result_to_ready_s;
+  int64_t phase_iterations, batches;
 } bore_engine_stats;
 
 typedef struct bore_engine bore_engine;

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Measurements of one build on the GPU box (run through gpurun from the repo root):
-#   bash scratch/profile_round.sh v10
+#   bash tools/profile_round.sh v10
 # writes gpurun_out/<tag>_*; copy what should be judged into profiles/r1/.
 set -o pipefail
 tag=${1:-vX}
@@ -13,19 +13,19 @@ tail -c 600 $O/${tag}_bench.json; echo
 echo "== rocprofv3 kernel trace"
 rm -rf $O/prof_${tag}_kt
 timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $O/prof_${tag}_kt --output-format csv -- python3 bench.py --steps 100 --warmup 3 --cpu-seconds 0 > $O/${tag}_bench_under_rocprof.json 2> $O/${tag}_rocprof_kt.err || exit 1
-python3 scratch/prof_summary.py $O/prof_${tag}_kt $O/${tag} > $O/${tag}_kt_summary.txt; cat $O/${tag}_kt_summary.txt
+python3 tools/prof_summary.py $O/prof_${tag}_kt $O/${tag} > $O/${tag}_kt_summary.txt; cat $O/${tag}_kt_summary.txt
 for pmc in FETCH_SIZE WRITE_SIZE; do
   echo "== rocprofv3 --pmc $pmc"
   rm -rf $O/prof_${tag}_$pmc
   timeout -k 10 400 rocprofv3 --pmc $pmc -d $O/prof_${tag}_$pmc --output-format csv -- python3 bench.py --steps 4 --warmup 1 --cpu-seconds 0 --loops 512 > /dev/null 2> $O/${tag}_rocprof_$pmc.err || exit 1
-  python3 scratch/prof_summary.py $O/prof_${tag}_$pmc $O/${tag}_$pmc | tail -12
+  python3 tools/prof_summary.py $O/prof_${tag}_$pmc $O/${tag}_$pmc | tail -12
 done
 echo "== rocprofv3 --pmc SQ"
 rm -rf $O/prof_${tag}_sq
 timeout -k 10 400 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_ACTIVE_INST_ANY -d $O/prof_${tag}_sq --output-format csv -- python3 bench.py --steps 4 --warmup 1 --cpu-seconds 0 --loops 512 > /dev/null 2> $O/${tag}_rocprof_sq.err || exit 1
-python3 scratch/prof_summary.py $O/prof_${tag}_sq $O/${tag}_sq | tail -12
+python3 tools/prof_summary.py $O/prof_${tag}_sq $O/${tag}_sq | tail -12
 echo "== lock-step groups schedule"; timeout -k 10 300 python3 bench.py --cpu-seconds 0 --schedule groups > $O/${tag}_bench_groups.json 2>/dev/null; tail -c 300 $O/${tag}_bench_groups.json | head -c 10; python3 -c "import json;d=json.loads(open('$O/${tag}_bench_groups.json').read().strip().splitlines()[-1]);print('groups schedule: %.0f it/s'%d['value'])"
-echo "== configs 2/3/5, one model"; timeout -k 10 300 python3 scratch/cfg_time.py > $O/${tag}_cfg_time.txt 2>&1; cat $O/${tag}_cfg_time.txt
+echo "== configs 2/3/5, one model"; timeout -k 10 300 python3 tools/cfg_time.py > $O/${tag}_cfg_time.txt 2>&1; cat $O/${tag}_cfg_time.txt
 echo "== loops per GPU"
 for L in 64 128 256 512 1024 2048 4096; do
   timeout -k 10 200 python3 bench.py --steps 40 --warmup 3 --cpu-seconds 0 --loops $L > $O/${tag}_loops_$L.json 2>/dev/null || exit 1
