@@ -640,9 +640,13 @@ def run_rank(args):
                        "host_loop": "native" if r["native"] else "python",
                        "schedule": args.schedule if r["native"] else "groups",
                        "stream_groups": None if (r["native"] and args.schedule == "async") else r["n_groups"],
-                       "worker_streams": (int(os.environ.get("BORE_ASYNC_WORKERS", 12))
-                                          if (r["native"] and args.schedule == "async") else None),
-                       "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
+                       "worker_streams": st.get("worker_streams"),
+                       # (measured by the engine at creation: streams the device ran at once)
+                       "stream_concurrency": st.get("stream_concurrency"),
+                       "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"),
+                       # how long a loop's workgroup waits on its CU for the objective value
+                       # before it gives the slot up (0 = one launch per loop-iteration)
+                       "resident_wait_us": float(os.environ.get("BORE_ASYNC_RESIDENT_US", 500)),
                        "N_start": int(r["n_start"]),
                        "N_end": int(r["n_end"]), "parallelism": f"replica-shard x{world}"},
             "roofline": dominant,

@@ -14,7 +14,8 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(CSRC, "libbore_hip.so")
+# (BORE_LIB_PATH: another build of the same ABI, for A/B comparisons -- tools/ab_fit.py)
+LIB_PATH = os.environ.get("BORE_LIB_PATH") or os.path.join(CSRC, "libbore_hip.so")
 SOURCES = ["bore_all.hip"]   # a unity build of bore_{hip,argmax,svgd,iter,engine}.hip
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "bore_hip.h")
 
@@ -82,7 +83,8 @@ class EngineStats(C.Structure):
                 ("phase_ns_screen", C.c_double), ("phase_ns_lbfgsb", C.c_double),
                 ("ready_to_launch_s", C.c_double), ("launch_to_result_s", C.c_double),
                 ("result_to_ready_s", C.c_double), ("phase_iterations", C.c_int64),
-                ("batches", C.c_int64)]
+                ("batches", C.c_int64), ("worker_streams", C.c_int64),
+                ("stream_concurrency", C.c_int64)]
 
 
 OBJECTIVE_FN = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_double), C.c_int64, C.c_int32,
@@ -177,9 +179,14 @@ def lib():
     return L
 
 
+class UnsupportedError(RuntimeError):
+    """BORE_E_UNSUPPORTED: the request does not fit this build's kernels (shape, LDS budget, ...)."""
+
+
 def check(rc):
     if rc != 0:
-        raise RuntimeError(f"libbore_hip: {lib().bore_last_error().decode()} (code {rc})")
+        cls = UnsupportedError if rc == -2 else RuntimeError
+        raise cls(f"libbore_hip: {lib().bore_last_error().decode()} (code {rc})")
 
 
 COMPUTE = dict(float32=0, bfloat16=1)

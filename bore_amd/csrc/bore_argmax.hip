@@ -20,12 +20,14 @@ using namespace bore;
 __device__ __forceinline__ void labels_body(const double *y, int N, double vi, float *z,
                                             double *tau_out, const int *ids, const int *its,
                                             int n_init, long long cap, double gamma,
-                                            long long model) {
+                                            long long model, int it_now = -1) {
+  // (it_now >= 0: the slot's iteration count, given by a caller that runs several iterations of
+  // the loop in one launch -- bore_iter.hip -- instead of its[model])
   extern __shared__ float smem[];
   double *ys = reinterpret_cast<double *>(smem);  // [N] + 2 (a, b)
   long long stride = N;
   if (ids) {
-    N = n_init + its[model];
+    N = n_init + (it_now >= 0 ? it_now : its[model]);
     model = ids[model];
     stride = cap;
     vi = (double)(N - 1) * gamma;  // numpy's virtual index for this slot's N
@@ -184,7 +186,8 @@ __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
 }
 
 template <int SHAPE, bool BF16 = false>
-__device__ __forceinline__ void screen_body(const ScreenArgs &a, const long long model) {
+__device__ __forceinline__ void screen_body(const ScreenArgs &a, const long long model,
+                                            const int it_now = -1) {
   extern __shared__ float smem[];
   constexpr MlpLayout Lc = bore_static_layout(SHAPE > 0 ? SHAPE : 0, 0, BORE_BATCH_MAX);
   const MlpLayout &L = begin_kernel<SHAPE>(Lc, a.L, smem, a.total, a.o_layout);
@@ -204,7 +207,9 @@ __device__ __forceinline__ void screen_body(const ScreenArgs &a, const long long
     bhi[tid] = a.box.hi[tid];
   }
   const unsigned long long cbase =
-      a.sampled ? candidate_base(a.seed, a.model0 + lid, a.ids ? (long long)a.its[model] : a.draw) : 0ULL;
+      a.sampled ? candidate_base(a.seed, a.model0 + lid,
+                                 a.ids ? (long long)(it_now >= 0 ? it_now : a.its[model]) : a.draw)
+                : 0ULL;
   auto xval = [&](long long row, int d) -> double {
     if (a.sampled) {
       const long long i = row * D + d;
@@ -499,7 +504,7 @@ extern "C" int bore_debug_lpp(unsigned long long *out) {  // [LB_PP_MAX][16]
 // living in registers across the optimiser (the fused iteration kernel is held to 256 VGPRs).
 template <int SHAPE, bool BF16 = false, bool LEAN = false>
 __device__ __forceinline__ void lbfgsb_body(const LbfgsbArgs &a, const long long model,
-                                            const int block_y) {
+                                            const int block_y, const int it_now = -1) {
   extern __shared__ float smem[];
   constexpr MlpLayout Lc = bore_static_layout(SHAPE > 0 ? SHAPE : 0, 2, BORE_BATCH_MAX);
   const MlpLayout &L = begin_kernel<SHAPE>(Lc, a.L, smem, a.total, a.o_layout);
@@ -525,10 +530,22 @@ __device__ __forceinline__ void lbfgsb_body(const LbfgsbArgs &a, const long long
   // Which problem this thread works on.  With at most one problem per wave (np <= 4: the
   // BASELINE config-1 shape, 3 restarts) ALL 64 lanes of wave wv run problem wv together
   // (lbfgsb::Coop); otherwise lane s < 16 of wave wv runs problem 4 s + wv on its own.
-  const bool coop = np <= 4;
-  const int myp = coop ? (wv < np ? wv : -1) : ((lane < 16 && lane * 4 + wv < np) ? lane * 4 + wv : -1);
+  // Batch mode with 5..16 restarts (the reference's default is num_starts = 5) keeps the loop in
+  // ONE workgroup, as the per-loop pick below needs: wave wv runs problems wv, wv + 4, .. one
+  // after the other, each with all its lanes (`passes`).  Same bits every way (tested).
+  const bool multi = a.result && np > 4 && np <= 16;
+  const bool coop = np <= 4 || multi;
+  const int passes = multi ? (np + 3) / 4 : 1;
   const int myrow = coop ? wv * 16 : wv * 16 + lane;
   const lbfgsb::Coop cp = coop ? lbfgsb::Coop{lane, 64} : lbfgsb::Coop{0, 1};
+  __syncthreads();  // weights staged; from here on the waves are independent
+  if (wv >= np) return;  // wave without problems (np < 4)
+  double *res = reinterpret_cast<double *>(smem + a.o_res);  // batch mode: [np][D + 3] fun, status, nfev, x
+  int *cnt = reinterpret_cast<int *>(res + (multi ? np : 4) * (D + 3));
+  for (int pass = 0; pass < passes; ++pass) {
+  const int myp = coop ? (wv + 4 * pass < np ? wv + 4 * pass : -1)
+                       : ((lane < 16 && lane * 4 + wv < np) ? lane * 4 + wv : -1);
+  if (coop && myp < 0) break;
   // The scalar state of the optimiser stays in this thread's REGISTERS for the whole launch
   // (its vectors and matrices are in LDS): kept in memory, every store to a workspace array
   // would force the compiler to reload the state fields it may alias.
@@ -541,8 +558,7 @@ __device__ __forceinline__ void lbfgsb_body(const LbfgsbArgs &a, const long long
     const double *x0 = a.x0 + (model * a.R + p0 + myp) * (long long)D;
     lbfgsb::lbfgsb_init(st, wk, D, a.opt.m, x0, blo, bhi, bnbd);
   }
-  __syncthreads();  // weights staged; from here on the waves are independent
-  if (wv >= np) return;  // wave without problems (np < 4)
+  wave_lds_sync();  // (the workspace of a problem is private to its wave / lane)
 
   // static shapes: the network (small ones: with its weight operands, 30 registers for shape 1)
   // lives in registers for the whole optimisation
@@ -657,13 +673,11 @@ __device__ __forceinline__ void lbfgsb_body(const LbfgsbArgs &a, const long long
     int *inf = a.info + q * 5;
     inf[0] = st.nit; inf[1] = st.nfev; inf[2] = st.status; inf[3] = st.task; inf[4] = st.msg;
   }
-  if (!a.result) return;
+  if (!a.result) continue;  // (not batch mode: one pass)
   // ---- batch mode: the loop's pick (bore_select_best's rule), published by whichever of its
-  // waves finishes last, while other loops of the launch are still optimising ----
-  double *res = reinterpret_cast<double *>(smem + a.o_res);  // [np][D + 3]: fun, status, nfev, x
-  int *cnt = reinterpret_cast<int *>(res + 4 * (D + 3));
+  // waves finishes the loop's last problem, while other loops of the launch are still optimising ----
   if (lane == 0) {
-    double *r = res + wv * (D + 3);
+    double *r = res + myp * (D + 3);
     r[0] = st.f;
     r[1] = (double)st.status;
     r[2] = (double)st.nfev;
@@ -673,9 +687,10 @@ __device__ __forceinline__ void lbfgsb_body(const LbfgsbArgs &a, const long long
   int last = 0;
   if (lane == 0) last = atomicAdd(cnt, 1) == np - 1;
   last = __shfl(last, 0, 64);
-  if (!last) return;
+  if (!last) continue;
   wave_lds_sync();
-  const int N = a.n_init + a.its[model];
+  const int it_done = it_now >= 0 ? it_now : a.its[model];
+  const int N = a.n_init + it_done;
   const double *Xs = a.dedup ? a.X_seen + lid * a.cap * D : nullptr;
   int best = -1;
   double best_fun = 0.0, nfev_sum = 0.0, nfev_max = 0.0;
@@ -722,8 +737,9 @@ __device__ __forceinline__ void lbfgsb_body(const LbfgsbArgs &a, const long long
     }
     out[D + 7] = 0.0;
     __threadfence_system();
-    __hip_atomic_store(a.flag + lid, a.its[model] + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(a.flag + lid, it_done + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
+  }  // passes
 }
 
 template <int SHAPE, bool BF16 = false>
@@ -781,7 +797,7 @@ static int lbfgsb_build(const bore_mlp_desc *desc, int n_models, const float *th
   // One problem per WAVE (all 64 lanes on it, lbfgsb::Coop) finishes a problem ~1.6x sooner than one
   // problem per lane and uses every lane; prefer it while the launch still fits the GPU a few
   // times over (256 CUs): 4 problems per workgroup, grid = models x ceil(R / 4).
-  if (PB > 4 && (long long)n_models * ((num_starts + 3) / 4) <= 8192) PB = 4;
+  if (PB > 4 && !g_batch && (long long)n_models * ((num_starts + 3) / 4) <= 8192) PB = 4;
   const int flavour = bore_kernel_flavour(desc, true);
   const int shape = flavour > 0 ? flavour : 0;  // constexpr-layout kernels assume a 64-row tile
   size_t off = 0;
@@ -800,7 +816,8 @@ static int lbfgsb_build(const bore_mlp_desc *desc, int n_models, const float *th
     off = (off + 3) & ~(size_t)3;
     a.o_prob = (int)off; off += (size_t)a.prob_floats * PB;
     off = (off + 3) & ~(size_t)3;
-    a.o_res = (int)off; off += g_batch ? 2 * 4 * ((size_t)D + 3) + 4 : 0;
+    a.o_res = (int)off;  // batch mode: [max(R, 4)][D + 3] fp64 + the finished-problem counter
+    off += g_batch ? 2 * (size_t)(num_starts > 4 ? num_starts : 4) * ((size_t)D + 3) + 4 : 0;
     a.total = (int)off;
     off = (off + 3) & ~(size_t)3;
     a.o_layout = (int)off; off += BORE_LAYOUT_FLOATS;
@@ -814,8 +831,8 @@ static int lbfgsb_build(const bore_mlp_desc *desc, int n_models, const float *th
   a.ids = a.its = nullptr; a.n_init = a.dedup = 0; a.cap = 0;
   a.X_seen = nullptr; a.result = nullptr; a.flag = nullptr; a.stamps = nullptr;
   if (g_batch) {
-    if (num_starts > 4 || PB < num_starts)
-      return fail(BORE_E_UNSUPPORTED, "lbfgsb_minimize: batch mode needs num_starts <= 4 in one workgroup");
+    if (num_starts > 16 || PB < num_starts)
+      return fail(BORE_E_UNSUPPORTED, "lbfgsb_minimize: batch mode needs num_starts <= 16 in one workgroup");
     if (!g_batch->ids || !g_batch->its || !g_batch->result || !g_batch->flag ||
         (g_batch->deduplicate && !g_batch->X_seen))
       return fail(BORE_E_INVALID, "lbfgsb_minimize: incomplete bore_batch");

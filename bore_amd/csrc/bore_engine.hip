@@ -110,10 +110,18 @@ struct Async {
   std::vector<int32_t> it, target, state;        // per loop: iterations done; 0 ready 1 in flight 2 done
   std::vector<double> x_new, y_new, ready_since; // per loop: the row to append at its next launch
   std::vector<double> seen_at;                   // per loop: when the host took its result
+  // residency (fused kernel; include/bore_hip.h bore_batch): one pinned block, host <-> device
+  double *ynew = nullptr;                        // pinned [L][D + 1]: the newest row of each loop
+  int32_t *yseq = nullptr, *parked = nullptr;    // pinned [L]
+  int32_t *abort_flag = nullptr;                 // pinned [1]
+  int64_t wait_ticks = 0;                        // how long a workgroup waits for its next row
+  std::vector<uint8_t> via_launch;               // per loop: the iteration in flight came with a launch
   std::vector<Worker> workers;
   std::vector<int> scratch_ids, done_ids;
   std::vector<double> cb_x, cb_y;
   bool fused = false;  // one kernel per launch (bore_iter.hip) instead of the five-launch chain
+  long long n_resident = 0, n_parked = 0;
+  int stream_concurrency = 0;  // worker streams the device ran at once in the creation probe
   // diagnostics (BORE_ASYNC_DEBUG): waits between a loop's states
   std::vector<double> launched_at;
   double sum_wait = 0, sum_flight = 0;
@@ -121,6 +129,12 @@ struct Async {
 };
 
 }  // namespace
+
+// Busy-waits `ticks` of the device wall clock: the probe of async_create.
+__global__ void bore_spin_kernel(long long ticks) {
+  const long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
 
 struct bore_engine {
   bore_mlp_desc desc;
@@ -136,6 +150,10 @@ struct bore_engine {
   bore_engine_stats st;
   std::vector<double> y_tmp;
   Async *as = nullptr;  // asynchronous mode (cfg.async_loops)
+  // set when a run stopped half-way (objective error, watchdog, HIP error): loops are then at
+  // different iteration counts and some device-side updates have no host-side record, so the
+  // engine refuses further use instead of silently diverging
+  bool poisoned = false;
 };
 
 namespace {
@@ -313,7 +331,7 @@ int async_alloc(bore_engine *e, int64_t cap) {
 
 int async_create(bore_engine *e, const double *X0, const double *y0) {
   const size_t L = e->cfg.n_loops, D = e->D, R = e->cfg.num_starts, n0 = e->cfg.n_init;
-  if (R > 4) return fail(BORE_E_UNSUPPORTED, "engine_create: async_loops needs num_starts <= 4");
+  if (R > 16) return fail(BORE_E_UNSUPPORTED, "engine_create: async_loops needs num_starts <= 16");
   e->as = new (std::nothrow) Async();
   if (!e->as) return fail(BORE_E_HIP, "engine_create: out of memory");
   Async &A = *e->as;
@@ -336,12 +354,29 @@ int async_create(bore_engine *e, const double *X0, const double *y0) {
       A.ns_per_tick = 1e6 / khz;
   }
   A.seen_at.assign(L, 0.0);
+  A.via_launch.assign(L, 1);
+  {  // ynew [L][D + 1] fp64 | yseq [L] | parked [L] | abort [1]  (int32), one pinned block
+    char *blk = nullptr;
+    const size_t bytes = L * (D + 1) * 8 + (2 * L + 1) * 4;
+    if ((rc = pin_alloc(&blk, bytes))) return rc;
+    std::memset(blk, 0, bytes);
+    A.ynew = reinterpret_cast<double *>(blk);
+    A.yseq = reinterpret_cast<int32_t *>(blk + L * (D + 1) * 8);
+    A.parked = A.yseq + L;
+    A.abort_flag = A.parked + L;
+    for (size_t l = 0; l < L; ++l) A.parked[l] = -1;
+  }
   A.it.assign(L, 0); A.target.assign(L, 0); A.state.assign(L, 2);
   A.x_new.assign(L * D, 0.0); A.y_new.assign(L, 0.0); A.ready_since.assign(L, 0.0);
   A.scratch_ids.reserve(L); A.cb_x.resize(L * D); A.cb_y.resize(L);
   A.launched_at.assign(L, 0.0);
   A.done_ids.assign(L, 0);
   A.fused = iteration_supported(&e->desc) && !(getenv("BORE_ASYNC_CHAIN") && atoi(getenv("BORE_ASYNC_CHAIN")));
+  // Residency: a loop's workgroup stays on its CU between iterations and waits this long for the
+  // objective value before it gives its slot up (BORE_ASYNC_RESIDENT_US; 0 = one iteration per
+  // launch).  Dropped by the launcher when the device cannot hold all loops at once.
+  const double resident_us = getenv("BORE_ASYNC_RESIDENT_US") ? atof(getenv("BORE_ASYNC_RESIDENT_US")) : 500.0;
+  A.wait_ticks = A.fused && resident_us > 0 ? (int64_t)(resident_us * 1e3 / A.ns_per_tick) : 0;
   // Worker streams: a dozen independent single-kernel launches in flight when fused (each stream
   // needs its own hardware queue -- streams sharing one serialise, which halves the throughput --
   // so no more than GPU_MAX_HW_QUEUES - 2 of them); four dependent launch chains otherwise.
@@ -356,9 +391,10 @@ int async_create(bore_engine *e, const double *X0, const double *y0) {
     HIP_TRY(hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&w.done, hipEventDisableTiming));
     for (hipEvent_t &ev : w.ev) HIP_TRY(hipEventCreate(&ev));
-    // ONE staging block per side -- IterArgs | x_new [L][D] | y_new [L] | ids [L] | its [L] -- so
-    // that a launch is preceded by one upload (each small copy is its own ~30 us blit packet)
-    w.stage_bytes = ((sizeof(IterArgs) + 15) & ~(size_t)15) + L * (D + 1) * 8 + 2 * L * 4;
+    // ONE staging block per side -- IterArgs | x_new [L][D] | y_new [L] | ids [L] | its [L] |
+    // targets [L] -- so that a launch is preceded by one upload (each small copy is its own ~30 us
+    // blit packet)
+    w.stage_bytes = ((sizeof(IterArgs) + 15) & ~(size_t)15) + L * (D + 1) * 8 + 3 * L * 4;
     char *hb = nullptr, *db = nullptr;
     if ((rc = pin_alloc(&hb, w.stage_bytes)) || (rc = dev_alloc(&db, w.stage_bytes))) return rc;
     const size_t o_dbl = (sizeof(IterArgs) + 15) & ~(size_t)15, o_int = o_dbl + L * (D + 1) * 8;
@@ -369,6 +405,30 @@ int async_create(bore_engine *e, const double *X0, const double *y0) {
         (rc = dev_alloc(&w.jac, L * R * D)) || (rc = dev_alloc(&w.fun, L * R)) ||
         (rc = dev_alloc(&w.idx, L * R)) || (rc = dev_alloc(&w.info, L * R * 5)))
       return rc;
+  }
+  // Do the worker streams really run side by side?  ROCm multiplexes streams onto
+  // GPU_MAX_HW_QUEUES hardware queues, fixed when the runtime initialised (default 4): a caller
+  // that touched the GPU before that variable was set gets fewer queues than streams, and streams
+  // sharing a queue serialise -- half the throughput of the non-resident schedule, silently.
+  // Probe: one 1 ms spinning single-wave kernel per stream, all at once.
+  if (A.workers.size() > 1 && !(getenv("BORE_ASYNC_NO_PROBE") && atoi(getenv("BORE_ASYNC_NO_PROBE")))) {
+    const long long ticks = (long long)(1e6 / A.ns_per_tick);
+    hipLaunchKernelGGL(bore_spin_kernel, dim3(1), dim3(64), 0, A.workers[0].stream, 1000LL);  // (code load)
+    HIP_TRY(hipStreamSynchronize(A.workers[0].stream));
+    const double t0 = now_s();
+    for (Worker &w : A.workers) hipLaunchKernelGGL(bore_spin_kernel, dim3(1), dim3(64), 0, w.stream, ticks);
+    for (Worker &w : A.workers) HIP_TRY(hipStreamSynchronize(w.stream));
+    const double dt = now_s() - t0;
+    int conc = (int)(A.workers.size() * 1e-3 / (dt > 1e-3 ? dt : 1e-3) + 0.5);
+    conc = conc < 1 ? 1 : (conc > (int)A.workers.size() ? (int)A.workers.size() : conc);
+    A.stream_concurrency = conc;
+    if (conc < (int)A.workers.size())
+      fprintf(stderr,
+              "bore_engine: %zu worker streams, but the device ran only %d of them at once (%.2f ms for "
+              "%zu 1-ms probes): streams share hardware queues.  Set GPU_MAX_HW_QUEUES >= %zu in the "
+              "environment BEFORE the first GPU call of the process (it is %s now).\n",
+              A.workers.size(), conc, 1e3 * dt, A.workers.size(), A.workers.size() + 2,
+              getenv("GPU_MAX_HW_QUEUES") ? getenv("GPU_MAX_HW_QUEUES") : "unset");
   }
   return 0;
 }
@@ -391,11 +451,13 @@ void async_destroy(bore_engine *e) {
     if (p) (void)hipFree(p);
   if (A.result) (void)hipHostFree(A.result);
   if (A.flag) (void)hipHostFree(A.flag);
+  if (A.ynew) (void)hipHostFree(A.ynew);
   delete e->as;
   e->as = nullptr;
 }
 
-// One launch chain of worker w over the loops listed in A.scratch_ids.
+// One launch of worker w over the loops listed in A.scratch_ids (fused: one kernel whose
+// workgroups may go on to later iterations of their loops; otherwise the five-launch chain).
 int async_launch(bore_engine *e, Worker &w) {
   const double t0 = now_s();
   Async &A = *e->as;
@@ -403,30 +465,39 @@ int async_launch(bore_engine *e, Worker &w) {
   const int L = c.n_loops, D = e->D, R = c.num_starts, B = (int)A.scratch_ids.size();
   int max_it = 0;
   double *hx = w.h_dbl, *hy = w.h_dbl + (size_t)L * D;
-  w.fit_bytes = 0;
   for (int b = 0; b < B; ++b) {
     const int l = A.scratch_ids[b], it = A.it[l];
     w.h_int[b] = l;
     w.h_int[L + b] = it;
+    w.h_int[2 * L + b] = A.target[l];
     std::memcpy(hx + (size_t)b * D, &A.x_new[(size_t)l * D], (size_t)D * 8);
     hy[b] = A.y_new[l];
     max_it = it > max_it ? it : max_it;
     A.state[l] = 1;
+    A.via_launch[l] = 1;
     A.launched_at[l] = t0;
     A.sum_wait += t0 - A.ready_since[l];
     e->st.ready_to_launch_s += t0 - A.ready_since[l];
     ++A.n_wait;
-    const double N = c.n_init + it, steps = std::ceil(N / c.batch_size);
-    w.fit_bytes += c.epochs * (4.0 * N * (D + 1) + steps * 24.0 * e->P);
+    // (the previous workgroup of this loop, if it parked, wrote `parked` as its last act)
+    __atomic_store_n(&A.parked[l], -1, __ATOMIC_RELAXED);
+    __atomic_store_n(&A.yseq[l], it, __ATOMIC_RELEASE);
   }
   if (!A.fused)  // (the fused launch uploads the whole block together with its arguments)
     HIP_TRY(hipMemcpyAsync(w.d_dbl, w.h_dbl, w.stage_bytes - ((sizeof(IterArgs) + 15) & ~(size_t)15),
                            hipMemcpyHostToDevice, w.stream));
   const int64_t N_max = c.n_init + max_it;
   bore_batch bt;
+  std::memset(&bt, 0, sizeof(bt));
   bt.ids = w.d_int; bt.its = w.d_int + L; bt.n_init = c.n_init; bt.deduplicate = c.deduplicate;
   bt.cap = A.cap; bt.X_seen = A.X_seen; bt.result = A.result; bt.flag = A.flag;
   bt.stamps = A.stamps;
+  if (A.fused) {
+    bt.targets = w.d_int + 2 * L;
+    bt.ynew = A.ynew; bt.yseq = A.yseq; bt.parked = A.parked; bt.abort_flag = A.abort_flag;
+    bt.wait_ticks = A.wait_ticks;
+    bt.resident_loops = L;
+  }
   bore_set_batch(&bt);
   void *sp = w.stream;
   if (A.fused) {
@@ -477,11 +548,16 @@ int async_launch(bore_engine *e, Worker &w) {
   return 0;
 }
 
+// Stop: workgroups waiting for a row give up (abort flag), everything in flight runs out.  What the
+// device did after the host stopped listening has no host-side record: the engine is poisoned.
 int async_drain(bore_engine *e) {
+  __atomic_store_n(e->as->abort_flag, 1, __ATOMIC_RELEASE);
   for (Worker &w : e->as->workers) {
     (void)hipStreamSynchronize(w.stream);
     w.busy = false;
   }
+  __atomic_store_n(e->as->abort_flag, 0, __ATOMIC_RELEASE);
+  e->poisoned = true;
   return 0;
 }
 
@@ -504,21 +580,37 @@ int async_run(bore_engine *e, int n_steps) {
     A.state[l] = 0;
     A.ready_since[l] = start;
   }
-  // launch policy: a free worker takes the ready loops once there are `min_batch` of them or the
-  // oldest has waited `max_wait` (or nothing else is running)
-  const int min_batch = getenv("BORE_ASYNC_MIN") ? atoi(getenv("BORE_ASYNC_MIN")) : (L >= 16 ? L / 8 : 1);
-  const double max_wait = getenv("BORE_ASYNC_WAIT_US") ? 1e-6 * atof(getenv("BORE_ASYNC_WAIT_US")) : 150e-6;
+  // Launch policy: a free worker takes the ready loops once there are `min_batch` of them or the
+  // oldest has waited `max_wait` (or nothing else is running).  With resident workgroups a loop
+  // only needs a launch at the start of a run and after its workgroup gave up waiting: at once.
+  const bool resident = A.fused && A.wait_ticks > 0;
+  const int min_batch = getenv("BORE_ASYNC_MIN") ? atoi(getenv("BORE_ASYNC_MIN"))
+                                                 : (resident ? 1 : (L >= 16 ? L / 8 : 1));
+  const double max_wait = getenv("BORE_ASYNC_WAIT_US") ? 1e-6 * atof(getenv("BORE_ASYNC_WAIT_US"))
+                                                       : (resident ? 0.0 : 150e-6);
   double last_progress = start, first_done = start;
   int n_done = 0;
-  const int cb_min = getenv("BORE_ASYNC_CB_MIN") ? atoi(getenv("BORE_ASYNC_CB_MIN")) : (L >= 64 ? L / 16 : 1);
-  const double cb_wait = getenv("BORE_ASYNC_CB_WAIT_US") ? 1e-6 * atof(getenv("BORE_ASYNC_CB_WAIT_US")) : 40e-6;
+  // Objective calls are bunched (a call into the interpreter costs tens of microseconds).  Resident
+  // workgroups wait for the value on their CUs: call as soon as anything is there -- the results
+  // that arrive during a call form the next bunch.
+  const int cb_min = getenv("BORE_ASYNC_CB_MIN") ? atoi(getenv("BORE_ASYNC_CB_MIN"))
+                                                 : (resident ? 1 : (L >= 64 ? L / 16 : 1));
+  const double cb_wait = getenv("BORE_ASYNC_CB_WAIT_US") ? 1e-6 * atof(getenv("BORE_ASYNC_CB_WAIT_US"))
+                                                         : (resident ? 0.0 : 40e-6);
   while (remaining) {
-    // 1. loops whose result has arrived: collected over polling passes, handed to the objective
-    // callback in bunches (a call into the interpreter costs tens of microseconds)
+    // 1. loops on the device: a result has arrived, or the workgroup has left the next iteration
+    // to a later launch (parked)
     const double t0 = now_s();
     for (int l = 0; l < L; ++l) {
       if (A.state[l] != 1) continue;
-      if (__atomic_load_n(&A.flag[l], __ATOMIC_ACQUIRE) != A.it[l] + 1) continue;
+      if (__atomic_load_n(&A.flag[l], __ATOMIC_ACQUIRE) != A.it[l] + 1) {
+        if (A.fused && !A.via_launch[l] && __atomic_load_n(&A.parked[l], __ATOMIC_ACQUIRE) == A.it[l]) {
+          A.state[l] = 0;  // its row was delivered too late (or nobody waited): needs a launch
+          A.ready_since[l] = t0;
+          ++A.n_parked;
+        }
+        continue;
+      }
       A.state[l] = 3;  // result taken, objective pending
       if (n_done == 0) first_done = t0;
       const double *r = A.result + (size_t)l * (D + 8);
@@ -541,6 +633,8 @@ int async_run(bore_engine *e, int n_steps) {
       e->st.n_fg_rows += (int64_t)r[D + 1];
       e->st.n_rounds += (int64_t)r[D + 2];
       e->st.argmax_bytes += r[D + 1] * 4.0 * (2 * D + 1) + r[D + 2] * 4.0 * e->P;
+      const double N = c.n_init + A.it[l], steps = std::ceil(N / c.batch_size);
+      e->st.fit_bytes += c.epochs * (4.0 * N * (D + 1) + steps * 24.0 * e->P);
       A.done_ids[n_done++] = l;
     }
     if (n_done && (n_done >= cb_min || t0 - first_done >= cb_wait)) {
@@ -559,6 +653,17 @@ int async_run(bore_engine *e, int n_steps) {
         if (A.it[l] >= A.target[l]) {
           A.state[l] = 2;
           --remaining;
+        } else if (A.fused) {
+          // hand the row to the loop's workgroup, which may still be waiting for it on its CU;
+          // if it has given up (parked[l] == it[l], seen in pass 1) the loop joins a launch
+          double *yn = A.ynew + (size_t)l * (D + 1);
+          std::memcpy(yn, &A.cb_x[(size_t)k * D], (size_t)D * 8);
+          yn[D] = A.cb_y[k];
+          __atomic_store_n(&A.yseq[l], A.it[l], __ATOMIC_RELEASE);
+          A.state[l] = 1;
+          A.via_launch[l] = 0;
+          A.launched_at[l] = now;
+          ++A.n_resident;
         } else {
           A.state[l] = 0;
           A.ready_since[l] = now;
@@ -568,7 +673,7 @@ int async_run(bore_engine *e, int n_steps) {
       e->st.host_finalize_s += now - t0;
       n_done = 0;
     }
-    // 2. workers that have finished their chain
+    // 2. workers whose launch has run out
     int busy = 0;
     for (Worker &w : A.workers) {
       if (!w.busy) continue;
@@ -577,14 +682,16 @@ int async_run(bore_engine *e, int n_steps) {
         ++busy;
         continue;
       }
-      if (q != hipSuccess) return fail(BORE_E_HIP, "engine_run: %s", hipGetErrorString(q));
+      if (q != hipSuccess) {
+        e->poisoned = true;
+        return fail(BORE_E_HIP, "engine_run: %s", hipGetErrorString(q));
+      }
       float ms = 0.f;
       if (!A.fused) {
         HIP_TRY(hipEventElapsedTime(&ms, w.ev[0], w.ev[1]));
         e->st.fit_ms += ms;
       }
       e->st.fit_launches += 1;
-      e->st.fit_bytes += w.fit_bytes;
       HIP_TRY(hipEventElapsedTime(&ms, w.ev[2], w.ev[3]));
       e->st.argmax_ms += ms;
       e->st.argmax_launches += 1;
@@ -618,10 +725,11 @@ int async_run(bore_engine *e, int n_steps) {
     }
   }
   if (getenv("BORE_ASYNC_DEBUG"))
-    fprintf(stderr, "[async] %lld batches, %.1f loops/batch; ready->launch %.0f us, launch->result %.0f us (means)\n",
-            A.n_batches, (double)A.n_slots / (double)(A.n_batches ? A.n_batches : 1),
+    fprintf(stderr, "[async] %lld launches, %.1f loops/launch; %lld iterations continued on their CU, %lld parked; "
+            "ready->launch %.0f us, launch->result %.0f us (means)\n",
+            A.n_batches, (double)A.n_slots / (double)(A.n_batches ? A.n_batches : 1), A.n_resident, A.n_parked,
             1e6 * A.sum_wait / (double)(A.n_wait ? A.n_wait : 1), 1e6 * A.sum_flight / (double)(A.n_wait ? A.n_wait : 1));
-  // let the chains run out (their loops are done; the streams may still hold the slowest ones)
+  // let the launches run out (their loops are done: the workgroups exit after the last iteration)
   for (Worker &w : A.workers)
     if (w.busy) {
       HIP_TRY(hipStreamSynchronize(w.stream));
@@ -631,7 +739,6 @@ int async_run(bore_engine *e, int n_steps) {
         e->st.fit_ms += ms;
       }
       e->st.fit_launches += 1;
-      e->st.fit_bytes += w.fit_bytes;
       HIP_TRY(hipEventElapsedTime(&ms, w.ev[2], w.ev[3]));
       e->st.argmax_ms += ms;
       e->st.argmax_launches += 1;
@@ -641,6 +748,10 @@ int async_run(bore_engine *e, int n_steps) {
 }
 
 }  // namespace
+
+static const char kPoisoned[] =
+    "engine: an earlier bore_engine_run stopped half-way (objective error, watchdog or HIP error); "
+    "its loops are at different iterations -- create a new engine";
 
 extern "C" void bore_engine_destroy(bore_engine *e) {
   if (!e) return;
@@ -758,6 +869,7 @@ extern "C" int bore_engine_create(const bore_mlp_desc *desc, const bore_engine_c
 // reacts to completion events.
 extern "C" int bore_engine_run(bore_engine *e, int n_steps) {
   if (!e || n_steps < 0) return fail(BORE_E_INVALID, "engine_run: bad argument");
+  if (e->poisoned) return fail(BORE_E_INVALID, kPoisoned);
   if (n_steps == 0) return 0;
   if (e->as) return async_run(e, n_steps);
   std::vector<int64_t> target(e->groups.size());
@@ -778,13 +890,17 @@ extern "C" int bore_engine_run(bore_engine *e, int n_steps) {
       if (!g.inflight) continue;
       const hipError_t q = hipEventQuery(g.done);
       if (q == hipErrorNotReady) continue;
-      if (q != hipSuccess) return fail(BORE_E_HIP, "engine_run: %s", hipGetErrorString(q));
+      if (q != hipSuccess) {
+        e->poisoned = true;
+        return fail(BORE_E_HIP, "engine_run: %s", hipGetErrorString(q));
+      }
       if ((rc = finalize(e, g)) || (g.steps < target[k] && (rc = enqueue(e, g)))) {
-        // stop: let the other groups' launches finish, keep their iterations out of the record
+        // stop: let the other groups' launches finish; their iterations are not in the record
         for (Group &o : e->groups) {
           (void)hipStreamSynchronize(o.stream);
           o.inflight = false;
         }
+        e->poisoned = true;
         return rc;
       }
       if (g.steps >= target[k]) --remaining;
@@ -803,6 +919,7 @@ extern "C" int64_t bore_engine_size(const bore_engine *e) {
 // The record of every loop: X host [n_loops][N][D], y host [n_loops][N], N = bore_engine_size().
 extern "C" int bore_engine_observations(bore_engine *e, double *X, double *y) {
   if (!e || !X || !y) return fail(BORE_E_INVALID, "engine_observations: NULL argument");
+  if (e->poisoned) return fail(BORE_E_INVALID, kPoisoned);
   const int D = e->D;
   const int64_t N = bore_engine_size(e);
   if (e->as) {  // rows on the device: all but the newest, which waits on the host for its launch
@@ -840,6 +957,7 @@ extern "C" int bore_engine_observations(bore_engine *e, double *X, double *y) {
 extern "C" int bore_engine_state(bore_engine *e, float *theta, float *adam_m, float *adam_v,
                                  int64_t *adam_t) {
   if (!e) return fail(BORE_E_INVALID, "engine_state: NULL engine");
+  if (e->poisoned) return fail(BORE_E_INVALID, kPoisoned);
   HIP_TRY(hipDeviceSynchronize());
   const size_t n = (size_t)e->cfg.n_loops * e->P;
   if (theta) HIP_TRY(hipMemcpy(theta, e->theta, n * 4, hipMemcpyDeviceToHost));
@@ -852,6 +970,8 @@ extern "C" int bore_engine_state(bore_engine *e, float *theta, float *adam_m, fl
 extern "C" int bore_engine_get_stats(bore_engine *e, bore_engine_stats *out, int reset) {
   if (!e || !out) return fail(BORE_E_INVALID, "engine_get_stats: NULL argument");
   *out = e->st;
+  out->worker_streams = e->as ? (int64_t)e->as->workers.size() : (int64_t)e->groups.size();
+  out->stream_concurrency = e->as ? e->as->stream_concurrency : 0;
   if (reset) std::memset(&e->st, 0, sizeof(e->st));
   return 0;
 }

@@ -32,6 +32,32 @@ __device__ int g_stamp_on;
 #define BORE_TSTAMP(i)
 #endif
 
+// -DBORE_WIDE_STAMPS: cycles per phase of the wide fits' Adam step, summed over the launch by
+// every wave's lane 0 of workgroup 0 (diagnostic builds only; tools/wide_stamps.py)
+#ifdef BORE_WIDE_STAMPS
+__device__ long long g_wstamps[4][16];
+#define BORE_WSTAMP_DECL long long ws_t = clock64(); (void)ws_t
+#define BORE_WSTAMP(i)                                                   \
+  do {                                                                   \
+    if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) {                    \
+      const long long ws_n = clock64();                                  \
+      g_wstamps[threadIdx.x >> 6][(i)] += ws_n - ws_t;                   \
+      ws_t = ws_n;                                                       \
+    }                                                                    \
+  } while (0)
+extern "C" int bore_debug_wide_stamps(long long *out, int reset) {
+  int rc = (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wstamps), sizeof(long long) * 64);
+  if (reset) {
+    long long z[64] = {0};
+    rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(g_wstamps), z, sizeof(z));
+  }
+  return rc;
+}
+#else
+#define BORE_WSTAMP_DECL
+#define BORE_WSTAMP(i)
+#endif
+
 extern "C" int bore_abi_version(void) { return BORE_ABI_VERSION; }
 
 extern "C" void bore_set_batch(const bore_batch *batch) {
@@ -66,7 +92,7 @@ struct FitArgs {
   float lr, beta1, beta2, eps;
   int state_in_lds, data_in_lds;
   // LDS carve (float offsets)
-  int o_tile, o_zt, o_misc, o_m, o_v, o_perm, o_keys, o_X, o_z, o_layout, total;
+  int o_tile, o_zt, o_misc, o_m, o_v, o_perm, o_keys, o_X, o_z, o_g, o_layout, total;
   // batch mode (bore_set_batch): slot -> loop ids[slot] at iteration its[slot]; N above is the
   // largest of the batch and the data buffers are `cap`-strided per loop
   const int *ids, *its;
@@ -365,9 +391,175 @@ __device__ __forceinline__ void dw_adam_wide(const FitArgs &a, float *smem, floa
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Weight gradients + Adam of a WIDE static shape whose Adam slots live in HBM, in two phases.
+//
+// dw_adam_wide above updates tile by tile: each tile's m / v (and, for the mixed-precision fit,
+// master weight) slots make an HBM round trip that one tile of look-ahead (~1 k cycles of MFMAs)
+// does not cover -- measured 4.3 k cycles per tile for 16->64-64-64-1 (40 tiles: 43 k of the
+// step's 65 k cycles) and 5.8 k for 32->128-128-1 in bf16 (88 tiles).  Here
+//   A. every wave forms ALL of its gradient tiles back to back (pure LDS + MFMA; the 16x16
+//      results stay in registers: 5 per tile),
+//   B. after a barrier (the A / D copies are dead) the gradients go to LDS in PACKED parameter
+//      order, over the tile region,
+//   C. after another barrier all 256 threads walk the packed vector: g from LDS, m / v (/ master
+//      weight) from HBM with coalesced loads, a dozen elements in flight per thread -- one memory
+//      latency per dozen elements instead of one per tile.
+// Same sums, same Adam expression per element: results are bit-identical to the tile-by-tile form.
+// ---------------------------------------------------------------------------------------------
+template <int SHAPE>
+constexpr int wide_total_tiles() {
+  constexpr MlpLayout L = bore_static_layout(SHAPE, 1, BORE_BATCH_MAX);
+  int total = 0;
+  for (int l = 1; l <= L.n_layers; ++l) total += (L.Np[l - 1] >> 4) * (L.Np[l] >> 4);
+  return total;
+}
+template <int SHAPE>
+constexpr int wide_tiles_per_wave() {
+  return (wide_total_tiles<SHAPE>() + BORE_THREADS / 64 - 1) / (BORE_THREADS / 64);
+}
+
+// Phase A: G[i][q] = gradient slot q of this wave's i-th tile (t = wave + 4 i).  ET = element type
+// of the A / D images (float, or unsigned short holding bfloat16).
+template <int SHAPE, typename ET>
+__device__ __forceinline__ void wide_grads(const ET *tile, float (&G)[wide_tiles_per_wave<SHAPE>()][5]) {
+  constexpr int KCH = BORE_BATCH_MAX / 4, TOTAL = wide_total_tiles<SHAPE>();
+  constexpr int TPW = wide_tiles_per_wave<SHAPE>(), STEP = BORE_THREADS / 64;
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, m16 = lane & 15, q4 = lane >> 4;
+#pragma unroll
+  for (int i = 0; i < TPW; ++i) {
+    const int t = wv + STEP * i;
+#pragma unroll
+    for (int q = 0; q < 5; ++q) G[i][q] = 0.f;
+    if (TOTAL % STEP != 0 && t >= TOTAL) continue;
+    const WideTile cur = wide_tile<SHAPE>(t);
+    const ET *ap = tile + cur.aoff + q4 * cur.lda_p + cur.kb * 16 + m16;
+    const ET *bp = tile + cur.doff + q4 * cur.ldd + cur.cb * 16 + m16;
+    float av[KCH], bv[KCH];
+#pragma unroll
+    for (int kc = 0; kc < KCH; ++kc) {
+      if constexpr (sizeof(ET) == 2) {
+        av[kc] = bf16_to_f32(ap[kc * 4 * cur.lda_p]);
+        bv[kc] = bf16_to_f32(bp[kc * 4 * cur.ldd]);
+      } else {
+        av[kc] = ap[kc * 4 * cur.lda_p];
+        bv[kc] = bp[kc * 4 * cur.ldd];
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    float bsum = 0.f;
+#pragma unroll
+    for (int kc = 0; kc < KCH; ++kc) {
+      const float x = cur.transposed ? bv[kc] : av[kc], y = cur.transposed ? av[kc] : bv[kc];
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x, y, acc, 0, 0, 0);
+      bsum += bv[kc];
+    }
+    G[i][0] = acc[0]; G[i][1] = acc[1]; G[i][2] = acc[2]; G[i][3] = acc[3];
+    if (cur.want_bias) {
+      const float gb = rows_sum4(bsum);
+      if (cur.transposed) G[i][0] = lane == 16 ? gb : G[i][0];
+      else G[i][4] = gb;
+    }
+  }
+}
+
+// Phase B: the gradients to gl[packed parameter index].
+template <int SHAPE>
+__device__ __forceinline__ void wide_scatter(const float (&G)[wide_tiles_per_wave<SHAPE>()][5], float *gl) {
+  constexpr int TOTAL = wide_total_tiles<SHAPE>(), TPW = wide_tiles_per_wave<SHAPE>();
+  constexpr int STEP = BORE_THREADS / 64;
+  const int wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < TPW; ++i) {
+    const int t = wv + STEP * i;
+    if (TOTAL % STEP != 0 && t >= TOTAL) continue;
+    const WideTile cur = wide_tile<SHAPE>(t);
+#pragma unroll
+    for (int q = 0; q < 5; ++q)
+      if (cur.ok[q]) gl[cur.gi[q]] = G[i][q];
+  }
+}
+
+// Phase C, float32 fit: theta is the padded LDS image, m / v are packed in HBM.
+template <int SHAPE>
+__device__ __forceinline__ void wide_adam_f32(float *th, const float *gl, float *m_g, float *v_g,
+                                              float alpha, float omb1, float omb2, float eps) {
+  constexpr MlpLayout L = bore_static_layout(SHAPE, 1, BORE_BATCH_MAX);
+  constexpr int U = 10;
+  for (int p0 = threadIdx.x; p0 < L.P; p0 += BORE_THREADS * U) {
+    float g[U], mm[U], vv[U], w[U];
+    int li[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int p = p0 + BORE_THREADS * u;
+      const bool ok = p < L.P;
+      li[u] = param_ref(L, ok ? p : 0, L.n_layers).lds;
+      mm[u] = ok ? m_g[p] : 0.f;
+      vv[u] = ok ? v_g[p] : 0.f;
+      g[u] = ok ? gl[p] : 0.f;
+      w[u] = th[li[u]];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    float wn[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) wn[u] = adam_update(w[u], g[u], mm[u], vv[u], alpha, omb1, omb2, eps);
+#pragma unroll
+    for (int u = 0; u < U; ++u) asm volatile("" : "+v"(wn[u]), "+v"(mm[u]), "+v"(vv[u]));
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int p = p0 + BORE_THREADS * u;
+      if (p < L.P) {
+        th[li[u]] = wn[u];
+        m_g[p] = mm[u];
+        v_g[p] = vv[u];
+      }
+    }
+  }
+}
+
+// Phase C, mixed-precision fit: float32 master weights, m, v packed in HBM; the LDS image of
+// theta holds their bfloat16 rounding.
+template <int SHAPE>
+__device__ __forceinline__ void wide_adam_bf16(unsigned short *th16, const float *gl, float *theta_g,
+                                               float *m_g, float *v_g, float alpha, float omb1,
+                                               float omb2, float eps) {
+  constexpr MlpLayout L = bore_static_layout(SHAPE, 1, BORE_BATCH_MAX);
+  constexpr int U = 8;
+  for (int p0 = threadIdx.x; p0 < L.P; p0 += BORE_THREADS * U) {
+    float g[U], mm[U], vv[U], w[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int p = p0 + BORE_THREADS * u;
+      const bool ok = p < L.P;
+      w[u] = ok ? theta_g[p] : 0.f;
+      mm[u] = ok ? m_g[p] : 0.f;
+      vv[u] = ok ? v_g[p] : 0.f;
+      g[u] = ok ? gl[p] : 0.f;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    float wn[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) wn[u] = adam_update(w[u], g[u], mm[u], vv[u], alpha, omb1, omb2, eps);
+#pragma unroll
+    for (int u = 0; u < U; ++u) asm volatile("" : "+v"(wn[u]), "+v"(mm[u]), "+v"(vv[u]));
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int p = p0 + BORE_THREADS * u;
+      if (p < L.P) {
+        th16[param_ref(L, p, L.n_layers).lds] = f32_to_bf16(wn[u]);
+        theta_g[p] = wn[u];
+        m_g[p] = mm[u];
+        v_g[p] = vv[u];
+      }
+    }
+  }
+}
+
 // (the body is a device function so that the fused iteration kernel of bore_iter.hip can run it)
 template <int SHAPE>
-__device__ __forceinline__ void fit_body(const FitArgs &a, const long long slot) {
+__device__ __forceinline__ void fit_body(const FitArgs &a, const long long slot,
+                                         const int it_now = -1) {
   extern __shared__ float smem[];
   constexpr MlpLayout Lc = bore_static_layout(SHAPE > 0 ? SHAPE : 0, 1, BORE_BATCH_MAX);
   const MlpLayout &L = begin_kernel<SHAPE>(Lc, a.L, smem, a.total, a.o_layout);
@@ -375,8 +567,9 @@ __device__ __forceinline__ void fit_body(const FitArgs &a, const long long slot)
   const int wv = tid >> 6, lane = tid & 63, m16 = lane & 15, q4 = lane >> 4;
   const long long model = a.ids ? a.ids[slot] : slot;  // the loop this workgroup fits
   const int P = L.P, n = layer_count<SHAPE>(L), D = L.w[0];
-  const int N = a.ids ? a.n_init + a.its[slot] : a.N;
-  const long long epoch0 = a.ids ? (long long)a.its[slot] * a.epochs : a.epoch0;
+  const int it_cur = a.ids ? (it_now >= 0 ? it_now : a.its[slot]) : 0;
+  const int N = a.ids ? a.n_init + it_cur : a.N;
+  const long long epoch0 = a.ids ? (long long)it_cur * a.epochs : a.epoch0;
 
   float *th = smem;
   float *tile = smem + a.o_tile;
@@ -393,6 +586,7 @@ __device__ __forceinline__ void fit_body(const FitArgs &a, const long long slot)
   const float *X_g = a.X + model * (a.ids ? a.cap : (long long)N) * D;
   const float *z_g = a.z + model * (a.ids ? a.cap : (long long)N);
   float *sm = smem + a.o_m, *sv = smem + a.o_v;  // padded images (when state_in_lds)
+  float *gacc = smem + a.o_g;  // weight-gradient sums carried between sub-tiles (batch_size > 64)
 
   load_theta(L, n, theta_g, th);
   if (a.state_in_lds) {
@@ -451,17 +645,28 @@ __device__ __forceinline__ void fit_body(const FitArgs &a, const long long slot)
     for (int s = 0; s < steps; ++s) {
       const int row0 = s * a.B;
       const int nb = min(a.B, N - row0);
+      const float alpha = first_step ? alpha_first : misc[5];
+      first_step = false;
+      float reg = 0.f;
+      // A mini-batch of more than 64 rows (Keras takes any batch_size; flavours without a
+      // compile-time layout) is walked in 64-row SUB-TILES: forward / loss / backward per sub-tile,
+      // the weight-gradient sums carried from one sub-tile to the next in an LDS image (the MFMA
+      // chain of a tile starts from the partial sum, so the k-ordered sum runs over all rows of the
+      // batch), Adam once after the last.  One sub-tile = the path every batch_size <= 64 takes.
+      const int nsub = SHAPE > 0 ? 1 : (nb + BORE_BATCH_MAX - 1) / BORE_BATCH_MAX;
+      for (int sub = 0; sub < nsub; ++sub) {
+      const int r0 = row0 + sub * BORE_BATCH_MAX;  // the sub-tile's first row in the epoch's order
+      const int nr = SHAPE > 0 ? nb : min(BORE_BATCH_MAX, nb - sub * BORE_BATCH_MAX);
+      const bool first_sub = sub == 0, last_sub = sub + 1 == nsub;
       // ---- forward / loss / backward: wave wv owns rows [16 wv, 16 wv + 16), no barriers ----
       BORE_STAMP(0);
       int src = 0;  // static path: this lane's mini-batch row, requested ahead of the arithmetic below
       if constexpr (SHAPE > 0) {
         if (wv * 16 + m16 < nb) src = perm_s[row0 + wv * 16 + m16];
       }
-      const float alpha = first_step ? alpha_first : misc[5];
-      first_step = false;
       // (wide shapes: every wave runs, rows past the batch are dead -- x = 0, delta = 0 -- so
       // that the weight-gradient tiles can always sum over all 64 rows)
-      if (wv * 16 < nb || bore_shape_is_wide(SHAPE > 0 ? SHAPE : 0)) {
+      if (wv * 16 < nr || bore_shape_is_wide(SHAPE > 0 ? SHAPE : 0)) {
         const int rb = wv;
         if constexpr (SHAPE > 0) {
           // static shape: the row-block's activations and deltas stay in registers
@@ -515,16 +720,16 @@ __device__ __forceinline__ void fit_body(const FitArgs &a, const long long slot)
           net.template store_D<1, Net::n - 1>(tile, rb);
           BORE_STAMP(4);
         } else {
-        {  // gather the mini-batch rows of this row-block (rows >= nb: zeros)
+        {  // gather the mini-batch rows of this row-block (rows past the sub-tile: zeros)
           float *A0 = tile + L.aoff[0] + (rb * 16 + m16) * L.lda[0];
           const int row = rb * 16 + m16;
-          const int src = row < nb ? perm_s[row0 + row] : 0;
+          const int src = row < nr ? perm_s[r0 + row] : 0;
           if (a.data_in_lds) {  // (two branches: a selected pointer would make these flat loads)
-            for (int d = q4; d < D; d += 4) A0[d] = row < nb ? smem[a.o_X + src * D + d] : 0.f;
-            if (q4 == 0) zt[row] = row < nb ? smem[a.o_z + src] : 0.f;
+            for (int d = q4; d < D; d += 4) A0[d] = row < nr ? smem[a.o_X + src * D + d] : 0.f;
+            if (q4 == 0) zt[row] = row < nr ? smem[a.o_z + src] : 0.f;
           } else {
-            for (int d = q4; d < D; d += 4) A0[d] = row < nb ? X_g[src * D + d] : 0.f;
-            if (q4 == 0) zt[row] = row < nb ? z_g[src] : 0.f;
+            for (int d = q4; d < D; d += 4) A0[d] = row < nr ? X_g[src * D + d] : 0.f;
+            if (q4 == 0) zt[row] = row < nr ? z_g[src] : 0.f;
           }
         }
         wave_lds_sync();
@@ -532,7 +737,7 @@ __device__ __forceinline__ void fit_body(const FitArgs &a, const long long slot)
         if (lane < 16) {  // loss + d loss / d logit (the final layer has one unit)
           const int row = rb * 16 + lane;
           float delta = 0.f;
-          if (row < nb) {
+          if (row < nr) {
             const float x = tile[L.aoff[n] + row * L.lda[n]];
             const float zz = zt[row];
             const float ex = expf(-fabsf(x));  // shared by the loss and the sigmoid
@@ -551,7 +756,7 @@ __device__ __forceinline__ void fit_body(const FitArgs &a, const long long slot)
           wave_lds_sync();
         }
         }
-        if (tid == 0 && L.any_l2) {
+        if (tid == 0 && L.any_l2 && first_sub) {
           eloss += misc[0] * (float)nb;
           misc[0] = 0.f;  // consumed; re-accumulated from the updated weights below
         }
@@ -564,12 +769,19 @@ __device__ __forceinline__ void fit_body(const FitArgs &a, const long long slot)
       BORE_STAMP(5);
 
       // ---- weight gradients (sums over all rows) + Adam, one 16x16 tile per wave at a time ----
-      const int kch = (nb + 3) >> 2;
-      float reg = 0.f;
+      const int kch = (nr + 3) >> 2;
       int t = 0;
       if constexpr (bore_shape_is_wide(SHAPE > 0 ? SHAPE : 0)) {
-        if (a.state_in_lds) dw_adam_wide<SHAPE, true>(a, smem, m_g, v_g, alpha, omb1, omb2);
-        else dw_adam_wide<SHAPE, false>(a, smem, m_g, v_g, alpha, omb1, omb2);
+        if (a.state_in_lds) {
+          dw_adam_wide<SHAPE, true>(a, smem, m_g, v_g, alpha, omb1, omb2);
+        } else {  // gradients of all tiles -> packed image over A_0.. (the D_l are not touched)
+          float G[wide_tiles_per_wave<SHAPE>()][5];
+          wide_grads<SHAPE, float>(tile, G);
+          __syncthreads();
+          wide_scatter<SHAPE>(G, tile);
+          __syncthreads();
+          wide_adam_f32<SHAPE>(th, tile, m_g, v_g, alpha, omb1, omb2, a.eps);
+        }
       } else if constexpr (SHAPE > 0) {
         switch ((nb + 15) >> 4) {
           case 1: dw_adam_static<SHAPE, 1>(a, smem, alpha, omb1, omb2); break;
@@ -596,10 +808,17 @@ __device__ __forceinline__ void fit_body(const FitArgs &a, const long long slot)
             const bool want_bias = kb == 0;
             const int col = cb * 16 + m16;
             const bool cvalid = col < Nw;
+            if (!first_sub) {  // go on from the sums over the batch's earlier sub-tiles
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const int row = kb * 16 + q4 * 4 + r;
+                if (cvalid && row < K) acc[r] = gacc[L.woff[l] + row * ldw + col];
+              }
+            }
             // Adam slots that live in HBM (wide nets): fetch this tile's m, v now, so that the
             // loads are in flight under the MFMA chain instead of in front of every update
             float pm[4] = {0.f, 0.f, 0.f, 0.f}, pv[4] = {0.f, 0.f, 0.f, 0.f}, pmb = 0.f, pvb = 0.f;
-            if (!a.state_in_lds) {
+            if (!a.state_in_lds && last_sub) {
 #pragma unroll
               for (int r = 0; r < 4; ++r) {
                 const int row = kb * 16 + q4 * 4 + r;
@@ -629,6 +848,19 @@ __device__ __forceinline__ void fit_body(const FitArgs &a, const long long slot)
               const float av = ap[kc * 4 * lda_p], bv = bp[kc * 4 * ldd];
               acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
               bsum += bv;
+            }
+            if (!last_sub) {  // park the partial sums; Adam comes after the batch's last sub-tile
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const int row = kb * 16 + q4 * 4 + r;
+                if (cvalid && row < K) gacc[L.woff[l] + row * ldw + col] = acc[r];
+              }
+              if (want_bias) {
+                const float gb = rows_sum4(bsum);
+                if (q4 == 0 && cvalid)
+                  gacc[L.boff[l] + col] = first_sub ? gb : gacc[L.boff[l] + col] + gb;
+              }
+              continue;
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -660,7 +892,7 @@ __device__ __forceinline__ void fit_body(const FitArgs &a, const long long slot)
               if (q4 == 0 && cvalid) {
                 const int li = L.boff[l] + col;
                 float w = th[li];
-                float g = gb;
+                float g = first_sub ? gb : gacc[li] + gb;
                 const float l2 = L.l2_b[l];
                 if (l2 != 0.f) g = fmaf(2.f * l2, w, g);
                 if (a.state_in_lds) {
@@ -681,6 +913,8 @@ __device__ __forceinline__ void fit_body(const FitArgs &a, const long long slot)
             }
           }
       }
+      if (!last_sub) __syncthreads();  // (the next sub-tile overwrites the A_l / D_l copies)
+      }  // sub-tiles
       if (L.any_l2) {  // penalty of the UPDATED weights = the one the next step's loss sees
         reg = wave_sum(reg);
         if (lane == 0) atomicAdd(&misc[0], reg);
@@ -882,6 +1116,7 @@ __global__ __launch_bounds__(BORE_THREADS) void fit_bf16_kernel(const FitBf16Arg
       const int nb = min(a.B, N - row0);
       const float alpha = first_step ? alpha_first : misc[5];
       first_step = false;
+      BORE_WSTAMP_DECL;
       {  // every wave runs its 16 rows; rows past the batch are dead (x = 0, delta = 0)
         Net net;
         if constexpr (Net::RT_ACT) net.set_acts(a.L);
@@ -900,7 +1135,9 @@ __global__ __launch_bounds__(BORE_THREADS) void fit_bf16_kernel(const FitBf16Arg
         }
         float zz = 0.f;
         if (q4 == 0 && live) zz = z_g[src];
+        BORE_WSTAMP(0);
         net.forward(th16, xin, /*keep_logits=*/true);
+        BORE_WSTAMP(1);
         net.template store_A<1, n - 1>(tile16, rb);
         float delta = 0.f;
         if (lane < 16 && live) {
@@ -913,11 +1150,31 @@ __global__ __launch_bounds__(BORE_THREADS) void fit_bf16_kernel(const FitBf16Arg
         }
         if (lane < 16) tile16[L.doff[n] + row * L.lda[n]] = f32_to_bf16(delta);
         net.set_output_delta(delta);
+        BORE_WSTAMP(2);
         net.template backward<n, 2>(th16);
+        BORE_WSTAMP(3);
         net.template store_D<1, n - 1>(tile16, rb);
+        BORE_WSTAMP(4);
       }
       __syncthreads();
-      dw_adam_bf16<SHAPE>(a, th16, tile16, theta_g, m_g, v_g, alpha, omb1, omb2);
+      BORE_WSTAMP(5);
+      {
+        float G[wide_tiles_per_wave<SHAPE>()][5];
+        wide_grads<SHAPE, unsigned short>(tile16, G);
+        BORE_WSTAMP(6);
+        __syncthreads();
+        float *gl = reinterpret_cast<float *>(tile16);  // [P] floats: the tile region + its extension
+        wide_scatter<SHAPE>(G, gl);
+        __syncthreads();
+        BORE_WSTAMP(7);
+        wide_adam_bf16<SHAPE>(th16, gl, theta_g, m_g, v_g, alpha, omb1, omb2, a.eps);
+        BORE_WSTAMP(8);
+        __syncthreads();
+        BORE_WSTAMP(9);
+        // the image overwrote D_n, whose columns past the single output unit must read zero (the
+        // next step stores column 0 only); the other A_l / D_l rows are rewritten in full
+        for (int i = tid; i < BORE_BATCH_MAX * L.lda[n]; i += nthr) tile16[L.doff[n] + i] = 0;
+      }
       if (wv == (BORE_THREADS / 64) - 1) {
         b1p *= (double)a.beta1;
         b2p *= (double)a.beta2;
@@ -1129,12 +1386,12 @@ static int fit_build(const bore_mlp_desc *desc, int n_models, float *theta, floa
                      int epochs, int batch_size, const int32_t *perm, uint64_t seed,
                      int64_t model_index0, int64_t epoch0, const bore_adam_cfg *adam,
                      float *epoch_loss, FitArgs &a, size_t &lds_floats, int &shape_out) {
-  if (batch_size < 1 || batch_size > BORE_BATCH_MAX)
-    return fail(BORE_E_UNSUPPORTED, "fit: batch_size must be 1..%d (got %d)", BORE_BATCH_MAX,
-                batch_size);
+  if (batch_size < 1) return fail(BORE_E_INVALID, "fit: batch_size must be positive (got %d)", batch_size);
   if (N < 1 || N > (1 << 20)) return fail(BORE_E_INVALID, "fit: N=%lld out of range", (long long)N);
-  // the whole mini-batch is one tile; perm (+ keys) and the batch targets ride along
-  int rc = check_common(desc, n_models, 1, batch_size, false,
+  // a mini-batch of up to 64 rows is one tile (larger ones: 64-row sub-tiles, fit_body); perm
+  // (+ keys) and the batch targets ride along
+  const int tile_rows = batch_size < BORE_BATCH_MAX ? batch_size : BORE_BATCH_MAX;
+  int rc = check_common(desc, n_models, 1, tile_rows, false,
                         BORE_BATCH_MAX + 8 + BORE_LAYOUT_FLOATS + 12 + (size_t)N * (perm ? 1 : 3),
                         &a.L);
   if (rc) return rc;
@@ -1177,6 +1434,8 @@ static int fit_build(const bore_mlp_desc *desc, int n_models, float *theta, floa
   a.o_perm = (int)off; off += perm_f;
   off = (off + 3) & ~(size_t)3;  // keys: 64-bit words fetched two at a time
   a.o_keys = (int)off; off += keys_f;
+  a.o_g = (int)off;
+  if (batch_size > BORE_BATCH_MAX) off += L.P_lds;  // gradient sums carried between sub-tiles
   if ((off + BORE_LAYOUT_FLOATS + 4) * 4 > BORE_LDS_BYTES)
     return fail(BORE_E_UNSUPPORTED, "fit: theta+tile+perm need %zu B of LDS (> %d)", off * 4,
                 BORE_LDS_BYTES);
@@ -1273,7 +1532,9 @@ static int fit_bf16_impl(const bore_mlp_desc *desc, int n_models, float *theta, 
   // LDS carve (bytes): theta bf16 | A/D copies bf16 | misc | perm | keys
   size_t off = 2 * (size_t)a.L.P_lds;
   off = (off + 15) & ~(size_t)15;
-  a.o_tile = (int)off; off += 2 * (size_t)a.L.tile_floats;
+  // (the weight-gradient phase parks the packed fp32 gradient image over the A / D copies)
+  a.o_tile = (int)off;
+  off += 2 * (size_t)a.L.tile_floats > 4 * (size_t)a.L.P ? 2 * (size_t)a.L.tile_floats : 4 * (size_t)a.L.P;
   off = (off + 15) & ~(size_t)15;
   a.o_misc = (int)off; off += 8 * 4;
   const int PG = perm ? 1 : perm_group(N, BORE_THREADS);

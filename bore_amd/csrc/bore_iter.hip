@@ -19,44 +19,107 @@ struct IterArgs {
   LbfgsbArgs b;
   double *X_seen, *y_seen;  // records, cap-strided per loop
   float *X32, *z;
-  const double *x_new, *y_new;  // per slot: the row to append
+  const double *x_new, *y_new;  // per slot: the row to append before the launch's first iteration
   long long *stamps;            // [n_loops][4] device-clock stamps of the phase boundaries, or NULL
   double gamma;
   int D;
+  // Residency (include/bore_hip.h: bore_batch).  A workgroup may run SEVERAL consecutive iterations
+  // of its loop in one launch: after publishing iteration it's suggestion it waits up to
+  // wait_ticks of the device clock for the host to deliver the objective value (ynew / yseq,
+  // pinned host memory polled over the bus by one lane) and goes on with iteration it + 1 without
+  // a launch, an upload or a place in a batch.  If the row does not come in time (a slow
+  // objective, wait_ticks = 0, an abort) it says so in parked[] and exits: every wave of the grid
+  // ends within wait_ticks of host silence.
+  const int *targets;        // per slot: run iterations its[slot] .. targets[slot] - 1 at most
+  const double *ynew;        // pinned [n_loops][D + 1]: x | y of each loop's newest observation
+  const int *yseq;           // pinned [n_loops]: iterations whose row the host has delivered
+  int *parked;               // pinned [n_loops]: the iteration this workgroup left to a later launch
+  const int *abort_flag;     // pinned [1]: non-zero = stop waiting
+  long long wait_ticks;
 };
 
+// 64-bit load from host memory that the host may have written since the kernel started
+__device__ __forceinline__ double load_host_f64(const double *p) {
+  const long long v = __hip_atomic_load(reinterpret_cast<const long long *>(p), __ATOMIC_RELAXED,
+                                        __HIP_MEMORY_SCOPE_SYSTEM);
+  return __longlong_as_double(v);
+}
+
+// One iteration of the loop in `slot`.  NOT inlined into the kernel's loop: inlined, the compiler
+// hoists the phases' argument loads and address arithmetic out of the loop and keeps them live
+// around it (307 SGPR + 109 VGPR spills, 420 B of scratch per lane against 24 B for this body on
+// its own); the call costs a few dozen cycles once per BO iteration.
 template <int SHAPE>
-__global__ __launch_bounds__(BORE_THREADS, 2) void iteration_kernel(const IterArgs *__restrict__ pa) {
+__device__ __attribute__((noinline)) void iteration_once(const IterArgs *__restrict__ pa,
+                                                         const long long slot, const int it,
+                                                         const bool staged) {
   const IterArgs &a = *pa;
-  const long long slot = blockIdx.x;
-  const int it = a.f.its[slot];
   const long long lid = a.f.ids[slot], cap = a.f.cap;
   long long *stp = a.stamps ? a.stamps + lid * 4 : nullptr;  // read back by the restart phase's epilogue
   if (stp && threadIdx.x == 0) stp[0] = wall_clock64();
   if (it > 0) {  // append (append_kernel's batch branch)
     const long long row = a.f.n_init + it - 1;
+    // (the launch brought the row of its first iteration; later ones come from the host)
     for (int d = threadIdx.x; d < a.D; d += blockDim.x) {
-      const double v = a.x_new[slot * a.D + d];
+      const double v = staged ? a.x_new[slot * a.D + d] : load_host_f64(a.ynew + lid * (a.D + 1) + d);
       a.X_seen[(lid * cap + row) * a.D + d] = v;
       a.X32[(lid * cap + row) * a.D + d] = (float)v;
     }
-    if (threadIdx.x == 0) a.y_seen[lid * cap + row] = a.y_new[slot];
+    if (threadIdx.x == 0)
+      a.y_seen[lid * cap + row] = staged ? a.y_new[slot] : load_host_f64(a.ynew + lid * (a.D + 1) + a.D);
   }
   __threadfence();
   __syncthreads();
-  labels_body(a.y_seen, 0, 0.0, a.z, nullptr, a.f.ids, a.f.its, a.f.n_init, cap, a.gamma, slot);
+  labels_body(a.y_seen, 0, 0.0, a.z, nullptr, a.f.ids, a.f.its, a.f.n_init, cap, a.gamma, slot, it);
   if (stp && threadIdx.x == 0) stp[1] = wall_clock64();
   __threadfence();
   __syncthreads();
-  fit_body<SHAPE>(a.f, slot);
+  fit_body<SHAPE>(a.f, slot, it);
   if (stp && threadIdx.x == 0) stp[2] = wall_clock64();
   __threadfence();
   __syncthreads();
-  screen_body<SHAPE, false>(a.s, slot);
+  screen_body<SHAPE, false>(a.s, slot, it);
   if (stp && threadIdx.x == 0) stp[3] = wall_clock64();
   __threadfence();
   __syncthreads();
-  lbfgsb_body<SHAPE, false, true>(a.b, slot, 0);
+  lbfgsb_body<SHAPE, false, true>(a.b, slot, 0, it);  // (publishes flag[lid] = it + 1)
+}
+
+template <int SHAPE>
+__global__ __launch_bounds__(BORE_THREADS, 2) void iteration_kernel(const IterArgs *__restrict__ pa) {
+  __shared__ __attribute__((aligned(16))) int s_go4[4];  // (16 B: the dynamic LDS keeps its alignment)
+  const long long slot = blockIdx.x;
+  const int it_first = pa->f.its[slot];
+  const int target = pa->targets ? pa->targets[slot] : it_first + 1;
+  for (int it = it_first;;) {
+    iteration_once<SHAPE>(pa, slot, it, it == it_first);
+    __syncthreads();  // the waves leave the restart phase one by one: LDS is reused below
+    ++it;
+    if (it >= target) break;
+    // ---- the next row: delivered while we were busy, or within wait_ticks, or not our business ----
+    if (threadIdx.x == 0) {
+      const long long lid = pa->f.ids[slot], wait_ticks = pa->wait_ticks;
+      const int *yseq = pa->yseq + lid, *abort_flag = pa->abort_flag;
+      int go = 0;
+      const long long t0 = wall_clock64();
+      for (;;) {
+        if (__hip_atomic_load(yseq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) >= it) {
+          go = 1;
+          break;
+        }
+        if (wait_ticks <= 0 || wall_clock64() - t0 > wait_ticks) break;
+        if (__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) break;
+        __builtin_amdgcn_s_sleep(16);
+      }
+      // (after this store the workgroup touches nothing of the loop: the host may relaunch it)
+      if (!go) __hip_atomic_store(pa->parked + lid, it, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      s_go4[0] = go;
+    }
+    __syncthreads();
+    const int go = s_go4[0];
+    __syncthreads();
+    if (!go) break;
+  }
 }
 
 // One fused launch for the batch currently set (bore_set_batch): fills *h (pinned host copy of the
@@ -97,6 +160,13 @@ static int iteration_launch(const bore_mlp_desc *desc, int n_slots, float *theta
   h->x_new = x_new; h->y_new = y_new;
   h->stamps = reinterpret_cast<long long *>(g_batch->stamps);
   h->b.stamps = h->stamps;
+  h->targets = g_batch->targets;
+  h->ynew = g_batch->ynew; h->yseq = g_batch->yseq; h->parked = g_batch->parked;
+  h->abort_flag = g_batch->abort_flag;
+  const bool resident = g_batch->targets && g_batch->ynew && g_batch->yseq && g_batch->parked &&
+                        g_batch->abort_flag;
+  if (!resident) h->targets = nullptr;  // one iteration per launch
+  h->wait_ticks = resident ? g_batch->wait_ticks : 0;
   h->gamma = gamma;
   h->D = desc->input_dim;
   size_t floats = lf > ls ? lf : ls;
@@ -104,6 +174,20 @@ static int iteration_launch(const bore_mlp_desc *desc, int n_slots, float *theta
   const size_t labels_floats = 2 * ((size_t)cap + 2);
   floats = floats > labels_floats ? floats : labels_floats;
   if ((rc = allow_lds(iteration_kernel<1>, floats * 4))) return rc;
+  if (h->wait_ticks > 0) {  // waiting workgroups hold their slots: only when all of them fit at once
+    static thread_local size_t cap_bytes = ~(size_t)0;
+    static thread_local int cap_wgs = 0;
+    if (cap_bytes != floats * 4) {
+      int per_cu = 0, dev = 0, cus = 0;
+      HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, iteration_kernel<1>, BORE_THREADS,
+                                                           floats * 4));
+      HIP_TRY(hipGetDevice(&dev));
+      HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+      cap_bytes = floats * 4;
+      cap_wgs = per_cu * cus;
+    }
+    if (g_batch->resident_loops > cap_wgs) h->wait_ticks = 0;
+  }
   // h heads the caller's staging block (arguments | per-slot inputs | index lists): one upload
   HIP_TRY(hipMemcpyAsync(const_cast<IterArgs *>(d_args), h, upload_bytes, hipMemcpyHostToDevice,
                          (hipStream_t)stream));

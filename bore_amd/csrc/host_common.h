@@ -4,6 +4,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <mutex>
 
 #include "mlp_layout.h"
 
@@ -35,19 +36,25 @@ inline int allow_lds(K kernel, size_t bytes) {
   if (bytes > BORE_LDS_BYTES)
     return fail(BORE_E_UNSUPPORTED, "model needs %zu B of LDS per workgroup (> %d)", bytes,
                 BORE_LDS_BYTES);
-  struct Seen { const void *k; size_t bytes; };
-  static Seen seen[64];
+  // the attribute is per device; callers on different host threads (ctypes releases the GIL)
+  // share this table
+  struct Seen { const void *k; int dev; size_t bytes; };
+  static Seen seen[256];
   static int n_seen = 0;
+  static std::mutex mu;
   const void *kp = reinterpret_cast<const void *>(kernel);
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lock(mu);
   for (int i = 0; i < n_seen; ++i)
-    if (seen[i].k == kp) {
+    if (seen[i].k == kp && seen[i].dev == dev) {
       if (bytes <= seen[i].bytes) return 0;
       HIP_TRY(hipFuncSetAttribute(kp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
       seen[i].bytes = bytes;
       return 0;
     }
   HIP_TRY(hipFuncSetAttribute(kp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-  if (n_seen < 64) seen[n_seen++] = Seen{kp, bytes};
+  if (n_seen < 256) seen[n_seen++] = Seen{kp, dev, bytes};
   return 0;
 }
 

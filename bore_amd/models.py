@@ -144,16 +144,23 @@ class Sequential:
     # -- Keras surface -------------------------------------------------------
     def fit(self, x, y, batch_size=None, epochs=1, verbose=False, callbacks=None, shuffle=True,
             perm=None, **kwargs):
-        """Keras ``fit`` (README.rst:93).  ``perm`` (epochs, N) is an extension: explicit
-        per-epoch shuffles (used by the parity tests); default draws them on the device."""
-        if callbacks:
-            raise NotImplementedError("callbacks are not supported: the whole fit is one kernel")
+        """Keras ``fit`` (README.rst:93; bore/plugins/hpbandster/base.py:184).  Any ``batch_size``
+        (more than 64 rows: 64-row sub-tiles inside one Adam step, same sums).  ``perm``
+        (epochs, N) is an extension: explicit per-epoch shuffles (used by the parity tests);
+        default draws them on the device.
+
+        ``callbacks``: objects with any of Keras' ``set_model``, ``on_train_begin``,
+        ``on_epoch_begin``, ``on_epoch_end(epoch, logs)`` (logs = {"loss": ...}),
+        ``on_train_end``.  Without callbacks the whole fit is ONE kernel; with them it is one
+        launch per epoch, so that ``model.stop_training = True`` (early stopping) takes effect at
+        the epoch boundary as in Keras -- same arithmetic either way (Adam state and the shuffle
+        stream carry over between launches)."""
         x = np.asarray(x) if not isinstance(x, torch.Tensor) else x
         self._ensure_built(x)
         self._check_loss()
         batch_size = 32 if batch_size is None else int(batch_size)
-        if not 1 <= batch_size <= _lib.BATCH_MAX:
-            raise NotImplementedError(f"batch_size must be 1..{_lib.BATCH_MAX} on the HIP path")
+        if batch_size < 1:
+            raise ValueError(f"batch_size must be positive, got {batch_size}")
         X = self._to_dev(x, torch.float32).reshape(1, -1, self._input_dim)
         N = X.shape[1]
         z = self._to_dev(np.asarray(y).reshape(-1) if not isinstance(y, torch.Tensor)
@@ -169,12 +176,38 @@ class Sequential:
             perm = torch.from_numpy(np.ascontiguousarray(perm, dtype=np.int32)) \
                 .to(self.theta.device).reshape(1, epochs, N)
         o = self._optimizer
-        loss = ops.mlp_fit(self._desc, self.theta, self.adam_m, self.adam_v, self.adam_t, X, z,
-                           epochs, batch_size, perm=perm, seed=self._shuffle_seed,
-                           epoch0=self._epochs_seen, lr=o.learning_rate, beta1=o.beta_1,
-                           beta2=o.beta_2, eps=o.epsilon)
-        self._epochs_seen += epochs
-        return History(loss[0].cpu().numpy())
+
+        def launch(e0, n_epochs):
+            loss = ops.mlp_fit(self._desc, self.theta, self.adam_m, self.adam_v, self.adam_t, X, z,
+                               n_epochs, batch_size,
+                               perm=None if perm is None else perm[:, e0:e0 + n_epochs].contiguous(),
+                               seed=self._shuffle_seed, epoch0=self._epochs_seen,
+                               lr=o.learning_rate, beta1=o.beta_1, beta2=o.beta_2, eps=o.epsilon)
+            self._epochs_seen += n_epochs
+            return loss[0].cpu().numpy()
+
+        callbacks = list(callbacks or [])
+        if not callbacks:
+            return History(launch(0, epochs))
+
+        def call(name, *args):
+            for cb in callbacks:
+                fn = getattr(cb, name, None)
+                if fn is not None:
+                    fn(*args)
+
+        self.stop_training = False
+        call("set_model", self)
+        call("on_train_begin", {})
+        losses = []
+        for e in range(epochs):
+            call("on_epoch_begin", e, {})
+            losses.append(float(launch(e, 1)[0]))
+            call("on_epoch_end", e, {"loss": losses[-1]})
+            if self.stop_training:
+                break
+        call("on_train_end", {})
+        return History(np.asarray(losses, dtype=np.float32))
 
     def evaluate(self, x, y, batch_size=None, verbose=False, **kwargs):
         """Keras ``evaluate``: loss, or [loss, accuracy] when compiled with metrics."""

@@ -324,6 +324,22 @@ typedef struct bore_batch {
   double *result;        /* pinned [n_loops][D + 8] */
   int32_t *flag;         /* pinned [n_loops] */
   int64_t *stamps;       /* device [n_loops][4] scratch for the phase clock stamps, or NULL */
+  /* Residency (fused iteration kernel only; all five pointers or none).  A workgroup runs
+   * iterations its[b] .. targets[b] - 1 of its loop in ONE launch as long as the host keeps up:
+   * after publishing iteration k's suggestion it waits up to wait_ticks of the device clock for
+   * yseq[ids[b]] >= k + 1, meaning ynew[ids[b]] = {x[D], y} holds the row iteration k + 1
+   * appends, and goes on without a launch.  If the row does not come in time (or wait_ticks is 0,
+   * or *abort_flag is set) it stores parked[ids[b]] = k + 1 and exits; the caller launches
+   * iteration k + 1 in a later batch.  Every wave therefore ends within wait_ticks of host
+   * silence.  ynew, yseq, parked and abort_flag are host-visible (pinned) memory. */
+  const int32_t *targets;    /* device [n_models] */
+  const double *ynew;        /* pinned [n_loops][D + 1], written by the host */
+  const int32_t *yseq;       /* pinned [n_loops], written by the host after ynew */
+  int32_t *parked;           /* pinned [n_loops], written by the device */
+  const int32_t *abort_flag; /* pinned [1] */
+  int64_t wait_ticks;        /* hipDeviceAttributeWallClockRate ticks; 0 = never wait */
+  int32_t resident_loops;    /* workgroups the caller wants resident at once (all its loops): the
+                                wait is dropped when the device cannot hold that many */
 } bore_batch;
 void bore_set_batch(const bore_batch *batch);
 
@@ -380,6 +396,11 @@ typedef struct bore_engine_stats {
   double phase_ns_labels, phase_ns_fit, phase_ns_screen, phase_ns_lbfgsb;
   double ready_to_launch_s, launch_to_result_s, result_to_ready_s;
   int64_t phase_iterations, batches;
+  /* asynchronous schedule: worker streams, and how many of them the device was seen to run at
+   * once when the engine was created (a probe of spinning kernels).  Fewer than worker_streams
+   * means streams share hardware queues -- GPU_MAX_HW_QUEUES was below worker_streams + 2 when
+   * the HIP runtime initialised -- and launches of different batches serialise.  Not reset. */
+  int64_t worker_streams, stream_concurrency;
 } bore_engine_stats;
 
 typedef struct bore_engine bore_engine;

@@ -194,3 +194,53 @@ def test_mixed_bfloat16_policy_runs_config5(gpu):
     assert model.predict(res.x[None])[0, 0] >= np.quantile(model.predict(X), 0.99)
     with pytest.raises(ValueError):
         MaximizableSequential(dtype_policy="float16")
+
+
+def test_fit_callbacks_and_large_batches(gpu):
+    """Keras' callback protocol at epoch boundaries (incl. model.stop_training) and batch sizes
+    above 64: same trajectory as the single-launch fit."""
+    from bore_amd.layers import Dense
+    from bore_amd.models import MaximizableSequential
+    rs = np.random.RandomState(3)
+    X = rs.uniform(size=(150, 2))
+    z = X[:, 0] + X[:, 1] < 0.8
+
+    def make():
+        m = MaximizableSequential(seed=5)
+        m.add(Dense(16, activation="relu"))
+        m.add(Dense(16, activation="relu"))
+        m.add(Dense(1, activation="sigmoid"))
+        m.compile(optimizer="adam", loss="binary_crossentropy")
+        return m
+
+    class Log:
+        def __init__(self, stop_at=None):
+            self.events, self.stop_at = [], stop_at
+
+        def set_model(self, model):
+            self.model = model
+
+        def on_train_begin(self, logs):
+            self.events.append("begin")
+
+        def on_epoch_end(self, epoch, logs):
+            self.events.append((epoch, logs["loss"]))
+            if self.stop_at is not None and epoch == self.stop_at:
+                self.model.stop_training = True
+
+        def on_train_end(self, logs):
+            self.events.append("end")
+
+    a, b, c = make(), make(), make()
+    ha = a.fit(X, z, epochs=6, batch_size=100)
+    log = Log()
+    hb = b.fit(X, z, epochs=6, batch_size=100, callbacks=[log])
+    np.testing.assert_allclose(ha.history["loss"], hb.history["loss"], rtol=1e-6)
+    for u, v in zip(a.get_weights(), b.get_weights()):
+        np.testing.assert_allclose(u, v, rtol=1e-5, atol=1e-7)
+    assert log.events[0] == "begin" and log.events[-1] == "end" and len(log.events) == 8
+    assert [e[0] for e in log.events[1:-1]] == list(range(6))
+    stop = Log(stop_at=2)
+    hc = c.fit(X, z, epochs=6, batch_size=100, callbacks=[stop])
+    assert len(hc.history["loss"]) == 3
+    np.testing.assert_allclose(hc.history["loss"], ha.history["loss"][:3], rtol=1e-6)

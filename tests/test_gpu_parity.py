@@ -299,7 +299,7 @@ def test_bad_arguments_fail_loudly(gpu):
         ops.mlp_fit(desc, th, th.clone(), th.clone(), t, X, z, 1, 64,
                     perm=torch.full((1, 1, 5), 7, dtype=torch.int32, device="cuda"))
     with pytest.raises(RuntimeError, match="batch_size"):
-        ops.mlp_fit(desc, th, th.clone(), th.clone(), t, X, z, 1, 128)
+        ops.mlp_fit(desc, th, th.clone(), th.clone(), t, X, z, 1, 0)
     d2 = _lib.make_desc(2, [4, 2], ["relu", None])
     with pytest.raises(RuntimeError, match="1 unit"):
         ops.mlp_forward(d2, torch.zeros(1, ops.param_count(d2), device="cuda"), X[0])
@@ -453,3 +453,34 @@ def test_fit_properties_at_baseline_sizes(gpu, name, D, units, compute, L, N):
     assert torch.equal(t2, t[:2])
     tol = dict(rtol=2e-2, atol=2e-3) if compute == "bfloat16" else dict(rtol=1e-4, atol=1e-6)
     np.testing.assert_allclose(th2.cpu().numpy(), th[:2].cpu().numpy(), **tol)
+
+
+@pytest.mark.parametrize("N,B", [(65, 65), (300, 100), (256, 128), (200, 200), (513, 256), (90, 1000)])
+def test_fit_with_more_than_64_rows_per_batch_against_oracle(gpu, N, B):
+    """Keras takes any batch_size (the plugin's default is 64): larger batches run
+    as 64-row sub-tiles of ONE Adam step, the weight-gradient sums carried between them."""
+    rs = np.random.RandomState(N * 3 + B)
+    for D, units, acts, l2 in [(2, [16, 16, 1], ["relu", "relu", "sigmoid"], None),
+                               (5, [24, 7, 1], ["elu", "tanh", "linear"], 1e-3)]:
+        p = rand_model(rs, D, units)
+        X = rs.uniform(size=(N, D))
+        z = rs.uniform(size=N) < 0.3
+        E = 3
+        perms = np.stack([rs.permutation(N) for _ in range(E)])
+        p64 = [a.astype(np.float64) for a in p]
+        st = O.AdamState(p64)
+        l2s = None if l2 is None else [l2] * (2 * len(units) - 2) + [0.0, 0.0]
+        hist = O.fit(p64, acts, st, X.astype(np.float32), z, perms, batch_size=B, l2=l2s,
+                     dtype=np.float64)
+        lk = None if l2 is None else [l2] * (len(units) - 1) + [0.0]
+        desc = _lib.make_desc(D, units, acts, lk, lk)
+        theta = dev(pack(p)).reshape(1, -1)
+        m, v = torch.zeros_like(theta), torch.zeros_like(theta)
+        t = torch.zeros(1, dtype=torch.int64, device="cuda")
+        h = ops.mlp_fit(desc, theta, m, v, t, dev(X, torch.float32).reshape(1, N, D),
+                        dev(z.astype(np.float32)).reshape(1, N), E, B,
+                        perm=dev(perms.astype(np.int32)).reshape(1, E, N))
+        assert int(t[0]) == st.t == E * O.steps_per_epoch(N, B)
+        np.testing.assert_allclose(h.cpu().numpy()[0], hist, rtol=5e-5)
+        np.testing.assert_allclose(theta.cpu().numpy()[0], pack(p64), rtol=2e-4, atol=1e-5)
+        np.testing.assert_allclose(m.cpu().numpy()[0], pack(st.m), rtol=2e-3, atol=1e-7)
