@@ -4,11 +4,13 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 #include "host_common.h"
 #include "mlp_device.h"
 #include "mlp_regs.h"
+#include "fit_bf16_mfma.h"
 
 using namespace bore;
 
@@ -420,12 +422,29 @@ constexpr int wide_tiles_per_wave() {
 }
 
 // Phase A: G[i][q] = gradient slot q of this wave's i-th tile (t = wave + 4 i).  ET = element type
-// of the A / D images (float, or unsigned short holding bfloat16).
+// of the A / D images (float, or unsigned short holding bfloat16).  A tile's 2 x 16 operands are
+// requested one tile ahead of its MFMA chain (raw: the widening of a bfloat16 happens beside the
+// MFMAs, not in front of them).
 template <int SHAPE, typename ET>
 __device__ __forceinline__ void wide_grads(const ET *tile, float (&G)[wide_tiles_per_wave<SHAPE>()][5]) {
   constexpr int KCH = BORE_BATCH_MAX / 4, TOTAL = wide_total_tiles<SHAPE>();
   constexpr int TPW = wide_tiles_per_wave<SHAPE>(), STEP = BORE_THREADS / 64;
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, m16 = lane & 15, q4 = lane >> 4;
+  auto widen = [](ET raw) -> float {
+    if constexpr (sizeof(ET) == 2) return bf16_to_f32(raw);
+    else return raw;
+  };
+  ET av[2][KCH], bv[2][KCH];
+  {
+    const WideTile w0 = wide_tile<SHAPE>(wv < TOTAL ? wv : 0);
+    const ET *ap = tile + w0.aoff + q4 * w0.lda_p + w0.kb * 16 + m16;
+    const ET *bp = tile + w0.doff + q4 * w0.ldd + w0.cb * 16 + m16;
+#pragma unroll
+    for (int kc = 0; kc < KCH; ++kc) {
+      av[0][kc] = ap[kc * 4 * w0.lda_p];
+      bv[0][kc] = bp[kc * 4 * w0.ldd];
+    }
+  }
 #pragma unroll
   for (int i = 0; i < TPW; ++i) {
     const int t = wv + STEP * i;
@@ -433,17 +452,14 @@ __device__ __forceinline__ void wide_grads(const ET *tile, float (&G)[wide_tiles
     for (int q = 0; q < 5; ++q) G[i][q] = 0.f;
     if (TOTAL % STEP != 0 && t >= TOTAL) continue;
     const WideTile cur = wide_tile<SHAPE>(t);
-    const ET *ap = tile + cur.aoff + q4 * cur.lda_p + cur.kb * 16 + m16;
-    const ET *bp = tile + cur.doff + q4 * cur.ldd + cur.cb * 16 + m16;
-    float av[KCH], bv[KCH];
+    if (i + 1 < TPW) {  // the next tile's operands (clamped: a wave past the end re-reads its last)
+      const WideTile nx = wide_tile<SHAPE>(t + STEP < TOTAL ? t + STEP : t);
+      const ET *ap = tile + nx.aoff + q4 * nx.lda_p + nx.kb * 16 + m16;
+      const ET *bp = tile + nx.doff + q4 * nx.ldd + nx.cb * 16 + m16;
 #pragma unroll
-    for (int kc = 0; kc < KCH; ++kc) {
-      if constexpr (sizeof(ET) == 2) {
-        av[kc] = bf16_to_f32(ap[kc * 4 * cur.lda_p]);
-        bv[kc] = bf16_to_f32(bp[kc * 4 * cur.ldd]);
-      } else {
-        av[kc] = ap[kc * 4 * cur.lda_p];
-        bv[kc] = bp[kc * 4 * cur.ldd];
+      for (int kc = 0; kc < KCH; ++kc) {
+        av[(i + 1) & 1][kc] = ap[kc * 4 * nx.lda_p];
+        bv[(i + 1) & 1][kc] = bp[kc * 4 * nx.ldd];
       }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -451,9 +467,10 @@ __device__ __forceinline__ void wide_grads(const ET *tile, float (&G)[wide_tiles
     float bsum = 0.f;
 #pragma unroll
     for (int kc = 0; kc < KCH; ++kc) {
-      const float x = cur.transposed ? bv[kc] : av[kc], y = cur.transposed ? av[kc] : bv[kc];
+      const float a = widen(av[i & 1][kc]), b = widen(bv[i & 1][kc]);
+      const float x = cur.transposed ? b : a, y = cur.transposed ? a : b;
       acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x, y, acc, 0, 0, 0);
-      bsum += bv[kc];
+      bsum += b;
     }
     G[i][0] = acc[0]; G[i][1] = acc[1]; G[i][2] = acc[2]; G[i][3] = acc[3];
     if (cur.want_bias) {
@@ -461,6 +478,7 @@ __device__ __forceinline__ void wide_grads(const ET *tile, float (&G)[wide_tiles
       if (cur.transposed) G[i][0] = lane == 16 ? gb : G[i][0];
       else G[i][4] = gb;
     }
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
@@ -478,81 +496,68 @@ __device__ __forceinline__ void wide_scatter(const float (&G)[wide_tiles_per_wav
 #pragma unroll
     for (int q = 0; q < 5; ++q)
       if (cur.ok[q]) gl[cur.gi[q]] = G[i][q];
+    // (tile by tile: hoisted, the index arithmetic of all tiles is live at once -- 22 x 10 registers)
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
-// Phase C, float32 fit: theta is the padded LDS image, m / v are packed in HBM.
-template <int SHAPE>
-__device__ __forceinline__ void wide_adam_f32(float *th, const float *gl, float *m_g, float *v_g,
-                                              float alpha, float omb1, float omb2, float eps) {
+// Phase C: all threads walk the packed parameter vector in batches of U elements per thread.  The
+// NEXT batch's loads are issued before this batch's arithmetic and stores: gfx950 counts loads and
+// stores on one counter (vmcnt), so a load issued after a store cannot be waited for without
+// waiting for the store's round trip as well -- batch by batch that was two memory latencies per U
+// elements (64 k of the 163 k cycles of a 32->128-128-1 step, profiles/r2 wide_stamps).
+// MASTER: float32 master weights packed in HBM beside m / v, LDS image bfloat16 (mixed precision);
+// otherwise theta is the float32 LDS image.
+template <int SHAPE, bool MASTER>
+__device__ __forceinline__ void wide_adam(void *th_lds, const float *gl, float *theta_g, float *m_g,
+                                          float *v_g, float alpha, float omb1, float omb2, float eps) {
   constexpr MlpLayout L = bore_static_layout(SHAPE, 1, BORE_BATCH_MAX);
-  constexpr int U = 10;
-  for (int p0 = threadIdx.x; p0 < L.P; p0 += BORE_THREADS * U) {
-    float g[U], mm[U], vv[U], w[U];
-    int li[U];
+  constexpr int U = 8, STRIDE = BORE_THREADS * U;
+  constexpr int NB = (L.P + STRIDE - 1) / STRIDE;
+  float *th = reinterpret_cast<float *>(th_lds);
+  unsigned short *th16 = reinterpret_cast<unsigned short *>(th_lds);
+  float g[2][U], mm[2][U], vv[2][U], w[2][U];
+  int li[2][U];
+  auto request = [&](int b, int buf) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int p = p0 + BORE_THREADS * u;
+      const int p = b * STRIDE + BORE_THREADS * u + (int)threadIdx.x;
       const bool ok = p < L.P;
-      li[u] = param_ref(L, ok ? p : 0, L.n_layers).lds;
-      mm[u] = ok ? m_g[p] : 0.f;
-      vv[u] = ok ? v_g[p] : 0.f;
-      g[u] = ok ? gl[p] : 0.f;
-      w[u] = th[li[u]];
+      li[buf][u] = param_ref(L, ok ? p : 0, L.n_layers).lds;
+      mm[buf][u] = ok ? m_g[p] : 0.f;
+      vv[buf][u] = ok ? v_g[p] : 0.f;
+      g[buf][u] = ok ? gl[p] : 0.f;
+      if constexpr (MASTER) w[buf][u] = ok ? theta_g[p] : 0.f;
+      else w[buf][u] = th[li[buf][u]];
     }
+  };
+  request(0, 0);
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    const int cur = b & 1;
+    if (b + 1 < NB) request(b + 1, cur ^ 1);
     __builtin_amdgcn_sched_barrier(0);
     float wn[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) wn[u] = adam_update(w[u], g[u], mm[u], vv[u], alpha, omb1, omb2, eps);
+    for (int u = 0; u < U; ++u)
+      wn[u] = adam_update(w[cur][u], g[cur][u], mm[cur][u], vv[cur][u], alpha, omb1, omb2, eps);
 #pragma unroll
-    for (int u = 0; u < U; ++u) asm volatile("" : "+v"(wn[u]), "+v"(mm[u]), "+v"(vv[u]));
+    for (int u = 0; u < U; ++u) asm volatile("" : "+v"(wn[u]), "+v"(mm[cur][u]), "+v"(vv[cur][u]));
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int p = p0 + BORE_THREADS * u;
+      const int p = b * STRIDE + BORE_THREADS * u + (int)threadIdx.x;
       if (p < L.P) {
-        th[li[u]] = wn[u];
-        m_g[p] = mm[u];
-        v_g[p] = vv[u];
+        if constexpr (MASTER) {
+          th16[li[cur][u]] = f32_to_bf16(wn[u]);
+          theta_g[p] = wn[u];
+        } else {
+          th[li[cur][u]] = wn[u];
+        }
+        m_g[p] = mm[cur][u];
+        v_g[p] = vv[cur][u];
       }
-    }
-  }
-}
-
-// Phase C, mixed-precision fit: float32 master weights, m, v packed in HBM; the LDS image of
-// theta holds their bfloat16 rounding.
-template <int SHAPE>
-__device__ __forceinline__ void wide_adam_bf16(unsigned short *th16, const float *gl, float *theta_g,
-                                               float *m_g, float *v_g, float alpha, float omb1,
-                                               float omb2, float eps) {
-  constexpr MlpLayout L = bore_static_layout(SHAPE, 1, BORE_BATCH_MAX);
-  constexpr int U = 8;
-  for (int p0 = threadIdx.x; p0 < L.P; p0 += BORE_THREADS * U) {
-    float g[U], mm[U], vv[U], w[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int p = p0 + BORE_THREADS * u;
-      const bool ok = p < L.P;
-      w[u] = ok ? theta_g[p] : 0.f;
-      mm[u] = ok ? m_g[p] : 0.f;
-      vv[u] = ok ? v_g[p] : 0.f;
-      g[u] = ok ? gl[p] : 0.f;
     }
     __builtin_amdgcn_sched_barrier(0);
-    float wn[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) wn[u] = adam_update(w[u], g[u], mm[u], vv[u], alpha, omb1, omb2, eps);
-#pragma unroll
-    for (int u = 0; u < U; ++u) asm volatile("" : "+v"(wn[u]), "+v"(mm[u]), "+v"(vv[u]));
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int p = p0 + BORE_THREADS * u;
-      if (p < L.P) {
-        th16[param_ref(L, p, L.n_layers).lds] = f32_to_bf16(wn[u]);
-        theta_g[p] = wn[u];
-        m_g[p] = mm[u];
-        v_g[p] = vv[u];
-      }
-    }
   }
 }
 
@@ -780,7 +785,7 @@ __device__ __forceinline__ void fit_body(const FitArgs &a, const long long slot,
           __syncthreads();
           wide_scatter<SHAPE>(G, tile);
           __syncthreads();
-          wide_adam_f32<SHAPE>(th, tile, m_g, v_g, alpha, omb1, omb2, a.eps);
+          wide_adam<SHAPE, false>(th, tile, nullptr, m_g, v_g, alpha, omb1, omb2, a.eps);
         }
       } else if constexpr (SHAPE > 0) {
         switch ((nb + 15) >> 4) {
@@ -1167,7 +1172,7 @@ __global__ __launch_bounds__(BORE_THREADS) void fit_bf16_kernel(const FitBf16Arg
         wide_scatter<SHAPE>(G, gl);
         __syncthreads();
         BORE_WSTAMP(7);
-        wide_adam_bf16<SHAPE>(th16, gl, theta_g, m_g, v_g, alpha, omb1, omb2, a.eps);
+        wide_adam<SHAPE, true>(th16, gl, theta_g, m_g, v_g, alpha, omb1, omb2, a.eps);
         BORE_WSTAMP(8);
         __syncthreads();
         BORE_WSTAMP(9);
@@ -1182,6 +1187,305 @@ __global__ __launch_bounds__(BORE_THREADS) void fit_bf16_kernel(const FitBf16Arg
         if (lane == 0) misc[5] = an;
       }
       __syncthreads();
+    }
+    if (a.epoch_loss) {
+      eloss = wave_sum(eloss);
+      if (lane == 0) misc[1 + wv] = eloss;
+      __syncthreads();
+      if (tid == 0)
+        a.epoch_loss[model * a.epochs + e] = (misc[1] + misc[2] + misc[3] + misc[4]) / (float)N;
+    }
+  }
+  if (tid == 0) a.at[model] = t0 + (long long)a.epochs * steps;
+}
+
+// The mixed-precision fit on the bf16 matrix cores (fit_bf16_mfma.h has the design).
+template <int SHAPE>
+__global__ __launch_bounds__(BORE_THREADS) void fit_bf16_mfma_kernel(const FitBf16Args a) {
+  extern __shared__ float smem[];
+  using Pl = Bf16Plan<SHAPE>;
+  using Net = Bf16Net<SHAPE>;
+  constexpr MlpLayout L = Pl::L;
+  constexpr int P = L.P, n = Pl::n, D = L.w[0], RS = Pl::RS;
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int wv = tid >> 6, lane = tid & 63, m16 = lane & 15, q4 = lane >> 4;
+  const long long model = blockIdx.x;
+  const int N = a.N;
+  for (int i = tid; i < (a.total >> 2); i += nthr) smem[i] = 0.f;
+  __syncthreads();
+  char *base = reinterpret_cast<char *>(smem);
+  unsigned short *wf = reinterpret_cast<unsigned short *>(base + Pl::o_wf);
+  unsigned short *wb = reinterpret_cast<unsigned short *>(base + Pl::o_wb);
+  float *bias = reinterpret_cast<float *>(base + Pl::o_bias);
+  unsigned short *img = reinterpret_cast<unsigned short *>(base + Pl::o_img);
+  float *gl = reinterpret_cast<float *>(base + Pl::o_img);  // gradient image of one layer group
+  float *misc = reinterpret_cast<float *>(base + a.o_misc);
+  int *perm_all = reinterpret_cast<int *>(base + a.o_perm);
+  int *perm_s = perm_all;
+  unsigned *keys = reinterpret_cast<unsigned *>(base + a.o_keys);
+  const int PG = a.perm ? 1 : perm_group(N, BORE_THREADS);
+
+  float *theta_g = a.theta + model * P;
+  float *m_g = a.am + model * P;
+  float *v_g = a.av + model * P;
+  const float *X_g = a.X + model * (long long)N * D;
+  const float *z_g = a.z + model * (long long)N;
+  for (int p = tid; p < P; p += nthr) bf16_put<SHAPE>(wf, wb, bias, p, theta_g[p]);
+
+  const long long t0 = a.at[model];
+  double b1p = pow((double)a.beta1, (double)t0);
+  double b2p = pow((double)a.beta2, (double)t0);
+  const float omb1 = 1.f - a.beta1, omb2 = 1.f - a.beta2;
+  const int steps = (N + a.B - 1) / a.B;
+  b1p *= (double)a.beta1;
+  b2p *= (double)a.beta2;
+  const float alpha_first = a.lr * sqrtf(1.f - (float)b2p) / (1.f - (float)b1p);
+  bool first_step = true;
+  __syncthreads();
+
+  for (int e = 0; e < a.epochs; ++e) {
+    if (a.perm) {
+      const int *pg = a.perm + (model * a.epochs + e) * (long long)N;
+      for (int i = tid; i < N; i += nthr) perm_s[i] = pg[i];
+      __syncthreads();
+    } else if (PG > 1) {
+      const int eg = e & (PG - 1);
+      if (eg == 0)
+        make_perm_group(a.seed, a.model0 + model, a.epoch0 + e, min(PG, a.epochs - e), N, keys,
+                        perm_all);
+      perm_s = perm_all + eg * N;
+    } else {
+      make_perm(shuffle_base(a.seed, a.model0 + model, a.epoch0 + e), N, keys, perm_s);
+    }
+    float eloss = 0.f;
+    for (int s = 0; s < steps; ++s) {
+      const int row0 = s * a.B;
+      const int nb = min(a.B, N - row0);
+      const float alpha = first_step ? alpha_first : misc[5];
+      first_step = false;
+      BORE_WSTAMP_DECL;
+      // (index arithmetic below must not be hoisted out of the step loop as tables: see wide_adam)
+      int tid_o = tid;
+      asm volatile("" : "+v"(tid_o));
+      {  // every wave runs its 16 rows; rows past the batch are dead (x = 0, delta = 0)
+        Net net;
+        net.set_acts(a.L);
+        const int row = wv * 16 + m16;
+        const bool live = row < nb;
+        const int src = live ? perm_s[row0 + row] : 0;
+        // the input rows as the B fragments of layer 1 (k-slot (q, i) = column 32c + 16(i>>2) + 4q + (i&3)),
+        // and, transposed, into the image of A_0 for the weight gradients
+        bf16x8_t xfrag[Pl::CF(1)];
+#pragma unroll
+        for (int c = 0; c < Pl::CF(1); ++c) {
+          float lo[4] = {0.f, 0.f, 0.f, 0.f}, hi[4] = {0.f, 0.f, 0.f, 0.f};
+          const int c_lo = 32 * c + 4 * q4, c_hi = c_lo + 16;
+          if (live && c_lo < D) {
+            const float4 v = *reinterpret_cast<const float4 *>(X_g + (long long)src * D + c_lo);
+            lo[0] = bf16_round_hw(v.x); lo[1] = bf16_round_hw(v.y); lo[2] = bf16_round_hw(v.z); lo[3] = bf16_round_hw(v.w);
+          }
+          if (live && c_hi < D) {
+            const float4 v = *reinterpret_cast<const float4 *>(X_g + (long long)src * D + c_hi);
+            hi[0] = bf16_round_hw(v.x); hi[1] = bf16_round_hw(v.y); hi[2] = bf16_round_hw(v.z); hi[3] = bf16_round_hw(v.w);
+          }
+          xfrag[c] = pack_frag(lo, hi);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            if (c_lo < L.Np[0]) img[Pl::at_off(0) + Pl::t_index(c_lo + i, row)] = (unsigned short)(__float_as_uint(lo[i]) >> 16);
+            if (c_hi < L.Np[0]) img[Pl::at_off(0) + Pl::t_index(c_hi + i, row)] = (unsigned short)(__float_as_uint(hi[i]) >> 16);
+          }
+        }
+        float zz = 0.f;
+        if (q4 == 0 && live) zz = z_g[src];
+        BORE_WSTAMP(0);
+        net.forward(wf, bias, xfrag);
+        BORE_WSTAMP(1);
+        float delta = 0.f;
+        if (lane < 16 && live) {
+          const float x = net.h[n][0][0];
+          const float ex = expf(-fabsf(x));
+          const float den = 1.f + ex;
+          const float sig = x >= 0.f ? 1.f / den : ex / den;
+          if (a.epoch_loss) eloss += fmaxf(x, 0.f) - x * zz + log1pf(ex);
+          delta = bf16_round_hw((sig - zz) / (float)nb);
+        }
+#pragma unroll
+        for (int t = 0; t < Net::TM; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) net.d[n][t][r] = 0.f;
+        net.d[n][0][0] = lane < 16 ? delta : 0.f;
+        BORE_WSTAMP(2);
+        net.backward(wb, bias);
+        BORE_WSTAMP(3);
+        net.store_images(img, row);
+        BORE_WSTAMP(4);
+      }
+      __syncthreads();
+      BORE_WSTAMP(5);
+      {
+        // ---- weight gradients + Adam, tile by tile: this wave's tiles t = wave, wave + 4, ...  A tile
+        // is two MFMAs (k = the 64 batch rows) and leaves lane (q, m) holding dW_l[16kb + 4q + r][16cb + m],
+        // r = 0..3 -- four elements a whole row of W_l apart in the packed vector.  The four lanes of a
+        // quad transpose their 4 x 4 block (two DPP exchanges), after which lane a = m & 3 owns
+        // dW_l[16kb + 4q + a][16cb + (m & ~3) + 0..3]: CONTIGUOUS, so the master weight / m / v of a
+        // tile are one 16-byte load and store each per lane -- the CU's one vector-memory pipe, at
+        // 30 dword instructions per tile and wave, was what bounded this phase (62 k cycles a step).
+        // They are requested TWO tiles ahead of use and ahead of the stores in between (loads and
+        // stores share one counter); the new weights go to HBM and, rounded, into the LDS images. ----
+        constexpr int TPW = Pl::tiles_per_wave(), TOTAL = Pl::total_tiles(), AHEAD = 3;
+        typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+        // (lane coordinates re-derived from an opaque copy of the thread id: computed from the
+        // loop-invariant ones, the slot indices of all tiles are hoisted out of the step loop and
+        // kept live across it -- 22 tiles x 10 registers, most of them spilled)
+        const int wv = __builtin_amdgcn_readfirstlane(tid_o >> 6), lane = tid_o & 63, m16 = lane & 15, q4 = lane >> 4;
+        const int qa = lane & 3, m4 = m16 & ~3;
+        f4u pw[AHEAD + 1], pm[AHEAD + 1], pv[AHEAD + 1];
+        float bw[AHEAD + 1], bm[AHEAD + 1], bv[AHEAD + 1];
+        static_assert(Pl::layers_aligned() && TOTAL % 4 == 0, "tiles of a layer must start at a multiple of 4");
+        // this lane's slots of tile t = wave + 4 I (layer l known at compile time): kb / cb = the
+        // tile's block row / column, p4 = packed index of the lane's four contiguous weights, pb = of
+        // its bias
+        auto slots = [&](auto ic, int &kb, int &cb, int &p4, bool &ok4, int &pb, bool &okb) {
+          constexpr int I = decltype(ic)::value, l = Pl::layer_of_tile(4 * I);
+          constexpr int K = L.w[l - 1], Nw = L.w[l], ncb = Pl::T(l);
+          const int r = wv + 4 * I - Pl::tiles_before(l);
+          kb = r / ncb;
+          cb = r - kb * ncb;
+          if constexpr (Nw == 1) {  // one column: the C layout's four rows ARE contiguous (lanes m = 0)
+            p4 = L.goff_w[l] + 16 * kb + 4 * q4;
+            ok4 = m16 == 0 && 16 * kb + 4 * q4 < K;
+          } else {
+            p4 = L.goff_w[l] + (16 * kb + 4 * q4 + qa) * Nw + 16 * cb + m4;
+            ok4 = 16 * kb + 4 * q4 + qa < K && 16 * cb + m4 < Nw;
+          }
+          okb = kb == 0 && q4 == 0 && 16 * cb + m16 < Nw;
+          pb = L.goff_b[l] + 16 * cb + m16;
+        };
+        auto request = [&](auto ic) {
+          constexpr int I = decltype(ic)::value;
+          int kb, cb, p4, pb;
+          bool ok4, okb;
+          slots(ic, kb, cb, p4, ok4, pb, okb);
+          const f4u z4 = {0.f, 0.f, 0.f, 0.f};
+          pw[I % (AHEAD + 1)] = ok4 ? *reinterpret_cast<const f4u *>(theta_g + p4) : z4;
+          pm[I % (AHEAD + 1)] = ok4 ? *reinterpret_cast<const f4u *>(m_g + p4) : z4;
+          pv[I % (AHEAD + 1)] = ok4 ? *reinterpret_cast<const f4u *>(v_g + p4) : z4;
+          if (kb == 0) {  // (wave-uniform: only these tiles carry a bias)
+            bw[I % (AHEAD + 1)] = okb ? theta_g[pb] : 0.f;
+            bm[I % (AHEAD + 1)] = okb ? m_g[pb] : 0.f;
+            bv[I % (AHEAD + 1)] = okb ? v_g[pb] : 0.f;
+          }
+        };
+        static_for<0, (AHEAD < TPW ? AHEAD : TPW)>([&](auto ic) { request(ic); });
+        static_for<0, TPW>([&](auto ic) {
+          constexpr int I = decltype(ic)::value, l = Pl::layer_of_tile(4 * I);
+          constexpr int Nw = L.w[l];
+          if constexpr (I + AHEAD < TPW) request(std::integral_constant<int, I + AHEAD>{});
+          int kb, cb, p4, pb;
+          bool ok4, okb;
+          slots(ic, kb, cb, p4, ok4, pb, okb);
+          // rows 32c + 8 q4 .. + 7 of unit row 16 kb|cb + m16: chunk 4c + q4, swizzled (Bf16Plan::t_index)
+          const int ua = 16 * kb + m16, ub = 16 * cb + m16;
+          const unsigned short *ap = img + Pl::at_off(l - 1) + ua * RS, *bp = img + Pl::dt_off(l) + ub * RS;
+          const int sa = (ua >> 1) & 7, sb = (ub >> 1) & 7;
+          const u32x4_t a0 = *reinterpret_cast<const u32x4_t *>(ap + ((q4 ^ sa) << 3)),
+                        a1 = *reinterpret_cast<const u32x4_t *>(ap + (((4 + q4) ^ sa) << 3));
+          const u32x4_t b0 = *reinterpret_cast<const u32x4_t *>(bp + ((q4 ^ sb) << 3)),
+                        b1 = *reinterpret_cast<const u32x4_t *>(bp + (((4 + q4) ^ sb) << 3));
+          __builtin_amdgcn_sched_barrier(0);
+          f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a0), __builtin_bit_cast(bf16x8_t, b0), acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a1), __builtin_bit_cast(bf16x8_t, b1), acc, 0, 0, 0);
+          float g[4] = {acc[0], acc[1], acc[2], acc[3]};
+          if constexpr (Nw != 1) {  // 4 x 4 transpose inside the lane quad: g[jj] <- lane jj's g[qa]
+            float x = (qa & 1) ? g[0] : g[1], y = (qa & 1) ? g[2] : g[3];
+            x = __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(x), 0xB1, 0xF, 0xF, true));
+            y = __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(y), 0xB1, 0xF, 0xF, true));
+            if (qa & 1) { g[0] = x; g[2] = y; } else { g[1] = x; g[3] = y; }
+            x = (qa & 2) ? g[0] : g[2];
+            y = (qa & 2) ? g[1] : g[3];
+            x = __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(x), 0x4E, 0xF, 0xF, true));
+            y = __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(y), 0x4E, 0xF, 0xF, true));
+            if (qa & 2) { g[0] = x; g[1] = y; } else { g[2] = x; g[3] = y; }
+          }
+          // Adam (ResourceApplyAdam form; v_sqrt_f32 / v_rcp_f32, 1 ulp: the new weight is rounded to
+          // bfloat16 for the next step anyway and the master copy carries 24 bits either way)
+          constexpr int cur = I % (AHEAD + 1);
+          float wn[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float mm = pm[cur][r], vv = pv[cur][r];
+            mm += (g[r] - mm) * omb1;
+            vv += (g[r] * g[r] - vv) * omb2;
+            wn[r] = pw[cur][r] - (mm * alpha) * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(vv) + a.eps);
+            pm[cur][r] = mm;
+            pv[cur][r] = vv;
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) asm volatile("" : "+v"(wn[r]));
+          if (ok4) {
+            const f4u w4 = {wn[0], wn[1], wn[2], wn[3]};
+            *reinterpret_cast<f4u *>(theta_g + p4) = w4;
+            *reinterpret_cast<f4u *>(m_g + p4) = pm[cur];
+            *reinterpret_cast<f4u *>(v_g + p4) = pv[cur];
+          }
+          // the LDS images (fragment orders: fit_bf16_mfma.h) and the float copies
+          if (ok4) {
+            uint2 h4;
+            h4.x = pack2_bf16(wn[0], wn[1]);
+            h4.y = pack2_bf16(wn[2], wn[3]);
+            const unsigned short hs[4] = {(unsigned short)h4.x, (unsigned short)(h4.x >> 16),
+                                          (unsigned short)h4.y, (unsigned short)(h4.y >> 16)};
+            if constexpr (l == n) {  // (k = 16kb + 4q + r, column 0): consecutive k-slots of one forward fragment
+              *reinterpret_cast<uint2 *>(wf + Pl::wf_off(l) + ((kb >> 1) * 64 + q4 * 16) * 8 + (kb & 1) * 4) = h4;
+              float4 f4;
+              f4.x = bf16_to_f32(hs[0]); f4.y = bf16_to_f32(hs[1]); f4.z = bf16_to_f32(hs[2]); f4.w = bf16_to_f32(hs[3]);
+              *reinterpret_cast<float4 *>(bias + Pl::wlast_off() + 16 * kb + 4 * q4) = f4;
+            } else {  // (k = 16kb + 4q + qa, columns 16cb + m4 + jj)
+#pragma unroll
+              for (int jj = 0; jj < 4; ++jj)
+                wf[Pl::wf_off(l) + ((cb * Pl::CF(l) + (kb >> 1)) * 64 + q4 * 16 + m4 + jj) * 8 + (kb & 1) * 4 + qa] = hs[jj];
+              if constexpr (l >= 2)
+                *reinterpret_cast<uint2 *>(wb + Pl::wb_off(l) + ((kb * Pl::CB(l) + (cb >> 1)) * 64 + (m16 >> 2) * 16 + 4 * q4 + qa) * 8 + (cb & 1) * 4) = h4;
+            }
+          }
+          if (kb == 0) {  // bias: gradient = the sums of D_l's columns = of this lane's 16 rows, then of the 4 lane rows
+            float bs = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+              bs += __uint_as_float(b0[w] << 16);
+              bs += __uint_as_float(b0[w] & 0xffff0000u);
+            }
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+              bs += __uint_as_float(b1[w] << 16);
+              bs += __uint_as_float(b1[w] & 0xffff0000u);
+            }
+            const float gb = rows_sum4(bs);
+            float mm = bm[cur], vv = bv[cur];
+            mm += (gb - mm) * omb1;
+            vv += (gb * gb - vv) * omb2;
+            const float wnb = bw[cur] - (mm * alpha) * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(vv) + a.eps);
+            if (okb) {
+              theta_g[pb] = wnb;
+              m_g[pb] = mm;
+              v_g[pb] = vv;
+              bias[Pl::bias_off(l) + 16 * cb + m16] = bf16_round_hw(wnb);
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        });
+        BORE_WSTAMP(6);
+        BORE_WSTAMP(8);
+      }
+      if (wv == (BORE_THREADS / 64) - 1) {
+        b1p *= (double)a.beta1;
+        b2p *= (double)a.beta2;
+        const float an = a.lr * sqrtf(1.f - (float)b2p) / (1.f - (float)b1p);
+        if (lane == 0) misc[5] = an;
+      }
+      __syncthreads();
+      BORE_WSTAMP(9);
     }
     if (a.epoch_loss) {
       eloss = wave_sum(eloss);
@@ -1529,12 +1833,27 @@ static int fit_bf16_impl(const bore_mlp_desc *desc, int n_models, float *theta, 
   a.seed = seed; a.model0 = model_index0; a.epoch0 = epoch0;
   a.N = (int)N; a.epochs = epochs; a.B = batch_size;
   a.lr = adam->lr; a.beta1 = adam->beta1; a.beta2 = adam->beta2; a.eps = adam->eps;
-  // LDS carve (bytes): theta bf16 | A/D copies bf16 | misc | perm | keys
-  size_t off = 2 * (size_t)a.L.P_lds;
-  off = (off + 15) & ~(size_t)15;
-  // (the weight-gradient phase parks the packed fp32 gradient image over the A / D copies)
-  a.o_tile = (int)off;
-  off += 2 * (size_t)a.L.tile_floats > 4 * (size_t)a.L.P ? 2 * (size_t)a.L.tile_floats : 4 * (size_t)a.L.P;
+  // The bf16-MFMA kernel keeps two fragment-order weight images in LDS; with a long shuffle
+  // (perm + keys grow with N) it no longer fits beside them and the fp32-MFMA form takes over.
+  const int PGn = perm ? 1 : perm_group(N, BORE_THREADS);
+  const size_t perm_bytes = 4 * (size_t)PGn * N + (perm ? 0 : 4 * (size_t)perm_group_scratch_floats(N, PGn)) + 96;
+  const size_t new_bytes = (shape == 3 ? Bf16Plan<3>::o_end : Bf16Plan<4>::o_end) + perm_bytes;
+  const bool old_form = (getenv("BORE_BF16_FP32MFMA") && atoi(getenv("BORE_BF16_FP32MFMA"))) ||
+                        new_bytes > BORE_LDS_BYTES;
+  // LDS carve (bytes).  bf16-MFMA form: weight images | biases | A^T / D^T images (= gradient
+  // image) | misc | perm | keys;  fp32-MFMA form: theta bf16 | A/D copies bf16 | misc | perm | keys
+  size_t off;
+  if (old_form) {
+    off = 2 * (size_t)a.L.P_lds;
+    off = (off + 15) & ~(size_t)15;
+    // (the weight-gradient phase parks the packed fp32 gradient image over the A / D copies)
+    a.o_tile = (int)off;
+    off += 2 * (size_t)a.L.tile_floats > 4 * (size_t)a.L.P ? 2 * (size_t)a.L.tile_floats : 4 * (size_t)a.L.P;
+  } else {
+    a.o_tile = 0;
+    off = shape == 3 ? Bf16Plan<3>::o_end : Bf16Plan<4>::o_end;
+    static_assert(Bf16Plan<3>::fits() && Bf16Plan<4>::fits(), "a layer's gradients must fit the image region");
+  }
   off = (off + 15) & ~(size_t)15;
   a.o_misc = (int)off; off += 8 * 4;
   const int PG = perm ? 1 : perm_group(N, BORE_THREADS);
@@ -1544,20 +1863,23 @@ static int fit_bf16_impl(const bore_mlp_desc *desc, int n_models, float *theta, 
   off = (off + 15) & ~(size_t)15;
   a.total = (int)off;
   if (off > BORE_LDS_BYTES)
-    return fail(BORE_E_UNSUPPORTED, "fit_bf16: theta+tile+perm need %zu B of LDS (> %d)", off,
+    return fail(BORE_E_UNSUPPORTED, "fit_bf16: weights+images+perm need %zu B of LDS (> %d)", off,
                 BORE_LDS_BYTES);
   int rc = 0;
-  if (shape == 3) {
-    rc = allow_lds(fit_bf16_kernel<3>, off);
-    if (rc) return rc;
-    hipLaunchKernelGGL(fit_bf16_kernel<3>, dim3(n_models), dim3(BORE_THREADS), off,
-                       (hipStream_t)stream, a);
-  } else {
-    rc = allow_lds(fit_bf16_kernel<4>, off);
-    if (rc) return rc;
-    hipLaunchKernelGGL(fit_bf16_kernel<4>, dim3(n_models), dim3(BORE_THREADS), off,
-                       (hipStream_t)stream, a);
+#define BORE_LAUNCH_BF16(KERNEL)                                                             \
+  {                                                                                          \
+    rc = allow_lds(KERNEL, off);                                                             \
+    if (rc) return rc;                                                                       \
+    hipLaunchKernelGGL(KERNEL, dim3(n_models), dim3(BORE_THREADS), off, (hipStream_t)stream, a); \
   }
+  if (old_form) {
+    if (shape == 3) BORE_LAUNCH_BF16(fit_bf16_kernel<3>)
+    else BORE_LAUNCH_BF16(fit_bf16_kernel<4>)
+  } else {
+    if (shape == 3) BORE_LAUNCH_BF16(fit_bf16_mfma_kernel<3>)
+    else BORE_LAUNCH_BF16(fit_bf16_mfma_kernel<4>)
+  }
+#undef BORE_LAUNCH_BF16
   HIP_TRY(hipGetLastError());
   return 0;
 }

@@ -67,6 +67,12 @@ struct RegNet {
     if constexpr (BF16) return bf16_round(x);
     else return x;
   }
+  // an LDS element as loaded (raw) and as an MFMA operand: the widening shift of a bfloat16 is
+  // kept out of the load phase, where it would wait for the load to return
+  static __device__ __forceinline__ float cvt(WT raw) {
+    if constexpr (BF16) return bf16_to_f32(raw);
+    else return raw;
+  }
   static constexpr MlpLayout L = bore_static_layout(SHAPE, DELTAS, BORE_BATCH_MAX);
   static constexpr int n = L.n_layers;
   static constexpr int max_tiles() {
@@ -231,6 +237,20 @@ struct RegNet {
       make_bop<L.w[l - 1]>(h[l - 1], bop);
     }
     const int a = (keep_logits && l == n) ? BORE_ACT_LINEAR : act_of<l>();
+    // Wide nets fetch one output tile's operands at a time -- W_l[4kc + q][16t + m],
+    // b_l[16t + 4q + r] -- and ONE TILE AHEAD of the MFMA chain that uses them: left to the
+    // scheduler (at its register limit in these kernels) each ds_read sat directly in front of
+    // its MFMA with a full s_waitcnt -- an LDS round trip per 32-cycle MFMA, forward and backward
+    // 2.8x their MFMA time (profiles/r2: wide_stamps).
+    WT wraw[PRELOAD ? 1 : 2][PRELOAD ? 1 : kch], braw[PRELOAD ? 1 : 2][4];
+    if constexpr (!PRELOAD) {
+      const WT *wp = th + L.woff[l] + q * ldw + m;
+      const WT *bp = th + L.boff[l] + 4 * q;
+#pragma unroll
+      for (int kc = 0; kc < kch; ++kc) wraw[0][kc] = wp[kc * 4 * ldw];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) braw[0][r] = bp[r];
+    }
 #pragma unroll
     for (int t = 0; t < ftiles(l); ++t) {
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -241,17 +261,22 @@ struct RegNet {
           acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[fofs(l) + t * kch + kc], bop[kc], acc, 0, 0, 0);
 #pragma unroll
         for (int r = 0; r < 4; ++r) bias[r] = bf[biasofs(l) + 4 * t + r];
-      } else {  // this tile's operands: W_l[4kc + q][16t + m], b_l[16t + 4q + r]
-        const WT *wp = th + L.woff[l] + q * ldw + 16 * t + m;
-        const WT *bp = th + L.boff[l] + 16 * t + 4 * q;
-        float wt[kch];
+      } else {
+        if (t + 1 < ftiles(l)) {  // the next tile's operands
+          const WT *wp = th + L.woff[l] + q * ldw + 16 * (t + 1) + m;
+          const WT *bp = th + L.boff[l] + 16 * (t + 1) + 4 * q;
 #pragma unroll
-        for (int kc = 0; kc < kch; ++kc) wt[kc] = ld(wp + kc * 4 * ldw);
+          for (int kc = 0; kc < kch; ++kc) wraw[(t + 1) & 1][kc] = wp[kc * 4 * ldw];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) bias[r] = ld(bp + r);
+          for (int r = 0; r < 4; ++r) braw[(t + 1) & 1][r] = bp[r];
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int kc = 0; kc < kch; ++kc)
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wt[kc], bop[kc], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(cvt(wraw[t & 1][kc]), bop[kc], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bias[r] = cvt(braw[t & 1][r]);
+        __builtin_amdgcn_sched_barrier(0);
       }
       if constexpr (RT_ACT) {  // pre-activations; the activation follows for the whole layer
 #pragma unroll
@@ -282,6 +307,12 @@ struct RegNet {
     float bop[4 * T];
     make_bop<L.w[l]>(d[l], bop);
     const int ap = act_of<(l > 1 ? l - 1 : 1)>();
+    WT wraw[PRELOAD ? 1 : 2][PRELOAD ? 1 : kch];  // W_l[16t + m][4kc + q], one tile ahead (fwd_layer)
+    if constexpr (!PRELOAD) {
+      const WT *wp = th + L.woff[l] + m * ldw + q;
+#pragma unroll
+      for (int kc = 0; kc < kch; ++kc) wraw[0][kc] = wp[kc * 4];
+    }
 #pragma unroll
     for (int t = 0; t < btiles(l); ++t) {
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -289,14 +320,17 @@ struct RegNet {
 #pragma unroll
         for (int kc = 0; kc < kch; ++kc)
           acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[bofs(l) + t * kch + kc], bop[kc], acc, 0, 0, 0);
-      } else {  // W_l[16t + m][4kc + q]
-        const WT *wp = th + L.woff[l] + (16 * t + m) * ldw + q;
-        float wt[kch];
+      } else {
+        if (t + 1 < btiles(l)) {
+          const WT *wp = th + L.woff[l] + (16 * (t + 1) + m) * ldw + q;
 #pragma unroll
-        for (int kc = 0; kc < kch; ++kc) wt[kc] = ld(wp + kc * 4);
+          for (int kc = 0; kc < kch; ++kc) wraw[(t + 1) & 1][kc] = wp[kc * 4];
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int kc = 0; kc < kch; ++kc)
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wt[kc], bop[kc], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(cvt(wraw[t & 1][kc]), bop[kc], acc, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {

@@ -3,11 +3,11 @@ bore_amd/csrc/libbore_hip_dbg.so = the library compiled with -DBORE_WIDE_STAMPS;
 import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ["BORE_LIB_PATH"] = os.path.join(ROOT, "bore_amd", "csrc", "libbore_hip_dbg.so")
+os.environ.setdefault("BORE_LIB_PATH", os.path.join(ROOT, "bore_amd", "csrc", "libbore_hip_dbg.so"))
 import numpy as np, torch
 from bore_amd import _lib, ops
-NAMES = ["gather", "forward", "store_A+loss", "backward", "store_D", "barrier", "grads (MFMA)",
-         "barrier+scatter+barrier", "adam (packed)", "barrier"]
+NAMES = ["gather (+A_0 image)", "forward", "loss + delta", "backward", "store A^T / D^T images", "barrier",
+         "grads (MFMA)", "-", "scatter + packed Adam", "barrier"]
 for name, D, units, compute in [("shape4_bf16", 32, [128, 128, 1], "bfloat16"), ("shape3_bf16", 16, [64, 64, 64, 1], "bfloat16")]:
     rs = np.random.RandomState(7)
     acts = ["relu"] * (len(units) - 1) + ["sigmoid"]
