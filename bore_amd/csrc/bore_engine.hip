@@ -412,20 +412,26 @@ int async_create(bore_engine *e, const double *X0, const double *y0) {
   // sharing a queue serialise -- half the throughput of the non-resident schedule, silently.
   // Probe: one 1 ms spinning single-wave kernel per stream, all at once.
   if (A.workers.size() > 1 && !(getenv("BORE_ASYNC_NO_PROBE") && atoi(getenv("BORE_ASYNC_NO_PROBE")))) {
-    const long long ticks = (long long)(1e6 / A.ns_per_tick);
+    const long long ticks = (long long)(2e6 / A.ns_per_tick);  // 2 ms
     hipLaunchKernelGGL(bore_spin_kernel, dim3(1), dim3(64), 0, A.workers[0].stream, 1000LL);  // (code load)
     HIP_TRY(hipStreamSynchronize(A.workers[0].stream));
-    const double t0 = now_s();
+    double t0 = now_s();
+    hipLaunchKernelGGL(bore_spin_kernel, dim3(1), dim3(64), 0, A.workers[0].stream, ticks);
+    HIP_TRY(hipStreamSynchronize(A.workers[0].stream));
+    const double one = now_s() - t0;  // one probe alone (launch + 2 ms + sync)
+    t0 = now_s();
     for (Worker &w : A.workers) hipLaunchKernelGGL(bore_spin_kernel, dim3(1), dim3(64), 0, w.stream, ticks);
     for (Worker &w : A.workers) HIP_TRY(hipStreamSynchronize(w.stream));
     const double dt = now_s() - t0;
-    int conc = (int)(A.workers.size() * 1e-3 / (dt > 1e-3 ? dt : 1e-3) + 0.5);
+    // all side by side: about `one` plus a launch each; k streams per queue: about k x `one`
+    int conc = (int)A.workers.size();
+    if (dt > 1.5 * one) conc = (int)(A.workers.size() * one / dt + 0.5);
     conc = conc < 1 ? 1 : (conc > (int)A.workers.size() ? (int)A.workers.size() : conc);
     A.stream_concurrency = conc;
     if (conc < (int)A.workers.size())
       fprintf(stderr,
-              "bore_engine: %zu worker streams, but the device ran only %d of them at once (%.2f ms for "
-              "%zu 1-ms probes): streams share hardware queues.  Set GPU_MAX_HW_QUEUES >= %zu in the "
+              "bore_engine: %zu worker streams, but the device ran only about %d of them at once (%.2f ms for "
+              "%zu 2-ms probes): streams share hardware queues.  Set GPU_MAX_HW_QUEUES >= %zu in the "
               "environment BEFORE the first GPU call of the process (it is %s now).\n",
               A.workers.size(), conc, 1e3 * dt, A.workers.size(), A.workers.size() + 2,
               getenv("GPU_MAX_HW_QUEUES") ? getenv("GPU_MAX_HW_QUEUES") : "unset");

@@ -85,11 +85,51 @@ __device__ __attribute__((noinline)) void iteration_once(const IterArgs *__restr
   lbfgsb_body<SHAPE, false, true>(a.b, slot, 0, it);  // (publishes flag[lid] = it + 1)
 }
 
-template <int SHAPE>
+// RESIDENT: the workgroup may go on to later iterations of its loop (a loop around a real call).
+// Otherwise ONE iteration, inlined -- the launch for loops that do not wait on their CU (more loops
+// than the device holds at once, wait_ticks = 0): no call, no callee-saved registers to park in the
+// private segment (24 B of scratch per lane against 792).
+template <int SHAPE, bool RESIDENT>
 __global__ __launch_bounds__(BORE_THREADS, 2) void iteration_kernel(const IterArgs *__restrict__ pa) {
-  __shared__ __attribute__((aligned(16))) int s_go4[4];  // (16 B: the dynamic LDS keeps its alignment)
   const long long slot = blockIdx.x;
   const int it_first = pa->f.its[slot];
+  if constexpr (!RESIDENT) {
+    const IterArgs &a = *pa;
+    const long long lid = a.f.ids[slot], cap = a.f.cap;
+    const int it = it_first;
+    long long *stp = a.stamps ? a.stamps + lid * 4 : nullptr;
+    if (stp && threadIdx.x == 0) stp[0] = wall_clock64();
+    if (it > 0) {  // append (append_kernel's batch branch)
+      const long long row = a.f.n_init + it - 1;
+      for (int d = threadIdx.x; d < a.D; d += blockDim.x) {
+        const double v = a.x_new[slot * a.D + d];
+        a.X_seen[(lid * cap + row) * a.D + d] = v;
+        a.X32[(lid * cap + row) * a.D + d] = (float)v;
+      }
+      if (threadIdx.x == 0) a.y_seen[lid * cap + row] = a.y_new[slot];
+    }
+    __threadfence();
+    __syncthreads();
+    labels_body(a.y_seen, 0, 0.0, a.z, nullptr, a.f.ids, a.f.its, a.f.n_init, cap, a.gamma, slot);
+    if (stp && threadIdx.x == 0) stp[1] = wall_clock64();
+    __threadfence();
+    __syncthreads();
+    fit_body<SHAPE>(a.f, slot);
+    if (stp && threadIdx.x == 0) stp[2] = wall_clock64();
+    __threadfence();
+    __syncthreads();
+    screen_body<SHAPE, false>(a.s, slot);
+    if (stp && threadIdx.x == 0) stp[3] = wall_clock64();
+    __threadfence();
+    __syncthreads();
+    lbfgsb_body<SHAPE, false, true>(a.b, slot, 0);  // (publishes flag[lid] = it + 1)
+    // not the loop's last iteration: leave the next one to a later launch.  (Any wave may say so,
+    // and before the others are done: the host reacts to `parked` only after the flag.)
+    if (a.targets && threadIdx.x == 0 && it + 1 < a.targets[slot])
+      __hip_atomic_store(a.parked + lid, it + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    return;
+  }
+  __shared__ __attribute__((aligned(16))) int s_go4[4];  // (16 B: the dynamic LDS keeps its alignment)
   const int target = pa->targets ? pa->targets[slot] : it_first + 1;
   for (int it = it_first;;) {
     iteration_once<SHAPE>(pa, slot, it, it == it_first);
@@ -173,13 +213,15 @@ static int iteration_launch(const bore_mlp_desc *desc, int n_slots, float *theta
   floats = floats > lb ? floats : lb;
   const size_t labels_floats = 2 * ((size_t)cap + 2);
   floats = floats > labels_floats ? floats : labels_floats;
-  if ((rc = allow_lds(iteration_kernel<1>, floats * 4))) return rc;
+  if ((rc = allow_lds(iteration_kernel<1, true>, floats * 4)) ||
+      (rc = allow_lds(iteration_kernel<1, false>, floats * 4)))
+    return rc;
   if (h->wait_ticks > 0) {  // waiting workgroups hold their slots: only when all of them fit at once
     static thread_local size_t cap_bytes = ~(size_t)0;
     static thread_local int cap_wgs = 0;
     if (cap_bytes != floats * 4) {
       int per_cu = 0, dev = 0, cus = 0;
-      HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, iteration_kernel<1>, BORE_THREADS,
+      HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, iteration_kernel<1, true>, BORE_THREADS,
                                                            floats * 4));
       HIP_TRY(hipGetDevice(&dev));
       HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
@@ -191,8 +233,12 @@ static int iteration_launch(const bore_mlp_desc *desc, int n_slots, float *theta
   // h heads the caller's staging block (arguments | per-slot inputs | index lists): one upload
   HIP_TRY(hipMemcpyAsync(const_cast<IterArgs *>(d_args), h, upload_bytes, hipMemcpyHostToDevice,
                          (hipStream_t)stream));
-  hipLaunchKernelGGL(iteration_kernel<1>, dim3(n_slots), dim3(BORE_THREADS), floats * 4,
-                     (hipStream_t)stream, d_args);
+  if (h->wait_ticks > 0)
+    hipLaunchKernelGGL((iteration_kernel<1, true>), dim3(n_slots), dim3(BORE_THREADS), floats * 4,
+                       (hipStream_t)stream, d_args);
+  else
+    hipLaunchKernelGGL((iteration_kernel<1, false>), dim3(n_slots), dim3(BORE_THREADS), floats * 4,
+                       (hipStream_t)stream, d_args);
   HIP_TRY(hipGetLastError());
   return 0;
 }

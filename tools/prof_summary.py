@@ -1,12 +1,17 @@
 """Condense rocprofv3 output directories into small CSVs (run on the GPU box).
 usage: prof_summary.py <dir> <out_prefix>"""
-import csv, glob, os, sys, collections
+import csv, glob, os, re, sys, collections
 d, outp = sys.argv[1], sys.argv[2]
+KNOWN = ("iteration_kernel", "fit_bf16_mfma_kernel", "fit_bf16_kernel", "fit_kernel", "lbfgsb_kernel",
+         "screen_topk_kernel", "rows_kernel", "candidates_kernel", "labels_kernel", "evaluate_kernel",
+         "shuffle_kernel", "svgd_kernel", "append_kernel", "select_kernel", "bore_spin_kernel")
 def short(n):
-    n = n.split("(")[0]
-    for k in ("fit_kernel","lbfgsb_kernel","screen_topk_kernel","rows_kernel","candidates_kernel","labels_kernel","evaluate_kernel","shuffle_kernel"):
-        if k in n: return k
-    return n[:60]
+    m = re.match(r"(?:void )?([A-Za-z_0-9:]+)(<[^>]*>)?", n)
+    base, targs = (m.group(1), m.group(2) or "") if m else (n, "")
+    for k in KNOWN:
+        if base.endswith(k):
+            return k + targs.replace(" ", "")
+    return n.split("(")[0][:70]
 for f in glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True):
     rows = list(csv.DictReader(open(f)))
     with open(outp + "_kernel_stats.csv", "w") as o:
