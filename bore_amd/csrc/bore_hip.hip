@@ -1695,9 +1695,17 @@ static int fit_build(const bore_mlp_desc *desc, int n_models, float *theta, floa
   // a mini-batch of up to 64 rows is one tile (larger ones: 64-row sub-tiles, fit_body); perm
   // (+ keys) and the batch targets ride along
   const int tile_rows = batch_size < BORE_BATCH_MAX ? batch_size : BORE_BATCH_MAX;
-  int rc = check_common(desc, n_models, 1, tile_rows, false,
-                        BORE_BATCH_MAX + 8 + BORE_LAYOUT_FLOATS + 12 + (size_t)N * (perm ? 1 : 3),
+  const size_t fixed_extra = BORE_BATCH_MAX + 8 + BORE_LAYOUT_FLOATS + 12;
+  int rc = check_common(desc, n_models, 1, tile_rows, false, fixed_extra + (size_t)N * (perm ? 1 : 3),
                         &a.L);
+  if (rc == BORE_E_UNSUPPORTED && !check_common(desc, n_models, 1, tile_rows, false, fixed_extra, &a.L)) {
+    // the network fits, the epoch's shuffle (drawn and ranked in LDS) does not: say how far N goes
+    const size_t avail = BORE_LDS_BYTES / 4 - ((size_t)a.L.P_lds + a.L.tile_floats + fixed_extra);
+    return fail(BORE_E_UNSUPPORTED,
+                "fit: N=%lld rows exceed what one workgroup's LDS holds beside this network (the "
+                "epoch's shuffle lives there): at most %zu rows",
+                (long long)N, avail / (perm ? 1 : 3));
+  }
   if (rc) return rc;
   const MlpLayout &L = a.L;
   if (L.w[L.n_layers] != 1)
