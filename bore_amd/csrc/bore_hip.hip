@@ -561,6 +561,214 @@ __device__ __forceinline__ void wide_adam(void *th_lds, const float *gl, float *
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The float32 fit of a WIDE static shape (16->64-64-64-1), round-2 form.  Same arithmetic as before
+// (v_mfma_f32_16x16x4_f32 chains k-ordered over the batch rows, IEEE Adam): bit-identical results.
+// What changed is how the weight-gradient phase is fed and how its results are used:
+//  * the copies of A_l / D_l that the gradients sum over are stored TRANSPOSED and row-permuted,
+//    img[unit][(row & 3) * 16 + (row >> 2)] with a 68-float pitch: lane (q, m)'s sixteen operands
+//    of a tile -- rows 4 kc + q, kc = 0..15, of unit 16 kb + m -- are then contiguous: four 16-byte
+//    LDS reads per operand instead of sixteen 4-byte ones (the pitch keeps the 16 lanes of a read
+//    on distinct banks);
+//  * the four waves' i-th tiles lie in ONE layer, known at compile time (static_for): no per-tile
+//    layer dispatch;
+//  * the wave that formed a tile updates it: a 4 x 4 transpose inside every lane quad (two DPP
+//    exchanges) makes lane a = m & 3 own dW_l[16kb + 4q + a][16cb + (m & ~3) + 0..3] -- contiguous in
+//    the packed vector, so m and v are ONE 16-byte load and store each per tile and lane, requested
+//    three tiles ahead (and ahead of the stores in between: loads and stores share a counter).
+// ---------------------------------------------------------------------------------------------
+template <int SHAPE>
+struct WideTp {
+  static constexpr MlpLayout L = bore_static_layout(SHAPE, 1, BORE_BATCH_MAX);
+  static constexpr int n = L.n_layers, PITCH = 68;
+  static constexpr int a_off(int l) {  // image of A_l, l = 0..n-1 (float offset inside the tile region)
+    int o = 0;
+    for (int i = 0; i < l; ++i) o += L.Np[i] * PITCH;
+    return o;
+  }
+  static constexpr int d_off(int l) {  // image of D_l, l = 1..n
+    int o = a_off(n);
+    for (int i = 1; i < l; ++i) o += L.Np[i] * PITCH;
+    return o;
+  }
+  static constexpr int total() { return d_off(n + 1); }
+  static __host__ __device__ constexpr int idx(int unit, int row) {
+    return unit * PITCH + (row & 3) * 16 + (row >> 2);
+  }
+  static constexpr int tiles_before(int l) {
+    int t = 0;
+    for (int i = 1; i < l; ++i) t += (L.Np[i - 1] >> 4) * (L.Np[i] >> 4);
+    return t;
+  }
+  static constexpr int total_tiles() { return tiles_before(n + 1); }
+  static constexpr int layer_of_tile(int t) {
+    for (int l = 1; l <= n; ++l)
+      if (t < tiles_before(l + 1)) return l;
+    return n;
+  }
+  static constexpr bool aligned() {
+    for (int l = 1; l <= n + 1; ++l)
+      if (tiles_before(l) % 4 != 0) return false;
+    return true;
+  }
+};
+
+// C-layout registers of a layer (lane (q, m): row m of the wave's block, units 16t + 4q + r) -> its
+// transposed image
+template <int SHAPE, int NP, int TMAX>
+__device__ __forceinline__ void store_rows_tp(const float (&src)[TMAX][4], float *img, int row) {
+  const int q = (threadIdx.x & 63) >> 4;
+#pragma unroll
+  for (int t = 0; t < NP / 16; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) img[WideTp<SHAPE>::idx(16 * t + 4 * q + r, row)] = src[t][r];
+}
+
+template <int SHAPE>
+__device__ __forceinline__ void wide_fused_f32(float *th, const float *img, float *m_g, float *v_g,
+                                               float alpha, float omb1, float omb2, float eps, int tid_o) {
+  using Tp = WideTp<SHAPE>;
+  constexpr MlpLayout L = Tp::L;
+  constexpr int TOTAL = Tp::total_tiles(), TPW = TOTAL / 4, AHEAD = 3, PITCH = Tp::PITCH;
+  static_assert(Tp::aligned() && TOTAL % 4 == 0, "tiles of a layer must start at a multiple of 4");
+  typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+  const int wv = __builtin_amdgcn_readfirstlane(tid_o >> 6), lane = tid_o & 63, m16 = lane & 15, q4 = lane >> 4;
+  const int qa = lane & 3, m4 = m16 & ~3;
+  constexpr int RING = AHEAD + 2;  // (tile I - 1 is still in use when tile I + AHEAD is requested)
+  f4u pm[RING], pv[RING];
+  float bm[RING], bv[RING];
+  auto slots = [&](auto ic, int &kb, int &cb, int &p4, bool &ok4, int &pb, bool &okb) {
+    constexpr int I = decltype(ic)::value, l = Tp::layer_of_tile(4 * I);
+    constexpr int K = L.w[l - 1], Nw = L.w[l], ncb = L.Np[l] >> 4;
+    const int r = wv + 4 * I - Tp::tiles_before(l);
+    kb = r / ncb;
+    cb = r - kb * ncb;
+    if constexpr (Nw == 1) {  // one column: the C layout's four rows ARE contiguous (lanes m = 0)
+      p4 = L.goff_w[l] + 16 * kb + 4 * q4;
+      ok4 = m16 == 0 && 16 * kb + 4 * q4 < K;
+    } else {
+      p4 = L.goff_w[l] + (16 * kb + 4 * q4 + qa) * Nw + 16 * cb + m4;
+      ok4 = 16 * kb + 4 * q4 + qa < K && 16 * cb + m4 < Nw;
+    }
+    okb = kb == 0 && q4 == 0 && 16 * cb + m16 < Nw;
+    pb = L.goff_b[l] + 16 * cb + m16;
+  };
+  auto request = [&](auto ic) {
+    constexpr int I = decltype(ic)::value;
+    int kb, cb, p4, pb;
+    bool ok4, okb;
+    slots(ic, kb, cb, p4, ok4, pb, okb);
+    const f4u z4 = {0.f, 0.f, 0.f, 0.f};
+    pm[I % RING] = ok4 ? *reinterpret_cast<const f4u *>(m_g + p4) : z4;
+    pv[I % RING] = ok4 ? *reinterpret_cast<const f4u *>(v_g + p4) : z4;
+    if (kb == 0) {  // (wave-uniform: only these tiles carry a bias)
+      bm[I % RING] = okb ? m_g[pb] : 0.f;
+      bv[I % RING] = okb ? v_g[pb] : 0.f;
+    }
+  };
+  static_for<0, (AHEAD < TPW ? AHEAD : TPW)>([&](auto ic) { request(ic); });
+  // Software pipeline: the MFMA chain of tile I (16 dependent matrix instructions, 32 cycles each,
+  // 8 of them issue) shares its scheduling region with the Adam arithmetic of tile I - 1, which
+  // fills the chain's gaps instead of following it.
+  f32x4 acc_prev = {0.f, 0.f, 0.f, 0.f};
+  float bsum_prev = 0.f;
+  auto finish = [&](auto ic, const f32x4 &acc, float bsum) {  // quad transpose, Adam, stores of tile I
+    constexpr int I = decltype(ic)::value, l = Tp::layer_of_tile(4 * I);
+    constexpr int Nw = L.w[l], ldw = L.ldw[l];
+    int kb, cb, p4, pb;
+    bool ok4, okb;
+    slots(ic, kb, cb, p4, ok4, pb, okb);
+    float g[4] = {acc[0], acc[1], acc[2], acc[3]};
+    if constexpr (Nw != 1) {  // 4 x 4 transpose inside the lane quad: g[jj] <- lane jj's g[qa]
+      float x = (qa & 1) ? g[0] : g[1], y = (qa & 1) ? g[2] : g[3];
+      x = __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(x), 0xB1, 0xF, 0xF, true));
+      y = __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(y), 0xB1, 0xF, 0xF, true));
+      if (qa & 1) { g[0] = x; g[2] = y; } else { g[1] = x; g[3] = y; }
+      x = (qa & 2) ? g[0] : g[2];
+      y = (qa & 2) ? g[1] : g[3];
+      x = __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(x), 0x4E, 0xF, 0xF, true));
+      y = __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(y), 0x4E, 0xF, 0xF, true));
+      if (qa & 2) { g[0] = x; g[1] = y; } else { g[2] = x; g[3] = y; }
+    }
+    // this lane's four weights in the padded LDS image of theta
+    const int li0 = Nw == 1 ? L.woff[l] + (16 * kb + 4 * q4) * ldw : L.woff[l] + (16 * kb + 4 * q4 + qa) * ldw + 16 * cb + m4;
+    constexpr int lstep = Nw == 1 ? ldw : 1;
+    constexpr int cur = I % RING;
+    float w[4], wn[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) w[r] = ok4 ? th[li0 + r * lstep] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float mm = pm[cur][r], vv = pv[cur][r];
+      wn[r] = adam_update(w[r], g[r], mm, vv, alpha, omb1, omb2, eps);
+      pm[cur][r] = mm;
+      pv[cur][r] = vv;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) asm volatile("" : "+v"(wn[r]));
+    if (ok4) {
+      *reinterpret_cast<f4u *>(m_g + p4) = pm[cur];
+      *reinterpret_cast<f4u *>(v_g + p4) = pv[cur];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) th[li0 + r * lstep] = wn[r];
+    }
+    if (kb == 0) {  // bias: the column sums of D_l (every lane of the column holds them)
+      const float gb = rows_sum4(bsum);
+      const int lb = L.boff[l] + 16 * cb + m16;
+      float mm = bm[cur], vv = bv[cur];
+      const float wb0 = okb ? th[lb] : 0.f;
+      const float wnb = adam_update(wb0, gb, mm, vv, alpha, omb1, omb2, eps);
+      if (okb) {
+        th[lb] = wnb;
+        m_g[pb] = mm;
+        v_g[pb] = vv;
+      }
+    }
+  };
+  static_for<0, TPW + 1>([&](auto ic) {
+    constexpr int I = decltype(ic)::value;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    float bsum = 0.f;
+    if constexpr (I < TPW) {
+      constexpr int l = Tp::layer_of_tile(4 * I);
+      // (tile I + AHEAD's slots must be requested after tile I - 1's stores were... no: the slots of
+      // different tiles are disjoint; the request only has to precede its use by a few tiles)
+      if constexpr (I + AHEAD < TPW) request(std::integral_constant<int, I + AHEAD>{});
+      int kb, cb, p4, pb;
+      bool ok4, okb;
+      slots(ic, kb, cb, p4, ok4, pb, okb);
+      // operands: rows 4 kc + q4 (kc = 0..15) of unit 16 kb|cb + m16 = sixteen consecutive floats
+      // (16-byte aligned: pitch 272 B, image offsets multiples of 16 B -> ds_read_b128)
+      const float4 *ap = reinterpret_cast<const float4 *>(img + Tp::a_off(l - 1) + (16 * kb + m16) * PITCH + 16 * q4);
+      const float4 *bp = reinterpret_cast<const float4 *>(img + Tp::d_off(l) + (16 * cb + m16) * PITCH + 16 * q4);
+      float av[4][4], bq[4][4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float4 x = ap[c], y = bp[c];
+        av[c][0] = x.x; av[c][1] = x.y; av[c][2] = x.z; av[c][3] = x.w;
+        bq[c][0] = y.x; bq[c][1] = y.y; bq[c][2] = y.z; bq[c][3] = y.w;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int kc = 0; kc < 16; ++kc) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kc >> 2][kc & 3], bq[kc >> 2][kc & 3], acc, 0, 0, 0);
+        bsum += bq[kc >> 2][kc & 3];
+      }
+    }
+    if constexpr (I > 0) finish(std::integral_constant<int, I - 1>{}, acc_prev, bsum_prev);
+    if constexpr (I < TPW) {  // one MFMA, then a handful of the other tile's vector instructions
+#pragma unroll
+      for (int kc = 0; kc < 16; ++kc) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 12, 0);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    acc_prev = acc;
+    bsum_prev = bsum;
+  });
+}
+
 // (the body is a device function so that the fused iteration kernel of bore_iter.hip can run it)
 template <int SHAPE>
 __device__ __forceinline__ void fit_body(const FitArgs &a, const long long slot,
@@ -665,6 +873,7 @@ __device__ __forceinline__ void fit_body(const FitArgs &a, const long long slot,
       const bool first_sub = sub == 0, last_sub = sub + 1 == nsub;
       // ---- forward / loss / backward: wave wv owns rows [16 wv, 16 wv + 16), no barriers ----
       BORE_STAMP(0);
+      BORE_WSTAMP_DECL;
       int src = 0;  // static path: this lane's mini-batch row, requested ahead of the arithmetic below
       if constexpr (SHAPE > 0) {
         if (wv * 16 + m16 < nb) src = perm_s[row0 + wv * 16 + m16];
@@ -703,12 +912,24 @@ __device__ __forceinline__ void fit_body(const FitArgs &a, const long long slot,
           }
 #pragma unroll
           for (int kc = 0; kc < Net::KC0; ++kc)
-            if (4 * kc + q4 < D) A0[4 * kc + q4] = xin[kc];
+            if (4 * kc + q4 < D) {
+              if constexpr (bore_shape_is_wide(SHAPE)) tile[WideTp<SHAPE>::a_off(0) + WideTp<SHAPE>::idx(4 * kc + q4, row)] = xin[kc];
+              else A0[4 * kc + q4] = xin[kc];
+            }
           __builtin_amdgcn_sched_barrier(0);  // every operand load is in flight before the chain
           BORE_STAMP(1);
+          BORE_WSTAMP(0);
           net.forward(th, xin, /*keep_logits=*/true);
           BORE_STAMP(2);
-          net.template store_A<1, Net::n - 1>(tile, rb);
+          BORE_WSTAMP(1);
+          if constexpr (bore_shape_is_wide(SHAPE)) {
+            static_for<1, Net::n>([&](auto lc) {
+              constexpr int l = decltype(lc)::value;
+              store_rows_tp<SHAPE, Net::L.Np[l], Net::T>(net.h[l], tile + WideTp<SHAPE>::a_off(l), row);
+            });
+          } else {
+            net.template store_A<1, Net::n - 1>(tile, rb);
+          }
           float delta = 0.f;
           if (lane < 16 && live) {
             const float x = net.h[Net::n][0][0];
@@ -718,12 +939,25 @@ __device__ __forceinline__ void fit_body(const FitArgs &a, const long long slot,
             if (a.epoch_loss) eloss += fmaxf(x, 0.f) - x * zz + log1pf(ex);
             delta = (sig - zz) / (float)nb;
           }
-          if (lane < 16) tile[L.doff[Net::n] + row * L.lda[Net::n]] = delta;
+          if (lane < 16) {
+            if constexpr (bore_shape_is_wide(SHAPE)) tile[WideTp<SHAPE>::d_off(Net::n) + WideTp<SHAPE>::idx(0, row)] = delta;
+            else tile[L.doff[Net::n] + row * L.lda[Net::n]] = delta;
+          }
           net.set_output_delta(delta);
           BORE_STAMP(3);
+          BORE_WSTAMP(2);
           net.template backward<Net::n, 2>(th);
-          net.template store_D<1, Net::n - 1>(tile, rb);
+          BORE_WSTAMP(3);
+          if constexpr (bore_shape_is_wide(SHAPE)) {
+            static_for<1, Net::n>([&](auto lc) {
+              constexpr int l = decltype(lc)::value;
+              store_rows_tp<SHAPE, Net::L.Np[l], Net::T>(net.d[l], tile + WideTp<SHAPE>::d_off(l), row);
+            });
+          } else {
+            net.template store_D<1, Net::n - 1>(tile, rb);
+          }
           BORE_STAMP(4);
+          BORE_WSTAMP(4);
         } else {
         {  // gather the mini-batch rows of this row-block (rows past the sub-tile: zeros)
           float *A0 = tile + L.aoff[0] + (rb * 16 + m16) * L.lda[0];
@@ -777,16 +1011,12 @@ __device__ __forceinline__ void fit_body(const FitArgs &a, const long long slot,
       const int kch = (nr + 3) >> 2;
       int t = 0;
       if constexpr (bore_shape_is_wide(SHAPE > 0 ? SHAPE : 0)) {
-        if (a.state_in_lds) {
-          dw_adam_wide<SHAPE, true>(a, smem, m_g, v_g, alpha, omb1, omb2);
-        } else {  // gradients of all tiles -> packed image over A_0.. (the D_l are not touched)
-          float G[wide_tiles_per_wave<SHAPE>()][5];
-          wide_grads<SHAPE, float>(tile, G);
-          __syncthreads();
-          wide_scatter<SHAPE>(G, tile);
-          __syncthreads();
-          wide_adam<SHAPE, false>(th, tile, nullptr, m_g, v_g, alpha, omb1, omb2, a.eps);
-        }
+        // (a wide net's m / v never fit in LDS beside theta and the 64-row images: fit_build)
+        int tid_o = tid;  // opaque per step: nothing derived from it is hoisted out of the step loop
+        asm volatile("" : "+v"(tid_o));
+        BORE_WSTAMP(5);
+        wide_fused_f32<SHAPE>(th, tile, m_g, v_g, alpha, omb1, omb2, a.eps, tid_o);
+        BORE_WSTAMP(6);
       } else if constexpr (SHAPE > 0) {
         switch ((nb + 15) >> 4) {
           case 1: dw_adam_static<SHAPE, 1>(a, smem, alpha, omb1, omb2); break;
@@ -1773,6 +2003,12 @@ static int fit_build(const bore_mlp_desc *desc, int n_models, float *theta, floa
   int shape = bore_kernel_flavour(desc, batch_size == BORE_BATCH_MAX);
   if (shape > 0 && (!bore_shape_has_static_fit(shape) || (!a.state_in_lds && !bore_shape_is_wide(shape))))
     shape = -desc->n_layers;
+  if (shape > 0 && bore_shape_is_wide(shape)) {
+    // the wide static fit keeps m / v in HBM and its A / D images transposed (WideTp)
+    static_assert(WideTp<3>::total() <= bore_static_layout(3, 1, BORE_BATCH_MAX).tile_floats,
+                  "the transposed images must fit the tile region");
+    if (a.state_in_lds) return fail(BORE_E_UNSUPPORTED, "fit: internal: wide shape with Adam slots in LDS");
+  }
   lds_floats = off;
   shape_out = shape;
   return 0;

@@ -8,7 +8,9 @@ import numpy as np, torch
 from bore_amd import _lib, ops
 NAMES = ["gather (+A_0 image)", "forward", "loss + delta", "backward", "store A^T / D^T images", "barrier",
          "grads (MFMA)", "-", "scatter + packed Adam", "barrier"]
-for name, D, units, compute in [("shape4_bf16", 32, [128, 128, 1], "bfloat16"), ("shape3_bf16", 16, [64, 64, 64, 1], "bfloat16")]:
+for name, D, units, compute in [("shape4_bf16", 32, [128, 128, 1], "bfloat16"), ("shape3_bf16", 16, [64, 64, 64, 1], "bfloat16"),
+                                ("shape3_f32 (phases: gather, forward, store_A+loss, backward, store_D, barrier, grads, barrier+scatter+barrier, packed Adam)",
+                                 16, [64, 64, 64, 1], "float32")]:
     rs = np.random.RandomState(7)
     acts = ["relu"] * (len(units) - 1) + ["sigmoid"]
     desc = _lib.make_desc(D, units, acts, compute=compute)
