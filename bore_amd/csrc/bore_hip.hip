@@ -255,9 +255,9 @@ struct WideTile {
 };
 
 template <int SHAPE>
-__device__ __forceinline__ WideTile wide_tile(int t) {
+__device__ __forceinline__ WideTile wide_tile(int t, int lane_in = -1) {
   constexpr MlpLayout L = bore_static_layout(SHAPE, 1, BORE_BATCH_MAX);
-  const int lane = threadIdx.x & 63, m16 = lane & 15, q4 = lane >> 4;
+  const int lane = lane_in >= 0 ? lane_in : (int)(threadIdx.x & 63), m16 = lane & 15, q4 = lane >> 4;
   WideTile w;
   // tile t -> (layer, kb, cb); every per-layer quantity is picked by a scalar compare chain
   int woff = 0, boff = 0, goff_w = 0, goff_b = 0, ncb = 1, r = t, start = 0;
@@ -298,106 +298,11 @@ __device__ __forceinline__ WideTile wide_tile(int t) {
   return w;
 }
 
-// Weight gradients + Adam for a WIDE static shape (mlp_shapes.h: 64-wide hidden layers): too
-// many tiles to unroll (40 for 16->64-64-64-1), so the wave walks its tiles t = wv, wv + 4, ...
-// in a run-time loop; per tile the same plan as dw_task -- all 2 x 16 MFMA operands and the
-// tile's theta slots requested up front, k-ordered MFMA sum over the 64 batch rows (rows past
-// the batch hold zeros), bias = column sums, branch-free Adam, one-unit layers transposed.
-// m and v of such a net do not fit in LDS beside theta and the tile: they stay in HBM, and the
-// NEXT tile's slots are requested before this tile's MFMA chain (one tile of software
-// pipelining hides the HBM latency).
-template <int SHAPE, bool STATE_LDS>
-__device__ __forceinline__ void dw_adam_wide(const FitArgs &a, float *smem, float *m_g,
-                                             float *v_g, float alpha, float omb1, float omb2) {
-  constexpr MlpLayout L = bore_static_layout(SHAPE, 1, BORE_BATCH_MAX);
-  constexpr int KCH = BORE_BATCH_MAX / 4;
-  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, m16 = lane & 15, q4 = lane >> 4;
-  float *th = smem, *tile = smem + a.o_tile, *sm = smem + a.o_m, *sv = smem + a.o_v;
-  int total = 0;
-#pragma unroll
-  for (int l = 1; l <= L.n_layers; ++l) total += (L.Np[l - 1] >> 4) * (L.Np[l] >> 4);
-  constexpr int STEP = BORE_THREADS / 64;
-  if (wv >= total) return;
-  WideTile cur = wide_tile<SHAPE>(wv);
-  float mm[5], vv[5];
-#pragma unroll
-  for (int q = 0; q < 5; ++q) {
-    mm[q] = STATE_LDS ? sm[cur.li[q]] : (cur.ok[q] ? m_g[cur.gi[q]] : 0.f);
-    vv[q] = STATE_LDS ? sv[cur.li[q]] : (cur.ok[q] ? v_g[cur.gi[q]] : 0.f);
-  }
-  for (int t = wv; t < total; t += STEP) {
-    const bool more = t + STEP < total;
-    if (t == wv) BORE_TSTAMP(8);
-    const WideTile nxt = wide_tile<SHAPE>(more ? t + STEP : t);
-    float mn[5], vn[5];
-#pragma unroll
-    for (int q = 0; q < 5; ++q) {  // the next tile's Adam slots (distinct from this tile's)
-      mn[q] = STATE_LDS ? sm[nxt.li[q]] : (more && nxt.ok[q] ? m_g[nxt.gi[q]] : 0.f);
-      vn[q] = STATE_LDS ? sv[nxt.li[q]] : (more && nxt.ok[q] ? v_g[nxt.gi[q]] : 0.f);
-    }
-    const float *ap = tile + cur.aoff + q4 * cur.lda_p + cur.kb * 16 + m16;
-    const float *bp = tile + cur.doff + q4 * cur.ldd + cur.cb * 16 + m16;
-    float av[KCH], bv[KCH], w[5];
-#pragma unroll
-    for (int kc = 0; kc < KCH; ++kc) {
-      av[kc] = ap[kc * 4 * cur.lda_p];
-      bv[kc] = bp[kc * 4 * cur.ldd];
-    }
-#pragma unroll
-    for (int q = 0; q < 5; ++q) w[q] = th[cur.li[q]];
-    __builtin_amdgcn_sched_barrier(0);
-    if (t == wv) BORE_TSTAMP(9);
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    float bsum = 0.f;
-#pragma unroll
-    for (int kc = 0; kc < KCH; ++kc) {
-      const float x = cur.transposed ? bv[kc] : av[kc], y = cur.transposed ? av[kc] : bv[kc];
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x, y, acc, 0, 0, 0);
-      bsum += bv[kc];
-    }
-    float g[5] = {acc[0], acc[1], acc[2], acc[3], 0.f};
-    if (t == wv) BORE_TSTAMP(10);
-    if (cur.want_bias) {
-      const float gb = rows_sum4(bsum);
-      if (cur.transposed) g[0] = lane == 16 ? gb : g[0];
-      else g[4] = gb;
-    }
-    float wn[5];
-    wn[4] = 0.f;
-#pragma unroll
-    for (int q = 0; q < 5; ++q) {
-      if (q == 4 && !cur.want_bias) continue;  // (wave-uniform: only kb == 0 tiles carry a bias)
-      wn[q] = adam_update(w[q], g[q], mm[q], vv[q], alpha, omb1, omb2, a.eps);
-    }
-    // pin the five updates HERE: left alone the compiler sinks each one behind the predicate of
-    // its store, where a conservative s_waitcnt vmcnt(0) then waits for the previous slot's HBM
-    // store and the next tile's prefetch -- five HBM round trips per tile
-#pragma unroll
-    for (int q = 0; q < 5; ++q) asm volatile("" : "+v"(wn[q]), "+v"(mm[q]), "+v"(vv[q]));
-#pragma unroll
-    for (int q = 0; q < 5; ++q) {
-      if (!cur.ok[q]) continue;
-      th[cur.li[q]] = wn[q];
-      if (STATE_LDS) {
-        sm[cur.li[q]] = mm[q];
-        sv[cur.li[q]] = vv[q];
-      } else {
-        m_g[cur.gi[q]] = mm[q];
-        v_g[cur.gi[q]] = vv[q];
-      }
-    }
-    if (t == wv) BORE_TSTAMP(11);
-    cur = nxt;
-#pragma unroll
-    for (int q = 0; q < 5; ++q) { mm[q] = mn[q]; vv[q] = vn[q]; }
-  }
-}
-
 // ---------------------------------------------------------------------------------------------
 // Weight gradients + Adam of a WIDE static shape whose Adam slots live in HBM, in two phases.
 //
-// dw_adam_wide above updates tile by tile: each tile's m / v (and, for the mixed-precision fit,
-// master weight) slots make an HBM round trip that one tile of look-ahead (~1 k cycles of MFMAs)
+// Round 1 updated tile by tile: each tile's m / v (and, for the mixed-precision fit, master weight)
+// slots made an HBM round trip that one tile of look-ahead (~1 k cycles of MFMAs)
 // does not cover -- measured 4.3 k cycles per tile for 16->64-64-64-1 (40 tiles: 43 k of the
 // step's 65 k cycles) and 5.8 k for 32->128-128-1 in bf16 (88 tiles).  Here
 //   A. every wave forms ALL of its gradient tiles back to back (pure LDS + MFMA; the 16x16
@@ -426,17 +331,20 @@ constexpr int wide_tiles_per_wave() {
 // requested one tile ahead of its MFMA chain (raw: the widening of a bfloat16 happens beside the
 // MFMAs, not in front of them).
 template <int SHAPE, typename ET>
-__device__ __forceinline__ void wide_grads(const ET *tile, float (&G)[wide_tiles_per_wave<SHAPE>()][5]) {
+__device__ __forceinline__ void wide_grads(const ET *tile, float (&G)[wide_tiles_per_wave<SHAPE>()][5],
+                                           int tid_o) {
+  // (tid_o: an opaque copy of the thread id made inside the caller's step loop -- from the
+  // loop-invariant id the per-tile indices of all tiles are hoisted out of that loop and spilled)
   constexpr int KCH = BORE_BATCH_MAX / 4, TOTAL = wide_total_tiles<SHAPE>();
   constexpr int TPW = wide_tiles_per_wave<SHAPE>(), STEP = BORE_THREADS / 64;
-  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, m16 = lane & 15, q4 = lane >> 4;
+  const int wv = __builtin_amdgcn_readfirstlane(tid_o >> 6), lane = tid_o & 63, m16 = lane & 15, q4 = lane >> 4;
   auto widen = [](ET raw) -> float {
     if constexpr (sizeof(ET) == 2) return bf16_to_f32(raw);
     else return raw;
   };
   ET av[2][KCH], bv[2][KCH];
   {
-    const WideTile w0 = wide_tile<SHAPE>(wv < TOTAL ? wv : 0);
+    const WideTile w0 = wide_tile<SHAPE>(wv < TOTAL ? wv : 0, lane);
     const ET *ap = tile + w0.aoff + q4 * w0.lda_p + w0.kb * 16 + m16;
     const ET *bp = tile + w0.doff + q4 * w0.ldd + w0.cb * 16 + m16;
 #pragma unroll
@@ -451,9 +359,9 @@ __device__ __forceinline__ void wide_grads(const ET *tile, float (&G)[wide_tiles
 #pragma unroll
     for (int q = 0; q < 5; ++q) G[i][q] = 0.f;
     if (TOTAL % STEP != 0 && t >= TOTAL) continue;
-    const WideTile cur = wide_tile<SHAPE>(t);
+    const WideTile cur = wide_tile<SHAPE>(t, lane);
     if (i + 1 < TPW) {  // the next tile's operands (clamped: a wave past the end re-reads its last)
-      const WideTile nx = wide_tile<SHAPE>(t + STEP < TOTAL ? t + STEP : t);
+      const WideTile nx = wide_tile<SHAPE>(t + STEP < TOTAL ? t + STEP : t, lane);
       const ET *ap = tile + nx.aoff + q4 * nx.lda_p + nx.kb * 16 + m16;
       const ET *bp = tile + nx.doff + q4 * nx.ldd + nx.cb * 16 + m16;
 #pragma unroll
@@ -484,15 +392,16 @@ __device__ __forceinline__ void wide_grads(const ET *tile, float (&G)[wide_tiles
 
 // Phase B: the gradients to gl[packed parameter index].
 template <int SHAPE>
-__device__ __forceinline__ void wide_scatter(const float (&G)[wide_tiles_per_wave<SHAPE>()][5], float *gl) {
+__device__ __forceinline__ void wide_scatter(const float (&G)[wide_tiles_per_wave<SHAPE>()][5], float *gl,
+                                             int tid_o) {
   constexpr int TOTAL = wide_total_tiles<SHAPE>(), TPW = wide_tiles_per_wave<SHAPE>();
   constexpr int STEP = BORE_THREADS / 64;
-  const int wv = threadIdx.x >> 6;
+  const int wv = __builtin_amdgcn_readfirstlane(tid_o >> 6), lane = tid_o & 63;
 #pragma unroll
   for (int i = 0; i < TPW; ++i) {
     const int t = wv + STEP * i;
     if (TOTAL % STEP != 0 && t >= TOTAL) continue;
-    const WideTile cur = wide_tile<SHAPE>(t);
+    const WideTile cur = wide_tile<SHAPE>(t, lane);
 #pragma unroll
     for (int q = 0; q < 5; ++q)
       if (cur.ok[q]) gl[cur.gi[q]] = G[i][q];
@@ -510,7 +419,8 @@ __device__ __forceinline__ void wide_scatter(const float (&G)[wide_tiles_per_wav
 // otherwise theta is the float32 LDS image.
 template <int SHAPE, bool MASTER>
 __device__ __forceinline__ void wide_adam(void *th_lds, const float *gl, float *theta_g, float *m_g,
-                                          float *v_g, float alpha, float omb1, float omb2, float eps) {
+                                          float *v_g, float alpha, float omb1, float omb2, float eps,
+                                          int tid_o) {
   constexpr MlpLayout L = bore_static_layout(SHAPE, 1, BORE_BATCH_MAX);
   constexpr int U = 8, STRIDE = BORE_THREADS * U;
   constexpr int NB = (L.P + STRIDE - 1) / STRIDE;
@@ -521,7 +431,7 @@ __device__ __forceinline__ void wide_adam(void *th_lds, const float *gl, float *
   auto request = [&](int b, int buf) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int p = b * STRIDE + BORE_THREADS * u + (int)threadIdx.x;
+      const int p = b * STRIDE + BORE_THREADS * u + tid_o;
       const bool ok = p < L.P;
       li[buf][u] = param_ref(L, ok ? p : 0, L.n_layers).lds;
       mm[buf][u] = ok ? m_g[p] : 0.f;
@@ -545,7 +455,7 @@ __device__ __forceinline__ void wide_adam(void *th_lds, const float *gl, float *
     for (int u = 0; u < U; ++u) asm volatile("" : "+v"(wn[u]), "+v"(mm[cur][u]), "+v"(vv[cur][u]));
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int p = b * STRIDE + BORE_THREADS * u + (int)threadIdx.x;
+      const int p = b * STRIDE + BORE_THREADS * u + tid_o;
       if (p < L.P) {
         if constexpr (MASTER) {
           th16[li[cur][u]] = f32_to_bf16(wn[u]);
@@ -1194,7 +1104,7 @@ __global__ __launch_bounds__(BORE_THREADS) void fit_kernel(const FitArgs a) {
 // LDS holds the bf16 image of theta (same padded tile layout, 2-byte elements) and the bf16
 // copies of A_l / D_l for the weight-gradient tiles: half the bytes of the fp32 fit, which is
 // what lets a 128-wide net fit at all (fp32: 248 KB > 160 KB).  The fp32 master weights, m and
-// v stay in HBM; a tile's slots are prefetched one tile ahead (dw_adam_bf16), updated in fp32
+// v stay in HBM (wide_grads / wide_scatter / wide_adam below), updated in fp32
 // and written back together with the tile's new bf16 image.  Products run on the fp32 MFMA
 // (bf16 x bf16 is exact in fp32; k-ordered fp32 sums) -- the step is bound by the Adam chains
 // and the barrier structure, not by MFMA rate.  Every layer output, logit and delta is rounded
@@ -1213,84 +1123,6 @@ struct FitBf16Args {
   float lr, beta1, beta2, eps;
   int o_tile, o_misc, o_perm, o_keys, total;  // BYTE offsets into the dynamic LDS
 };
-
-template <int SHAPE>
-__device__ __forceinline__ void dw_adam_bf16(const FitBf16Args &a, unsigned short *th16,
-                                             const unsigned short *tile16, float *theta_g,
-                                             float *m_g, float *v_g, float alpha, float omb1,
-                                             float omb2) {
-  constexpr MlpLayout L = bore_static_layout(SHAPE, 1, BORE_BATCH_MAX);
-  constexpr int KCH = BORE_BATCH_MAX / 4;
-  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, m16 = lane & 15, q4 = lane >> 4;
-  int total = 0;
-#pragma unroll
-  for (int l = 1; l <= L.n_layers; ++l) total += (L.Np[l - 1] >> 4) * (L.Np[l] >> 4);
-  constexpr int STEP = BORE_THREADS / 64;
-  if (wv >= total) return;
-  WideTile cur = wide_tile<SHAPE>(wv);
-  float w[5], mm[5], vv[5];
-#pragma unroll
-  for (int q = 0; q < 5; ++q) {
-    w[q] = cur.ok[q] ? theta_g[cur.gi[q]] : 0.f;
-    mm[q] = cur.ok[q] ? m_g[cur.gi[q]] : 0.f;
-    vv[q] = cur.ok[q] ? v_g[cur.gi[q]] : 0.f;
-  }
-  for (int t = wv; t < total; t += STEP) {
-    const bool more = t + STEP < total;
-    const WideTile nxt = wide_tile<SHAPE>(more ? t + STEP : t);
-    float wx[5], mn[5], vn[5];
-#pragma unroll
-    for (int q = 0; q < 5; ++q) {  // the next tile's master weights and Adam slots
-      const bool go = more && nxt.ok[q];
-      wx[q] = go ? theta_g[nxt.gi[q]] : 0.f;
-      mn[q] = go ? m_g[nxt.gi[q]] : 0.f;
-      vn[q] = go ? v_g[nxt.gi[q]] : 0.f;
-    }
-    const unsigned short *ap = tile16 + cur.aoff + q4 * cur.lda_p + cur.kb * 16 + m16;
-    const unsigned short *bp = tile16 + cur.doff + q4 * cur.ldd + cur.cb * 16 + m16;
-    float av[KCH], bv[KCH];
-#pragma unroll
-    for (int kc = 0; kc < KCH; ++kc) {
-      av[kc] = bf16_to_f32(ap[kc * 4 * cur.lda_p]);
-      bv[kc] = bf16_to_f32(bp[kc * 4 * cur.ldd]);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    float bsum = 0.f;
-#pragma unroll
-    for (int kc = 0; kc < KCH; ++kc) {
-      const float x = cur.transposed ? bv[kc] : av[kc], y = cur.transposed ? av[kc] : bv[kc];
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x, y, acc, 0, 0, 0);
-      bsum += bv[kc];
-    }
-    float g[5] = {acc[0], acc[1], acc[2], acc[3], 0.f};
-    if (cur.want_bias) {
-      const float gb = rows_sum4(bsum);
-      if (cur.transposed) g[0] = lane == 16 ? gb : g[0];
-      else g[4] = gb;
-    }
-    float wn[5];
-    wn[4] = 0.f;
-#pragma unroll
-    for (int q = 0; q < 5; ++q) {
-      if (q == 4 && !cur.want_bias) continue;  // (wave-uniform: only kb == 0 tiles carry a bias)
-      wn[q] = adam_update(w[q], g[q], mm[q], vv[q], alpha, omb1, omb2, a.eps);
-    }
-#pragma unroll
-    for (int q = 0; q < 5; ++q) asm volatile("" : "+v"(wn[q]), "+v"(mm[q]), "+v"(vv[q]));
-#pragma unroll
-    for (int q = 0; q < 5; ++q) {
-      if (!cur.ok[q]) continue;
-      th16[cur.li[q]] = f32_to_bf16(wn[q]);
-      theta_g[cur.gi[q]] = wn[q];
-      m_g[cur.gi[q]] = mm[q];
-      v_g[cur.gi[q]] = vv[q];
-    }
-    cur = nxt;
-#pragma unroll
-    for (int q = 0; q < 5; ++q) { w[q] = wx[q]; mm[q] = mn[q]; vv[q] = vn[q]; }
-  }
-}
 
 template <int SHAPE>
 __global__ __launch_bounds__(BORE_THREADS) void fit_bf16_kernel(const FitBf16Args a) {
@@ -1395,14 +1227,16 @@ __global__ __launch_bounds__(BORE_THREADS) void fit_bf16_kernel(const FitBf16Arg
       BORE_WSTAMP(5);
       {
         float G[wide_tiles_per_wave<SHAPE>()][5];
-        wide_grads<SHAPE, unsigned short>(tile16, G);
+        int tid_o = tid;
+        asm volatile("" : "+v"(tid_o));
+        wide_grads<SHAPE, unsigned short>(tile16, G, tid_o);
         BORE_WSTAMP(6);
         __syncthreads();
         float *gl = reinterpret_cast<float *>(tile16);  // [P] floats: the tile region + its extension
-        wide_scatter<SHAPE>(G, gl);
+        wide_scatter<SHAPE>(G, gl, tid_o);
         __syncthreads();
         BORE_WSTAMP(7);
-        wide_adam<SHAPE, true>(th16, gl, theta_g, m_g, v_g, alpha, omb1, omb2, a.eps);
+        wide_adam<SHAPE, true>(th16, gl, theta_g, m_g, v_g, alpha, omb1, omb2, a.eps, tid_o);
         BORE_WSTAMP(8);
         __syncthreads();
         BORE_WSTAMP(9);
