@@ -375,7 +375,7 @@ int async_create(bore_engine *e, const double *X0, const double *y0) {
   // Residency: a loop's workgroup stays on its CU between iterations and waits this long for the
   // objective value before it gives its slot up (BORE_ASYNC_RESIDENT_US; 0 = one iteration per
   // launch).  Dropped by the launcher when the device cannot hold all loops at once.
-  const double resident_us = getenv("BORE_ASYNC_RESIDENT_US") ? atof(getenv("BORE_ASYNC_RESIDENT_US")) : 500.0;
+  const double resident_us = getenv("BORE_ASYNC_RESIDENT_US") ? atof(getenv("BORE_ASYNC_RESIDENT_US")) : 2000.0;
   A.wait_ticks = A.fused && resident_us > 0 ? (int64_t)(resident_us * 1e3 / A.ns_per_tick) : 0;
   // Worker streams: a dozen independent single-kernel launches in flight when fused (each stream
   // needs its own hardware queue -- streams sharing one serialise, which halves the throughput --

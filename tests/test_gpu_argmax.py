@@ -562,3 +562,34 @@ def test_async_engine_with_the_reference_default_of_five_restarts(gpu):
         assert np.array_equal(u, v)
     sa, sb = a.take_stats(), b.take_stats()
     assert sa["none_results"] == sb["none_results"] and sa["n_fg_rows"] == sb["n_fg_rows"]
+
+
+def test_resident_workgroups_park_and_resume_with_a_slow_objective(gpu, monkeypatch):
+    """A workgroup waits a bounded time on its CU for the objective value (include/bore_hip.h,
+    bore_batch residency); with an objective slower than that it parks, and the host launches the
+    loop's next iteration when the value is there.  Same trajectories as the lock-step engine --
+    and as with an objective that answers at once (no parking)."""
+    import time
+    from bore_amd.engine import NativeEngine, branin01
+    monkeypatch.setenv("BORE_ASYNC_RESIDENT_US", "150")
+    calls = []
+
+    def slow(X):
+        calls.append(len(X))
+        time.sleep(0.002)                      # >> 150 us: every waiting workgroup gives up
+        return branin01(X)
+
+    kw = dict(epochs=20, num_samples=64)
+    a = NativeEngine(np.arange(5, 30), async_loops=True, objective=slow, **kw)
+    b = NativeEngine(np.arange(5, 30), groups=2, **kw)
+    a.run(6)
+    b.run(6)
+    assert np.array_equal(a.X, b.X) and np.array_equal(a.y, b.y)
+    for u, v in zip(a.state(), b.state()):
+        assert np.array_equal(u, v)
+    st = a.take_stats()
+    assert st["batches"] > 6                   # parked loops came back through later launches
+    monkeypatch.setenv("BORE_ASYNC_RESIDENT_US", "0")   # one launch per loop-iteration (inlined kernel)
+    c = NativeEngine(np.arange(5, 30), async_loops=True, **kw)
+    c.run(6)
+    assert np.array_equal(c.X, b.X) and np.array_equal(c.state()[0], b.state()[0])

@@ -1,8 +1,8 @@
 #!/bin/bash
 # Per-kernel register / scratch / occupancy report of the library (no GPU needed).
 # usage: tools/resource_usage.sh [out_file]
+out=$(realpath -m "${1:-/tmp/bore_resource_usage.txt}")
 cd "$(dirname "$0")/../bore_amd/csrc" || exit 1
-out=${1:-/tmp/bore_resource_usage.txt}
 /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -std=c++17 -c -fPIC -ffp-contract=off \
   -Rpass-analysis=kernel-resource-usage bore_all.hip -o /tmp/bore_all.o 2> /tmp/bore_ru_raw.txt
 python3 - "$out" <<'PY'
