@@ -593,3 +593,20 @@ def test_resident_workgroups_park_and_resume_with_a_slow_objective(gpu, monkeypa
     c = NativeEngine(np.arange(5, 30), async_loops=True, **kw)
     c.run(6)
     assert np.array_equal(c.X, b.X) and np.array_equal(c.state()[0], b.state()[0])
+
+
+def test_resident_engine_at_full_occupancy_equals_lockstep_engine(gpu):
+    """512 loops = two resident workgroups on every CU (the bench's configuration), BASELINE fit
+    length: every loop's trajectory is the lock-step engine's, bit for bit."""
+    from bore_amd.engine import NativeEngine
+    a = NativeEngine(np.arange(512), async_loops=True)
+    b = NativeEngine(np.arange(512), groups=4)
+    a.run(3)
+    a.run(5)
+    b.run(8)
+    assert np.array_equal(a.X, b.X) and np.array_equal(a.y, b.y)
+    for u, v in zip(a.state(), b.state()):
+        assert np.array_equal(u, v)
+    sa, sb = a.take_stats(), b.take_stats()
+    assert sa["n_fg_rows"] == sb["n_fg_rows"] and sa["none_results"] == sb["none_results"]
+    assert sa["phase_iterations"] == 512 * 8
