@@ -96,6 +96,12 @@ CASES = [(2, [16, 16, 1], ["relu", "relu", "sigmoid"], "identity", 3),
          (16, [64, 64, 64, 1], ["relu"] * 3 + ["linear"], "sigmoid", 70)]
 
 
+# lower bounds on the share of restarts whose whole record (nit, nfev, status, x) is scipy's, by input
+# dimension of the case -- set just below what this test measures (printed)
+# (measured r2: D=2 6/6, D=6 79/80, D=3 18/18, D=16 116/140)
+MIN_SAME = {2: 1.0, 6: 0.95, 3: 0.95, 16: 0.78}
+
+
 @pytest.mark.parametrize("D,units,acts,tr,R", CASES)
 def test_device_lbfgsb_equals_host_build_and_tracks_scipy(gpu, D, units, acts, tr, R):
     rs = np.random.RandomState(D)
@@ -134,7 +140,9 @@ def test_device_lbfgsb_equals_host_build_and_tracks_scipy(gpu, D, units, acts, t
             assert v[0] == fun[l, r] and np.array_equal(g[0], jac[l, r])
     # fp32 noise + rounding can send a long search (hundreds of evaluations in 16-D) to a
     # neighbouring stationary point; the bulk must coincide
-    assert n_same_scipy >= 0.7 * L * R
+    print(f"\n[lbfgsb vs scipy, random nets D={D} R={R}] identical (nit, nfev, status, x to 1e-7): "
+          f"{n_same_scipy}/{L * R}; |dfun| median {np.median(dfun):.1e}, within 2e-5: {np.mean(np.array(dfun) < 2e-5):.3f}")
+    assert n_same_scipy >= MIN_SAME[D] * L * R
     assert np.median(dfun) < 1e-6 and np.mean(np.array(dfun) < 2e-5) >= 0.9
 
 
