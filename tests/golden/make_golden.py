@@ -180,29 +180,8 @@ def svgd_vectors():
     np.savez_compressed(os.path.join(HERE, "ref_svgd.npz"), **out)
 
 
-def dedup_vectors():
-    """Outputs of the REFERENCE's bore.utils.deduplicate (imports without TensorFlow)."""
-    from bore.utils.deduplicate import pad_unique_random, set_diff_2d
-    out = {}
-    rs = np.random.RandomState(3)
-    for k, (n, d, size, with_b) in enumerate([(6, 2, 8, True), (5, 3, 5, False), (12, 2, 7, True),
-                                              (4, 6, 10, True)]):
-        A = np.round(rs.uniform(size=(n, d)), 1)          # coarse grid -> duplicates
-        A = np.vstack([A, A[:2]])
-        B = A[1:3] + 1e-10 if with_b else None             # within tol of two rows of A
-        bounds = [(0.0, 1.0)] * d
-        if size < len(np.unique(A, axis=0)):                # the reference recurses forever then
-            size = len(np.unique(A, axis=0)) + 2
-        out[f"A{k}"], out[f"size{k}"] = A, np.array(size)
-        if B is not None:
-            out[f"B{k}"] = B
-            out[f"diff{k}"] = set_diff_2d(np.unique(A, axis=0), B)
-        out[f"out{k}"] = pad_unique_random(A, size=size, bounds=bounds, B=B, random_state=11 + k)
-    np.savez_compressed(os.path.join(HERE, "ref_dedup.npz"), **out)
-
 
 if __name__ == "__main__":
-    dedup_vectors()
     ref_vectors()
     mlp_vectors()
     svgd_vectors()

@@ -1,5 +1,5 @@
-"""Host-side callers of the hot path: candidate post-processing, batch
-de-duplication and the plugin's suggest/observe control flow (no GPU needed for these parts)."""
+"""Host-side callers of the hot path: candidate post-processing and the plugin's
+suggest/observe control flow (no GPU needed for these parts)."""
 import os
 
 import numpy as np
@@ -9,23 +9,8 @@ from scipy.stats import truncnorm
 
 from bore_amd.base import maybe_distort, truncated_normal
 from bore_amd.plugins import ClassifierSuggester
-from bore_amd.utils.deduplicate import pad_unique_random, set_diff_2d
 
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
-
-
-def test_deduplicate_matches_reference_goldens():
-    """tests/golden/ref_dedup.npz holds outputs of the reference's bore.utils.deduplicate."""
-    g = np.load(os.path.join(GOLDEN, "ref_dedup.npz"))
-    for k in range(4):
-        A, size = g[f"A{k}"], int(g[f"size{k}"])
-        B = g[f"B{k}"] if f"B{k}" in g.files else None
-        d = A.shape[1]
-        if B is not None:
-            assert np.array_equal(set_diff_2d(np.unique(A, axis=0), B), g[f"diff{k}"])
-        out = pad_unique_random(A, size=size, bounds=[(0.0, 1.0)] * d, B=B, random_state=11 + k)
-        assert np.array_equal(out, g[f"out{k}"]), k
-        assert out.shape == (size, d) and len(np.unique(out, axis=0)) == size
 
 
 def test_maybe_distort_follows_bore_base():
