@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 #include "host_common.h"
@@ -795,9 +796,14 @@ static int lbfgsb_build(const bore_mlp_desc *desc, int n_models, const float *th
   // (tile rows: one 16-row block per wave that has a problem)
   int PB = num_starts < BORE_BATCH_MAX ? num_starts : BORE_BATCH_MAX;
   // One problem per WAVE (all 64 lanes on it, lbfgsb::Coop) finishes a problem ~1.6x sooner than one
-  // problem per lane and uses every lane; prefer it while the launch still fits the GPU a few
-  // times over (256 CUs): 4 problems per workgroup, grid = models x ceil(R / 4).
-  if (PB > 4 && !g_batch && (long long)n_models * ((num_starts + 3) / 4) <= 8192) PB = 4;
+  // problem per lane and uses every lane: 4 problems per workgroup, grid = models x ceil(R / 4).
+  // (round 2: measured on BASELINE configs 2 / 3 with 256 loops -- 16 384 and 65 536 workgroups --
+  // the one-problem-per-wave mapping is 2.0x / 1.5x faster than 64 problems per workgroup there as
+  // well: lanes that each run their own state machine diverge; profiles/r2/lbfgsb_mapping.txt.  The
+  // lane-per-problem mapping is kept for grids beyond 4 M workgroups and for BORE_LBFGSB_COOP_GRID.)
+  const long long coop_grid_max =
+      getenv("BORE_LBFGSB_COOP_GRID") ? atoll(getenv("BORE_LBFGSB_COOP_GRID")) : (1LL << 22);
+  if (PB > 4 && !g_batch && (long long)n_models * ((num_starts + 3) / 4) <= coop_grid_max) PB = 4;
   const int flavour = bore_kernel_flavour(desc, true);
   const int shape = flavour > 0 ? flavour : 0;  // constexpr-layout kernels assume a 64-row tile
   size_t off = 0;

@@ -618,3 +618,21 @@ def test_resident_engine_at_full_occupancy_equals_lockstep_engine(gpu):
     sa, sb = a.take_stats(), b.take_stats()
     assert sa["n_fg_rows"] == sb["n_fg_rows"] and sa["none_results"] == sb["none_results"]
     assert sa["phase_iterations"] == 512 * 8
+
+
+def test_lbfgsb_problem_to_lane_mappings_give_the_same_bits(gpu, monkeypatch):
+    """lbfgsb_kernel runs one problem per wave (all 64 lanes, the default) or one per lane (64 per
+    workgroup; kept for enormous grids, BORE_LBFGSB_COOP_GRID): same results bit for bit."""
+    rs = np.random.RandomState(8)
+    D, units, acts = 6, [32, 32, 1], ["relu", "relu", "sigmoid"]
+    desc = _lib.make_desc(D, units, acts)
+    th = dev(np.stack([pack(rand_model(rs, D, units)) for _ in range(3)]))
+    X0 = dev(rs.uniform(size=(3, 70, D)))
+    lo, hi = np.zeros(D), np.ones(D)
+    outs = []
+    for grid in ("4194304", "0"):
+        monkeypatch.setenv("BORE_LBFGSB_COOP_GRID", grid)
+        outs.append([t.cpu().numpy() for t in ops.lbfgsb_minimize(desc, th, X0, lo, hi, "identity", True,
+                                                                  maxiter=1000, ftol=1e-9)])
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)
