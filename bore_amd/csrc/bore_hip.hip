@@ -547,33 +547,55 @@ __device__ __forceinline__ void wide_fused_f32(float *th, const float *img, floa
   constexpr int RING = AHEAD + 2;  // (tile I - 1 is still in use when tile I + AHEAD is requested)
   f4u pm[RING], pv[RING];
   float bm[RING], bv[RING];
-  auto slots = [&](auto ic, int &kb, int &cb, int &p4, bool &ok4, int &pb, bool &okb) {
+  const bool odd = qa & 1, hi2 = qa & 2;
+  // The packed index of the lane's four contiguous slots = a wave-uniform part pu (scalar) + a lane
+  // part lb4 (bytes); m / v are addressed as buffers (resource + lane offset + scalar offset: one
+  // instruction per access, no 64-bit address arithmetic).  pbu / 4 m16 = the same for the bias.
+  // Layers whose K and width are multiples of 16 need no predicates.
+  constexpr int P = L.P;
+  const BufF32 b_m(m_g, P), b_v(v_g, P);
+  const unsigned lbb = 4u * (unsigned)m16;
+  auto slots = [&](auto ic, int &kb, int &cb, int &pu, unsigned &lb4, bool &ok4, int &pbu, bool &okb) {
     constexpr int I = decltype(ic)::value, l = Tp::layer_of_tile(4 * I);
     constexpr int K = L.w[l - 1], Nw = L.w[l], ncb = L.Np[l] >> 4;
+    constexpr bool FULL = K % 16 == 0 && Nw % 16 == 0;
     const int r = wv + 4 * I - Tp::tiles_before(l);
     kb = r / ncb;
     cb = r - kb * ncb;
     if constexpr (Nw == 1) {  // one column: the C layout's four rows ARE contiguous (lanes m = 0)
-      p4 = L.goff_w[l] + 16 * kb + 4 * q4;
+      pu = L.goff_w[l] + 16 * kb;
+      lb4 = 16u * (unsigned)q4;
       ok4 = m16 == 0 && 16 * kb + 4 * q4 < K;
+    } else if constexpr (FULL) {  // tile order: tile (kb, cb) = 256 consecutive floats, the lane's at 4 * lane
+      pu = L.goff_w[l] + (kb * ncb + cb) * 256;
+      lb4 = 16u * (unsigned)lane;
+      ok4 = true;
     } else {
-      p4 = L.goff_w[l] + (16 * kb + 4 * q4 + qa) * Nw + 16 * cb + m4;
+      pu = L.goff_w[l] + 16 * kb * Nw + 16 * cb;
+      lb4 = 4u * (unsigned)((4 * q4 + qa) * Nw + m4);
       ok4 = 16 * kb + 4 * q4 + qa < K && 16 * cb + m4 < Nw;
     }
-    okb = kb == 0 && q4 == 0 && 16 * cb + m16 < Nw;
-    pb = L.goff_b[l] + 16 * cb + m16;
+    okb = kb == 0 && q4 == 0 && (FULL || 16 * cb + m16 < Nw);
+    pbu = L.goff_b[l] + 16 * cb;
   };
   auto request = [&](auto ic) {
-    constexpr int I = decltype(ic)::value;
-    int kb, cb, p4, pb;
+    constexpr int I = decltype(ic)::value, l = Tp::layer_of_tile(4 * I);
+    constexpr bool FULL = L.w[l - 1] % 16 == 0 && L.w[l] % 16 == 0;
+    int kb, cb, pu, pbu;
+    unsigned lb4;
     bool ok4, okb;
-    slots(ic, kb, cb, p4, ok4, pb, okb);
+    slots(ic, kb, cb, pu, lb4, ok4, pbu, okb);
     const f4u z4 = {0.f, 0.f, 0.f, 0.f};
-    pm[I % RING] = ok4 ? *reinterpret_cast<const f4u *>(m_g + p4) : z4;
-    pv[I % RING] = ok4 ? *reinterpret_cast<const f4u *>(v_g + p4) : z4;
+    if constexpr (FULL) {
+      pm[I % RING] = b_m.ld4(pu, lb4);
+      pv[I % RING] = b_v.ld4(pu, lb4);
+    } else {
+      pm[I % RING] = ok4 ? b_m.ld4(pu, lb4) : z4;
+      pv[I % RING] = ok4 ? b_v.ld4(pu, lb4) : z4;
+    }
     if (kb == 0) {  // (wave-uniform: only these tiles carry a bias)
-      bm[I % RING] = okb ? m_g[pb] : 0.f;
-      bv[I % RING] = okb ? v_g[pb] : 0.f;
+      bm[I % RING] = okb ? b_m.ld1(pbu, lbb) : 0.f;
+      bv[I % RING] = okb ? b_v.ld1(pbu, lbb) : 0.f;
     }
   };
   static_for<0, (AHEAD < TPW ? AHEAD : TPW)>([&](auto ic) { request(ic); });
@@ -585,21 +607,12 @@ __device__ __forceinline__ void wide_fused_f32(float *th, const float *img, floa
   auto finish = [&](auto ic, const f32x4 &acc, float bsum) {  // quad transpose, Adam, stores of tile I
     constexpr int I = decltype(ic)::value, l = Tp::layer_of_tile(4 * I);
     constexpr int Nw = L.w[l], ldw = L.ldw[l];
-    int kb, cb, p4, pb;
+    int kb, cb, pu, pbu;
+    unsigned lb4;
     bool ok4, okb;
-    slots(ic, kb, cb, p4, ok4, pb, okb);
+    slots(ic, kb, cb, pu, lb4, ok4, pbu, okb);
     float g[4] = {acc[0], acc[1], acc[2], acc[3]};
-    if constexpr (Nw != 1) {  // 4 x 4 transpose inside the lane quad: g[jj] <- lane jj's g[qa]
-      float x = (qa & 1) ? g[0] : g[1], y = (qa & 1) ? g[2] : g[3];
-      x = __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(x), 0xB1, 0xF, 0xF, true));
-      y = __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(y), 0xB1, 0xF, 0xF, true));
-      if (qa & 1) { g[0] = x; g[2] = y; } else { g[1] = x; g[3] = y; }
-      x = (qa & 2) ? g[0] : g[2];
-      y = (qa & 2) ? g[1] : g[3];
-      x = __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(x), 0x4E, 0xF, 0xF, true));
-      y = __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(y), 0x4E, 0xF, 0xF, true));
-      if (qa & 2) { g[0] = x; g[1] = y; } else { g[2] = x; g[3] = y; }
-    }
+    if constexpr (Nw != 1) quad_transpose4(g, odd, hi2);  // g[jj] <- lane jj's g[qa]
     // this lane's four weights in the padded LDS image of theta
     const int li0 = Nw == 1 ? L.woff[l] + (16 * kb + 4 * q4) * ldw : L.woff[l] + (16 * kb + 4 * q4 + qa) * ldw + 16 * cb + m4;
     constexpr int lstep = Nw == 1 ? ldw : 1;
@@ -617,8 +630,8 @@ __device__ __forceinline__ void wide_fused_f32(float *th, const float *img, floa
 #pragma unroll
     for (int r = 0; r < 4; ++r) asm volatile("" : "+v"(wn[r]));
     if (ok4) {
-      *reinterpret_cast<f4u *>(m_g + p4) = pm[cur];
-      *reinterpret_cast<f4u *>(v_g + p4) = pv[cur];
+      b_m.st4(pm[cur], pu, lb4);
+      b_v.st4(pv[cur], pu, lb4);
 #pragma unroll
       for (int r = 0; r < 4; ++r) th[li0 + r * lstep] = wn[r];
     }
@@ -630,8 +643,8 @@ __device__ __forceinline__ void wide_fused_f32(float *th, const float *img, floa
       const float wnb = adam_update(wb0, gb, mm, vv, alpha, omb1, omb2, eps);
       if (okb) {
         th[lb] = wnb;
-        m_g[pb] = mm;
-        v_g[pb] = vv;
+        b_m.st1(mm, pbu, lbb);
+        b_v.st1(vv, pbu, lbb);
       }
     }
   };
@@ -644,9 +657,10 @@ __device__ __forceinline__ void wide_fused_f32(float *th, const float *img, floa
       // (tile I + AHEAD's slots must be requested after tile I - 1's stores were... no: the slots of
       // different tiles are disjoint; the request only has to precede its use by a few tiles)
       if constexpr (I + AHEAD < TPW) request(std::integral_constant<int, I + AHEAD>{});
-      int kb, cb, p4, pb;
+      int kb, cb, pu, pbu;
+      unsigned lb4;
       bool ok4, okb;
-      slots(ic, kb, cb, p4, ok4, pb, okb);
+      slots(ic, kb, cb, pu, lb4, ok4, pbu, okb);
       // operands: rows 4 kc + q4 (kc = 0..15) of unit 16 kb|cb + m16 = sixteen consecutive floats
       // (16-byte aligned: pitch 272 B, image offsets multiples of 16 B -> ds_read_b128)
       const float4 *ap = reinterpret_cast<const float4 *>(img + Tp::a_off(l - 1) + (16 * kb + m16) * PITCH + 16 * q4);
@@ -685,6 +699,12 @@ __device__ __forceinline__ void fit_body(const FitArgs &a, const long long slot,
                                          const int it_now = -1) {
   extern __shared__ float smem[];
   constexpr MlpLayout Lc = bore_static_layout(SHAPE > 0 ? SHAPE : 0, 1, BORE_BATCH_MAX);
+  constexpr bool WIDE = bore_shape_is_wide(SHAPE > 0 ? SHAPE : 0);
+  if constexpr (WIDE) {  // m / v (in HBM for a wide net) go to tile order for the launch (TileOrder)
+    const long long mdl = a.ids ? a.ids[slot] : slot;
+    TileOrder<WIDE ? SHAPE : 1>::convert(a.am + mdl * Lc.P, smem, true);
+    TileOrder<WIDE ? SHAPE : 1>::convert(a.av + mdl * Lc.P, smem, true);
+  }
   const MlpLayout &L = begin_kernel<SHAPE>(Lc, a.L, smem, a.total, a.o_layout);
   const int tid = threadIdx.x, nthr = blockDim.x;
   const int wv = tid >> 6, lane = tid & 63, m16 = lane & 15, q4 = lane >> 4;
@@ -1089,6 +1109,11 @@ __device__ __forceinline__ void fit_body(const FitArgs &a, const long long slot,
     store_theta(L, n, sm, m_g);
     store_theta(L, n, sv, v_g);
   }
+  if constexpr (WIDE) {  // m / v back to the packed order (the LDS copy of theta is stored)
+    __syncthreads();
+    TileOrder<WIDE ? SHAPE : 1>::convert(m_g, smem, false);
+    TileOrder<WIDE ? SHAPE : 1>::convert(v_g, smem, false);
+  }
   if (tid == 0) a.at[model] = t0 + (long long)a.epochs * steps;
 }
 
@@ -1275,6 +1300,14 @@ __global__ __launch_bounds__(BORE_THREADS) void fit_bf16_mfma_kernel(const FitBf
   const int wv = tid >> 6, lane = tid & 63, m16 = lane & 15, q4 = lane >> 4;
   const long long model = blockIdx.x;
   const int N = a.N;
+  float *theta_g = a.theta + model * P;
+  float *m_g = a.am + model * P;
+  float *v_g = a.av + model * P;
+  // the per-parameter state goes to tile order for the launch (TileOrder, fit_bf16_mfma.h)
+  using TO = TileOrder<SHAPE>;
+  TO::convert(theta_g, smem, true);
+  TO::convert(m_g, smem, true);
+  TO::convert(v_g, smem, true);
   for (int i = tid; i < (a.total >> 2); i += nthr) smem[i] = 0.f;
   __syncthreads();
   char *base = reinterpret_cast<char *>(smem);
@@ -1289,12 +1322,9 @@ __global__ __launch_bounds__(BORE_THREADS) void fit_bf16_mfma_kernel(const FitBf
   unsigned *keys = reinterpret_cast<unsigned *>(base + a.o_keys);
   const int PG = a.perm ? 1 : perm_group(N, BORE_THREADS);
 
-  float *theta_g = a.theta + model * P;
-  float *m_g = a.am + model * P;
-  float *v_g = a.av + model * P;
   const float *X_g = a.X + model * (long long)N * D;
   const float *z_g = a.z + model * (long long)N;
-  for (int p = tid; p < P; p += nthr) bf16_put<SHAPE>(wf, wb, bias, p, theta_g[p]);
+  for (int p = tid; p < P; p += nthr) bf16_put<SHAPE>(wf, wb, bias, p, theta_g[TO::index(p)]);
 
   const long long t0 = a.at[model];
   double b1p = pow((double)a.beta1, (double)t0);
@@ -1397,84 +1427,109 @@ __global__ __launch_bounds__(BORE_THREADS) void fit_bf16_mfma_kernel(const FitBf
         // They are requested TWO tiles ahead of use and ahead of the stores in between (loads and
         // stores share one counter); the new weights go to HBM and, rounded, into the LDS images. ----
         constexpr int TPW = Pl::tiles_per_wave(), TOTAL = Pl::total_tiles(), AHEAD = 3;
+        constexpr int RING = AHEAD + 2;  // (tile I - 1 is still in use when tile I + AHEAD is requested)
         typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
         // (lane coordinates re-derived from an opaque copy of the thread id: computed from the
         // loop-invariant ones, the slot indices of all tiles are hoisted out of the step loop and
         // kept live across it -- 22 tiles x 10 registers, most of them spilled)
         const int wv = __builtin_amdgcn_readfirstlane(tid_o >> 6), lane = tid_o & 63, m16 = lane & 15, q4 = lane >> 4;
         const int qa = lane & 3, m4 = m16 & ~3;
-        f4u pw[AHEAD + 1], pm[AHEAD + 1], pv[AHEAD + 1];
-        float bw[AHEAD + 1], bm[AHEAD + 1], bv[AHEAD + 1];
+        f4u pw[RING], pm[RING], pv[RING];
+        float bw[RING], bm[RING], bv[RING];
         static_assert(Pl::layers_aligned() && TOTAL % 4 == 0, "tiles of a layer must start at a multiple of 4");
-        // this lane's slots of tile t = wave + 4 I (layer l known at compile time): kb / cb = the
-        // tile's block row / column, p4 = packed index of the lane's four contiguous weights, pb = of
-        // its bias
-        auto slots = [&](auto ic, int &kb, int &cb, int &p4, bool &ok4, int &pb, bool &okb) {
+        const bool odd = qa & 1, hi2 = qa & 2;
+        // this lane's slots of tile t = wave + 4 I (layer l known at compile time): kb / cb = the tile's
+        // block row / column; the packed index of the lane's four contiguous weights is split into a
+        // wave-uniform part pu (scalar registers; added to the base pointer) and a lane part lb4 (bytes,
+        // one register per layer width) so that every access is base + 32-bit lane offset; pbu / m16 =
+        // the same for its bias.  Layers whose K and width are multiples of 16 need no predicates.
+        auto slots = [&](auto ic, int &kb, int &cb, int &pu, unsigned &lb4, bool &ok4, int &pbu, bool &okb) {
           constexpr int I = decltype(ic)::value, l = Pl::layer_of_tile(4 * I);
           constexpr int K = L.w[l - 1], Nw = L.w[l], ncb = Pl::T(l);
+          constexpr bool FULL = K % 16 == 0 && Nw % 16 == 0;
           const int r = wv + 4 * I - Pl::tiles_before(l);
           kb = r / ncb;
           cb = r - kb * ncb;
           if constexpr (Nw == 1) {  // one column: the C layout's four rows ARE contiguous (lanes m = 0)
-            p4 = L.goff_w[l] + 16 * kb + 4 * q4;
+            pu = L.goff_w[l] + 16 * kb;
+            lb4 = 16u * (unsigned)q4;
             ok4 = m16 == 0 && 16 * kb + 4 * q4 < K;
+          } else if constexpr (FULL) {  // tile order: tile (kb, cb) = 256 consecutive floats, the lane's at 4 * lane
+            pu = L.goff_w[l] + (kb * ncb + cb) * 256;
+            lb4 = 16u * (unsigned)lane;
+            ok4 = true;
           } else {
-            p4 = L.goff_w[l] + (16 * kb + 4 * q4 + qa) * Nw + 16 * cb + m4;
+            pu = L.goff_w[l] + 16 * kb * Nw + 16 * cb;
+            lb4 = 4u * (unsigned)((4 * q4 + qa) * Nw + m4);
             ok4 = 16 * kb + 4 * q4 + qa < K && 16 * cb + m4 < Nw;
           }
-          okb = kb == 0 && q4 == 0 && 16 * cb + m16 < Nw;
-          pb = L.goff_b[l] + 16 * cb + m16;
+          okb = kb == 0 && q4 == 0 && (FULL || 16 * cb + m16 < Nw);
+          pbu = L.goff_b[l] + 16 * cb;
         };
+        // buffer addressing (resource + 32-bit lane offset + scalar offset): one instruction per access
+        // and no 64-bit address arithmetic (as flat pointers every access cost a 64-bit vector add)
+        const BufF32 b_th(theta_g, P), b_m(m_g, P), b_v(v_g, P);
+        const unsigned lbb = 4u * (unsigned)m16;
         auto request = [&](auto ic) {
-          constexpr int I = decltype(ic)::value;
-          int kb, cb, p4, pb;
+          constexpr int I = decltype(ic)::value, l = Pl::layer_of_tile(4 * I);
+          constexpr bool FULL = L.w[l - 1] % 16 == 0 && L.w[l] % 16 == 0;
+          int kb, cb, pu, pbu;
+          unsigned lb4;
           bool ok4, okb;
-          slots(ic, kb, cb, p4, ok4, pb, okb);
+          slots(ic, kb, cb, pu, lb4, ok4, pbu, okb);
           const f4u z4 = {0.f, 0.f, 0.f, 0.f};
-          pw[I % (AHEAD + 1)] = ok4 ? *reinterpret_cast<const f4u *>(theta_g + p4) : z4;
-          pm[I % (AHEAD + 1)] = ok4 ? *reinterpret_cast<const f4u *>(m_g + p4) : z4;
-          pv[I % (AHEAD + 1)] = ok4 ? *reinterpret_cast<const f4u *>(v_g + p4) : z4;
+          if constexpr (FULL) {
+            pw[I % RING] = b_th.ld4(pu, lb4);
+            pm[I % RING] = b_m.ld4(pu, lb4);
+            pv[I % RING] = b_v.ld4(pu, lb4);
+          } else {
+            pw[I % RING] = ok4 ? b_th.ld4(pu, lb4) : z4;
+            pm[I % RING] = ok4 ? b_m.ld4(pu, lb4) : z4;
+            pv[I % RING] = ok4 ? b_v.ld4(pu, lb4) : z4;
+          }
           if (kb == 0) {  // (wave-uniform: only these tiles carry a bias)
-            bw[I % (AHEAD + 1)] = okb ? theta_g[pb] : 0.f;
-            bm[I % (AHEAD + 1)] = okb ? m_g[pb] : 0.f;
-            bv[I % (AHEAD + 1)] = okb ? v_g[pb] : 0.f;
+            bw[I % RING] = okb ? b_th.ld1(pbu, lbb) : 0.f;
+            bm[I % RING] = okb ? b_m.ld1(pbu, lbb) : 0.f;
+            bv[I % RING] = okb ? b_v.ld1(pbu, lbb) : 0.f;
           }
         };
         static_for<0, (AHEAD < TPW ? AHEAD : TPW)>([&](auto ic) { request(ic); });
-        static_for<0, TPW>([&](auto ic) {
+        // Software pipeline, two stages per tile: FRONT(I) = the tile's two MFMAs on operands that were
+        // read from LDS one iteration earlier, then the reads for tile I + 1; FINISH(I - 1) = transpose,
+        // Adam, stores of the previous tile.  Both sit in one scheduling region, so the LDS and MFMA
+        // latencies of one tile run under the other's vector arithmetic (one wave per SIMD: nobody
+        // else hides them; in tile-after-tile form they were half of the phase).
+        u32x4_t oa0, oa1, ob0, ob1;
+        auto fetch = [&](auto ic) {
           constexpr int I = decltype(ic)::value, l = Pl::layer_of_tile(4 * I);
-          constexpr int Nw = L.w[l];
-          if constexpr (I + AHEAD < TPW) request(std::integral_constant<int, I + AHEAD>{});
-          int kb, cb, p4, pb;
+          int kb, cb, pu, pbu;
+          unsigned lb4;
           bool ok4, okb;
-          slots(ic, kb, cb, p4, ok4, pb, okb);
+          slots(ic, kb, cb, pu, lb4, ok4, pbu, okb);
           // rows 32c + 8 q4 .. + 7 of unit row 16 kb|cb + m16: chunk 4c + q4, swizzled (Bf16Plan::t_index)
           const int ua = 16 * kb + m16, ub = 16 * cb + m16;
           const unsigned short *ap = img + Pl::at_off(l - 1) + ua * RS, *bp = img + Pl::dt_off(l) + ub * RS;
           const int sa = (ua >> 1) & 7, sb = (ub >> 1) & 7;
-          const u32x4_t a0 = *reinterpret_cast<const u32x4_t *>(ap + ((q4 ^ sa) << 3)),
-                        a1 = *reinterpret_cast<const u32x4_t *>(ap + (((4 + q4) ^ sa) << 3));
-          const u32x4_t b0 = *reinterpret_cast<const u32x4_t *>(bp + ((q4 ^ sb) << 3)),
-                        b1 = *reinterpret_cast<const u32x4_t *>(bp + (((4 + q4) ^ sb) << 3));
-          __builtin_amdgcn_sched_barrier(0);
-          f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a0), __builtin_bit_cast(bf16x8_t, b0), acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a1), __builtin_bit_cast(bf16x8_t, b1), acc, 0, 0, 0);
+          oa0 = *reinterpret_cast<const u32x4_t *>(ap + ((q4 ^ sa) << 3));
+          oa1 = *reinterpret_cast<const u32x4_t *>(ap + (((4 + q4) ^ sa) << 3));
+          ob0 = *reinterpret_cast<const u32x4_t *>(bp + ((q4 ^ sb) << 3));
+          ob1 = *reinterpret_cast<const u32x4_t *>(bp + (((4 + q4) ^ sb) << 3));
+        };
+        fetch(std::integral_constant<int, 0>{});
+        f32x4 acc_prev = {0.f, 0.f, 0.f, 0.f};
+        float bs_prev = 0.f;
+        auto finish = [&](auto ic, const f32x4 &acc, const float bs) {
+          constexpr int I = decltype(ic)::value, l = Pl::layer_of_tile(4 * I);
+          constexpr int Nw = L.w[l];
+          int kb, cb, pu, pbu;
+          unsigned lb4;
+          bool ok4, okb;
+          slots(ic, kb, cb, pu, lb4, ok4, pbu, okb);
           float g[4] = {acc[0], acc[1], acc[2], acc[3]};
-          if constexpr (Nw != 1) {  // 4 x 4 transpose inside the lane quad: g[jj] <- lane jj's g[qa]
-            float x = (qa & 1) ? g[0] : g[1], y = (qa & 1) ? g[2] : g[3];
-            x = __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(x), 0xB1, 0xF, 0xF, true));
-            y = __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(y), 0xB1, 0xF, 0xF, true));
-            if (qa & 1) { g[0] = x; g[2] = y; } else { g[1] = x; g[3] = y; }
-            x = (qa & 2) ? g[0] : g[2];
-            y = (qa & 2) ? g[1] : g[3];
-            x = __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(x), 0x4E, 0xF, 0xF, true));
-            y = __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(y), 0x4E, 0xF, 0xF, true));
-            if (qa & 2) { g[0] = x; g[1] = y; } else { g[2] = x; g[3] = y; }
-          }
+          if constexpr (Nw != 1) quad_transpose4(g, odd, hi2);  // lane a = m & 3 <- dW_l[16kb + 4q + a][16cb + m4 + 0..3]
           // Adam (ResourceApplyAdam form; v_sqrt_f32 / v_rcp_f32, 1 ulp: the new weight is rounded to
           // bfloat16 for the next step anyway and the master copy carries 24 bits either way)
-          constexpr int cur = I % (AHEAD + 1);
+          constexpr int cur = I % RING;
           float wn[4];
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
@@ -1489,9 +1544,9 @@ __global__ __launch_bounds__(BORE_THREADS) void fit_bf16_mfma_kernel(const FitBf
           for (int r = 0; r < 4; ++r) asm volatile("" : "+v"(wn[r]));
           if (ok4) {
             const f4u w4 = {wn[0], wn[1], wn[2], wn[3]};
-            *reinterpret_cast<f4u *>(theta_g + p4) = w4;
-            *reinterpret_cast<f4u *>(m_g + p4) = pm[cur];
-            *reinterpret_cast<f4u *>(v_g + p4) = pv[cur];
+            b_th.st4(w4, pu, lb4);
+            b_m.st4(pm[cur], pu, lb4);
+            b_v.st4(pv[cur], pu, lb4);
           }
           // the LDS images (fragment orders: fit_bf16_mfma.h) and the float copies
           if (ok4) {
@@ -1513,31 +1568,48 @@ __global__ __launch_bounds__(BORE_THREADS) void fit_bf16_mfma_kernel(const FitBf
                 *reinterpret_cast<uint2 *>(wb + Pl::wb_off(l) + ((kb * Pl::CB(l) + (cb >> 1)) * 64 + (m16 >> 2) * 16 + 4 * q4 + qa) * 8 + (cb & 1) * 4) = h4;
             }
           }
-          if (kb == 0) {  // bias: gradient = the sums of D_l's columns = of this lane's 16 rows, then of the 4 lane rows
-            float bs = 0.f;
-#pragma unroll
-            for (int w = 0; w < 4; ++w) {
-              bs += __uint_as_float(b0[w] << 16);
-              bs += __uint_as_float(b0[w] & 0xffff0000u);
-            }
-#pragma unroll
-            for (int w = 0; w < 4; ++w) {
-              bs += __uint_as_float(b1[w] << 16);
-              bs += __uint_as_float(b1[w] & 0xffff0000u);
-            }
+          if (kb == 0) {  // bias: gradient = the sums of D_l's columns = of this lane's 16 rows (bs), then of the 4 lane rows
             const float gb = rows_sum4(bs);
             float mm = bm[cur], vv = bv[cur];
             mm += (gb - mm) * omb1;
             vv += (gb * gb - vv) * omb2;
             const float wnb = bw[cur] - (mm * alpha) * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(vv) + a.eps);
             if (okb) {
-              theta_g[pb] = wnb;
-              m_g[pb] = mm;
-              v_g[pb] = vv;
+              b_th.st1(wnb, pbu, lbb);
+              b_m.st1(mm, pbu, lbb);
+              b_v.st1(vv, pbu, lbb);
               bias[Pl::bias_off(l) + 16 * cb + m16] = bf16_round_hw(wnb);
             }
           }
+        };
+        static_for<0, TPW + 1>([&](auto ic) {
+          constexpr int I = decltype(ic)::value;
+          f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+          float bs = 0.f;
+          if constexpr (I < TPW) {
+            constexpr int l = Pl::layer_of_tile(4 * I);
+            if constexpr (I + AHEAD < TPW) request(std::integral_constant<int, I + AHEAD>{});
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, oa0), __builtin_bit_cast(bf16x8_t, ob0), acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, oa1), __builtin_bit_cast(bf16x8_t, ob1), acc, 0, 0, 0);
+            const int r = wv + 4 * I - Pl::tiles_before(l);
+            if (r < Pl::T(l)) {  // kb == 0 (wave-uniform): the tile carries its columns' bias
+#pragma unroll
+              for (int w = 0; w < 4; ++w) {
+                bs += __uint_as_float(ob0[w] << 16);
+                bs += __uint_as_float(ob0[w] & 0xffff0000u);
+              }
+#pragma unroll
+              for (int w = 0; w < 4; ++w) {
+                bs += __uint_as_float(ob1[w] << 16);
+                bs += __uint_as_float(ob1[w] & 0xffff0000u);
+              }
+            }
+            if constexpr (I + 1 < TPW) fetch(std::integral_constant<int, I + 1>{});
+          }
+          if constexpr (I > 0) finish(std::integral_constant<int, I - 1>{}, acc_prev, bs_prev);
           __builtin_amdgcn_sched_barrier(0);
+          acc_prev = acc;
+          bs_prev = bs;
         });
         BORE_WSTAMP(6);
         BORE_WSTAMP(8);
@@ -1559,6 +1631,11 @@ __global__ __launch_bounds__(BORE_THREADS) void fit_bf16_mfma_kernel(const FitBf
         a.epoch_loss[model * a.epochs + e] = (misc[1] + misc[2] + misc[3] + misc[4]) / (float)N;
     }
   }
+  // back to the packed order (the LDS images are dead by now)
+  __syncthreads();
+  TO::convert(theta_g, smem, false);
+  TO::convert(m_g, smem, false);
+  TO::convert(v_g, smem, false);
   if (tid == 0) a.at[model] = t0 + (long long)a.epochs * steps;
 }
 

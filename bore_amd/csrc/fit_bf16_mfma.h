@@ -204,6 +204,63 @@ __device__ __forceinline__ Bf16Where<SHAPE> bf16_where(int p) {
   return r;
 }
 
+// ---------------------------------------------------------------------------------------------
+// TILE ORDER of the per-parameter state (theta master / m / v in HBM) while a wide fit runs.
+// The weight-gradient phase updates W_l in 16 x 16 tiles; after the quad transpose lane (q, m) owns
+// rows 16kb + 4q + (m & 3), columns 16cb + (m & ~3) + 0..3.  In the packed (Keras) order one tile is
+// 16 row pieces of 64 bytes, every 128-byte line shared with the neighbouring tile: each 16-byte
+// load / store instruction of a wave touches 16 half lines, and the CU's one vector-memory pipe --
+// 12 such instructions per tile -- bounded the phase (measured: removing either the loads or the
+// stores took 4.5 us off a 18.5 us step).  For the duration of the launch the weights of every
+// layer whose K and width are multiples of 16 are therefore kept in tile order: tile (kb, cb) =
+// 256 consecutive floats, lane's four at 4 * lane -- one instruction = 1 KiB contiguous = 8 full
+// lines.  The kernel permutes theta / m / v in place on entry and back on exit (staged through
+// LDS, a few microseconds per launch); biases and a one-column last layer stay where they are.
+// ---------------------------------------------------------------------------------------------
+template <int SHAPE>
+struct TileOrder {
+  static constexpr MlpLayout L = bore_static_layout(SHAPE, 1, BORE_BATCH_MAX);
+  static constexpr int n = L.n_layers;
+  static constexpr bool full(int l) { return L.w[l - 1] % 16 == 0 && L.w[l] % 16 == 0 && L.w[l] != 1; }
+  // offset inside layer l's weight block of element q = k * Nw + j (packed) in tile order
+  static __device__ __forceinline__ int local(int l_Nw, int q) {
+    const int k = q / l_Nw, j = q - k * l_Nw;
+    const int kb = k >> 4, q4 = (k >> 2) & 3, qa = k & 3, cb = j >> 4, m4 = j & 12, jj = j & 3;
+    return (kb * (l_Nw >> 4) + cb) * 256 + (16 * q4 + m4 + qa) * 4 + jj;
+  }
+  // position of packed parameter p during the launch
+  static __device__ __forceinline__ int index(int p) {
+    int r = p;
+#pragma unroll
+    for (int l = 1; l <= n; ++l)
+      if (full(l) && p >= L.goff_w[l] && p < L.goff_b[l]) r = L.goff_w[l] + local(L.w[l], p - L.goff_w[l]);
+    return r;
+  }
+  // in-place conversion of one array (all threads of the workgroup; stage = LDS, >= the largest
+  // weight block; ends with a barrier).  to_tiles: packed -> tile order, else the way back.
+  static __device__ __forceinline__ void convert(float *g, float *stage, bool to_tiles) {
+#pragma unroll
+    for (int l = 1; l <= n; ++l) {
+      if (!full(l)) continue;
+      const int cnt = L.w[l - 1] * L.w[l], Nw = L.w[l];
+      float *blk = g + L.goff_w[l];
+      for (int q = threadIdx.x; q < cnt; q += blockDim.x) {
+        if (to_tiles) stage[local(Nw, q)] = blk[q];
+        else stage[q] = blk[local(Nw, q)];
+      }
+      __syncthreads();
+      for (int q = threadIdx.x; q < cnt; q += blockDim.x) blk[q] = stage[q];
+      __syncthreads();
+    }
+  }
+  static constexpr int stage_floats() {
+    int m = 0;
+    for (int l = 1; l <= n; ++l)
+      if (full(l) && L.w[l - 1] * L.w[l] > m) m = L.w[l - 1] * L.w[l];
+    return m;
+  }
+};
+
 // write parameter p's new value into the LDS images (bf16 weights in both fragment orders, the
 // bias as the float32 value of its bfloat16 rounding)
 template <int SHAPE>

@@ -67,6 +67,49 @@ __device__ __forceinline__ float rows_sum4(float s) {
   return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
 
+// 4 x 4 transpose inside every lane quad: g[j] <- (lane of the quad with lane & 3 == j)'s g[lane & 3].
+// Two butterfly stages (quad_perm [1,0,3,2], then [2,3,0,1]), written as selects on purpose:
+// if / else assignments to g[] compile to execution-mask branches and per-register compares
+// (60 instructions instead of 16).  odd = lane & 1, hi = lane & 2.
+__device__ __forceinline__ float quad_xchg(float x, bool far) {
+  const unsigned u = __float_as_uint(x);
+  return __uint_as_float(far ? __builtin_amdgcn_update_dpp(0u, u, 0x4E, 0xF, 0xF, true)
+                             : __builtin_amdgcn_update_dpp(0u, u, 0xB1, 0xF, 0xF, true));
+}
+__device__ __forceinline__ void quad_transpose4(float (&g)[4], bool odd, bool hi) {
+  const float x = quad_xchg(odd ? g[0] : g[1], false), y = quad_xchg(odd ? g[2] : g[3], false);
+  const float a0 = odd ? x : g[0], a1 = odd ? g[1] : x, a2 = odd ? y : g[2], a3 = odd ? g[3] : y;
+  const float s = quad_xchg(hi ? a0 : a2, true), t = quad_xchg(hi ? a1 : a3, true);
+  g[0] = hi ? s : a0;
+  g[1] = hi ? t : a1;
+  g[2] = hi ? a2 : s;
+  g[3] = hi ? a3 : t;
+}
+
+// A float array addressed as a raw buffer: element offset u (wave-uniform: scalar register) + byte
+// offset lb of the lane.  buffer_load / buffer_store take both, so an access is one instruction;
+// the same access through a flat pointer costs a 64-bit vector add first.  Accesses past the
+// array read zero / are dropped (the descriptor carries the size), which nothing relies on.
+struct BufF32 {
+  typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+  typedef unsigned u4 __attribute__((ext_vector_type(4)));
+  __amdgpu_buffer_rsrc_t r;
+  __device__ __forceinline__ BufF32(float *base, int n_floats)
+      : r(__builtin_amdgcn_make_buffer_rsrc(base, 0, n_floats * 4, 0x00020000)) {}
+  __device__ __forceinline__ f4u ld4(int u, unsigned lb) const {
+    return __builtin_bit_cast(f4u, __builtin_amdgcn_raw_buffer_load_b128(r, (int)lb, u * 4, 0));
+  }
+  __device__ __forceinline__ float ld1(int u, unsigned lb) const {
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)lb, u * 4, 0));
+  }
+  __device__ __forceinline__ void st4(f4u v, int u, unsigned lb) const {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, v), r, (int)lb, u * 4, 0);
+  }
+  __device__ __forceinline__ void st1(float v, int u, unsigned lb) const {
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, (int)lb, u * 4, 0);
+  }
+};
+
 // Lanes of ONE wave exchange data through LDS between two program points: all of the
 // wave's earlier LDS accesses complete and the compiler may not move memory operations
 // across (a wave runs in lock-step, so no s_barrier is involved).
