@@ -508,7 +508,9 @@ __device__ __forceinline__ void lbfgsb_body(const LbfgsbArgs &a, const long long
                                             const int block_y, const int it_now = -1) {
   extern __shared__ float smem[];
   constexpr MlpLayout Lc = bore_static_layout(SHAPE > 0 ? SHAPE : 0, 2, BORE_BATCH_MAX);
+  const long long c_enter = BORE_LCLOCK();
   const MlpLayout &L = begin_kernel<SHAPE>(Lc, a.L, smem, a.total, a.o_layout);
+  const long long c_begun = BORE_LCLOCK();
   const int tid = threadIdx.x;
   const int wv = tid >> 6, lane = tid & 63;
   // `model` is the slot: it indexes x0 / x / fun / jac / info
@@ -540,6 +542,7 @@ __device__ __forceinline__ void lbfgsb_body(const LbfgsbArgs &a, const long long
   const int myrow = coop ? wv * 16 : wv * 16 + lane;
   const lbfgsb::Coop cp = coop ? lbfgsb::Coop{lane, 64} : lbfgsb::Coop{0, 1};
   __syncthreads();  // weights staged; from here on the waves are independent
+  const long long c_staged = BORE_LCLOCK();
   if (wv >= np) return;  // wave without problems (np < 4)
   double *res = reinterpret_cast<double *>(smem + a.o_res);  // batch mode: [np][D + 3] fun, status, nfev, x
   int *cnt = reinterpret_cast<int *>(res + (multi ? np : 4) * (D + 3));
@@ -574,6 +577,7 @@ __device__ __forceinline__ void lbfgsb_body(const LbfgsbArgs &a, const long long
     }
   }
   bool done = (myp < 0);
+  const long long c_init = BORE_LCLOCK();
   long long t_adv = 0, t_fg = 0, n_rounds = 0;
   for (int round = 0; round < a.max_rounds; ++round) {
     int pending = 0;
@@ -648,10 +652,12 @@ __device__ __forceinline__ void lbfgsb_body(const LbfgsbArgs &a, const long long
     t_fg += BORE_LCLOCK() - c1;
     ++n_rounds;
   }
-  (void)t_adv; (void)t_fg; (void)n_rounds;
+  (void)t_adv; (void)t_fg; (void)n_rounds; (void)c_enter; (void)c_begun; (void)c_staged; (void)c_init;
 #ifdef BORE_STAMPS
   if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) {
     g_lstamps[0] = t_adv; g_lstamps[1] = t_fg; g_lstamps[2] = n_rounds; g_lstamps[3] = st.nit;
+    g_lstamps[4] = c_begun - c_enter; g_lstamps[5] = c_staged - c_begun; g_lstamps[6] = c_init - c_staged;
+    g_lstamps[7] = BORE_LCLOCK() - c_enter;
   }
   if (coop && lane == 0 && 4 * blockIdx.x + wv < LB_PP_MAX) {
     atomicAdd(&lbfgsb::g_lb_pp[4 * blockIdx.x + wv][7], (unsigned long long)t_adv);
