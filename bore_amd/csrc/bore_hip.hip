@@ -482,10 +482,10 @@ __device__ __forceinline__ void wide_adam(void *th_lds, const float *gl, float *
 //    on distinct banks);
 //  * the four waves' i-th tiles lie in ONE layer, known at compile time (static_for): no per-tile
 //    layer dispatch;
-//  * the wave that formed a tile updates it: a 4 x 4 transpose inside every lane quad (two DPP
-//    exchanges) makes lane a = m & 3 own dW_l[16kb + 4q + a][16cb + (m & ~3) + 0..3] -- contiguous in
-//    the packed vector, so m and v are ONE 16-byte load and store each per tile and lane, requested
-//    three tiles ahead (and ahead of the stores in between: loads and stores share a counter).
+//  * the wave that formed a tile updates it; m and v are held in the MFMA's own result layout for the
+//    launch (TileOrder, fit_bf16_mfma.h), so they are ONE 16-byte load and store each per tile and lane,
+//    1 KiB contiguous per wave, requested three tiles ahead (and ahead of the stores in between:
+//    loads and stores share a counter).
 // ---------------------------------------------------------------------------------------------
 template <int SHAPE>
 struct WideTp {
@@ -543,15 +543,12 @@ __device__ __forceinline__ void wide_fused_f32(float *th, const float *img, floa
   static_assert(Tp::aligned() && TOTAL % 4 == 0, "tiles of a layer must start at a multiple of 4");
   typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
   const int wv = __builtin_amdgcn_readfirstlane(tid_o >> 6), lane = tid_o & 63, m16 = lane & 15, q4 = lane >> 4;
-  const int qa = lane & 3, m4 = m16 & ~3;
   constexpr int RING = AHEAD + 2;  // (tile I - 1 is still in use when tile I + AHEAD is requested)
   f4u pm[RING], pv[RING];
   float bm[RING], bv[RING];
-  const bool odd = qa & 1, hi2 = qa & 2;
-  // The packed index of the lane's four contiguous slots = a wave-uniform part pu (scalar) + a lane
-  // part lb4 (bytes); m / v are addressed as buffers (resource + lane offset + scalar offset: one
-  // instruction per access, no 64-bit address arithmetic).  pbu / 4 m16 = the same for the bias.
-  // Layers whose K and width are multiples of 16 need no predicates.
+  // m / v are kept in tile order for the launch (TileOrder, fit_bf16_mfma.h: the MFMA's result layout,
+  // tile (kb, cb) = 256 consecutive floats) and addressed as buffers: index = a wave-uniform part pu
+  // (scalar) + the lane's byte offset lb4; pbu / 4 m16 = the same for the bias.
   constexpr int P = L.P;
   const BufF32 b_m(m_g, P), b_v(v_g, P);
   const unsigned lbb = 4u * (unsigned)m16;
@@ -566,14 +563,11 @@ __device__ __forceinline__ void wide_fused_f32(float *th, const float *img, floa
       pu = L.goff_w[l] + 16 * kb;
       lb4 = 16u * (unsigned)q4;
       ok4 = m16 == 0 && 16 * kb + 4 * q4 < K;
-    } else if constexpr (FULL) {  // tile order: tile (kb, cb) = 256 consecutive floats, the lane's at 4 * lane
+    } else {  // tile order: tile (kb, cb) = 256 consecutive floats, the lane's four at 4 * lane
+      static_assert(FULL, "a wide static shape has layer sizes that are multiples of 16");
       pu = L.goff_w[l] + (kb * ncb + cb) * 256;
       lb4 = 16u * (unsigned)lane;
       ok4 = true;
-    } else {
-      pu = L.goff_w[l] + 16 * kb * Nw + 16 * cb;
-      lb4 = 4u * (unsigned)((4 * q4 + qa) * Nw + m4);
-      ok4 = 16 * kb + 4 * q4 + qa < K && 16 * cb + m4 < Nw;
     }
     okb = kb == 0 && q4 == 0 && (FULL || 16 * cb + m16 < Nw);
     pbu = L.goff_b[l] + 16 * cb;
@@ -611,11 +605,12 @@ __device__ __forceinline__ void wide_fused_f32(float *th, const float *img, floa
     unsigned lb4;
     bool ok4, okb;
     slots(ic, kb, cb, pu, lb4, ok4, pbu, okb);
-    float g[4] = {acc[0], acc[1], acc[2], acc[3]};
-    if constexpr (Nw != 1) quad_transpose4(g, odd, hi2);  // g[jj] <- lane jj's g[qa]
+    // g[r] = dW_l[16kb + 4q + r][16cb + m]: the tile order of m / v IS this layout
+    const float g[4] = {acc[0], acc[1], acc[2], acc[3]};
     // this lane's four weights in the padded LDS image of theta
-    const int li0 = Nw == 1 ? L.woff[l] + (16 * kb + 4 * q4) * ldw : L.woff[l] + (16 * kb + 4 * q4 + qa) * ldw + 16 * cb + m4;
-    constexpr int lstep = Nw == 1 ? ldw : 1;
+    static_assert(Nw == 1 || (L.w[l - 1] % 16 == 0 && Nw % 16 == 0), "tile-order layers only");
+    const int li0 = Nw == 1 ? L.woff[l] + (16 * kb + 4 * q4) * ldw : L.woff[l] + (16 * kb + 4 * q4) * ldw + 16 * cb + m16;
+    constexpr int lstep = ldw;
     constexpr int cur = I % RING;
     float w[4], wn[4];
 #pragma unroll
@@ -1419,13 +1414,12 @@ __global__ __launch_bounds__(BORE_THREADS) void fit_bf16_mfma_kernel(const FitBf
       {
         // ---- weight gradients + Adam, tile by tile: this wave's tiles t = wave, wave + 4, ...  A tile
         // is two MFMAs (k = the 64 batch rows) and leaves lane (q, m) holding dW_l[16kb + 4q + r][16cb + m],
-        // r = 0..3 -- four elements a whole row of W_l apart in the packed vector.  The four lanes of a
-        // quad transpose their 4 x 4 block (two DPP exchanges), after which lane a = m & 3 owns
-        // dW_l[16kb + 4q + a][16cb + (m & ~3) + 0..3]: CONTIGUOUS, so the master weight / m / v of a
-        // tile are one 16-byte load and store each per lane -- the CU's one vector-memory pipe, at
-        // 30 dword instructions per tile and wave, was what bounded this phase (62 k cycles a step).
-        // They are requested TWO tiles ahead of use and ahead of the stores in between (loads and
-        // stores share one counter); the new weights go to HBM and, rounded, into the LDS images. ----
+        // r = 0..3.  The master weight / m / v are kept in exactly that order for the launch
+        // (TileOrder, fit_bf16_mfma.h): one 16-byte load and store each per lane and tile, 1 KiB
+        // contiguous per wave -- the CU's one vector-memory pipe was what bounded this phase (30 dword
+        // instructions per tile, then 12 16-byte ones on half lines).  They are requested three tiles
+        // ahead of use and ahead of the stores in between (loads and stores share one counter); the
+        // new weights go to HBM and, rounded, into the LDS images. ----
         constexpr int TPW = Pl::tiles_per_wave(), TOTAL = Pl::total_tiles(), AHEAD = 3;
         constexpr int RING = AHEAD + 2;  // (tile I - 1 is still in use when tile I + AHEAD is requested)
         typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
@@ -1433,16 +1427,12 @@ __global__ __launch_bounds__(BORE_THREADS) void fit_bf16_mfma_kernel(const FitBf
         // loop-invariant ones, the slot indices of all tiles are hoisted out of the step loop and
         // kept live across it -- 22 tiles x 10 registers, most of them spilled)
         const int wv = __builtin_amdgcn_readfirstlane(tid_o >> 6), lane = tid_o & 63, m16 = lane & 15, q4 = lane >> 4;
-        const int qa = lane & 3, m4 = m16 & ~3;
         f4u pw[RING], pm[RING], pv[RING];
         float bw[RING], bm[RING], bv[RING];
         static_assert(Pl::layers_aligned() && TOTAL % 4 == 0, "tiles of a layer must start at a multiple of 4");
-        const bool odd = qa & 1, hi2 = qa & 2;
         // this lane's slots of tile t = wave + 4 I (layer l known at compile time): kb / cb = the tile's
-        // block row / column; the packed index of the lane's four contiguous weights is split into a
-        // wave-uniform part pu (scalar registers; added to the base pointer) and a lane part lb4 (bytes,
-        // one register per layer width) so that every access is base + 32-bit lane offset; pbu / m16 =
-        // the same for its bias.  Layers whose K and width are multiples of 16 need no predicates.
+        // block row / column; the index of the lane's four weights = a wave-uniform part pu (scalar
+        // registers) + a lane part lb4 (bytes); pbu / 4 m16 = the same for its bias
         auto slots = [&](auto ic, int &kb, int &cb, int &pu, unsigned &lb4, bool &ok4, int &pbu, bool &okb) {
           constexpr int I = decltype(ic)::value, l = Pl::layer_of_tile(4 * I);
           constexpr int K = L.w[l - 1], Nw = L.w[l], ncb = Pl::T(l);
@@ -1454,14 +1444,11 @@ __global__ __launch_bounds__(BORE_THREADS) void fit_bf16_mfma_kernel(const FitBf
             pu = L.goff_w[l] + 16 * kb;
             lb4 = 16u * (unsigned)q4;
             ok4 = m16 == 0 && 16 * kb + 4 * q4 < K;
-          } else if constexpr (FULL) {  // tile order: tile (kb, cb) = 256 consecutive floats, the lane's at 4 * lane
+          } else {  // tile order: tile (kb, cb) = 256 consecutive floats, the lane's four at 4 * lane
+            static_assert(FULL, "a wide static shape has layer sizes that are multiples of 16");
             pu = L.goff_w[l] + (kb * ncb + cb) * 256;
             lb4 = 16u * (unsigned)lane;
             ok4 = true;
-          } else {
-            pu = L.goff_w[l] + 16 * kb * Nw + 16 * cb;
-            lb4 = 4u * (unsigned)((4 * q4 + qa) * Nw + m4);
-            ok4 = 16 * kb + 4 * q4 + qa < K && 16 * cb + m4 < Nw;
           }
           okb = kb == 0 && q4 == 0 && (FULL || 16 * cb + m16 < Nw);
           pbu = L.goff_b[l] + 16 * cb;
@@ -1525,8 +1512,8 @@ __global__ __launch_bounds__(BORE_THREADS) void fit_bf16_mfma_kernel(const FitBf
           unsigned lb4;
           bool ok4, okb;
           slots(ic, kb, cb, pu, lb4, ok4, pbu, okb);
-          float g[4] = {acc[0], acc[1], acc[2], acc[3]};
-          if constexpr (Nw != 1) quad_transpose4(g, odd, hi2);  // lane a = m & 3 <- dW_l[16kb + 4q + a][16cb + m4 + 0..3]
+          // g[r] = dW_l[16kb + 4q + r][16cb + m]: the tile order of theta / m / v IS this layout
+          const float g[4] = {acc[0], acc[1], acc[2], acc[3]};
           // Adam (ResourceApplyAdam form; v_sqrt_f32 / v_rcp_f32, 1 ulp: the new weight is rounded to
           // bfloat16 for the next step anyway and the master copy carries 24 bits either way)
           constexpr int cur = I % RING;
@@ -1560,12 +1547,14 @@ __global__ __launch_bounds__(BORE_THREADS) void fit_bf16_mfma_kernel(const FitBf
               float4 f4;
               f4.x = bf16_to_f32(hs[0]); f4.y = bf16_to_f32(hs[1]); f4.z = bf16_to_f32(hs[2]); f4.w = bf16_to_f32(hs[3]);
               *reinterpret_cast<float4 *>(bias + Pl::wlast_off() + 16 * kb + 4 * q4) = f4;
-            } else {  // (k = 16kb + 4q + qa, columns 16cb + m4 + jj)
+            } else {  // (k = 16kb + 4q + r, column 16cb + m): four consecutive k-slots of one forward fragment
+              static_assert(L.w[l - 1] % 16 == 0 && L.w[l] % 16 == 0, "tile-order layers only");
+              *reinterpret_cast<uint2 *>(wf + Pl::wf_off(l) + ((cb * Pl::CF(l) + (kb >> 1)) * 64 + q4 * 16 + m16) * 8 + (kb & 1) * 4) = h4;
+              if constexpr (l >= 2) {
 #pragma unroll
-              for (int jj = 0; jj < 4; ++jj)
-                wf[Pl::wf_off(l) + ((cb * Pl::CF(l) + (kb >> 1)) * 64 + q4 * 16 + m4 + jj) * 8 + (kb & 1) * 4 + qa] = hs[jj];
-              if constexpr (l >= 2)
-                *reinterpret_cast<uint2 *>(wb + Pl::wb_off(l) + ((kb * Pl::CB(l) + (cb >> 1)) * 64 + (m16 >> 2) * 16 + 4 * q4 + qa) * 8 + (cb & 1) * 4) = h4;
+                for (int r = 0; r < 4; ++r)
+                  wb[Pl::wb_off(l) + ((kb * Pl::CB(l) + (cb >> 1)) * 64 + (m16 >> 2) * 16 + 4 * q4 + r) * 8 + (cb & 1) * 4 + (m16 & 3)] = hs[r];
+              }
             }
           }
           if (kb == 0) {  // bias: gradient = the sums of D_l's columns = of this lane's 16 rows (bs), then of the 4 lane rows

@@ -206,16 +206,18 @@ __device__ __forceinline__ Bf16Where<SHAPE> bf16_where(int p) {
 
 // ---------------------------------------------------------------------------------------------
 // TILE ORDER of the per-parameter state (theta master / m / v in HBM) while a wide fit runs.
-// The weight-gradient phase updates W_l in 16 x 16 tiles; after the quad transpose lane (q, m) owns
-// rows 16kb + 4q + (m & 3), columns 16cb + (m & ~3) + 0..3.  In the packed (Keras) order one tile is
-// 16 row pieces of 64 bytes, every 128-byte line shared with the neighbouring tile: each 16-byte
-// load / store instruction of a wave touches 16 half lines, and the CU's one vector-memory pipe --
-// 12 such instructions per tile -- bounded the phase (measured: removing either the loads or the
-// stores took 4.5 us off a 18.5 us step).  For the duration of the launch the weights of every
-// layer whose K and width are multiples of 16 are therefore kept in tile order: tile (kb, cb) =
-// 256 consecutive floats, lane's four at 4 * lane -- one instruction = 1 KiB contiguous = 8 full
-// lines.  The kernel permutes theta / m / v in place on entry and back on exit (staged through
-// LDS, a few microseconds per launch); biases and a one-column last layer stay where they are.
+// The weight-gradient phase updates W_l in 16 x 16 tiles; the MFMA leaves lane (q, m) holding rows
+// 16kb + 4q + 0..3 of column 16cb + m.  In the packed (Keras) order those four are a whole row of W_l
+// apart (4-byte accesses), and even after a 4 x 4 transpose inside the lane quads (four contiguous
+// columns per lane, 16-byte accesses) one tile is 16 row pieces of 64 bytes, every 128-byte line
+// shared with the neighbouring tile: each access of a wave touched 16 half lines, and the CU's one
+// vector-memory pipe -- 12 such instructions per tile -- bounded the phase (measured: removing
+// either the loads or the stores took 4.5 us off a 18.5 us step).  For the duration of the launch
+// the weights of every layer whose K and width are multiples of 16 are therefore kept in tile
+// order = the MFMA's own result layout: tile (kb, cb) = 256 consecutive floats, lane's four
+// registers at 4 * lane -- one instruction = 1 KiB contiguous = 8 full lines, and no transpose.
+// The kernel permutes theta / m / v in place on entry and back on exit (staged through LDS, a few
+// microseconds per launch); biases and a one-column last layer stay where they are.
 // ---------------------------------------------------------------------------------------------
 template <int SHAPE>
 struct TileOrder {
@@ -225,8 +227,8 @@ struct TileOrder {
   // offset inside layer l's weight block of element q = k * Nw + j (packed) in tile order
   static __device__ __forceinline__ int local(int l_Nw, int q) {
     const int k = q / l_Nw, j = q - k * l_Nw;
-    const int kb = k >> 4, q4 = (k >> 2) & 3, qa = k & 3, cb = j >> 4, m4 = j & 12, jj = j & 3;
-    return (kb * (l_Nw >> 4) + cb) * 256 + (16 * q4 + m4 + qa) * 4 + jj;
+    const int kb = k >> 4, q4 = (k >> 2) & 3, r = k & 3, cb = j >> 4, m = j & 15;
+    return (kb * (l_Nw >> 4) + cb) * 256 + (16 * q4 + m) * 4 + r;
   }
   // position of packed parameter p during the launch
   static __device__ __forceinline__ int index(int p) {
@@ -421,6 +423,7 @@ struct Bf16Net {
   static __device__ __forceinline__ void store_t(const float (&src)[TM][4], unsigned short *img, int row) {
     const int lane = threadIdx.x & 63, q = lane >> 4, a = lane & 3;
     const int r0 = row & ~3;
+    const unsigned sel = (a & 1) ? 0x07060302u : 0x01000504u;
 #pragma unroll
     for (int t = 0; t < Pl::T(l); ++t) {
       const unsigned p01 = pack2_bf16(src[t][0], src[t][1]), p23 = pack2_bf16(src[t][2], src[t][3]);
@@ -428,10 +431,9 @@ struct Bf16Net {
       const unsigned x01 = __builtin_amdgcn_update_dpp(0u, p01, 0xB1, 0xF, 0xF, true);
       const unsigned x23 = __builtin_amdgcn_update_dpp(0u, p23, 0xB1, 0xF, 0xF, true);
       // even lane: units 0 / 2 of rows (m, m + 1); odd lane: units 1 / 3 of rows (m - 1, m)
-      const unsigned A = (a & 1) ? __builtin_amdgcn_perm(p01, x01, 0x07060302u)   // (hi(x01), hi(p01))
-                                 : __builtin_amdgcn_perm(x01, p01, 0x05040100u);  // (lo(p01), lo(x01))
-      const unsigned B = (a & 1) ? __builtin_amdgcn_perm(p23, x23, 0x07060302u)
-                                 : __builtin_amdgcn_perm(x23, p23, 0x05040100u);
+      // (one v_perm with a per-lane selector; bytes 0..3 = the neighbour's word, 4..7 = this lane's)
+      const unsigned A = __builtin_amdgcn_perm(p01, x01, sel);  // odd: (hi(x01), hi(p01)); even: (lo(p01), lo(x01))
+      const unsigned B = __builtin_amdgcn_perm(p23, x23, sel);
       // lane ^ 2: quad_perm [2, 3, 0, 1]; lanes 0, 1 keep A (units 0, 1), lanes 2, 3 keep B (units 2, 3)
       const unsigned send = (a & 2) ? A : B;
       const unsigned recv = __builtin_amdgcn_update_dpp(0u, send, 0x4E, 0xF, 0xF, true);
