@@ -198,21 +198,9 @@ __device__ __forceinline__ int layer_count(const MlpLayout &L) {
 }
 
 // HBM -> LDS: packed vector into the (already zeroed) padded image; coalesced reads.
-// (eight loads per thread are requested before the first is used: one at a time, a 128-128-1 net's
-// 81 per thread cost 81 memory latencies -- most of the 0.39 ms a workgroup of the restart kernel
-// spent before its first evaluation)
-#define BORE_STAGE_UNROLL 8
 __device__ __forceinline__ void load_theta(const MlpLayout &L, int n, const float *__restrict__ g,
                                            float *th) {
-  const int P = L.P, step = blockDim.x;
-  for (int p0 = threadIdx.x; p0 < P; p0 += BORE_STAGE_UNROLL * step) {
-    float v[BORE_STAGE_UNROLL];
-#pragma unroll
-    for (int u = 0; u < BORE_STAGE_UNROLL; ++u) v[u] = p0 + u * step < P ? g[p0 + u * step] : 0.f;
-#pragma unroll
-    for (int u = 0; u < BORE_STAGE_UNROLL; ++u)
-      if (p0 + u * step < P) th[param_ref(L, p0 + u * step, n).lds] = v[u];
-  }
+  for (int p = threadIdx.x; p < L.P; p += blockDim.x) th[param_ref(L, p, n).lds] = g[p];
 }
 
 __device__ __forceinline__ void store_theta(const MlpLayout &L, int n, const float *th,

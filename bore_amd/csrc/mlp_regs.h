@@ -457,15 +457,7 @@ __device__ __forceinline__ void stage_theta(const MlpLayout &L, int n, const flo
                                             float *smem) {
   if constexpr (BF16) {
     unsigned short *t16 = reinterpret_cast<unsigned short *>(smem);
-    const int P = L.P, step = blockDim.x;
-    for (int p0 = threadIdx.x; p0 < P; p0 += BORE_STAGE_UNROLL * step) {  // (see load_theta)
-      float v[BORE_STAGE_UNROLL];
-#pragma unroll
-      for (int u = 0; u < BORE_STAGE_UNROLL; ++u) v[u] = p0 + u * step < P ? g[p0 + u * step] : 0.f;
-#pragma unroll
-      for (int u = 0; u < BORE_STAGE_UNROLL; ++u)
-        if (p0 + u * step < P) t16[param_ref(L, p0 + u * step, n).lds] = f32_to_bf16(v[u]);
-    }
+    for (int p = threadIdx.x; p < L.P; p += blockDim.x) t16[param_ref(L, p, n).lds] = f32_to_bf16(g[p]);
   } else {
     load_theta(L, n, g, smem);
   }
