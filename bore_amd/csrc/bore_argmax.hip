@@ -754,6 +754,13 @@ __global__ __launch_bounds__(BORE_THREADS) void lbfgsb_kernel(const LbfgsbArgs a
   lbfgsb_body<SHAPE, BF16>(a, blockIdx.x, blockIdx.y);
 }
 
+// Two workgroups per CU (256 registers per lane, operands re-requested per evaluation): for launches
+// with many more workgroups than the device has CUs.
+template <int SHAPE, bool BF16 = false>
+__global__ __launch_bounds__(BORE_THREADS, 2) void lbfgsb_kernel_occ2(const LbfgsbArgs a) {
+  lbfgsb_body<SHAPE, BF16, true>(a, blockIdx.x, blockIdx.y);
+}
+
 static int lbfgsb_build(const bore_mlp_desc *desc, int n_models, const float *theta,
                         int transform, int negate, const double *x0, int num_starts,
                         const double *lb, const double *ub, const bore_lbfgsb_opts *opts, double *x,
@@ -888,6 +895,23 @@ extern "C" int bore_lbfgsb_minimize(const bore_mlp_desc *desc, int n_models, con
     }
     HIP_TRY(hipGetLastError());
     return 0;
+  }
+  {
+    // More workgroups than CUs (many loops x many restarts): the 32-32-1 flavour, whose workgroup
+    // needs 48 KB of LDS, runs two workgroups per CU (256 registers per lane, operands re-requested
+    // per evaluation, 132 B of scratch) -- restarts of BASELINE config 2 with 256 loops 78.7 -> 43.1 ms,
+    // same bits.  A single loop's launch (64 workgroups) keeps the one-per-CU kernel: it finishes a
+    // problem sooner.  BORE_LBFGSB_OCC2 = 0 / 1 forces either (tests, measurements).
+    const int forced = getenv("BORE_LBFGSB_OCC2") ? atoi(getenv("BORE_LBFGSB_OCC2")) : -1;
+    const bool many = (long long)n_models * blocks > device_cus();
+    if (flavour == 2 && off * 4 <= BORE_LDS_BYTES / 2 && (forced < 0 ? many : forced != 0)) {
+      rc = allow_lds(lbfgsb_kernel_occ2<2>, off * 4);
+      if (rc) return rc;
+      hipLaunchKernelGGL(lbfgsb_kernel_occ2<2>, dim3(n_models, blocks), dim3(BORE_THREADS), off * 4,
+                         (hipStream_t)stream, a);
+      HIP_TRY(hipGetLastError());
+      return 0;
+    }
   }
 #define BORE_LAUNCH_LBFGSB(S)                                                                  \
   case S:                                                                                      \

@@ -58,6 +58,21 @@ inline int allow_lds(K kernel, size_t bytes) {
   return 0;
 }
 
+// Compute units of the current device (per device, cached).
+inline int device_cus() {
+  static int cus[64];
+  static std::mutex mu;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  std::lock_guard<std::mutex> lock(mu);
+  if (!cus[dev]) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256;
+    cus[dev] = n;
+  }
+  return cus[dev];
+}
+
 // Builds the layout with the largest tile (max_rows, then 16 rows fewer each try: a wave's
 // unit of work is a 16-row block) whose theta + tile + `extra_floats` fit the CU's LDS; the
 // tile may shrink only when `may_shrink`.

@@ -636,3 +636,22 @@ def test_lbfgsb_problem_to_lane_mappings_give_the_same_bits(gpu, monkeypatch):
                                                                   maxiter=1000, ftol=1e-9)])
     for a, b in zip(*outs):
         assert np.array_equal(a, b)
+
+
+def test_lbfgsb_two_workgroups_per_cu_gives_the_same_bits(gpu, monkeypatch):
+    """Launches with more workgroups than CUs run the 32-32-1 flavour two workgroups per CU (256
+    registers per lane, operands re-requested per evaluation); BORE_LBFGSB_OCC2 forces either kernel:
+    same results bit for bit."""
+    rs = np.random.RandomState(9)
+    D, units, acts = 6, [32, 32, 1], ["relu", "relu", "sigmoid"]
+    desc = _lib.make_desc(D, units, acts)
+    th = dev(np.stack([pack(rand_model(rs, D, units)) for _ in range(3)]))
+    X0 = dev(rs.uniform(size=(3, 70, D)))
+    lo, hi = np.zeros(D), np.ones(D)
+    outs = []
+    for occ2 in ("0", "1"):
+        monkeypatch.setenv("BORE_LBFGSB_OCC2", occ2)
+        outs.append([t.cpu().numpy() for t in ops.lbfgsb_minimize(desc, th, X0, lo, hi, "identity", True,
+                                                                  maxiter=1000, ftol=1e-9)])
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)
