@@ -536,8 +536,11 @@ __device__ __forceinline__ void lbfgsb_body(const LbfgsbArgs &a, const long long
   // Batch mode with 5..16 restarts (the reference's default is num_starts = 5) keeps the loop in
   // ONE workgroup, as the per-loop pick below needs: wave wv runs problems wv, wv + 4, .. one
   // after the other, each with all its lanes (`passes`).  Same bits every way (tested).
+  // (launches with more workgroups than CUs may run 5..8 waves per workgroup, one problem each:
+  // lbfgsb_kernel_w8; batch mode always has four)
+  const int NW = (int)(blockDim.x >> 6);
   const bool multi = a.result && np > 4 && np <= 16;
-  const bool coop = np <= 4 || multi;
+  const bool coop = np <= NW || multi;
   const int passes = multi ? (np + 3) / 4 : 1;
   const int myrow = coop ? wv * 16 : wv * 16 + lane;
   const lbfgsb::Coop cp = coop ? lbfgsb::Coop{lane, 64} : lbfgsb::Coop{0, 1};
@@ -760,12 +763,18 @@ template <int SHAPE, bool BF16 = false>
 __global__ __launch_bounds__(BORE_THREADS, 2) void lbfgsb_kernel_occ2(const LbfgsbArgs a) {
   lbfgsb_body<SHAPE, BF16, true>(a, blockIdx.x, blockIdx.y);
 }
+// The same for the wide shapes, whose weights take too much LDS for two workgroups: ONE workgroup of
+// up to eight waves (two per SIMD), one problem per wave, the weights staged once for all of them.
+template <int SHAPE, bool BF16 = false>
+__global__ __launch_bounds__(2 * BORE_THREADS) void lbfgsb_kernel_w8(const LbfgsbArgs a) {
+  lbfgsb_body<SHAPE, BF16, true>(a, blockIdx.x, blockIdx.y);
+}
 
 static int lbfgsb_build(const bore_mlp_desc *desc, int n_models, const float *theta,
                         int transform, int negate, const double *x0, int num_starts,
                         const double *lb, const double *ub, const bore_lbfgsb_opts *opts, double *x,
                         double *fun, double *jac, int32_t *info, LbfgsbArgs &a, size_t &lds_floats,
-                        int &flavour_out, int &blocks_out) {
+                        int &flavour_out, int &blocks_out, int *waves_out = nullptr) {
   if (!desc || !theta || !x0 || !lb || !ub || !opts || !x || !fun || !jac || !info)
     return fail(BORE_E_INVALID, "lbfgsb_minimize: null pointer");
   if (n_models < 1) return fail(BORE_E_INVALID, "n_models must be >= 1 (got %d)", n_models);
@@ -818,6 +827,15 @@ static int lbfgsb_build(const bore_mlp_desc *desc, int n_models, const float *th
       getenv("BORE_LBFGSB_COOP_GRID") ? atoll(getenv("BORE_LBFGSB_COOP_GRID")) : (1LL << 22);
   if (PB > 4 && !g_batch && (long long)n_models * ((num_starts + 3) / 4) <= coop_grid_max) PB = 4;
   const int flavour = bore_kernel_flavour(desc, true);
+  // More workgroups than CUs, wide static shape: up to eight problems = eight waves per workgroup
+  // (as many as fit beside the weights; lbfgsb_kernel_w8).  BORE_LBFGSB_W8 = 0 / 1 forces either.
+  bool w8 = false;
+  if (waves_out && !g_batch && PB == 4 && num_starts >= 8 &&
+      (flavour == 3 || (flavour == 4 && desc->compute == BORE_COMPUTE_BF16))) {
+    const int forced = getenv("BORE_LBFGSB_W8") ? atoi(getenv("BORE_LBFGSB_W8")) : -1;
+    w8 = forced < 0 ? (long long)n_models * ((num_starts + 3) / 4) > device_cus() : forced != 0;
+    if (w8) PB = 8;
+  }
   const int shape = flavour > 0 ? flavour : 0;  // constexpr-layout kernels assume a 64-row tile
   size_t off = 0;
   for (;; --PB) {
@@ -828,7 +846,10 @@ static int lbfgsb_build(const bore_mlp_desc *desc, int n_models, const float *th
     if (bore_make_layout(desc, 2, rows, &a.L)) return fail(BORE_E_INVALID, "bad bore_mlp_desc");
     off = a.L.P_lds;
     a.o_tile = (int)off;
-    off += shape ? 2 * (size_t)BORE_BATCH_MAX * a.L.lda[0] : (size_t)a.L.tile_floats;
+    // (one problem per wave -- up to 4 problems, 8 in the eight-wave kernel, 16 in batch mode -- reads
+    // its point straight from the optimiser's vector: no staging region at all)
+    const bool per_wave = PB <= (w8 ? 8 : 4) || (g_batch && PB <= 16);
+    off += shape ? (per_wave ? 0 : 2 * (size_t)BORE_BATCH_MAX * a.L.lda[0]) : (size_t)a.L.tile_floats;
     a.o_vals = (int)off; off += BORE_BATCH_MAX;
     off = (off + 3) & ~(size_t)3;  // 16-byte boundary for the fp64 regions
     a.o_box = (int)off; off += 4 * (size_t)D + (((size_t)D + 3) & ~(size_t)3) + (D & 1 ? 2 : 0);
@@ -843,6 +864,7 @@ static int lbfgsb_build(const bore_mlp_desc *desc, int n_models, const float *th
     if (off * 4 <= BORE_LDS_BYTES) break;
   }
   a.PB = PB;
+  if (waves_out) *waves_out = w8 && PB > 4 ? PB : 4;
   if (a.L.w[a.L.n_layers] != 1)
     return fail(BORE_E_INVALID, "lbfgsb_minimize: the last Dense layer must have 1 unit");
   a.theta = theta; a.x0 = x0; a.x = x; a.fun = fun; a.jac = jac; a.info = info;
@@ -876,10 +898,26 @@ extern "C" int bore_lbfgsb_minimize(const bore_mlp_desc *desc, int n_models, con
                                     double *jac, int32_t *info, void *stream) {
   LbfgsbArgs a;
   size_t off = 0;
-  int flavour = 0, blocks = 0;
+  int flavour = 0, blocks = 0, waves = 4;
   int rc = lbfgsb_build(desc, n_models, theta, transform, negate, x0, num_starts, lb, ub, opts, x, fun,
-                        jac, info, a, off, flavour, blocks);
+                        jac, info, a, off, flavour, blocks, &waves);
   if (rc) return rc;
+  if (waves > 4) {  // (wide static shape, more workgroups than CUs: see lbfgsb_build)
+    const bool bf = desc->compute == BORE_COMPUTE_BF16;
+#define BORE_LAUNCH_W8(K)                                                                          \
+  {                                                                                                \
+    rc = allow_lds((K), off * 4);                                                                  \
+    if (rc) return rc;                                                                             \
+    hipLaunchKernelGGL((K), dim3(n_models, blocks), dim3(64 * waves), off * 4, (hipStream_t)stream, a); \
+  }
+    if (flavour == 3 && !bf) BORE_LAUNCH_W8((lbfgsb_kernel_w8<3, false>))
+    else if (flavour == 3) BORE_LAUNCH_W8((lbfgsb_kernel_w8<3, true>))
+    else if (flavour == 4 && bf) BORE_LAUNCH_W8((lbfgsb_kernel_w8<4, true>))
+    else return fail(BORE_E_UNSUPPORTED, "lbfgsb_minimize: no eight-wave kernel for this flavour");
+#undef BORE_LAUNCH_W8
+    HIP_TRY(hipGetLastError());
+    return 0;
+  }
   if (desc->compute == BORE_COMPUTE_BF16) {
     if (!bore_shape_is_wide(flavour)) return fail(BORE_E_UNSUPPORTED, kBf16Shapes);
     if (flavour == 3) {

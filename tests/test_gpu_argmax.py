@@ -655,3 +655,24 @@ def test_lbfgsb_two_workgroups_per_cu_gives_the_same_bits(gpu, monkeypatch):
                                                                   maxiter=1000, ftol=1e-9)])
     for a, b in zip(*outs):
         assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("D,units,compute", [(16, [64, 64, 64, 1], "float32"), (16, [64, 64, 64, 1], "bfloat16"),
+                                             (32, [128, 128, 1], "bfloat16")])
+def test_lbfgsb_eight_waves_per_workgroup_give_the_same_bits(gpu, monkeypatch, D, units, compute):
+    """Wide shapes, launches with more workgroups than CUs: one workgroup of up to eight waves (as
+    many problems as fit in LDS beside the weights) instead of four; BORE_LBFGSB_W8 forces either
+    kernel: same results bit for bit (incl. a last workgroup with fewer problems than waves)."""
+    rs = np.random.RandomState(10)
+    acts = ["relu"] * (len(units) - 1) + ["sigmoid"]
+    desc = _lib.make_desc(D, units, acts, compute=compute)
+    th = dev(np.stack([pack(rand_model(rs, D, units)) for _ in range(2)]))
+    X0 = dev(rs.uniform(size=(2, 21, D)))
+    lo, hi = np.zeros(D), np.ones(D)
+    outs = []
+    for w8 in ("0", "1"):
+        monkeypatch.setenv("BORE_LBFGSB_W8", w8)
+        outs.append([t.cpu().numpy() for t in ops.lbfgsb_minimize(desc, th, X0, lo, hi, "identity", True,
+                                                                  maxiter=200, ftol=1e-9)])
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)
