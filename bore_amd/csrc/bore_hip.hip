@@ -1518,14 +1518,22 @@ __global__ __launch_bounds__(BORE_THREADS) void fit_bf16_mfma_kernel(const FitBf
           // bfloat16 for the next step anyway and the master copy carries 24 bits either way)
           constexpr int cur = I % RING;
           float wn[4];
+          // (two elements per instruction where the operation has a packed form -- v_pk_add_f32 /
+          // v_pk_mul_f32; the same IEEE operations in the same order)
+          typedef float f2 __attribute__((ext_vector_type(2)));
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            float mm = pm[cur][r], vv = pv[cur][r];
-            mm += (g[r] - mm) * omb1;
-            vv += (g[r] * g[r] - vv) * omb2;
-            wn[r] = pw[cur][r] - (mm * alpha) * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(vv) + a.eps);
-            pm[cur][r] = mm;
-            pv[cur][r] = vv;
+          for (int h = 0; h < 2; ++h) {
+            const f2 gg = {g[2 * h], g[2 * h + 1]};
+            f2 mm = {pm[cur][2 * h], pm[cur][2 * h + 1]}, vv = {pv[cur][2 * h], pv[cur][2 * h + 1]};
+            const f2 ww = {pw[cur][2 * h], pw[cur][2 * h + 1]};
+            mm += (gg - mm) * omb1;
+            vv += (gg * gg - vv) * omb2;
+            const f2 den = {__builtin_amdgcn_sqrtf(vv.x) + a.eps, __builtin_amdgcn_sqrtf(vv.y) + a.eps};
+            const f2 rcp = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+            const f2 w2 = ww - (mm * alpha) * rcp;
+            wn[2 * h] = w2.x; wn[2 * h + 1] = w2.y;
+            pm[cur][2 * h] = mm.x; pm[cur][2 * h + 1] = mm.y;
+            pv[cur][2 * h] = vv.x; pv[cur][2 * h + 1] = vv.y;
           }
 #pragma unroll
           for (int r = 0; r < 4; ++r) asm volatile("" : "+v"(wn[r]));
