@@ -1310,7 +1310,6 @@ __global__ __launch_bounds__(BORE_THREADS) void fit_bf16_mfma_kernel(const FitBf
   unsigned short *wb = reinterpret_cast<unsigned short *>(base + Pl::o_wb);
   float *bias = reinterpret_cast<float *>(base + Pl::o_bias);
   unsigned short *img = reinterpret_cast<unsigned short *>(base + Pl::o_img);
-  float *gl = reinterpret_cast<float *>(base + Pl::o_img);  // gradient image of one layer group
   float *misc = reinterpret_cast<float *>(base + a.o_misc);
   int *perm_all = reinterpret_cast<int *>(base + a.o_perm);
   int *perm_s = perm_all;
@@ -1507,7 +1506,6 @@ __global__ __launch_bounds__(BORE_THREADS) void fit_bf16_mfma_kernel(const FitBf
         float bs_prev = 0.f;
         auto finish = [&](auto ic, const f32x4 &acc, const float bs) {
           constexpr int I = decltype(ic)::value, l = Pl::layer_of_tile(4 * I);
-          constexpr int Nw = L.w[l];
           int kb, cb, pu, pbu;
           unsigned lb4;
           bool ok4, okb;
