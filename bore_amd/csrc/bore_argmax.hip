@@ -586,7 +586,8 @@ __device__ __forceinline__ void lbfgsb_body(const LbfgsbArgs &a, const long long
     int pending = 0;
     const long long c0 = BORE_LCLOCK();
     if (!done) {
-      const int rc = lbfgsb::lbfgsb_advance(st, wk, blo, bhi, bnbd, a.opt, cp);
+      // (2-D problems -- static shape 1, the fused iteration kernel -- keep the forms without a variable per lane)
+      const int rc = lbfgsb::lbfgsb_advance<SHAPE != 1>(st, wk, blo, bhi, bnbd, a.opt, cp);
       if (rc == lbfgsb::LB_NEED_FG) {
         if (!(SHAPE > 0 && coop)) {
           float *row = tile + L.aoff[0] + myrow * L.lda[0];

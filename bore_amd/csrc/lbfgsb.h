@@ -189,14 +189,34 @@ LB_HD double lane_bcast(double v, int src) {
   return __hiloint2double(hi, lo);
 }
 LB_HD bool lanes_any(bool p) { return __any(p) != 0; }
+LB_HD unsigned long long lanes_ballot(bool p) { return __ballot(p); }
+LB_HD int bits_below(unsigned long long mask, int lane) {  // set bits of mask below bit `lane`
+  return __popcll(mask & ((1ull << lane) - 1ull));
+}
+LB_HD int bits_set(unsigned long long mask) { return __popcll(mask); }
 
 #else
 LB_HD double lane_bcast(double v, int) { return v; }
 LB_HD bool lanes_any(bool p) { return p; }
+LB_HD unsigned long long lanes_ballot(bool p) { return p ? 1ull : 0ull; }
+LB_HD int bits_below(unsigned long long mask, int lane) {
+  int c = 0;
+  for (int i = 0; i < lane; ++i) c += (int)((mask >> i) & 1ull);
+  return c;
+}
+LB_HD int bits_set(unsigned long long mask) { return bits_below(mask, 64); }
 #endif
 
 // p mod m for 0 <= p < 2m (circular indices into the m correction pairs; no integer divide)
 LB_HD int wrap(int p, int m) { return p >= m ? p - m : p; }
+
+// sum_{i < n} term_i, left to right, where lane i holds term_i (n <= the number of lanes): the
+// same additions in the same order as the sequential loop, fed from registers instead of memory.
+LB_HD double lanes_sum_ordered(double term, int n) {
+  double s = 0.0;
+  for (int i = 0; i < n; ++i) s += lane_bcast(term, i);
+  return s;
+}
 
 // ---- small dense kernels ------------------------------------------------------
 // Sums strictly left to right (results do not depend on the unrolling); operands are fetched
@@ -215,6 +235,16 @@ LB_HD double ddot(int n, const double *a, const double *b) {
   }
   for (; i < n; ++i) s += a[i] * b[i];
   return s;
+}
+
+// ddot for lanes that cooperate on one problem: lane i forms term i, the sum runs over the lanes in
+// the order of i (bit for bit ddot's result)
+// (VL = false compiles the variable-per-lane forms out: the 2-D problems of the fused iteration
+// kernel gain nothing from them, and their code in that kernel cost its fit phase 5 %)
+template <bool VL = true>
+LB_HD double ddot_c(int n, const double *a, const double *b, const Coop c) {
+  if (VL && c.nl > 1 && n <= c.nl) return lanes_sum_ordered(c.lane < n ? a[c.lane] * b[c.lane] : 0.0, n);
+  return ddot(n, a, b);
 }
 
 // sum_i a[i*sa] * b[i*sb] * r[i*sr], left to right (r: stored reciprocals), operands fetched
@@ -552,6 +582,7 @@ struct IterArgs {
 // ---- generalized Cauchy point ----------------------------------------------------------
 // xcp = w.z, breakpoints in w.t, search direction in w.d, iorder = w.indx2,
 // p | c | wbp | v = w.wa.  Returns info (0 ok) in the low 8 bits and nseg above them.
+template <bool VL = true>
 LB_HDN int cauchy(const IterArgs s, const Work w, const double *l, const double *u,
                   const int *nbd) {
   const int n = s.n, m = s.m, col = s.col, col2 = 2 * s.col;
@@ -562,7 +593,12 @@ LB_HDN int cauchy(const IterArgs s, const Work w, const double *l, const double 
   const double theta = s.theta;
 
   if (s.sbgnrm <= 0.0) {
-    for (int i = 0; i < n; ++i) xcp[i] = x[i];
+    if (VL) {
+      for (int i = s.c.lane; i < n; i += s.c.nl) xcp[i] = x[i];
+      LB_LANES_SYNC();
+    } else {
+      for (int i = 0; i < n; ++i) xcp[i] = x[i];
+    }
     return 0;
   }
 #define LB_CAUCHY_RET(info) (((info) & 0xff) | (nseg << 8))
@@ -572,6 +608,93 @@ LB_HDN int cauchy(const IterArgs s, const Work w, const double *l, const double 
   const Coop cp = s.c;
   for (int i = cp.lane; i < col2; i += cp.nl) p[i] = 0.0;  // lane j owns p[j] throughout
 
+  if (VL && cp.nl > 1 && n <= cp.nl && m <= cp.nl) {
+    // One variable per lane: the classification of variable i, its direction component and its
+    // breakpoint depend on variable i alone.  What the sequential loop carries from one variable to
+    // the next -- the sums f1 and p (accumulated in the order of i), the compacted lists of
+    // breakpoints (front of iorder / t, in the order of i) and of free variables (back of iorder),
+    // the first smallest breakpoint -- is rebuilt in that order from the lanes' values, so every
+    // number is the one the loop below produces (this loop cost 2.4 k cycles per variable: 80 k of
+    // a 100 k-cycle iteration at n = 32).
+    const int i0 = cp.lane;
+    double neggi = 0.0, tbrk = 0.0;
+    int kind = 0;  // 0: stays (d = 0), 1: moves towards a bound (breakpoint), 2: moves freely
+    bool unb = false;
+    if (i0 < n) {
+      neggi = -g[i0];
+      const int nb = nbd[i0];
+      int iw = iwhere[i0];
+      double tl = 0.0, tu = 0.0;
+      if (iw != 3 && iw != -1) {
+        if (nb <= 2) tl = x[i0] - l[i0];
+        if (nb >= 2) tu = u[i0] - x[i0];
+        const bool xlower = nb <= 2 && tl <= 0.0;
+        const bool xupper = nb >= 2 && tu <= 0.0;
+        iw = 0;
+        if (xlower) {
+          if (neggi <= 0.0) iw = 1;
+        } else if (xupper) {
+          if (neggi >= 0.0) iw = 2;
+        } else {
+          if (fabs(neggi) <= 0.0) iw = -3;
+        }
+        iwhere[i0] = iw;
+      }
+      if (iw != 0 && iw != -1) {
+        d[i0] = 0.0;
+      } else {
+        d[i0] = neggi;
+        if (nb <= 2 && nb != 0 && neggi < 0.0) {
+          kind = 1;
+          tbrk = tl / (-neggi);
+        } else if (nb >= 2 && neggi > 0.0) {
+          kind = 1;
+          tbrk = tu / neggi;
+        } else {
+          kind = 2;
+          unb = fabs(neggi) > 0.0;
+        }
+      }
+    }
+    const unsigned long long mbrk = lanes_ballot(kind == 1), mfree = lanes_ballot(kind == 2);
+    const unsigned long long mmove = mbrk | mfree;
+    bnded = !lanes_any(unb);
+    // f1, p: sequential sums over the moving variables; lane j keeps p[j], p[col + j] in registers
+    double pa = 0.0, pb = 0.0;
+    const int jrow = cp.lane < col ? wrap(s.head + cp.lane, m) * n : 0;
+    int k = 0;
+    for (int i = 0; i < n; ++i) {
+      if (!((mmove >> i) & 1ull)) continue;  // (wave-uniform)
+      const double ng = lane_bcast(neggi, i);
+      f1 -= ng * ng;
+      if (cp.lane < col) {
+        pa += w.wy[jrow + i] * ng;
+        pb += w.ws[jrow + i] * ng;
+      }
+      if ((mbrk >> i) & 1ull) {  // the first smallest breakpoint, in list order
+        ++k;
+        const double tb = lane_bcast(tbrk, i);
+        if (k == 1 || tb < bkmin) {
+          bkmin = tb;
+          ibkmin = k;
+        }
+      }
+    }
+    if (cp.lane < col) {
+      p[cp.lane] = pa;
+      p[col + cp.lane] = pb;
+    }
+    nbreak = bits_set(mbrk);
+    nfree = n + 1 - bits_set(mfree);
+    if (kind == 1) {
+      const int pos = bits_below(mbrk, i0);
+      iorder[pos] = i0 + 1;
+      t[pos] = tbrk;
+    } else if (kind == 2) {
+      iorder[n - 1 - bits_below(mfree, i0)] = i0 + 1;
+    }
+    LB_LANES_SYNC();
+  } else
   for (int i = 1; i <= n; ++i) {
     const double neggi = -g[i - 1];
     double tl = 0.0, tu = 0.0;
@@ -625,7 +748,12 @@ LB_HDN int cauchy(const IterArgs s, const Work w, const double *l, const double 
   }
   if (theta != 1.0)
     for (int j = cp.lane; j < col; j += cp.nl) p[col + j] *= theta;
-  for (int i = 0; i < n; ++i) xcp[i] = x[i];
+  if (VL) {
+    for (int i = cp.lane; i < n; i += cp.nl) xcp[i] = x[i];
+    LB_LANES_SYNC();
+  } else {
+    for (int i = 0; i < n; ++i) xcp[i] = x[i];
+  }
   if (nbreak == 0 && nfree == n + 1) return LB_CAUCHY_RET(0);  // d is zero: GCP = x
   for (int j = cp.lane; j < col2; j += cp.nl) c[j] = 0.0;
   LB_LANES_SYNC();
@@ -721,7 +849,11 @@ LB_HDN int cauchy(const IterArgs s, const Work w, const double *l, const double 
   if (!skip_to_999) {
     if (dtm <= 0.0) dtm = 0.0;
     tsum += dtm;
-    for (int i = 0; i < n; ++i) xcp[i] += tsum * d[i];
+    if (VL) {
+      for (int i = cp.lane; i < n; i += cp.nl) xcp[i] += tsum * d[i];
+    } else {
+      for (int i = 0; i < n; ++i) xcp[i] += tsum * d[i];
+    }
   }
   if (col > 0)
     for (int j = cp.lane; j < col2; j += cp.nl) c[j] += dtm * p[j];
@@ -731,10 +863,36 @@ LB_HDN int cauchy(const IterArgs s, const Work w, const double *l, const double 
 }
 
 // ---- free / active bookkeeping at the GCP ------------------------------------------------
-LB_HD void freev(State &s, const Work &w) {
+template <bool VL = true>
+LB_HD void freev(State &s, const Work &w, const Coop c = Coop{0, 1}) {
   const int n = s.n;
   s.nenter = 0;
   s.ileave = n + 1;
+  if (VL && c.nl > 1 && n <= c.nl) {
+    // one list position (first two loops) / one variable (third) per lane; the lists are compacted
+    // in the order of the sequential loops
+    if (s.iter > 0 && s.cnstnd) {
+      const int pos = c.lane;  // 0-based position in the old index
+      const int k = pos < n ? w.index[pos] : 1;
+      const int iw = pos < n ? w.iwhere[k - 1] : 0;
+      const unsigned long long mleave = lanes_ballot(pos < s.nfree && iw > 0);
+      const unsigned long long menter = lanes_ballot(pos >= s.nfree && pos < n && iw <= 0);
+      if ((mleave >> pos) & 1ull) w.indx2[n - 1 - bits_below(mleave, pos)] = k;
+      if ((menter >> pos) & 1ull) w.indx2[bits_below(menter, pos)] = k;
+      s.ileave = n + 1 - bits_set(mleave);
+      s.nenter = bits_set(menter);
+    }
+    s.wrk = (s.ileave < n + 1) || (s.nenter > 0) || s.updatd;
+    LB_LANES_SYNC();  // (the old index has been read by every lane before it is rewritten)
+    const int i0 = c.lane;
+    const bool isfree = i0 < n && w.iwhere[i0] <= 0;
+    const unsigned long long mfree = lanes_ballot(isfree), mact = lanes_ballot(i0 < n && !isfree);
+    if (isfree) w.index[bits_below(mfree, i0)] = i0 + 1;
+    else if (i0 < n) w.index[n - 1 - bits_below(mact, i0)] = i0 + 1;
+    s.nfree = bits_set(mfree);
+    LB_LANES_SYNC();
+    return;
+  }
   if (s.iter > 0 && s.cnstnd) {
     for (int i = 1; i <= s.nfree; ++i) {
       const int k = w.index[i - 1];
@@ -944,6 +1102,7 @@ LB_HD int cmprlb(State &s, const Work &w, const Coop c) {
 // Subspace minimisation: on entry w.z = xcp and w.r = reduced gradient; on exit w.z is
 // the (projected) subspace minimiser.  wv = wa[0..2m).
 // Returns info (0 ok) in the low 8 bits and iword (1: the step hit a bound) in bit 8.
+template <bool VL = true>
 LB_HDN int subsm(const IterArgs s, const Work w, const double *l, const double *u,
                  const int *nbd) {
   const int n = s.n, m = s.m, col = s.col, nsub = s.nfree, m2 = 2 * s.m, col2 = 2 * s.col;
@@ -1012,7 +1171,11 @@ LB_HDN int subsm(const IterArgs s, const Work w, const double *l, const double *
   if (iword == 0) return 0;
   // sign of the directional derivative along the projected step
   double dd_p = 0.0;
-  for (int i = 0; i < n; ++i) dd_p += (x[i] - xx[i]) * gg[i];
+  if (VL && c.nl > 1 && n <= c.nl) {
+    dd_p = lanes_sum_ordered(c.lane < n ? (x[c.lane] - xx[c.lane]) * gg[c.lane] : 0.0, n);
+  } else {
+    for (int i = 0; i < n; ++i) dd_p += (x[i] - xx[i]) * gg[i];
+  }
   if (dd_p > 0.0) {  // not a descent direction: fall back to the backtracking step
     for (int i = 0; i < n; ++i) x[i] = xp[i];
     double alpha = 1.0, temp1 = alpha;
@@ -1217,17 +1380,42 @@ LB_HD void dcsrch(State &s, double f, double g, double &stp, double ftol, double
 // Returns 1 if f/g is needed at the new w.x, 0 if the search ended (s.info tells how).
 // (the element-wise loops over the n variables are dealt to the lanes of a cooperating wave;
 // the dot products stay sequential -- their summation order is part of the result)
+template <bool VL = true>
 LB_HD int lnsrlb(State &s, const Work &w, const double *l, const double *u, const int *nbd,
                  int first, const Coop c = Coop{0, 1}) {
   const int n = s.n;
   const double big = 1e10, ftol = 1e-3, gtol = 0.9, xtol = 0.1;
   if (first) {
-    s.dtd = ddot(n, w.d, w.d);
+    s.dtd = ddot_c<VL>(n, w.d, w.d, c);
     s.dnorm = sqrt(s.dtd);
     s.stpmx = big;
     if (s.cnstnd) {
       if (s.iter == 0) {
         s.stpmx = 1.0;
+      } else if (VL && c.nl > 1 && n <= c.nl) {
+        // lane i fetches variable i's operands; the scan itself (each step uses the stpmx so far)
+        // runs over the lanes in the order of i
+        double a1v = 0.0, a2lo = 0.0, a2hi = 0.0;
+        int nb = 0;
+        if (c.lane < n) {
+          a1v = w.d[c.lane];
+          nb = nbd[c.lane];
+          a2lo = l[c.lane] - w.x[c.lane];
+          a2hi = u[c.lane] - w.x[c.lane];
+        }
+        const unsigned long long mlo = lanes_ballot(nb != 0 && a1v < 0.0 && nb <= 2);
+        const unsigned long long mhi = lanes_ballot(nb != 0 && !(a1v < 0.0 && nb <= 2) && a1v > 0.0 && nb >= 2);
+        for (int i = 0; i < n; ++i) {
+          if ((mlo >> i) & 1ull) {
+            const double a1 = lane_bcast(a1v, i), a2 = lane_bcast(a2lo, i);
+            if (a2 >= 0.0) s.stpmx = 0.0;
+            else if (a1 * s.stpmx < a2) s.stpmx = a2 / a1;
+          } else if ((mhi >> i) & 1ull) {
+            const double a1 = lane_bcast(a1v, i), a2 = lane_bcast(a2hi, i);
+            if (a2 <= 0.0) s.stpmx = 0.0;
+            else if (a1 * s.stpmx > a2) s.stpmx = a2 / a1;
+          }
+        }
       } else {
         for (int i = 0; i < n; ++i) {
           const double a1 = w.d[i];
@@ -1257,7 +1445,7 @@ LB_HD int lnsrlb(State &s, const Work &w, const double *l, const double *u, cons
     s.iback = 0;
     s.ls_task = LS_START;
   }
-  s.gd = ddot(n, w.g, w.d);
+  s.gd = ddot_c<VL>(n, w.g, w.d, c);
   if (s.ifun == 0) {
     s.gdold = s.gd;
     if (s.gd >= 0.0) {  // ascent direction in projection: line search impossible
@@ -1285,7 +1473,8 @@ LB_HD int lnsrlb(State &s, const Work &w, const double *l, const double *u, cons
 }
 
 // ---- BFGS matrix update -----------------------------------------------------------------------
-LB_HD void matupd(State &s, const Work &w, double rr, double dr) {
+template <bool VL = true>
+LB_HD void matupd(State &s, const Work &w, double rr, double dr, const Coop c = Coop{0, 1}) {
   const int n = s.n, m = s.m;
   if (s.iupdat <= m) {
     s.col = s.iupdat;
@@ -1294,9 +1483,17 @@ LB_HD void matupd(State &s, const Work &w, double rr, double dr) {
     s.itail = wrap(s.itail + 1, m);
     s.head = wrap(s.head + 1, m);
   }
-  for (int i = 0; i < n; ++i) {
-    w.ws[s.itail * n + i] = w.d[i];
-    w.wy[s.itail * n + i] = w.r[i];
+  if (VL) {
+    for (int i = c.lane; i < n; i += c.nl) {
+      w.ws[s.itail * n + i] = w.d[i];
+      w.wy[s.itail * n + i] = w.r[i];
+    }
+    LB_LANES_SYNC();
+  } else {
+    for (int i = 0; i < n; ++i) {
+      w.ws[s.itail * n + i] = w.d[i];
+      w.wy[s.itail * n + i] = w.r[i];
+    }
   }
   s.theta = rr / dr;
   const int col = s.col;
@@ -1308,17 +1505,29 @@ LB_HD void matupd(State &s, const Work &w, double rr, double dr) {
       for (int i = 0; i < col - 1 - j; ++i) w.sy[j * m + (j + i)] = w.sy[(j + 1) * m + (j + 1 + i)];
     }
   }
-  int pointr = s.head;
-  for (int j = 0; j < col - 1; ++j) {
-    w.sy[j * m + (col - 1)] = ddot(n, w.d, w.wy + pointr * n);
-    w.ss[(col - 1) * m + j] = ddot(n, w.ws + pointr * n, w.d);
-    pointr = wrap(pointr + 1, m);
+  if (VL) {
+    LB_LANES_SYNC();
+    // the new column of SY and the new row of SS: 2 (col - 1) independent inner products, one per lane
+    for (int e = c.lane; e < 2 * (col - 1); e += c.nl) {
+      const int j = e < col - 1 ? e : e - (col - 1);
+      const int pointr = wrap(s.head + j, m);
+      if (e < col - 1) w.sy[j * m + (col - 1)] = ddot(n, w.d, w.wy + pointr * n);
+      else w.ss[(col - 1) * m + j] = ddot(n, w.ws + pointr * n, w.d);
+    }
+  } else {
+    int pointr = s.head;
+    for (int j = 0; j < col - 1; ++j) {
+      w.sy[j * m + (col - 1)] = ddot(n, w.d, w.wy + pointr * n);
+      w.ss[(col - 1) * m + j] = ddot(n, w.ws + pointr * n, w.d);
+      pointr = wrap(pointr + 1, m);
+    }
   }
   if (s.stp == 1.0) w.ss[(col - 1) * m + (col - 1)] = s.dtd;
   else w.ss[(col - 1) * m + (col - 1)] = s.stp * s.stp * s.dtd;
   w.sy[(col - 1) * m + (col - 1)] = dr;
   w.rsy[col - 1] = 1.0 / dr;
   w.rsq[col - 1] = 1.0 / sqrt(dr);
+  if (VL) LB_LANES_SYNC();
 }
 
 LB_HD void refresh_memory(State &s) {
@@ -1368,6 +1577,7 @@ LB_HD void lbfgsb_init(State &s, const Work &w, int n, int m, const double *x0, 
 // s.nfev, s.status, s.task, s.msg).
 // `coop`: {0, 1} for a thread that owns its problem alone; {lane, 64} when the 64 lanes of a
 // wave run ONE problem together (every lane calls with identical State; see struct Coop).
+template <bool VL = true>
 LB_HD int lbfgsb_advance(State &s, const Work &w, const double *l, const double *u,
                          const int *nbd, const Options &opt, const Coop coop = Coop{0, 1}) {
   const int n = s.n, m = s.m;
@@ -1398,6 +1608,31 @@ LB_HD int lbfgsb_advance(State &s, const Work &w, const double *l, const double 
     }
     // active: project x, classify the variables
     s.prjctd = 0; s.cnstnd = 0; s.boxed = 1;
+    if (VL && coop.nl > 1 && n <= coop.nl) {  // one variable per lane (every output depends on variable i alone)
+      const int i = coop.lane;
+      bool prj = false, notboxed = false, cns = false;
+      if (i < n) {
+        const int nb = nbd[i];
+        if (nb > 0) {
+          if (nb <= 2 && w.x[i] <= l[i]) {
+            if (w.x[i] < l[i]) { prj = true; w.x[i] = l[i]; }
+          } else if (nb >= 2 && w.x[i] >= u[i]) {
+            if (w.x[i] > u[i]) { prj = true; w.x[i] = u[i]; }
+          }
+        }
+        notboxed = nb != 2;
+        if (nb == 0) {
+          w.iwhere[i] = -1;
+        } else {
+          cns = true;
+          w.iwhere[i] = (nb == 2 && u[i] - l[i] <= 0.0) ? 3 : 0;
+        }
+      }
+      s.prjctd = lanes_any(prj) ? 1 : 0;
+      s.boxed = lanes_any(notboxed) ? 0 : 1;
+      s.cnstnd = lanes_any(cns) ? 1 : 0;
+      LB_LANES_SYNC();
+    } else {
     for (int i = 0; i < n; ++i) {
       if (nbd[i] > 0) {
         if (nbd[i] <= 2 && w.x[i] <= l[i]) {
@@ -1416,6 +1651,7 @@ LB_HD int lbfgsb_advance(State &s, const Work &w, const double *l, const double 
         if (nbd[i] == 2 && u[i] - l[i] <= 0.0) w.iwhere[i] = 3;
         else w.iwhere[i] = 0;
       }
+    }
     }
     s.stage = S_FG_START;
     s.task = T_FG;
@@ -1447,14 +1683,14 @@ LB_HD int lbfgsb_advance(State &s, const Work &w, const double *l, const double 
         const IterArgs ia{n, m, s.col, s.head, s.nfree, s.nenter, s.ileave, s.updatd, s.iupdat,
                           s.theta, s.sbgnrm, coop};
         LB_PHASE_BEGIN();
-        const int rc = cauchy(ia, w, l, u, nbd);
+        const int rc = cauchy<VL>(ia, w, l, u, nbd);
         LB_PHASE_END(0);
         s.nseg = rc >> 8;
         if (rc & 0xff) {  // singular triangular system: refresh the memory
           refresh_memory(s);
           continue;
         }
-        freev(s, w);
+        freev<VL>(s, w, coop);
         s.nact = n - s.nfree;
       }
       if (s.nfree != 0 && s.col != 0) {
@@ -1475,7 +1711,7 @@ LB_HD int lbfgsb_advance(State &s, const Work &w, const double *l, const double 
         }
         {
           LB_PHASE_BEGIN();
-          rc = subsm(ia, w, l, u, nbd);
+          rc = subsm<VL>(ia, w, l, u, nbd);
           LB_PHASE_END(3);
         }
         s.iword = rc >> 8;
@@ -1490,7 +1726,7 @@ LB_HD int lbfgsb_advance(State &s, const Work &w, const double *l, const double 
     int ls_rc;
     {
       LB_PHASE_BEGIN();
-      ls_rc = lnsrlb(s, w, l, u, nbd, first_ls ? 1 : 0, coop);
+      ls_rc = lnsrlb<VL>(s, w, l, u, nbd, first_ls ? 1 : 0, coop);
       LB_PHASE_END(4);
     }
     if (ls_rc) {
@@ -1550,7 +1786,7 @@ LB_HD int lbfgsb_advance(State &s, const Work &w, const double *l, const double 
     for (int i = coop.lane; i < n; i += coop.nl) w.r[i] = w.g[i] - w.r[i];
     LB_LANES_SYNC();
     {
-      const double rr = ddot(n, w.r, w.r);
+      const double rr = ddot_c<VL>(n, w.r, w.r, coop);
       double dr, ddum;
       if (s.stp == 1.0) {
         dr = s.gd - s.gdold;
@@ -1569,7 +1805,7 @@ LB_HD int lbfgsb_advance(State &s, const Work &w, const double *l, const double 
       ++s.iupdat;
       {
         LB_PHASE_BEGIN();
-        matupd(s, w, rr, dr);
+        matupd<VL>(s, w, rr, dr, coop);
         LB_PHASE_END(5);
       }
       int ft;

@@ -93,13 +93,14 @@ def test_sample_screen_topk_equals_the_two_launches(gpu, D, units, Ns, R):
 CASES = [(2, [16, 16, 1], ["relu", "relu", "sigmoid"], "identity", 3),
          (6, [32, 32, 1], ["relu", "relu", "linear"], "sigmoid", 40),
          (3, [32, 32, 32, 1], ["elu"] * 3 + ["linear"], "exp", 9),
-         (16, [64, 64, 64, 1], ["relu"] * 3 + ["linear"], "sigmoid", 70)]
+         (16, [64, 64, 64, 1], ["relu"] * 3 + ["linear"], "sigmoid", 70),
+         (32, [128, 128, 1], ["relu", "relu", "linear"], "sigmoid", 10)]
 
 
 # lower bounds on the share of restarts whose whole record (nit, nfev, status, x) is scipy's, by input
 # dimension of the case -- set just below what this test measures (printed)
-# (measured r2: D=2 6/6, D=6 79/80, D=3 18/18, D=16 116/140)
-MIN_SAME = {2: 1.0, 6: 0.95, 3: 0.95, 16: 0.78}
+# (measured r2: D=2 6/6, D=6 79/80, D=3 18/18, D=16 116/140, D=32 15/20)
+MIN_SAME = {2: 1.0, 6: 0.95, 3: 0.95, 16: 0.78, 32: 0.65}
 
 
 @pytest.mark.parametrize("D,units,acts,tr,R", CASES)
@@ -143,7 +144,8 @@ def test_device_lbfgsb_equals_host_build_and_tracks_scipy(gpu, D, units, acts, t
     print(f"\n[lbfgsb vs scipy, random nets D={D} R={R}] identical (nit, nfev, status, x to 1e-7): "
           f"{n_same_scipy}/{L * R}; |dfun| median {np.median(dfun):.1e}, within 2e-5: {np.mean(np.array(dfun) < 2e-5):.3f}")
     assert n_same_scipy >= MIN_SAME[D] * L * R
-    assert np.median(dfun) < 1e-6 and np.mean(np.array(dfun) < 2e-5) >= 0.9
+    # (32-D, random 128-128-1 nets: 17 of 20 within 2e-5, the others end 1e-5 .. 1e-4 apart)
+    assert np.median(dfun) < 1e-6 and np.mean(np.array(dfun) < 2e-5) >= (0.8 if D == 32 else 0.9)
 
 
 def test_lbfgsb_one_problem_per_lane_mode_equals_one_per_wave(gpu):
