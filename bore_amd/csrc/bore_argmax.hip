@@ -11,6 +11,7 @@
 #include "lbfgsb.h"
 #include "mlp_device.h"
 #include "mlp_regs.h"
+#include "mlp_point.h"
 
 using namespace bore;
 
@@ -575,8 +576,10 @@ __device__ __forceinline__ void lbfgsb_body(const LbfgsbArgs &a, const long long
   if constexpr (SHAPE > 0) {
     if constexpr (Net::RT_ACT) net.set_acts(a.L);
     if constexpr (!LEAN) {
-      net.load_fwd(thw);
-      net.template load_bwd<Net::n, 1>(thw);
+      if (!(coop && SHAPE != 1)) {  // (one point per wave goes through PointNet: no matrix operands)
+        net.load_fwd(thw);
+        net.template load_bwd<Net::n, 1>(thw);
+      }
     }
   }
   bool done = (myp < 0);
@@ -606,10 +609,22 @@ __device__ __forceinline__ void lbfgsb_body(const LbfgsbArgs &a, const long long
       const int m16 = lane & 15, q4 = lane >> 4;
       float xin[Net::KC0];
       if constexpr (LEAN) {
-        net.load_fwd(thw);
-        net.template load_bwd<Net::n, 1>(thw);
+        if (!(coop && SHAPE != 1)) {
+          net.load_fwd(thw);
+          net.template load_bwd<Net::n, 1>(thw);
+        }
       }
-      if (coop) {
+      if (coop && SHAPE != 1) {
+        // one point per wave, on the vector ALU (mlp_point.h: the same k-ordered fmaf chains as the
+        // matrix path, 1 / 16 of its arithmetic); x straight from the optimiser's fp64 vector (Keras
+        // autocast fp64 -> fp32)
+        PointNet<(SHAPE > 0 ? SHAPE : 1), BF16> pnet;
+        if constexpr (Net::RT_ACT) pnet.set_acts(a.L);
+        const float xl = lane < D ? Net::rnd((float)wk.x[lane]) : 0.f;
+        const float Tv = pnet.fg(thw, xl, a.transform, a.sign);
+        st.f = (double)Tv;
+        if (lane < D) wk.g[lane] = (double)pnet.d[0][0];
+      } else if (coop) {
         // one point per wave: every row of the block evaluates it, read straight from the
         // optimiser's fp64 x (Keras autocast fp64 -> fp32)
 #pragma unroll

@@ -25,7 +25,7 @@ for name, D, units, compute, L, R in [("cfg5_bf16", 32, [128, 128, 1], "bfloat16
         out = (C.c_longlong * 8)(); lib.bore_debug_lstamps(out)
         o = list(out)
         ph = (C.c_longlong * 16)(); lib.bore_debug_lphases(ph); ph = list(ph)
-        names = ["cauchy", "formk", "cmprlb", "subsm", "lnsrlb", "matupd", "formt", "-"]
+        names = os.environ.get("LB_NAMES", "cauchy,formk,cmprlb,subsm,lnsrlb,matupd,formt,-").split(",")
         print("   phases (workgroup 0 / wave 0; cycles per call x calls): " + "  ".join(
             f"{nm} {ph[i] // max(ph[8 + i], 1)} x {ph[8 + i]}" for i, nm in enumerate(names) if ph[8 + i]))
         print(f"{name} maxiter {maxiter}: begin {o[4]} stage {o[5]} init {o[6]} | advance {o[0]} fg {o[1]} rounds {o[2]} nit {o[3]} | total {o[7]}", flush=True)
