@@ -485,3 +485,35 @@ def test_fit_with_more_than_64_rows_per_batch_against_oracle(gpu, N, B):
         np.testing.assert_allclose(h.cpu().numpy()[0], hist, rtol=5e-5)
         np.testing.assert_allclose(theta.cpu().numpy()[0], pack(p64), rtol=2e-4, atol=1e-5)
         np.testing.assert_allclose(m.cpu().numpy()[0], pack(st.m), rtol=2e-3, atol=1e-7)
+
+
+@pytest.mark.parametrize("D,units,compute", [(16, [64, 64, 64, 1], "float32"), (16, [64, 64, 64, 1], "bfloat16"),
+                                             (32, [128, 128, 1], "bfloat16")])
+def test_wide_fit_in_several_launches_equals_one_launch(gpu, D, units, compute):
+    """The wide fits keep theta / m / v in tile order INSIDE a launch (fit_bf16_mfma.h: TileOrder)
+    and hand them back in the packed order: E epochs in one launch and in E launches of one epoch
+    (what Keras callbacks make of a fit) give the same bits, and a launch of zero epochs leaves
+    the state untouched."""
+    rs = np.random.RandomState(11)
+    acts = ["relu"] * (len(units) - 1) + ["sigmoid"]
+    desc = _lib.make_desc(D, units, acts, compute=compute)
+    P, L, N, E = ops.param_count(desc), 2, 150, 3
+    th0 = rs.normal(scale=0.2, size=(L, P)).astype(np.float32)
+    X = dev(rs.uniform(size=(L, N, D)).astype(np.float32))
+    z = dev((rs.uniform(size=(L, N)) < 0.25).astype(np.float32))
+
+    def state():
+        th = dev(th0)
+        return th, torch.zeros_like(th), torch.zeros_like(th), torch.zeros(L, dtype=torch.int64, device=th.device)
+
+    a = state()
+    ops.mlp_fit(desc, *a, X, z, E, 64, seed=5, want_loss=False)
+    b = state()
+    for e in range(E):
+        ops.mlp_fit(desc, *b, X, z, 1, 64, seed=5, epoch0=e, want_loss=False)
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)
+    keep = [t.clone() for t in a]
+    ops.mlp_fit(desc, *a, X, z, 0, 64, seed=5, epoch0=E, want_loss=False)
+    for u, v in zip(a, keep):
+        assert torch.equal(u, v)
