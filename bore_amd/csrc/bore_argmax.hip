@@ -187,7 +187,12 @@ __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
   return v;
 }
 
-template <int SHAPE, bool BF16 = false>
+// MODE 0: the whole screen in one workgroup per model.  For ONE (or a few) wide models that leaves
+// the device idle while a single CU walks thousands of candidates, so the launcher may split it:
+// MODE 1 = the predictions only, grid (models, parts), workgroup `part` taking every parts-th
+// round of row-blocks and writing a.pred; MODE 2 = the selection, reading the predictions back
+// (same predictions, same keys, same order: the two forms give the same bits).
+template <int SHAPE, bool BF16 = false, int MODE = 0>
 __device__ __forceinline__ void screen_body(const ScreenArgs &a, const long long model,
                                             const int it_now = -1) {
   extern __shared__ float smem[];
@@ -201,7 +206,7 @@ __device__ __forceinline__ void screen_body(const ScreenArgs &a, const long long
   float *th = smem, *tile = smem + a.o_tile;
   unsigned long long *keys = reinterpret_cast<unsigned long long *>(smem + a.o_keys);
   const int wv = tid >> 6, lane = tid & 63, m16 = lane & 15, q4 = lane >> 4;
-  stage_theta<BF16>(L, n, a.theta + lid * L.P, smem);
+  if constexpr (MODE != 2) stage_theta<BF16>(L, n, a.theta + lid * L.P, smem);
   const double *X = a.sampled ? nullptr : a.X + (a.x_shared ? 0 : model * a.n_samples * D);
   double *blo = reinterpret_cast<double *>(smem + a.o_box), *bhi = blo + D;
   if (a.sampled && tid < D) {  // the box is indexed per lane: LDS copy
@@ -229,12 +234,14 @@ __device__ __forceinline__ void screen_body(const ScreenArgs &a, const long long
   using Net = RegNet<(SHAPE > 0 ? SHAPE : 1), 0, BF16>;
   const typename Net::WT *thw = reinterpret_cast<const typename Net::WT *>(smem);
   Net net;  // static shapes: the weights stay in this lane's registers for every row-block
-  if constexpr (SHAPE > 0) {
+  if constexpr (SHAPE > 0 && MODE != 2) {
     if constexpr (Net::RT_ACT) net.set_acts(a.L);
     net.load_fwd(thw);
   }
-  if (wv < waves)
-    for (int g = wv; g < n_blocks; g += waves) {
+  const int g0 = MODE == 1 ? wv + waves * (int)blockIdx.y : wv;
+  const int gs = MODE == 1 ? waves * (int)gridDim.y : waves;
+  if (MODE != 2 && wv < waves)
+    for (int g = g0; g < n_blocks; g += gs) {
       const int row = g * 16 + m16;
       float p;  // prediction of row g*16 + lane, in the lanes < 16
       if constexpr (SHAPE > 0) {  // activations in registers (mlp_regs.h)
@@ -256,10 +263,14 @@ __device__ __forceinline__ void screen_body(const ScreenArgs &a, const long long
       }
       if (lane < 16 && g * 16 + lane < Ns) {
         const int r = g * 16 + lane;
-        keys[r] = ((unsigned long long)(~orderable(p)) << 32) | (unsigned)r;
-        if (a.pred) a.pred[model * a.n_samples + r] = p;
+        if constexpr (MODE == 0) keys[r] = ((unsigned long long)(~orderable(p)) << 32) | (unsigned)r;
+        if (MODE == 1 || a.pred) a.pred[model * a.n_samples + r] = p;
       }
     }
+  if constexpr (MODE == 1) return;
+  if constexpr (MODE == 2)
+    for (int r = tid; r < Ns; r += nthr)
+      keys[r] = ((unsigned long long)(~orderable(a.pred[model * a.n_samples + r])) << 32) | (unsigned)r;
   for (int i = Ns + tid; i < a.n_pad; i += nthr) keys[i] = ~0ULL;
   __syncthreads();
 
@@ -316,9 +327,9 @@ __device__ __forceinline__ void screen_body(const ScreenArgs &a, const long long
   }
 }
 
-template <int SHAPE, bool BF16 = false>
+template <int SHAPE, bool BF16 = false, int MODE = 0>
 __global__ __launch_bounds__(BORE_THREADS) void screen_topk_kernel(const ScreenArgs a) {
-  screen_body<SHAPE, BF16>(a, blockIdx.x);
+  screen_body<SHAPE, BF16, MODE>(a, blockIdx.x);
 }
 
 struct SampleSpec {
@@ -386,6 +397,36 @@ static int screen_launch(const bore_mlp_desc *desc, int n_models, const float *t
   int rc = screen_build(desc, n_models, theta, X_init, spec, n_samples, x_shared, num_starts, x0, idx,
                         pred, a, off, shape);
   if (rc) return rc;
+  // A few wide models, many candidates, and the caller gave a prediction buffer: the predictions run
+  // on `parts` workgroups per model, then one workgroup per model selects (screen_body, MODE 1 / 2).
+  // BORE_SCREEN_SPLIT = 0 / 1 forces either form.
+  if (pred && !g_batch && bore_shape_is_wide(shape)) {
+    const int forced = getenv("BORE_SCREEN_SPLIT") ? atoi(getenv("BORE_SCREEN_SPLIT")) : -1;
+    const int n_blocks = (int)((n_samples + 15) >> 4);
+    int parts = device_cus() / (n_models > 0 ? n_models : 1);
+    if (parts > n_blocks / 8) parts = n_blocks / 8;  // at least two row-blocks per wave
+    if (parts > 64) parts = 64;
+    if (forced < 0 ? parts >= 4 : (forced != 0 && parts >= 2)) {
+      const bool bf = desc->compute == BORE_COMPUTE_BF16;
+#define BORE_LAUNCH_SPLIT(S, B)                                                                          \
+  {                                                                                                      \
+    if ((rc = allow_lds((screen_topk_kernel<S, B, 1>), off * 4)) ||                                       \
+        (rc = allow_lds((screen_topk_kernel<S, B, 2>), off * 4)))                                         \
+      return rc;                                                                                         \
+    hipLaunchKernelGGL((screen_topk_kernel<S, B, 1>), dim3(n_models, parts), dim3(BORE_THREADS), off * 4, \
+                       (hipStream_t)stream, a);                                                          \
+    hipLaunchKernelGGL((screen_topk_kernel<S, B, 2>), dim3(n_models), dim3(BORE_THREADS), off * 4,        \
+                       (hipStream_t)stream, a);                                                          \
+  }
+      if (shape == 3 && !bf) BORE_LAUNCH_SPLIT(3, false)
+      else if (shape == 3) BORE_LAUNCH_SPLIT(3, true)
+      else if (!bf) BORE_LAUNCH_SPLIT(4, false)
+      else BORE_LAUNCH_SPLIT(4, true)
+#undef BORE_LAUNCH_SPLIT
+      HIP_TRY(hipGetLastError());
+      return 0;
+    }
+  }
   if (desc->compute == BORE_COMPUTE_BF16) {
     if (!bore_shape_is_wide(shape)) return fail(BORE_E_UNSUPPORTED, kBf16Shapes);
     if (shape == 3) {

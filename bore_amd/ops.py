@@ -184,7 +184,7 @@ def screen_topk(desc, theta, X_init, num_starts, want_pred=False):
     R = int(num_starts)
     x0 = torch.empty((L, R, D), dtype=torch.float64, device=theta.device)
     idx = torch.empty((L, R), dtype=torch.int32, device=theta.device)
-    pred = torch.empty((L, Ns), dtype=torch.float32, device=theta.device) if want_pred else None
+    pred = torch.empty((L, Ns), dtype=torch.float32, device=theta.device) if (want_pred or Ns >= 1024) else None
     _lib.check(_lib.lib().bore_screen_topk(C.byref(desc), L, _lib.ptr(theta), _lib.ptr(X_init), Ns,
                                            int(shared), R, _lib.ptr(x0), _lib.ptr(idx),
                                            _lib.ptr(pred), _lib.stream_ptr()))
@@ -203,7 +203,9 @@ def sample_screen_topk(desc, theta, seed, n_samples, low, high, num_starts, mode
     R, Ns = int(num_starts), int(n_samples)
     x0 = torch.empty((L, R, D), dtype=torch.float64, device=theta.device)
     idx = torch.empty((L, R), dtype=torch.int32, device=theta.device)
-    pred = torch.empty((L, Ns), dtype=torch.float32, device=theta.device) if want_pred else None
+    # (a prediction buffer lets the library spread the predictions of a few wide models over the
+    # device: bore_argmax.hip, screen_body MODE 1 / 2; same results)
+    pred = torch.empty((L, Ns), dtype=torch.float32, device=theta.device) if (want_pred or Ns >= 1024) else None
     _lib.check(_lib.lib().bore_sample_screen_topk(
         C.byref(desc), L, _lib.ptr(theta), C.c_uint64(seed & (2**64 - 1)), int(model_index0),
         int(draw_index), Ns, lo_p, hi_p, R, _lib.ptr(x0), _lib.ptr(idx), _lib.ptr(pred),

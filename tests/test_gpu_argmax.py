@@ -678,3 +678,28 @@ def test_lbfgsb_eight_waves_per_workgroup_give_the_same_bits(gpu, monkeypatch, D
                                                                   maxiter=200, ftol=1e-9)])
     for a, b in zip(*outs):
         assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("D,units,compute,Ns,R", [(16, [64, 64, 64, 1], "float32", 1024, 1024),
+                                                  (16, [64, 64, 64, 1], "bfloat16", 2048, 7),
+                                                  (32, [128, 128, 1], "bfloat16", 4096, 4096)])
+def test_screen_split_over_workgroups_gives_the_same_bits(gpu, monkeypatch, D, units, compute, Ns, R):
+    """A few wide models and many candidates: the predictions run on several workgroups per model,
+    one workgroup selects (screen_body MODE 1 / 2); BORE_SCREEN_SPLIT forces either form: same
+    starts, indices and predictions bit for bit, for the sampled and the in-memory candidates."""
+    rs = np.random.RandomState(12)
+    acts = ["relu"] * (len(units) - 1) + ["sigmoid"]
+    desc = _lib.make_desc(D, units, acts, compute=compute)
+    th = dev(np.stack([pack(rand_model(rs, D, units)) for _ in range(2)]))
+    lo, hi = np.zeros(D), np.ones(D)
+    Xc = ops.uniform_candidates(17, 2, Ns, lo, hi)
+    outs = []
+    for split in ("0", "1"):
+        monkeypatch.setenv("BORE_SCREEN_SPLIT", split)
+        a = ops.sample_screen_topk(desc, th, 17, Ns, lo, hi, R, want_pred=True)
+        b = ops.screen_topk(desc, th, Xc, R, want_pred=True)
+        outs.append([t.cpu().numpy() for t in (*a, *b)])
+    for u, v in zip(*outs):
+        assert np.array_equal(u, v)
+    for u, v in zip(outs[0][:3], outs[0][3:]):      # sampled == in-memory candidates
+        assert np.array_equal(u, v)
