@@ -688,6 +688,152 @@ __device__ __forceinline__ void wide_fused_f32(float *th, const float *img, floa
   });
 }
 
+// ---------------------------------------------------------------------------------------------
+// The float32 fit of 32->128-128-1: theta (84 KB) and the 64-row A / D images (152 KB) do not share
+// a CU's LDS.  Forward and backward still run on all four waves, 16 rows each, in registers; the
+// weight gradients are then formed in FOUR ROUNDS: in round r wave r publishes ITS 16 rows of
+// A_l / D_l (transposed, 20-float pitch: 45 KB), every wave adds those rows' four k-chunks to the
+// accumulators of its own tiles (22 tiles x 4 registers, kept across the rounds), and after the
+// last round updates them.  Rows enter every chain in the order 0..63, as in the one-pass form.
+// ---------------------------------------------------------------------------------------------
+template <int SHAPE>
+struct WideTp16 {
+  static constexpr MlpLayout L = bore_static_layout(SHAPE, 1, BORE_BATCH_MAX);
+  static constexpr int n = L.n_layers, PITCH = 20;
+  static constexpr int a_off(int l) {
+    int o = 0;
+    for (int i = 0; i < l; ++i) o += L.Np[i] * PITCH;
+    return o;
+  }
+  static constexpr int d_off(int l) {
+    int o = a_off(n);
+    for (int i = 1; i < l; ++i) o += L.Np[i] * PITCH;
+    return o;
+  }
+  static constexpr int total() { return d_off(n + 1); }
+  static __host__ __device__ constexpr int idx(int unit, int row) { return unit * PITCH + (row & 3) * 4 + (row >> 2); }
+};
+// shapes whose one-pass images do not fit beside theta
+static constexpr bool bore_shape_fit_in_rounds(int shape) {
+  return shape == 4;
+}
+
+template <int SHAPE, typename Net>
+__device__ __forceinline__ void wide_rounds_f32(const Net &net, const float (&xin)[Net::KC0], float delta,
+                                                float *th, float *img, float *m_g, float *v_g, float alpha,
+                                                float omb1, float omb2, float eps, int tid_o) {
+  using Tp = WideTp<SHAPE>;
+  using T16 = WideTp16<SHAPE>;
+  constexpr MlpLayout L = Tp::L;
+  constexpr int n = L.n_layers, TOTAL = Tp::total_tiles(), TPW = TOTAL / 4, PITCH = T16::PITCH, P = L.P;
+  static_assert(Tp::aligned() && TOTAL % 4 == 0, "tiles of a layer must start at a multiple of 4");
+  typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+  const int wv = __builtin_amdgcn_readfirstlane(tid_o >> 6), lane = tid_o & 63, m16 = lane & 15, q4 = lane >> 4;
+  f32x4 acc[TPW];
+  float bsum[TPW];
+#pragma unroll
+  for (int i = 0; i < TPW; ++i) {
+    acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bsum[i] = 0.f;
+  }
+  auto tile_of = [&](auto ic, int &kb, int &cb) {
+    constexpr int I = decltype(ic)::value, l = Tp::layer_of_tile(4 * I);
+    constexpr int ncb = L.Np[l] >> 4;
+    const int r = wv + 4 * I - Tp::tiles_before(l);
+    kb = r / ncb;
+    cb = r - kb * ncb;
+  };
+  for (int round = 0; round < 4; ++round) {
+    if (wv == round) {  // this wave's 16 rows become the shared images: row m16 of the round
+#pragma unroll
+      for (int kc = 0; kc < Net::KC0; ++kc)
+        if (4 * kc + q4 < L.Np[0]) img[T16::a_off(0) + T16::idx(4 * kc + q4, m16)] = xin[kc];
+      static_for<1, n>([&](auto lc) {
+        constexpr int l = decltype(lc)::value;
+#pragma unroll
+        for (int t = 0; t < L.Np[l] / 16; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            img[T16::a_off(l) + T16::idx(16 * t + 4 * q4 + r, m16)] = net.h[l][t][r];
+            img[T16::d_off(l) + T16::idx(16 * t + 4 * q4 + r, m16)] = net.d[l][t][r];
+          }
+      });
+      if (lane < 16) img[T16::d_off(n) + T16::idx(0, m16)] = delta;
+    }
+    __syncthreads();
+    static_for<0, TPW>([&](auto ic) {
+      constexpr int I = decltype(ic)::value, l = Tp::layer_of_tile(4 * I);
+      int kb, cb;
+      tile_of(ic, kb, cb);
+      // rows 4 kc + q4 (kc = 0..3) of unit 16 kb|cb + m16: four consecutive floats
+      const float4 av = *reinterpret_cast<const float4 *>(img + T16::a_off(l - 1) + (16 * kb + m16) * PITCH + 4 * q4);
+      const float4 bq = *reinterpret_cast<const float4 *>(img + T16::d_off(l) + (16 * cb + m16) * PITCH + 4 * q4);
+      acc[I] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bq.x, acc[I], 0, 0, 0);
+      acc[I] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bq.y, acc[I], 0, 0, 0);
+      acc[I] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bq.z, acc[I], 0, 0, 0);
+      acc[I] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bq.w, acc[I], 0, 0, 0);
+      bsum[I] += bq.x;
+      bsum[I] += bq.y;
+      bsum[I] += bq.z;
+      bsum[I] += bq.w;
+    });
+    __syncthreads();  // (the next round's wave overwrites the images)
+  }
+  // update: m / v in tile order (the MFMA result layout), theta in its LDS image
+  const BufF32 b_m(m_g, P), b_v(v_g, P);
+  const unsigned lbb = 4u * (unsigned)m16;
+  static_for<0, TPW>([&](auto ic) {
+    constexpr int I = decltype(ic)::value, l = Tp::layer_of_tile(4 * I);
+    constexpr int K = L.w[l - 1], Nw = L.w[l], ncb = L.Np[l] >> 4, ldw = L.ldw[l];
+    static_assert(Nw == 1 || (K % 16 == 0 && Nw % 16 == 0), "tile-order layers only");
+    int kb, cb;
+    tile_of(ic, kb, cb);
+    int pu;
+    unsigned lb4;
+    bool ok4;
+    if constexpr (Nw == 1) {
+      pu = L.goff_w[l] + 16 * kb;
+      lb4 = 16u * (unsigned)q4;
+      ok4 = m16 == 0 && 16 * kb + 4 * q4 < K;
+    } else {
+      pu = L.goff_w[l] + (kb * ncb + cb) * 256;
+      lb4 = 16u * (unsigned)lane;
+      ok4 = true;
+    }
+    const bool okb = kb == 0 && q4 == 0 && 16 * cb + m16 < Nw;
+    const int pbu = L.goff_b[l] + 16 * cb;
+    const int li0 = Nw == 1 ? L.woff[l] + (16 * kb + 4 * q4) * ldw : L.woff[l] + (16 * kb + 4 * q4) * ldw + 16 * cb + m16;
+    const f4u z4 = {0.f, 0.f, 0.f, 0.f};
+    f4u pm = ok4 ? b_m.ld4(pu, lb4) : z4, pv = ok4 ? b_v.ld4(pu, lb4) : z4;
+    const float g[4] = {acc[I][0], acc[I][1], acc[I][2], acc[I][3]};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float w = ok4 ? th[li0 + r * ldw] : 0.f;
+      float mm = pm[r], vv = pv[r];
+      const float wn = adam_update(w, g[r], mm, vv, alpha, omb1, omb2, eps);
+      pm[r] = mm;
+      pv[r] = vv;
+      if (ok4) th[li0 + r * ldw] = wn;
+    }
+    if (ok4) {
+      b_m.st4(pm, pu, lb4);
+      b_v.st4(pv, pu, lb4);
+    }
+    if (kb == 0) {  // bias: the column sums of D_l
+      const float gb = rows_sum4(bsum[I]);
+      const int lb = L.boff[l] + 16 * cb + m16;
+      float mm = okb ? b_m.ld1(pbu, lbb) : 0.f, vv = okb ? b_v.ld1(pbu, lbb) : 0.f;
+      const float wb0 = okb ? th[lb] : 0.f;
+      const float wnb = adam_update(wb0, gb, mm, vv, alpha, omb1, omb2, eps);
+      if (okb) {
+        th[lb] = wnb;
+        b_m.st1(mm, pbu, lbb);
+        b_v.st1(vv, pbu, lbb);
+      }
+    }
+  });
+}
+
 // (the body is a device function so that the fused iteration kernel of bore_iter.hip can run it)
 template <int SHAPE>
 __device__ __forceinline__ void fit_body(const FitArgs &a, const long long slot,
@@ -695,6 +841,7 @@ __device__ __forceinline__ void fit_body(const FitArgs &a, const long long slot,
   extern __shared__ float smem[];
   constexpr MlpLayout Lc = bore_static_layout(SHAPE > 0 ? SHAPE : 0, 1, BORE_BATCH_MAX);
   constexpr bool WIDE = bore_shape_is_wide(SHAPE > 0 ? SHAPE : 0);
+  constexpr bool ROUNDS = bore_shape_fit_in_rounds(SHAPE > 0 ? SHAPE : 0);  // (wide_rounds_f32)
   if constexpr (WIDE) {  // m / v (in HBM for a wide net) go to tile order for the launch (TileOrder)
     const long long mdl = a.ids ? a.ids[slot] : slot;
     TileOrder<WIDE ? SHAPE : 1>::convert(a.am + mdl * Lc.P, smem, true);
@@ -838,7 +985,8 @@ __device__ __forceinline__ void fit_body(const FitArgs &a, const long long slot,
 #pragma unroll
           for (int kc = 0; kc < Net::KC0; ++kc)
             if (4 * kc + q4 < D) {
-              if constexpr (bore_shape_is_wide(SHAPE)) tile[WideTp<SHAPE>::a_off(0) + WideTp<SHAPE>::idx(4 * kc + q4, row)] = xin[kc];
+              if constexpr (ROUNDS) {
+              } else if constexpr (bore_shape_is_wide(SHAPE)) tile[WideTp<SHAPE>::a_off(0) + WideTp<SHAPE>::idx(4 * kc + q4, row)] = xin[kc];
               else A0[4 * kc + q4] = xin[kc];
             }
           __builtin_amdgcn_sched_barrier(0);  // every operand load is in flight before the chain
@@ -847,7 +995,8 @@ __device__ __forceinline__ void fit_body(const FitArgs &a, const long long slot,
           net.forward(th, xin, /*keep_logits=*/true);
           BORE_STAMP(2);
           BORE_WSTAMP(1);
-          if constexpr (bore_shape_is_wide(SHAPE)) {
+          if constexpr (ROUNDS) {  // (the rows stay in registers until their round: wide_rounds_f32)
+          } else if constexpr (bore_shape_is_wide(SHAPE)) {
             static_for<1, Net::n>([&](auto lc) {
               constexpr int l = decltype(lc)::value;
               store_rows_tp<SHAPE, Net::L.Np[l], Net::T>(net.h[l], tile + WideTp<SHAPE>::a_off(l), row);
@@ -865,7 +1014,8 @@ __device__ __forceinline__ void fit_body(const FitArgs &a, const long long slot,
             delta = (sig - zz) / (float)nb;
           }
           if (lane < 16) {
-            if constexpr (bore_shape_is_wide(SHAPE)) tile[WideTp<SHAPE>::d_off(Net::n) + WideTp<SHAPE>::idx(0, row)] = delta;
+            if constexpr (ROUNDS) {
+            } else if constexpr (bore_shape_is_wide(SHAPE)) tile[WideTp<SHAPE>::d_off(Net::n) + WideTp<SHAPE>::idx(0, row)] = delta;
             else tile[L.doff[Net::n] + row * L.lda[Net::n]] = delta;
           }
           net.set_output_delta(delta);
@@ -873,7 +1023,11 @@ __device__ __forceinline__ void fit_body(const FitArgs &a, const long long slot,
           BORE_WSTAMP(2);
           net.template backward<Net::n, 2>(th);
           BORE_WSTAMP(3);
-          if constexpr (bore_shape_is_wide(SHAPE)) {
+          if constexpr (ROUNDS) {
+            int tid_r = tid;  // (opaque per step, as for the other wide fits)
+            asm volatile("" : "+v"(tid_r));
+            wide_rounds_f32<SHAPE>(net, xin, delta, th, tile, m_g, v_g, alpha, omb1, omb2, a.eps, tid_r);
+          } else if constexpr (bore_shape_is_wide(SHAPE)) {
             static_for<1, Net::n>([&](auto lc) {
               constexpr int l = decltype(lc)::value;
               store_rows_tp<SHAPE, Net::L.Np[l], Net::T>(net.d[l], tile + WideTp<SHAPE>::d_off(l), row);
@@ -935,7 +1089,9 @@ __device__ __forceinline__ void fit_body(const FitArgs &a, const long long slot,
       // ---- weight gradients (sums over all rows) + Adam, one 16x16 tile per wave at a time ----
       const int kch = (nr + 3) >> 2;
       int t = 0;
-      if constexpr (bore_shape_is_wide(SHAPE > 0 ? SHAPE : 0)) {
+      if constexpr (ROUNDS) {
+        // (gradients and update ran inside the row-block scope above: wide_rounds_f32)
+      } else if constexpr (bore_shape_is_wide(SHAPE > 0 ? SHAPE : 0)) {
         // (a wide net's m / v never fit in LDS beside theta and the 64-row images: fit_build)
         int tid_o = tid;  // opaque per step: nothing derived from it is hoisted out of the step loop
         asm volatile("" : "+v"(tid_o));
@@ -1832,8 +1988,27 @@ static int fit_build(const bore_mlp_desc *desc, int n_models, float *theta, floa
   // (+ keys) and the batch targets ride along
   const int tile_rows = batch_size < BORE_BATCH_MAX ? batch_size : BORE_BATCH_MAX;
   const size_t fixed_extra = BORE_BATCH_MAX + 8 + BORE_LAYOUT_FLOATS + 12;
-  int rc = check_common(desc, n_models, 1, tile_rows, false, fixed_extra + (size_t)N * (perm ? 1 : 3),
-                        &a.L);
+  // 32->128-128-1 in float32 with 64-row batches: theta and the 64-row images do not share the LDS;
+  // the weight gradients are formed in four rounds over 16-row images instead (wide_rounds_f32)
+  const bool rounds = desc && desc->compute != BORE_COMPUTE_BF16 && batch_size == BORE_BATCH_MAX && !g_batch &&
+                      bore_shape_fit_in_rounds(bore_kernel_flavour(desc, true));
+  int rc;
+  if (rounds) {
+    if (n_models < 1) return fail(BORE_E_INVALID, "n_models must be >= 1 (got %d)", n_models);
+    if (bore_make_layout(desc, 1, BORE_BATCH_MAX, &a.L)) return fail(BORE_E_INVALID, "bad bore_mlp_desc");
+    a.L.tile_floats = WideTp16<4>::total();  // (the kernel's images; the row-major tile is not used)
+    const size_t need = (size_t)a.L.P_lds + a.L.tile_floats + fixed_extra + (size_t)N * (perm ? 1 : 3);
+    rc = need * 4 <= BORE_LDS_BYTES ? 0 : BORE_E_UNSUPPORTED;
+    if (rc) {
+      const size_t avail = BORE_LDS_BYTES / 4 - ((size_t)a.L.P_lds + a.L.tile_floats + fixed_extra);
+      return fail(BORE_E_UNSUPPORTED,
+                  "fit: N=%lld rows exceed what one workgroup's LDS holds beside this network (the "
+                  "epoch's shuffle lives there): at most %zu rows",
+                  (long long)N, avail / (perm ? 1 : 3));
+    }
+  } else
+  rc = check_common(desc, n_models, 1, tile_rows, false, fixed_extra + (size_t)N * (perm ? 1 : 3),
+                    &a.L);
   if (rc == BORE_E_UNSUPPORTED && !check_common(desc, n_models, 1, tile_rows, false, fixed_extra, &a.L)) {
     // the network fits, the epoch's shuffle (drawn and ranked in LDS) does not: say how far N goes
     const size_t avail = BORE_LDS_BYTES / 4 - ((size_t)a.L.P_lds + a.L.tile_floats + fixed_extra);
@@ -1907,7 +2082,7 @@ static int fit_build(const bore_mlp_desc *desc, int n_models, float *theta, floa
   // the constexpr-layout instantiation needs the layout it was compiled for (64-row tile)
   // (and keeps the Adam slots in LDS unconditionally)
   int shape = bore_kernel_flavour(desc, batch_size == BORE_BATCH_MAX);
-  if (shape > 0 && (!bore_shape_has_static_fit(shape) || (!a.state_in_lds && !bore_shape_is_wide(shape))))
+  if (shape > 0 && !rounds && (!bore_shape_has_static_fit(shape) || (!a.state_in_lds && !bore_shape_is_wide(shape))))
     shape = -desc->n_layers;
   if (shape > 0 && bore_shape_is_wide(shape)) {
     // the wide static fit keeps m / v in HBM and its A / D images transposed (WideTp)
@@ -1947,6 +2122,7 @@ extern "C" int bore_mlp_fit(const bore_mlp_desc *desc, int n_models, float *thet
     BORE_LAUNCH_FIT(1)
     BORE_LAUNCH_FIT(2)
     BORE_LAUNCH_FIT(3)
+    BORE_LAUNCH_FIT(4)
     BORE_LAUNCH_FIT(-1)
     BORE_LAUNCH_FIT(-2)
     BORE_LAUNCH_FIT(-3)

@@ -517,3 +517,32 @@ def test_wide_fit_in_several_launches_equals_one_launch(gpu, D, units, compute):
     ops.mlp_fit(desc, *a, X, z, 0, 64, seed=5, epoch0=E, want_loss=False)
     for u, v in zip(a, keep):
         assert torch.equal(u, v)
+
+
+@pytest.mark.parametrize("N,acts", [(150, ["relu", "relu", "sigmoid"]), (64, ["tanh", "elu", "linear"]), (300, ["relu", "relu", "linear"])])
+def test_fp32_fit_of_128_128_1_in_rounds_against_oracle(gpu, N, acts):
+    """32->128-128-1 in float32 with 64-row batches (refused until round 2: theta and the 64-row
+    images do not share a CU's LDS): the weight gradients are formed in four rounds over 16-row images
+    (wide_rounds_f32, bore_hip.hip).  Same bar as the other float32 fits: theta / m / v and the
+    epoch losses against the float64 oracle on the same shuffle; two models, ragged last batch."""
+    rs = np.random.RandomState(N)
+    D, units, E, L = 32, [128, 128, 1], 3, 2
+    desc = _lib.make_desc(D, units, acts)
+    ps = [rand_model(rs, D, units) for _ in range(L)]
+    X = rs.uniform(size=(L, N, D)).astype(np.float32)
+    z = (rs.uniform(size=(L, N)) < 0.3)
+    perms = np.stack([np.stack([rs.permutation(N) for _ in range(E)]) for _ in range(L)]).astype(np.int32)
+    theta = dev(np.stack([pack(p) for p in ps]))
+    m, v = torch.zeros_like(theta), torch.zeros_like(theta)
+    t = torch.zeros(L, dtype=torch.int64, device="cuda")
+    h = ops.mlp_fit(desc, theta, m, v, t, dev(X), dev(z.astype(np.float32)), E, 64, perm=dev(perms, torch.int32))
+    for l in range(L):
+        p64 = [a.astype(np.float64) for a in ps[l]]
+        st = O.AdamState(p64)
+        hist = O.fit(p64, ["linear" if a is None else a for a in acts], st, X[l], z[l], perms[l], batch_size=64,
+                     dtype=np.float64)
+        assert int(t[l]) == st.t == E * O.steps_per_epoch(N, 64)
+        np.testing.assert_allclose(h.cpu().numpy()[l], hist, rtol=5e-5)
+        np.testing.assert_allclose(theta.cpu().numpy()[l], pack(p64), rtol=2e-4, atol=1e-5)
+        np.testing.assert_allclose(m.cpu().numpy()[l], pack(st.m), rtol=1e-3, atol=1e-7)
+        np.testing.assert_allclose(v.cpu().numpy()[l], pack(st.v), rtol=1e-3, atol=1e-10)
