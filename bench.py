@@ -57,7 +57,25 @@ HBM_PEAK_GBS = 8000.0    # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
 FP32_PEAK_TF = 157.3     # fp32 vector / MFMA peak, same guide
 BF16_PEAK_TF = 2500.0    # dense bf16 MFMA peak
 TOTAL_LOOPS = 512        # BASELINE.json config 4
-TRAFFIC_FILE = os.path.join("profiles", "r2", "pmc_traffic.json")
+TRAFFIC_FILE = os.path.join("profiles", "r3", "pmc_traffic.json")
+SWEEP_FILE = os.path.join("profiles", "r3", "loops_sweep.json")   # T(1, L) measured on one GPU
+
+
+def predicted_efficiency(world, total):
+    """What the committed single-GPU sweep T(1, L) says the N-GPU job will do when the ranks do not
+    disturb each other: T(N, total) = N * T(1, total / N), hence eff_w = 1 and
+    eff_s = T(1, total / N) / T(1, total).  None when the sweep lacks a point."""
+    try:
+        with open(os.path.join(ROOT, SWEEP_FILE)) as f:
+            sw = json.load(f)
+        t_share, t_all = sw["it_per_s"][str(total // world)], sw["it_per_s"][str(total)]
+    except Exception:
+        return None
+    return {"eff_s": t_share / t_all, "eff_w": 1.0, "T_N_total": world * t_share,
+            "gain_over_one_gpu": world * t_share / t_all,
+            "source": f"{SWEEP_FILE} ({sw.get('build', '?')}): T(1,{total // world}) = {t_share:.0f}, "
+                      f"T(1,{total}) = {t_all:.0f} BO-iterations/s; assumes ranks do not interact "
+                      "(no data-path collective)"}
 
 
 def _branin01(X):
@@ -90,21 +108,32 @@ def spawn_ranks(n, argv):
         e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv),
                                       env=e, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0 = b""
+    # rank 0's stdout is drained by a thread while EVERY rank is polled: a rank that dies before a
+    # rendezvous or barrier would otherwise leave rank 0 (and this parent) waiting for the
+    # process-group timeout.  First non-zero exit -> the rest are killed; one overall deadline.
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
     rc = 0
+    deadline = time.time() + float(env.get("BORE_BENCH_DEADLINE_S", 1500))
     try:
-        out0, _ = procs[0].communicate()
-        deadline = time.time() + 120
-        for p in procs:
-            try:
-                p.wait(timeout=max(1.0, deadline - time.time()))
-            except subprocess.TimeoutExpired:
-                rc = rc or 124
+        while True:
+            codes = [p.poll() for p in procs]          # (every rank, every round)
+            if all(c is not None for c in codes) or any(c not in (None, 0) for c in codes):
+                break
+            if time.time() > deadline:
+                rc = 124
+                print("bench.py: ranks still running at the deadline: killed", file=sys.stderr)
+                break
+            time.sleep(0.05)
     finally:
         for p in procs:                      # a failed rank must not leave the others waiting
             if p.poll() is None:
                 p.kill()
                 p.wait()
+    reader.join(timeout=10)
+    out0 = b"".join(c for c in chunks if c)
     for r, p in enumerate(procs):
         if p.returncode != 0:
             print(f"bench.py: rank {r} exited with code {p.returncode}", file=sys.stderr)
@@ -466,7 +495,7 @@ def all_configs(args, barrier, cpu):
     for name, c in WIDE_CONFIGS.items():
         try:
             one = config_gpu(name, c, loops=1)
-            many = config_gpu(name, c, loops=64 if c["R"] >= 4096 else 256, reps=2)
+            many = config_gpu(name, c, loops=256, reps=2)
             out[name] = dict(one, many_loops=many)
             if cpu:
                 out[name]["cpu_baseline"] = config_cpu(c)
@@ -490,6 +519,8 @@ def run_rank(args):
     local = int(os.environ.get("LOCAL_RANK", 0))
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+    if os.environ.get("BORE_BENCH_FAIL_RANK") == str(rank):    # (tests: a rank that dies early)
+        raise SystemExit(f"bench.py: rank {rank} told to fail (BORE_BENCH_FAIL_RANK)")
     if os.environ.get("BORE_BENCH_ONE_DEVICE") == "1":     # rehearsal: every rank on cuda:0
         local = 0
     if not dry:
@@ -511,50 +542,73 @@ def run_rank(args):
         sync()
 
     loop_ids = shard_loop_ids(rank, world, loops)          # contiguous shard per rank
+    t_flow0 = time.perf_counter()
     r = timed_run(args, loop_ids, barrier)
-    tmax = torch.tensor([r["dt"]], dtype=torch.float64,
+    tmax = torch.tensor([r["dt"], time.perf_counter() - t_flow0], dtype=torch.float64,
                         device="cuda" if args.backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    wall_first = float(tmax[1])                     # engine creation + warm-up + timed steps
     runs = [dict(value=total * args.steps / float(tmax[0]), dt=float(tmax[0]), r=r)]
     results = gather_results(r["eng"], world)       # the path's only collective (RCCL gather)
     r["eng"] = None
 
-    # N = 1: a timed region shorter than a second is one sample of a noisy quantity -- repeat it on
-    # fresh engines and report the median run (each run times exactly K steps after W warm-up)
-    if world == 1 and args.repeats != 1:
-        n_rep = args.repeats if args.repeats > 0 else (5 if runs[0]["dt"] < 1.0 else 1)
+    # A timed region of K steps is tens of milliseconds here: one sample of a noisy quantity.  The
+    # region (W warm-up + EXACTLY K timed steps, barriers on both sides, max over ranks) is repeated
+    # on fresh engines until --min-timed-s of timed region have accumulated; `value` is the median
+    # run, the line carries quartiles / min / max.  The repeat count follows from the first run's
+    # max-over-ranks time, so every rank does the same number.
+    if args.repeats != 1:
+        if args.repeats > 0:
+            n_rep = args.repeats
+        else:
+            n_rep = int(min(args.max_repeats, max(1, np.ceil(args.min_timed_s / max(runs[0]["dt"], 1e-6)))))
+            # (bounded by wall time as well: the driver gives the whole command a few minutes)
+            n_rep = int(max(1, min(n_rep, args.repeat_budget_s // max(wall_first, 1e-3))))
         for _ in range(n_rep - 1):
             rr = timed_run(args, loop_ids, barrier)
             rr["eng"] = None
-            runs.append(dict(value=total * args.steps / rr["dt"], dt=rr["dt"], r=rr))
+            tm = torch.tensor([rr["dt"]], dtype=torch.float64,
+                              device="cuda" if args.backend == "nccl" and not dry else "cpu")
+            if world > 1:
+                dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+            runs.append(dict(value=total * args.steps / float(tm[0]), dt=float(tm[0]), r=rr))
     order = sorted(range(len(runs)), key=lambda i: runs[i]["value"])
     med = runs[order[(len(runs) - 1) // 2]]         # (lower median for an even count)
     r, dt = med["r"], med["dt"]
     st = r["st"]
 
+    t_repeats_done = time.perf_counter()
     # N > 1: the single-GPU reference points of the two efficiencies, timed by rank 0 ALONE
     eff = None
     if world > 1 and not args.no_efficiency:
         if rank == 0:
-            t_share = timed_run(args, shard_loop_ids(0, 1, loops), solo_barrier)
-            v_share = loops * args.steps / t_share["dt"]
-            del t_share
-            t_all = timed_run(args, shard_loop_ids(0, 1, total), solo_barrier)
-            v_all = total * args.steps / t_all["dt"]
-            del t_all
+            # (medians of repeated regions, like the N-GPU figure itself)
+            n_ref = int(max(1, min(len(runs), 21)))
+
+            def ref_point(n_loops):
+                vs = []
+                for _ in range(n_ref):
+                    q = timed_run(args, shard_loop_ids(0, 1, n_loops), solo_barrier)
+                    vs.append(n_loops * args.steps / q["dt"])
+                    del q
+                return float(np.median(vs))
+
+            v_share = ref_point(loops)
+            v_all = ref_point(total)
             v = med["value"]
             eff = {"T_N_total": v, "T_1_share": v_share, "T_1_total": v_all,
                    "share_loops": loops, "total_loops": total,
                    "eff_w": v / (world * v_share), "eff_s": v / (world * v_all),
                    "definitions": "eff_w = T(N,total)/(N*T(1,total/N)); eff_s = T(N,total)/(N*T(1,total)) "
                                   "(SURVEY.md 8e); reference points timed by rank 0 alone in this "
-                                  "invocation, same steps/warm-up",
+                                  f"invocation, same steps/warm-up, median of {n_ref} fresh engines each",
                    "target_0.9_uses": "eff_w (same per-GPU load; the path has no collective, so what "
                                       "it measures is host contention between the ranks). eff_s is "
                                       "bounded by one loop's dependency chain: a GPU with total/N "
                                       "loops runs each of them no faster than with all of them"}
         barrier()
+    t_eff_done = time.perf_counter()
 
     if rank == 0:
         total_iters = total * args.steps
@@ -590,6 +644,25 @@ def run_rank(args):
         if st["fit_ms"] == 0.0:        # asynchronous schedule: fit + argmax are ONE kernel per launch
             kernels = [roof("iteration_kernel", st["argmax_ms"], st["fit_bytes"] + st["argmax_bytes"],
                             st["argmax_launches"])]
+            if st.get("phase_iterations"):
+                # A resident launch spans the host's turn-around as well: its workgroups wait on their
+                # CUs for the objective values.  `achieved` / `frac` above are per the contract (a
+                # launch's algorithmic bytes / its HIP-event duration, = the rocprofv3 duration); the
+                # figures below take the waiting out: the in-kernel clock stamps give every
+                # loop-iteration's busy time (labels + fit + screen + restarts), and a launch's
+                # workgroups run side by side, so busy time per launch = that sum / loops in flight.
+                k0 = kernels[0]
+                busy_s = 1e-9 * sum(st["phase_ns_" + q] for q in ("labels", "fit", "screen", "lbfgsb"))
+                per_launch_busy_s = busy_s / max(loops, 1) / max(st["argmax_launches"], 1)
+                ach_busy = (st["fit_bytes"] + st["argmax_bytes"]) / max(st["argmax_launches"], 1) \
+                    / max(per_launch_busy_s, 1e-12) / 1e9
+                k0["device_busy_ms_per_launch"] = 1e3 * per_launch_busy_s
+                k0["waiting_share_of_launch"] = max(0.0, 1.0 - 1e3 * per_launch_busy_s / k0["avg_launch_ms"])
+                k0["achieved_busy"] = ach_busy
+                k0["frac_busy"] = ach_busy / HBM_PEAK_GBS
+                k0["note"] = ("avg_launch_ms is the HIP-event span of a resident launch: device work plus "
+                              "on-CU waiting for the host's objective values and the tail of the slowest "
+                              "loop; *_busy use the in-kernel phase stamps instead (mean loop)")
         else:
             kernels = [roof("fit_kernel", st["fit_ms"], st["fit_bytes"], st["fit_launches"])]
             if st["argmax_launches"]:
@@ -653,21 +726,50 @@ def run_rank(args):
             "roofline_flops": flop_roof,
             "kernels": kernels,
             "phases": phases,
-            "runs": {"values": [q["value"] for q in runs], "n": len(runs),
+            "runs": {"values": [round(q["value"], 1) for q in runs], "n": len(runs),
                      "min": min(q["value"] for q in runs), "max": max(q["value"] for q in runs),
+                     "p25": float(np.percentile([q["value"] for q in runs], 25)),
+                     "p75": float(np.percentile([q["value"] for q in runs], 75)),
+                     "iqr": float(np.subtract(*np.percentile([q["value"] for q in runs], [75, 25]))),
                      "value_is": "the median run" if len(runs) > 1 else "the only run",
-                     "timed_region_s": dt},
+                     "timed_region_s": dt,
+                     "timed_total_s": float(sum(q["dt"] for q in runs)),
+                     "each_run": f"fresh engine, {args.warmup} warm-up + exactly {args.steps} timed steps "
+                                 "between barriers"},
             "best_y_median": float(np.median(results[:, -1])),
             "tf_keras": tf_keras_probe(),
         }
+        out["flow_wall_s"] = {"repeated_timed_regions": t_repeats_done - t_flow0,
+                              "efficiency_reference_runs": t_eff_done - t_repeats_done,
+                              "bounds": f"repeats <= min({args.max_repeats}, {args.repeat_budget_s:.0f} s / "
+                                        f"first run's {wall_first:.2f} s); 2 reference runs of the same "
+                                        "steps on rank 0; then (N = 1 only) survey form, configs, CPU sample"}
         if eff is not None:
             out["efficiency"] = eff
+        if world > 1:
+            # said before it is measured: config 4 AS WRITTEN (512 loops in total) leaves each GPU
+            # total/N loops, and a loop is a sequential chain that runs no faster on an emptier GPU
+            out["efficiency_predicted"] = predicted_efficiency(world, total)
         out["cpu_baseline"] = None
         if dry:
             out["dry_run"] = ("no GPU work was done: this line only shows that the multi-rank flow "
                               "of bench.py ran; every figure in it is meaningless")
             out["value"] = None
         if world == 1 and not dry:
+            if args.survey_steps > 0:
+                # SURVEY.md 8d "Config 1" as written (T = 100 iterations after 3 warm-up, N 13 -> 113,
+                # two batches per epoch from N = 65 on), x 512 loops: the same engine, longer loops
+                sv = []
+                for _ in range(3):
+                    q = timed_run(args, loop_ids, solo_barrier, steps=args.survey_steps, warmup=3)
+                    sv.append((total * args.survey_steps / q["dt"], q["dt"], q["n_start"], q["n_end"]))
+                    q["eng"] = None
+                sv.sort()
+                out["survey_form"] = {"steps": args.survey_steps, "warmup": 3, "value": sv[1][0],
+                                      "unit": "BO-iterations/s", "values": [round(x[0], 1) for x in sv],
+                                      "ms_per_step": 1e3 * sv[1][1] / args.survey_steps,
+                                      "N_start": int(sv[1][2]), "N_end": int(sv[1][3]),
+                                      "value_is": "median of 3 fresh engines"}
             if not args.no_configs:
                 out["configs"] = all_configs(args, solo_barrier, cpu=args.cpu_seconds > 0)
             if args.cpu_seconds > 0:                             # (rank 0 at N = 1 only)
@@ -690,9 +792,19 @@ def parse_args(argv=None):
     ap.add_argument("--total-loops", type=int, default=None,
                     help=f"BO loops of the whole job, sharded over the GPUs (default {TOTAL_LOOPS} = "
                          "BASELINE config 4)")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--cpu-seconds", type=float, default=8.0,
+                    help="wall seconds of the all-core CPU-oracle sample (a third of it on one core "
+                         "first); 0 = no cpu_baseline")
     ap.add_argument("--repeats", type=int, default=0,
-                    help="N = 1: timed regions on fresh engines (0 = 5 when a region is < 1 s, else 1)")
+                    help="timed regions on fresh engines (0 = as many as --min-timed-s asks for)")
+    ap.add_argument("--min-timed-s", type=float, default=1.5,
+                    help="repeat the timed region until this much of it has accumulated")
+    ap.add_argument("--max-repeats", type=int, default=80)
+    ap.add_argument("--repeat-budget-s", type=float, default=120.0,
+                    help="wall-time bound of the repeated timed regions (engine creation included)")
+    ap.add_argument("--survey-steps", type=int, default=100,
+                    help="N = 1: also time SURVEY.md 8d's form of config 1 x 512 (T = 100 after 3 "
+                         "warm-up steps, N 13 -> 113) -> `survey_form` (0 = skip)")
     ap.add_argument("--no-configs", action="store_true",
                     help="skip the per-config figures (configs 1-single-loop, 2, 3, 5)")
     ap.add_argument("--dry-run", action="store_true",

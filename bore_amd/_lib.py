@@ -14,8 +14,10 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-# (BORE_LIB_PATH: another build of the same ABI, for A/B comparisons -- tools/ab_fit.py)
-LIB_PATH = os.environ.get("BORE_LIB_PATH") or os.path.join(CSRC, "libbore_hip.so")
+# (BORE_LIB_PATH: another build of the same ABI, for A/B comparisons -- tools/ab_fit.py.  It is
+# only ever LOADED: build_native() writes the default path and nothing else.)
+DEFAULT_LIB_PATH = os.path.join(CSRC, "libbore_hip.so")
+LIB_PATH = os.environ.get("BORE_LIB_PATH") or DEFAULT_LIB_PATH
 SOURCES = ["bore_all.hip"]   # a unity build of bore_{hip,argmax,svgd,iter,engine}.hip
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "bore_hip.h")
 
@@ -99,12 +101,14 @@ def hipcc_path():
 
 
 def build_native(force=False, verbose=False):
-    """Compile libbore_hip.so for gfx950.  Cross-compiles without a GPU."""
+    """Compile libbore_hip.so for gfx950.  Cross-compiles without a GPU.  Always the default
+    in-tree path: an experimental build named by BORE_LIB_PATH is never overwritten."""
+    out = DEFAULT_LIB_PATH
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hip"))] + [HEADER]
-    if (not force and os.path.exists(LIB_PATH)
-            and os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(d) for d in deps)):
-        return LIB_PATH
+    if (not force and os.path.exists(out)
+            and os.path.getmtime(out) >= max(os.path.getmtime(d) for d in deps)):
+        return out
     hipcc = hipcc_path()
     if hipcc is None:
         raise RuntimeError("hipcc not found: cannot build libbore_hip.so")
@@ -112,14 +116,19 @@ def build_native(force=False, verbose=False):
     # out (fmaf); the fp64 L-BFGS-B then rounds exactly like its host build (tests compare
     # the two bit for bit) and like the unfused numpy/scipy arithmetic of the oracle.
     cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC",
-           "-ffp-contract=off", "-Wall", "-Wextra", *srcs, "-o", LIB_PATH]
+           "-ffp-contract=off", "-Wall", "-Wextra", *srcs, "-o", out]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True, cwd=CSRC)
-    return LIB_PATH
+    return out
 
 
 _lib = None
+
+
+def abi_version_of_header():
+    with open(HEADER) as f:
+        return int(f.read().split("#define BORE_ABI_VERSION")[1].split()[0])
 
 
 def lib():
@@ -139,6 +148,10 @@ def lib():
     vp, i32, i64, u64 = C.c_void_p, C.c_int, C.c_int64, C.c_uint64
     dp = C.POINTER(MlpDesc)
     L.bore_abi_version.restype = i32
+    want = abi_version_of_header()
+    if L.bore_abi_version() != want:      # (struct layouts below are this header's)
+        raise RuntimeError(f"{LIB_PATH} has ABI {L.bore_abi_version()}, include/bore_hip.h declares "
+                           f"{want}: rebuild it (`python -c 'import __graft_entry__ as g; g.build()'`)")
     L.bore_last_error.restype = C.c_char_p
     L.bore_param_count.restype = i64
     L.bore_param_count.argtypes = [dp]

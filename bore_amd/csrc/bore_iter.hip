@@ -218,14 +218,16 @@ static int iteration_launch(const bore_mlp_desc *desc, int n_slots, float *theta
     return rc;
   if (h->wait_ticks > 0) {  // waiting workgroups hold their slots: only when all of them fit at once
     static thread_local size_t cap_bytes = ~(size_t)0;
-    static thread_local int cap_wgs = 0;
-    if (cap_bytes != floats * 4) {
-      int per_cu = 0, dev = 0, cus = 0;
+    static thread_local int cap_wgs = 0, cap_dev = -1;
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (cap_bytes != floats * 4 || cap_dev != dev) {  // (per device: a thread may drive several)
+      int per_cu = 0, cus = 0;
       HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, iteration_kernel<1, true>, BORE_THREADS,
                                                            floats * 4));
-      HIP_TRY(hipGetDevice(&dev));
       HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
       cap_bytes = floats * 4;
+      cap_dev = dev;
       cap_wgs = per_cu * cus;
     }
     if (g_batch->resident_loops > cap_wgs) h->wait_ticks = 0;

@@ -46,3 +46,23 @@ def gpu():
     assert torch.cuda.is_available(), "GPU test on a box without a GPU"
     _lib.lib()
     return torch.device("cuda", 0)
+
+
+def record_measurement(name, values):
+    """GPU tests that assert statistical floors also RECORD what they measured: merged into
+    gpurun_out/parity_measured.json (which the GPU run brings back; the judged copy is committed
+    as profiles/r3/parity_measured.json)."""
+    import json
+    out_dir = os.path.join(ROOT, "gpurun_out")
+    try:
+        os.makedirs(out_dir, exist_ok=True)
+        path = os.path.join(out_dir, "parity_measured.json")
+        data = {}
+        if os.path.exists(path):
+            with open(path) as f:
+                data = json.load(f)
+        data[name] = values
+        with open(path, "w") as f:
+            json.dump(data, f, indent=1, sort_keys=True)
+    except OSError:          # a read-only tree must not fail a parity test
+        pass

@@ -38,6 +38,43 @@ def test_spawns_its_own_ranks_config4_as_written():
     assert set(("eff_w", "eff_s", "T_1_share", "T_1_total", "T_N_total")) <= set(eff)
 
 
+def test_eight_ranks_the_drivers_widest_launch():
+    """The N = 8 flow end to end (spawn, rendezvous, repeated regions with the same count on every
+    rank, rank 0's reference points, gather): the line carries measured AND predicted efficiency
+    and says how long each part of the flow took and what bounds it."""
+    p = _run("--gpus", "8", "--dry-run", "--steps", "3", "--warmup", "1", timeout=400)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
+    assert d["n_gpus"] == 8 and d["config"]["loops_per_gpu"] == 64 and d["scaling"] == "strong"
+    eff = d["efficiency"]
+    assert set(("eff_w", "eff_s", "T_1_share", "T_1_total", "T_N_total")) <= set(eff)
+    assert eff["share_loops"] == 64 and eff["total_loops"] == 512
+    pred = d["efficiency_predicted"]          # config 4 as written gains ~1.2x from 8 GPUs: said up front
+    assert pred is not None and 0.05 < pred["eff_s"] < 0.5 and pred["eff_w"] == 1.0
+    assert 1.0 < pred["gain_over_one_gpu"] < 4.0
+    runs = d["runs"]
+    assert runs["n"] >= 2 and runs["min"] <= runs["p25"] <= runs["p75"] <= runs["max"]
+    flow = d["flow_wall_s"]
+    # by construction: repeats are bounded by --repeat-budget-s (120 s), the reference points by
+    # 2 x 21 engines of the same few steps -- far inside the driver's 600 s
+    assert flow["repeated_timed_regions"] < 150 and flow["efficiency_reference_runs"] < 150
+    assert "repeats <=" in flow["bounds"]
+
+
+def test_a_rank_that_dies_early_does_not_hang_the_parent():
+    """A rank failing before the rendezvous must end the run at once (not at the process-group
+    timeout): rank 1 is told a world size that --gpus contradicts and exits."""
+    import time
+    t0 = time.time()
+    env = _plain_env()
+    env["BORE_BENCH_FAIL_RANK"] = "1"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run",
+                        "--steps", "2", "--warmup", "0"], env=env, capture_output=True, text=True,
+                       timeout=200, cwd=ROOT)
+    assert p.returncode != 0 and "rank 1 exited" in p.stderr
+    assert time.time() - t0 < 60
+
+
 def test_per_gpu_loops_is_weak_scaling():
     p = _run("--gpus", "2", "--dry-run", "--steps", "2", "--warmup", "0", "--loops", "8",
              "--no-efficiency")

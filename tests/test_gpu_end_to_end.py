@@ -36,6 +36,7 @@ from scipy.optimize import Bounds
 from bore_amd import sampling, shuffle
 from oracle import bore_oracle as O
 from test_gpu_parity import pack, unpack
+from conftest import record_measurement
 
 pytestmark = pytest.mark.gpu
 
@@ -157,13 +158,20 @@ def test_fused_iteration_kernel_against_the_oracle_teacher_forced(gpu):
           f"{n_rest_both}; suggestion within 1e-5 of the oracle's: {n_pick_same}/{n_iter} overall, "
           f"{n_clean_same}/{n_clean} where every restart's acceptance agrees; None on both sides "
           f"{n_none_both}, on one side {n_none_one}")
-    # measured (r2, 16 loops x 5 iterations): same starts 77/80; acceptance agrees 192/231; accepted
-    # restarts within 1e-5: 166/172; suggestion 48/50 where all acceptances agree, 64/80 overall
-    assert n_same_starts >= 0.9 * n_iter
-    assert n_rest_accept_agree >= 0.75 * n_rest
+    record_measurement("end_to_end_teacher_forced_cfg1", dict(
+        loops=L, iterations=T, worst_theta_error_over_tolerance=worst_theta,
+        same_starts=[int(n_same_starts), n_iter], acceptance_agrees=[int(n_rest_accept_agree), n_rest],
+        accepted_within_1e5=[int(n_rest_both_same), n_rest_both],
+        pick_same_overall=[int(n_pick_same), n_iter], pick_same_clean=[int(n_clean_same), n_clean],
+        none_both=int(n_none_both), none_one_side=int(n_none_one)))
+    # measured (r2, 16 loops x 5 iterations): same starts 77/80 (0.96); acceptance agrees 192/231
+    # (0.83); accepted restarts within 1e-5: 166/172 (0.97); suggestion 48/50 (0.96) where all
+    # acceptances agree, 64/80 (0.80) overall.  Floors = measured - 5 points.
+    assert n_same_starts >= 0.93 * n_iter
+    assert n_rest_accept_agree >= 0.78 * n_rest
     assert n_rest_both_same >= 0.93 * n_rest_both
-    assert n_clean_same >= 0.9 * n_clean and n_clean >= 0.5 * n_iter
-    assert n_pick_same >= 0.7 * n_iter
+    assert n_clean_same >= 0.92 * n_clean and n_clean >= 0.5 * n_iter
+    assert n_pick_same >= 0.75 * n_iter
 
 
 def test_fused_iteration_kernel_against_the_oracle_free_running(gpu):
@@ -190,4 +198,118 @@ def test_fused_iteration_kernel_against_the_oracle_free_running(gpu):
         same_loops += ok
     print(f"\n[end-to-end, free-running] {same_loops}/{L} loops keep the oracle's trajectory (1e-4) "
           f"for {T} iterations; first differing iteration of the others: {first_split}")
-    assert same_loops >= L // 4     # (fp32 noise decides line searches: see the module docstring)
+    record_measurement("end_to_end_free_running_cfg1", dict(loops=L, iterations=T, same_loops=int(same_loops),
+                                                            first_split=[int(i) for i in first_split]))
+    # measured (r2): 5/8.  (fp32 noise decides line searches: see the module docstring)
+    assert same_loops >= L // 2
+
+
+def test_config2_fit_and_argmax_chain_against_the_oracle_teacher_forced(gpu):
+    """One wide BASELINE config end to end: config 2 (Hartmann-6 box, 6 ->
+    32-32-1, many restarts) through the SAME launch chain the replica engine and bench.py's
+    `configs` leg use for wide models -- fit_kernel<2> -> sample + screen -> lbfgsb_kernel<2> ->
+    pick -- against oracle.fit + oracle.maxima / the reference's acceptance rule
+    (bore/mixins.py:57-89), iteration by iteration, teacher-forced (every iteration starts from
+    the kernels' state; the record grows by the kernels' suggestion)."""
+    import torch
+    from bore_amd import _lib, ops
+    D2, U2, A2 = 6, [32, 32, 1], ["relu", "relu", "sigmoid"]
+    lo, hi = np.zeros(D2), np.ones(D2)
+    bounds = Bounds(lo, hi)
+    L, T, R, NS, E, N0 = 4, 3, 32, 1024, 100, 96
+    desc = _lib.make_desc(D2, U2, A2)
+    P = ops.param_count(desc)
+    rs = np.random.RandomState(21)
+    th0 = np.stack([pack(O.glorot_uniform_params(D2, U2, rs)) for _ in range(L)])
+    c = rs.uniform(0.2, 0.8, size=D2)
+
+    def objective(X):
+        return np.sum((X - c) ** 2, axis=-1) + 0.1 * np.sin(5.0 * X.sum(axis=-1))
+
+    X = rs.uniform(size=(L, N0, D2))
+    y = objective(X)
+    theta = torch.from_numpy(th0).cuda()
+    m, v = torch.zeros_like(theta), torch.zeros_like(theta)
+    t = torch.zeros(L, dtype=torch.int64, device=theta.device)
+    worst_theta = 0.0
+    n_iter = n_same_starts = n_pick_same = n_clean = n_clean_same = 0
+    n_rest = n_acc_agree = n_both = n_both_same = 0
+    for it in range(T):
+        N = X.shape[1]
+        z = np.stack([O.labels(y[l], 0.25)[0] for l in range(L)]).astype(np.float32)
+        th_prev, m_prev, v_prev, t_prev = (a.cpu().numpy().copy() for a in (theta, m, v, t))
+        ops.mlp_fit(desc, theta, m, v, t, torch.from_numpy(X.astype(np.float32)).cuda(),
+                    torch.from_numpy(z).cuda(), E, 64, seed=5, model_index0=100, epoch0=it * E,
+                    want_loss=False)
+        x0d, _ = ops.sample_screen_topk(desc, theta, 5, NS, lo, hi, R, model_index0=100, draw_index=it)
+        xd, fund, _, infod = ops.lbfgsb_minimize(desc, theta, x0d, lo, hi, "identity", True,
+                                                 maxiter=1000, ftol=1e-9)
+        xbd, bestd = ops.select_best(xd, fund, infod)
+        th = theta.cpu().numpy()
+        x0d, xd, fund, infod, xbd, bestd = (a.cpu().numpy() for a in (x0d, xd, fund, infod, xbd, bestd))
+        assert np.array_equal(t.cpu().numpy(), t_prev + E * -(-N // 64))
+        x_next = np.empty((L, D2))
+        for l in range(L):
+            p = unpack(th_prev[l].copy(), D2, U2)
+            st = O.AdamState(p)
+            st.m, st.v, st.t = unpack(m_prev[l].copy(), D2, U2), unpack(v_prev[l].copy(), D2, U2), int(t_prev[l])
+            perms = shuffle.permutations(5, 1, E, N, model_index0=100 + l, epoch0=it * E)[0]
+            O.fit(p, A2, st, X[l], z[l], perms, batch_size=64)
+            ref = pack(p)
+            err = np.abs(th[l] - ref) / (2e-4 + 2e-3 * np.abs(ref))
+            worst_theta = max(worst_theta, float(err.max()))
+            assert err.max() <= 1.0, (it, l, float(err.max()))
+            # the oracle's argmax on the network the kernels fitted
+            pe = unpack(th[l].copy(), D2, U2)
+            Xc = sampling.uniform_candidates(5, 1, NS, lo, hi, model_index0=100 + l, draw_index=it)[0]
+            pred = O.predict(pe, A2, Xc).squeeze(axis=-1)
+            starts = Xc[np.argpartition(-pred, kth=R - 1, axis=None)[:R]]
+            results = O.maxima(pe, A2, bounds, num_starts=R, num_samples=NS, X_init=Xc)
+            n_iter += 1
+            same_starts = ({tuple(r) for r in starts} == {tuple(r) for r in x0d[l]})
+            n_same_starts += same_starts
+            best = None
+            for res in results:
+                if (res.success or res.status == 1) and (best is None or res.fun < best.fun):
+                    best = res
+            x_eng = xbd[l] if bestd[l] >= 0 else rs.uniform(lo, hi)
+            x_next[l] = x_eng
+            # "same pick": the same point, or an equally good one (a saturated sigmoid is flat:
+            # several restarts end at the same value in different corners)
+            pick_same = (best is not None and bestd[l] >= 0
+                         and (np.allclose(x_eng, best.x, rtol=0, atol=1e-5)
+                              or abs(fund[l, bestd[l]] - best.fun) <= 2e-6))
+            n_pick_same += pick_same
+            if not same_starts:
+                continue
+            clean = True
+            for r in range(R):
+                k = [tuple(s) for s in starts].index(tuple(x0d[l, r]))
+                res = results[k]
+                acc_o, acc_d = bool(res.success or res.status == 1), infod[l, r, 2] in (0, 1)
+                n_rest += 1
+                n_acc_agree += acc_o == acc_d
+                clean = clean and acc_o == acc_d
+                if acc_o and acc_d:
+                    n_both += 1
+                    n_both_same += np.allclose(xd[l, r], res.x, rtol=0, atol=1e-5)
+            if clean and best is not None and bestd[l] >= 0:
+                n_clean += 1
+                n_clean_same += pick_same
+        X = np.concatenate([X, x_next[:, None, :]], axis=1)
+        y = np.concatenate([y, objective(x_next)[:, None]], axis=1)
+    print(f"\n[end-to-end, config 2, teacher-forced] {L} models x {T} iterations x {R} restarts; worst "
+          f"theta error / tolerance {worst_theta:.3f}; same starts {n_same_starts}/{n_iter}; acceptance "
+          f"agrees {n_acc_agree}/{n_rest}; both accepted and x within 1e-5: {n_both_same}/{n_both}; pick "
+          f"equal or equally good: {n_pick_same}/{n_iter} overall, {n_clean_same}/{n_clean} where every "
+          f"restart's acceptance agrees")
+    record_measurement("end_to_end_teacher_forced_cfg2", dict(
+        models=L, iterations=T, restarts=R, worst_theta_error_over_tolerance=worst_theta,
+        same_starts=[int(n_same_starts), n_iter], acceptance_agrees=[int(n_acc_agree), n_rest],
+        accepted_within_1e5=[int(n_both_same), n_both], pick_same_overall=[int(n_pick_same), n_iter],
+        pick_same_clean=[int(n_clean_same), n_clean]))
+    # floors: set from the first measurement on the GPU (profiles/r3/parity_measured.json) minus margin
+    assert n_same_starts >= 0.75 * n_iter
+    assert n_acc_agree >= 0.85 * n_rest
+    assert n_both_same >= 0.85 * n_both
+    assert n_pick_same >= 0.75 * n_iter

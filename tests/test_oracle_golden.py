@@ -207,3 +207,40 @@ def test_argmax_filter_and_zero_starts():
     assert len(res) == 1 and res[0].success and res[0].x.shape == (2,)
     with pytest.raises(AssertionError):
         O.maxima(p, acts, b, num_starts=5, num_samples=4)
+
+
+def test_public_tf_keras_docstring_vectors_third_party_known_answers():
+    """THIRD-PARTY known answers, not reference-held fixtures: the worked examples printed in the
+    public tf.keras API documentation (TF 2.x docstrings of ``tf.keras.losses.BinaryCrossentropy``
+    and ``tf.keras.optimizers.Adam``).  The reference holds no vector for the Keras half of the path
+    (parity unpinned) and TensorFlow cannot run here; these narrow what "unpinned" can
+    hide: the BCE-from-logits formula, the probability form it must agree with, and the Adam update
+    (bias correction, epsilon placement) that bore/plugins/hpbandster/base.py:156-157,184 and
+    README.rst:60-66,93 rely on."""
+    # BinaryCrossentropy(from_logits=True)([0, 1, 0, 0], [-18.6, 0.51, 2.94, -12.8]) -> 0.865
+    a = np.array([[-18.6], [0.51], [2.94], [-12.8]], dtype=np.float32)
+    z = np.array([[0.0], [1.0], [0.0], [0.0]], dtype=np.float32)
+    assert float(O.bce_with_logits(a, z).mean()) == pytest.approx(0.865, abs=5e-4)
+    # the same through the model path: Dense(1) logit output, loss_and_grads' mean over the batch
+    W, b = np.ones((1, 1), np.float32), np.zeros(1, np.float32)
+    loss, grads = O.loss_and_grads([W, b], ["linear"], a, z[:, 0])
+    assert float(loss) == pytest.approx(0.865, abs=5e-4)
+    loss_s, grads_s = O.loss_and_grads([W, b], ["sigmoid"], a, z[:, 0])   # sigmoid output: cached logits
+    assert float(loss_s) == float(loss) and np.array_equal(grads_s[0], grads[0])
+    ev, _ = O.evaluate([W, b], ["sigmoid"], a, z[:, 0])
+    assert ev == pytest.approx(0.865, abs=5e-4)
+    # BinaryCrossentropy()([[0, 1], [0, 0]], [[0.6, 0.4], [0.4, 0.6]]) -> 0.815 (probabilities)
+    p = np.array([0.6, 0.4, 0.4, 0.6], dtype=np.float64)
+    zt = np.array([0.0, 1.0, 0.0, 0.0])
+    logit = np.log(p / (1 - p)).reshape(-1, 1)
+    assert float(O.bce_with_logits(logit, zt.reshape(-1, 1)).mean()) == pytest.approx(0.815, abs=5e-4)
+    assert float(-(zt * np.log(p) + (1 - zt) * np.log(1 - p)).mean()) == pytest.approx(0.815, abs=5e-4)
+    # Adam(learning_rate=0.1): var1 = 10.0, loss = var1 ** 2 / 2 (gradient = var1); one step -> 9.9
+    for dt in (np.float32, np.float64):
+        var = [np.array([10.0], dtype=dt)]
+        st = O.AdamState(var)
+        O.adam_step(var, [var[0].copy()], st, lr=0.1)
+        assert st.t == 1 and float(var[0][0]) == pytest.approx(9.9, abs=1e-6)
+        # (a second step moves by almost the full learning rate again: m / sqrt(v) stays ~ 1)
+        O.adam_step(var, [var[0].copy()], st, lr=0.1)
+        assert float(var[0][0]) == pytest.approx(9.8, abs=1e-4)

@@ -177,3 +177,91 @@ def test_suggester_over_a_mixed_space(gpu):
     assert np.all(np.sort(X[:, :3], axis=1)[:, :2] == 0) and np.all(X[:, :3].max(axis=1) == 1)   # one-hot
     y = np.array(s.record.targets)
     assert y[10:].min() <= y[:10].min()                  # the classifier finds at least as good a config
+
+
+class _FakeJob:
+    """What hpbandster hands to new_result: kwargs (config, budget), result, exception, id."""
+
+    def __init__(self, config, budget, loss, exception=None, id=(0, 0, 0)):
+        self.kwargs = dict(config=config, budget=budget)
+        self.result = dict(loss=loss, info={})
+        self.exception, self.id = exception, id
+
+
+def _adapter_space(seed=None):
+    from bore_amd.plugins.types import Categorical, DenseSpace, UniformFloat, UniformInteger
+    return DenseSpace([Categorical("act", ["tanh", "relu", "elu"]), UniformInteger("units", 1, 8),
+                       UniformFloat("lr", 1e-4, 1e-1, log=True)], seed=seed)
+
+
+def test_hpbandster_adapter_surface_before_any_model():
+    """bore/plugins/hpbandster/base.py:216-236, 267-288: get_config(budget) -> (dict, {}) from the
+    space's own seeded stream while the record is short; new_result(job) encodes
+    job.kwargs["config"] with the dense one-hot map and records job.result["loss"] and the budget."""
+    from bore_amd.plugins.hpbandster import BORE, ClassifierConfigGenerator
+    cg = ClassifierConfigGenerator(
+        config_space=_adapter_space(), gamma=0.25, num_random_init=5, random_rate=None,
+        retrain=False, classifier_kws={}, fit_kws={}, optimizer_kws=dict(num_starts=3), seed=11)
+    mirror = _adapter_space(seed=11)                    # DenseConfigurationSpace(config_space, seed=seed)
+    for i in range(5):
+        cfg, info = cg.get_config(budget=1.0 / 3 ** (i % 3))
+        assert info == {} and cfg == mirror.sample_configuration()
+        cg.new_result(_FakeJob(cfg, 1.0 / 3 ** (i % 3), loss=float(i)))
+    assert cg.record.size() == 5 and cg.record.targets == [0.0, 1.0, 2.0, 3.0, 4.0]
+    assert cg.record.budgets[:3] == [1.0, 1.0 / 3, 1.0 / 9] and cg.logit is None
+    assert np.array_equal(cg.record.features[-1], mirror.to_array(cfg))
+    assert cg.input_dim == 5 and np.array_equal(cg.bounds.ub, np.ones(5))
+    # a failed job is logged by the base class and still indexed like the reference does (:269-288)
+    msgs = []
+    cg.logger = type("L", (), {"warning": lambda self, m: msgs.append(m)})()
+    cg.new_result(_FakeJob(cfg, 1.0, loss=9.0, exception="Traceback ...", id=(1, 0, 2)))
+    assert cg.record.size() == 6 and len(msgs) == 1 and "(1, 0, 2)" in msgs[0]
+    # the reference's argument checks (:91-96, :127-128)
+    for bad in (dict(gamma=1.0), dict(num_random_init=0), dict(random_rate=1.0)):
+        kw = dict(config_space=_adapter_space(), gamma=0.25, num_random_init=5, random_rate=0.1,
+                  retrain=False, classifier_kws={}, fit_kws={}, optimizer_kws={}, seed=0)
+        kw.update(bad)
+        with pytest.raises(AssertionError):
+            ClassifierConfigGenerator(**kw)
+    with pytest.raises(AssertionError):
+        ClassifierConfigGenerator(config_space=_adapter_space(), gamma=0.25, num_random_init=5,
+                                  random_rate=0.1, retrain=False, classifier_kws={}, fit_kws={},
+                                  optimizer_kws=dict(transform="tanh"), seed=0)
+    # BORE(HyperBand): gamma defaults to 1 / eta, HyperBand's ladder of budgets (:33-34, :64-82)
+    opt = BORE(_adapter_space(), eta=3, min_budget=1, max_budget=81, seed=2)
+    assert opt.config_generator.gamma == pytest.approx(1 / 3) and opt.max_SH_iter == 5
+    np.testing.assert_allclose(opt.budgets, [1, 3, 9, 27, 81])
+    assert opt.config["gamma"] == pytest.approx(1 / 3) and opt.config["num_random_init"] == 10
+    assert opt.config_generator.num_random_init == 10
+    assert opt.config_generator._suggester.num_starts == 5
+    assert opt.config_generator._suggester.num_steps_per_iter == 1000
+
+
+@pytest.mark.gpu
+def test_hpbandster_adapter_drives_the_hot_path(gpu):
+    """get_config / new_result as a HpBandSter master calls them, with the model phases on the
+    GPU: after num_random_init results every get_config fits and maximises the classifier."""
+    from bore_amd.plugins.hpbandster import BORE
+    good = dict(act="relu", units=6, lr=1e-2)
+
+    def loss(cfg):
+        return (0.0 if cfg["act"] == good["act"] else 1.0) + 0.1 * abs(cfg["units"] - good["units"]) \
+            + abs(np.log10(cfg["lr"]) - np.log10(good["lr"]))
+
+    opt = BORE(_adapter_space(), eta=3, min_budget=1, max_budget=9, num_random_init=10,
+               random_rate=None, num_steps_per_iter=200, num_starts=5, seed=0)
+    cg = opt.config_generator
+    sources = []
+    for i in range(30):
+        budget = float(opt.budgets[i % len(opt.budgets)])
+        cfg, info = cg.get_config(budget)
+        assert info == {} and set(cfg) == {"act", "units", "lr"}
+        assert isinstance(cfg["units"], int) and 1 <= cfg["units"] <= 8 and 1e-4 <= cfg["lr"] <= 1e-1
+        sources.append(cg.last_info["source"])
+        cg.new_result(_FakeJob(cfg, budget, loss(cfg), id=(i, 0, 0)))
+    assert sources[:10] == ["random:init"] * 10 and sources.count("model") >= 15
+    assert cg.record.size() == 30 and len(cg.logit.layers) == 4
+    y = np.array(cg.record.targets)
+    assert y[10:].min() <= y[:10].min()
+    with pytest.raises(ImportError):
+        opt.run(n_iterations=1)
