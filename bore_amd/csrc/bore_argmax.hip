@@ -418,10 +418,15 @@ static int screen_launch(const bore_mlp_desc *desc, int n_models, const float *t
     hipLaunchKernelGGL((screen_topk_kernel<S, B, 2>), dim3(n_models), dim3(BORE_THREADS), off * 4,        \
                        (hipStream_t)stream, a);                                                          \
   }
+      if (!bore_flavour_built(shape)) return fail(BORE_E_UNSUPPORTED, BORE_FLAVOUR_LEFT_OUT);
+#if BORE_ON_3
       if (shape == 3 && !bf) BORE_LAUNCH_SPLIT(3, false)
-      else if (shape == 3) BORE_LAUNCH_SPLIT(3, true)
-      else if (!bf) BORE_LAUNCH_SPLIT(4, false)
-      else BORE_LAUNCH_SPLIT(4, true)
+      if (shape == 3 && bf) BORE_LAUNCH_SPLIT(3, true)
+#endif
+#if BORE_ON_4
+      if (shape == 4 && !bf) BORE_LAUNCH_SPLIT(4, false)
+      if (shape == 4 && bf) BORE_LAUNCH_SPLIT(4, true)
+#endif
 #undef BORE_LAUNCH_SPLIT
       HIP_TRY(hipGetLastError());
       return 0;
@@ -429,17 +434,23 @@ static int screen_launch(const bore_mlp_desc *desc, int n_models, const float *t
   }
   if (desc->compute == BORE_COMPUTE_BF16) {
     if (!bore_shape_is_wide(shape)) return fail(BORE_E_UNSUPPORTED, kBf16Shapes);
+    if (!bore_flavour_built(shape)) return fail(BORE_E_UNSUPPORTED, BORE_FLAVOUR_LEFT_OUT);
+#if BORE_ON_3
     if (shape == 3) {
       rc = allow_lds((screen_topk_kernel<3, true>), off * 4);
       if (rc) return rc;
       hipLaunchKernelGGL((screen_topk_kernel<3, true>), dim3(n_models), dim3(BORE_THREADS), off * 4,
                          (hipStream_t)stream, a);
-    } else {
+    }
+#endif
+#if BORE_ON_4
+    if (shape == 4) {
       rc = allow_lds((screen_topk_kernel<4, true>), off * 4);
       if (rc) return rc;
       hipLaunchKernelGGL((screen_topk_kernel<4, true>), dim3(n_models), dim3(BORE_THREADS), off * 4,
                          (hipStream_t)stream, a);
     }
+#endif
     HIP_TRY(hipGetLastError());
     return 0;
   }
@@ -450,17 +461,39 @@ static int screen_launch(const bore_mlp_desc *desc, int n_models, const float *t
     hipLaunchKernelGGL(screen_topk_kernel<S>, dim3(n_models), dim3(BORE_THREADS), off * 4,    \
                        (hipStream_t)stream, a);                                               \
     break;
+  if (!bore_flavour_built(shape)) return fail(BORE_E_UNSUPPORTED, BORE_FLAVOUR_LEFT_OUT);
   switch (shape) {
+#if BORE_ON_1
     BORE_LAUNCH_SCREEN(1)
+#endif
+#if BORE_ON_2
     BORE_LAUNCH_SCREEN(2)
+#endif
+#if BORE_ON_3
     BORE_LAUNCH_SCREEN(3)
+#endif
+#if BORE_ON_4
     BORE_LAUNCH_SCREEN(4)
+#endif
+#if BORE_ON_N1
     BORE_LAUNCH_SCREEN(-1)
+#endif
+#if BORE_ON_N2
     BORE_LAUNCH_SCREEN(-2)
+#endif
+#if BORE_ON_N3
     BORE_LAUNCH_SCREEN(-3)
+#endif
+#if BORE_ON_N4
     BORE_LAUNCH_SCREEN(-4)
+#endif
     default:
+#if !BORE_ON_0
+      return fail(BORE_E_UNSUPPORTED, BORE_FLAVOUR_LEFT_OUT);
+#endif
+#if BORE_ON_0
     BORE_LAUNCH_SCREEN(0)
+#endif
   }
 #undef BORE_LAUNCH_SCREEN
   HIP_TRY(hipGetLastError());
@@ -530,22 +563,29 @@ extern "C" int bore_debug_lphases(long long *out) {
 }
 extern "C" int bore_debug_lphases_reset(void) {
   long long z[16] = {0};
-  static unsigned long long zz[LB_PP_MAX][16];
+  static unsigned long long zz[LB_PP_MAX][64];
   (void)hipMemcpyToSymbol(HIP_SYMBOL(lbfgsb::g_lb_pp), zz, sizeof(zz));
   return (int)hipMemcpyToSymbol(HIP_SYMBOL(lbfgsb::g_lb_phase), z, sizeof(z));
 }
-extern "C" int bore_debug_lpp(unsigned long long *out) {  // [LB_PP_MAX][16]
+extern "C" int bore_debug_lpp(unsigned long long *out) {  // [LB_PP_MAX][64]
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(lbfgsb::g_lb_pp),
-                                  sizeof(unsigned long long) * LB_PP_MAX * 16);
+                                  sizeof(unsigned long long) * LB_PP_MAX * 64);
 }
 #define BORE_LCLOCK() clock64()
 #else
 #define BORE_LCLOCK() 0LL
 #endif
 
+// which static shapes evaluate a wave's single point on the vector ALU (mlp_point.h)
+#ifndef BORE_POINT_SHAPE
+#define BORE_POINT_SHAPE(S) ((S) != 1)
+#endif
+
 // LEAN: the network's weight operands are re-requested from LDS for every evaluation instead of
 // living in registers across the optimiser (the fused iteration kernel is held to 256 VGPRs).
-template <int SHAPE, bool BF16 = false, bool LEAN = false>
+// ALWAYS_COOP: the caller's launches never give a wave more than one problem at a time (the fused
+// iteration kernel): the lane-per-problem loop is not compiled.
+template <int SHAPE, bool BF16 = false, bool LEAN = false, bool ALWAYS_COOP = false>
 __device__ __forceinline__ void lbfgsb_body(const LbfgsbArgs &a, const long long model,
                                             const int block_y, const int it_now = -1) {
   extern __shared__ float smem[];
@@ -580,6 +620,9 @@ __device__ __forceinline__ void lbfgsb_body(const LbfgsbArgs &a, const long long
   // after the other, each with all its lanes (`passes`).  Same bits every way (tested).
   // (launches with more workgroups than CUs may run 5..8 waves per workgroup, one problem each:
   // lbfgsb_kernel_w8; batch mode always has four)
+#ifdef BORE_STAMPS
+  lbfgsb::g_lb_lds[wv & 7][lane] = 0;
+#endif
   const int NW = (int)(blockDim.x >> 6);
   const bool multi = a.result && np > 4 && np <= 16;
   const bool coop = np <= NW || multi;
@@ -606,6 +649,9 @@ __device__ __forceinline__ void lbfgsb_body(const LbfgsbArgs &a, const long long
                            reinterpret_cast<int *>(base + a.o_iw), D, a.opt.m);
     const double *x0 = a.x0 + (model * a.R + p0 + myp) * (long long)D;
     lbfgsb::lbfgsb_init(st, wk, D, a.opt.m, x0, blo, bhi, bnbd);
+#ifdef BORE_STAMPS
+    st.lb_last = clock64();
+#endif
   }
   wave_lds_sync();  // (the workspace of a problem is private to its wave / lane)
 
@@ -617,7 +663,7 @@ __device__ __forceinline__ void lbfgsb_body(const LbfgsbArgs &a, const long long
   if constexpr (SHAPE > 0) {
     if constexpr (Net::RT_ACT) net.set_acts(a.L);
     if constexpr (!LEAN) {
-      if (!(coop && SHAPE != 1)) {  // (one point per wave goes through PointNet: no matrix operands)
+      if (!(coop && BORE_POINT_SHAPE(SHAPE))) {  // (one point per wave goes through PointNet: no matrix operands)
         net.load_fwd(thw);
         net.template load_bwd<Net::n, 1>(thw);
       }
@@ -626,17 +672,75 @@ __device__ __forceinline__ void lbfgsb_body(const LbfgsbArgs &a, const long long
   bool done = (myp < 0);
   const long long c_init = BORE_LCLOCK();
   long long t_adv = 0, t_fg = 0, n_rounds = 0;
-  for (int round = 0; round < a.max_rounds; ++round) {
+  // ---- one problem per wave, static shape: the optimiser calls the evaluation (lbfgsb.h, DIRECT form) ----
+  bool direct = false;
+  if constexpr (SHAPE > 0) {
+    direct = coop;
+    if (coop && !done) {
+      const int m16 = lane & 15, q4 = lane >> 4;
+      auto evaluate = [&](lbfgsb::State &s, const lbfgsb::Work &w) {
+        wave_lds_sync();  // (x was written by the lanes that own its components)
+        const long long c1 = BORE_LCLOCK();
+        if constexpr (LEAN) {
+          if (!BORE_POINT_SHAPE(SHAPE)) {
+            net.load_fwd(thw);
+            net.template load_bwd<Net::n, 1>(thw);
+          }
+        }
+        if constexpr (BORE_POINT_SHAPE(SHAPE)) {
+          // one point per wave, on the vector ALU (mlp_point.h: the same k-ordered fmaf chains as the
+          // matrix path, 1 / 16 of its arithmetic); x straight from the optimiser's fp64 vector (Keras
+          // autocast fp64 -> fp32)
+          PointNet<(SHAPE > 0 ? SHAPE : 1), BF16> pnet;
+          if constexpr (Net::RT_ACT) pnet.set_acts(a.L);
+          const float xl = lane < D ? Net::rnd((float)w.x[lane]) : 0.f;
+          const float Tv = pnet.fg(thw, xl, a.transform, a.sign);
+          s.f = (double)Tv;
+          if (lane < D) w.g[lane] = (double)pnet.d[0][0];
+        } else {
+          // every row of the wave's 16-row block evaluates the point, read straight from the
+          // optimiser's fp64 x (Keras autocast fp64 -> fp32)
+          float xin[Net::KC0];
+#pragma unroll
+          for (int kc = 0; kc < Net::KC0; ++kc) {
+            const int d = 4 * kc + q4;
+            xin[kc] = d < D ? Net::rnd((float)w.x[d]) : 0.f;
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          const float Tv = net.fg(thw, xin, a.transform, a.sign);
+          s.f = (double)__uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(Tv)));
+          if (m16 == 0) {
+#pragma unroll
+            for (int t = 0; t < Net::L.Np[0] / 16; ++t)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const int d = 16 * t + 4 * q4 + r;
+                if (d < D) w.g[d] = (double)net.d[0][t][r];
+              }
+          }
+        }
+        wave_lds_sync();
+        t_fg += BORE_LCLOCK() - c1;
+        ++n_rounds;
+      };
+      const long long c0 = BORE_LCLOCK();
+      lbfgsb::lbfgsb_advance<SHAPE != 1>(st, wk, blo, bhi, bnbd, a.opt, cp, evaluate);
+      t_adv = BORE_LCLOCK() - c0 - t_fg;
+      done = true;
+    }
+  }
+  if constexpr (ALWAYS_COOP) {
+    if (!direct) return;  // (cannot happen: the fused kernel's launches keep np <= 16)
+  } else {
+  for (int round = 0; !direct && round < a.max_rounds; ++round) {
     int pending = 0;
     const long long c0 = BORE_LCLOCK();
     if (!done) {
       // (2-D problems -- static shape 1, the fused iteration kernel -- keep the forms without a variable per lane)
       const int rc = lbfgsb::lbfgsb_advance<SHAPE != 1>(st, wk, blo, bhi, bnbd, a.opt, cp);
       if (rc == lbfgsb::LB_NEED_FG) {
-        if (!(SHAPE > 0 && coop)) {
-          float *row = tile + L.aoff[0] + myrow * L.lda[0];
-          for (int d = 0; d < D; ++d) row[d] = (float)wk.x[d];  // Keras autocast fp64 -> fp32
-        }
+        float *row = tile + L.aoff[0] + myrow * L.lda[0];
+        for (int d = 0; d < D; ++d) row[d] = (float)wk.x[d];  // Keras autocast fp64 -> fp32
         pending = 1;
       } else {
         done = true;
@@ -646,58 +750,25 @@ __device__ __forceinline__ void lbfgsb_body(const LbfgsbArgs &a, const long long
     wave_lds_sync();
     const long long c1 = BORE_LCLOCK();
     if constexpr (SHAPE > 0) {
-      // static shape: the 16-row block goes through the network in registers (mlp_regs.h)
+      // static shape: the 16-row block goes through the network in registers (mlp_regs.h); lane
+      // s < 16 owns row s (a wave's single problem takes the DIRECT form above)
       const int m16 = lane & 15, q4 = lane >> 4;
       float xin[Net::KC0];
       if constexpr (LEAN) {
-        if (!(coop && SHAPE != 1)) {
-          net.load_fwd(thw);
-          net.template load_bwd<Net::n, 1>(thw);
-        }
+        net.load_fwd(thw);
+        net.template load_bwd<Net::n, 1>(thw);
       }
-      if (coop && SHAPE != 1) {
-        // one point per wave, on the vector ALU (mlp_point.h: the same k-ordered fmaf chains as the
-        // matrix path, 1 / 16 of its arithmetic); x straight from the optimiser's fp64 vector (Keras
-        // autocast fp64 -> fp32)
-        PointNet<(SHAPE > 0 ? SHAPE : 1), BF16> pnet;
-        if constexpr (Net::RT_ACT) pnet.set_acts(a.L);
-        const float xl = lane < D ? Net::rnd((float)wk.x[lane]) : 0.f;
-        const float Tv = pnet.fg(thw, xl, a.transform, a.sign);
+      const float *A0 = tile + L.aoff[0] + (wv * 16 + m16) * L.lda[0];
+#pragma unroll
+      for (int kc = 0; kc < Net::KC0; ++kc) xin[kc] = Net::rnd(A0[4 * kc + q4]);
+      __builtin_amdgcn_sched_barrier(0);
+      const float Tv = net.fg(thw, xin, a.transform, a.sign);
+      Net::template store_rows_f32<0>(net.d[0], tile + BORE_BATCH_MAX * L.lda[0], wv);
+      wave_lds_sync();
+      if (pending) {  // lane s < 16 owns row s: its value is already in this lane
         st.f = (double)Tv;
-        if (lane < D) wk.g[lane] = (double)pnet.d[0][0];
-      } else if (coop) {
-        // one point per wave: every row of the block evaluates it, read straight from the
-        // optimiser's fp64 x (Keras autocast fp64 -> fp32)
-#pragma unroll
-        for (int kc = 0; kc < Net::KC0; ++kc) {
-          const int d = 4 * kc + q4;
-          xin[kc] = d < D ? Net::rnd((float)wk.x[d]) : 0.f;
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        const float Tv = net.fg(thw, xin, a.transform, a.sign);
-        st.f = (double)__uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(Tv)));
-        if (m16 == 0) {
-#pragma unroll
-          for (int t = 0; t < Net::L.Np[0] / 16; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const int d = 16 * t + 4 * q4 + r;
-              if (d < D) wk.g[d] = (double)net.d[0][t][r];
-            }
-        }
-      } else {
-        const float *A0 = tile + L.aoff[0] + (wv * 16 + m16) * L.lda[0];
-#pragma unroll
-        for (int kc = 0; kc < Net::KC0; ++kc) xin[kc] = Net::rnd(A0[4 * kc + q4]);
-        __builtin_amdgcn_sched_barrier(0);
-        const float Tv = net.fg(thw, xin, a.transform, a.sign);
-        Net::template store_rows_f32<0>(net.d[0], tile + BORE_BATCH_MAX * L.lda[0], wv);
-        wave_lds_sync();
-        if (pending) {  // lane s < 16 owns row s: its value is already in this lane
-          st.f = (double)Tv;
-          const float *g = tile + BORE_BATCH_MAX * L.lda[0] + myrow * L.lda[0];
-          for (int d = 0; d < D; ++d) wk.g[d] = (double)g[d];
-        }
+        const float *g = tile + BORE_BATCH_MAX * L.lda[0] + myrow * L.lda[0];
+        for (int d = 0; d < D; ++d) wk.g[d] = (double)g[d];
       }
     } else {
       fg_rowblock(L, n_lay, th, tile, wv, a.transform, a.sign, vals);
@@ -712,6 +783,7 @@ __device__ __forceinline__ void lbfgsb_body(const LbfgsbArgs &a, const long long
     t_fg += BORE_LCLOCK() - c1;
     ++n_rounds;
   }
+  }
   (void)t_adv; (void)t_fg; (void)n_rounds; (void)c_enter; (void)c_begun; (void)c_staged; (void)c_init;
 #ifdef BORE_STAMPS
   if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) {
@@ -719,10 +791,21 @@ __device__ __forceinline__ void lbfgsb_body(const LbfgsbArgs &a, const long long
     g_lstamps[4] = c_begun - c_enter; g_lstamps[5] = c_staged - c_begun; g_lstamps[6] = c_init - c_staged;
     g_lstamps[7] = BORE_LCLOCK() - c_enter;
   }
-  if (coop && lane == 0 && 4 * blockIdx.x + wv < LB_PP_MAX) {
-    atomicAdd(&lbfgsb::g_lb_pp[4 * blockIdx.x + wv][7], (unsigned long long)t_adv);
-    atomicAdd(&lbfgsb::g_lb_pp[4 * blockIdx.x + wv][15], (unsigned long long)t_fg);
+  if (coop && lane == 0 && 4 * blockIdx.x + wv < LB_PP_MAX) {  // (one writer per row: plain adds)
+    unsigned long long *pp = lbfgsb::g_lb_pp[4 * blockIdx.x + wv];
+    for (int i = 0; i < 64; ++i) {
+      pp[i] += lbfgsb::g_lb_lds[wv & 7][i];
+      lbfgsb::g_lb_lds[wv & 7][i] = 0;
+    }
+    pp[13] += (unsigned long long)t_adv;
+    pp[14] += (unsigned long long)t_fg;
+    pp[32 + 13] += (unsigned long long)n_rounds;
   }
+  if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0)   // (the r2 tool's view: cycles 0..7, calls 8..15)
+    for (int i = 0; i < 8; ++i) {
+      lbfgsb::g_lb_phase[i] = (long long)lbfgsb::g_lb_pp[0][i];
+      lbfgsb::g_lb_phase[8 + i] = (long long)lbfgsb::g_lb_pp[0][32 + i];
+    }
 #endif
 
   if (myp >= 0 && st.stage != lbfgsb::S_FINISHED) {  // round cap hit (cannot happen with a sane cap)
@@ -967,27 +1050,39 @@ extern "C" int bore_lbfgsb_minimize(const bore_mlp_desc *desc, int n_models, con
     if (rc) return rc;                                                                             \
     hipLaunchKernelGGL((K), dim3(n_models, blocks), dim3(64 * waves), off * 4, (hipStream_t)stream, a); \
   }
+    if (!bore_flavour_built(flavour)) return fail(BORE_E_UNSUPPORTED, BORE_FLAVOUR_LEFT_OUT);
+    if (!(flavour == 3 || (flavour == 4 && bf)))
+      return fail(BORE_E_UNSUPPORTED, "lbfgsb_minimize: no eight-wave kernel for this flavour");
+#if BORE_ON_3
     if (flavour == 3 && !bf) BORE_LAUNCH_W8((lbfgsb_kernel_w8<3, false>))
-    else if (flavour == 3) BORE_LAUNCH_W8((lbfgsb_kernel_w8<3, true>))
-    else if (flavour == 4 && bf) BORE_LAUNCH_W8((lbfgsb_kernel_w8<4, true>))
-    else return fail(BORE_E_UNSUPPORTED, "lbfgsb_minimize: no eight-wave kernel for this flavour");
+    if (flavour == 3 && bf) BORE_LAUNCH_W8((lbfgsb_kernel_w8<3, true>))
+#endif
+#if BORE_ON_4
+    if (flavour == 4 && bf) BORE_LAUNCH_W8((lbfgsb_kernel_w8<4, true>))
+#endif
 #undef BORE_LAUNCH_W8
     HIP_TRY(hipGetLastError());
     return 0;
   }
   if (desc->compute == BORE_COMPUTE_BF16) {
     if (!bore_shape_is_wide(flavour)) return fail(BORE_E_UNSUPPORTED, kBf16Shapes);
+    if (!bore_flavour_built(flavour)) return fail(BORE_E_UNSUPPORTED, BORE_FLAVOUR_LEFT_OUT);
+#if BORE_ON_3
     if (flavour == 3) {
       rc = allow_lds((lbfgsb_kernel<3, true>), off * 4);
       if (rc) return rc;
       hipLaunchKernelGGL((lbfgsb_kernel<3, true>), dim3(n_models, blocks), dim3(BORE_THREADS),
                          off * 4, (hipStream_t)stream, a);
-    } else {
+    }
+#endif
+#if BORE_ON_4
+    if (flavour == 4) {
       rc = allow_lds((lbfgsb_kernel<4, true>), off * 4);
       if (rc) return rc;
       hipLaunchKernelGGL((lbfgsb_kernel<4, true>), dim3(n_models, blocks), dim3(BORE_THREADS),
                          off * 4, (hipStream_t)stream, a);
     }
+#endif
     HIP_TRY(hipGetLastError());
     return 0;
   }
@@ -999,6 +1094,7 @@ extern "C" int bore_lbfgsb_minimize(const bore_mlp_desc *desc, int n_models, con
     // problem sooner.  BORE_LBFGSB_OCC2 = 0 / 1 forces either (tests, measurements).
     const int forced = getenv("BORE_LBFGSB_OCC2") ? atoi(getenv("BORE_LBFGSB_OCC2")) : -1;
     const bool many = (long long)n_models * blocks > device_cus();
+#if BORE_ON_2
     if (flavour == 2 && off * 4 <= BORE_LDS_BYTES / 2 && (forced < 0 ? many : forced != 0)) {
       rc = allow_lds(lbfgsb_kernel_occ2<2>, off * 4);
       if (rc) return rc;
@@ -1007,7 +1103,11 @@ extern "C" int bore_lbfgsb_minimize(const bore_mlp_desc *desc, int n_models, con
       HIP_TRY(hipGetLastError());
       return 0;
     }
+#else
+    (void)forced; (void)many;
+#endif
   }
+  if (!bore_flavour_built(flavour)) return fail(BORE_E_UNSUPPORTED, BORE_FLAVOUR_LEFT_OUT);
 #define BORE_LAUNCH_LBFGSB(S)                                                                  \
   case S:                                                                                      \
     rc = allow_lds(lbfgsb_kernel<S>, off * 4);                                                 \
@@ -1016,16 +1116,37 @@ extern "C" int bore_lbfgsb_minimize(const bore_mlp_desc *desc, int n_models, con
                        (hipStream_t)stream, a);                                                \
     break;
   switch (flavour) {
+#if BORE_ON_1
     BORE_LAUNCH_LBFGSB(1)
+#endif
+#if BORE_ON_2
     BORE_LAUNCH_LBFGSB(2)
+#endif
+#if BORE_ON_3
     BORE_LAUNCH_LBFGSB(3)
+#endif
+#if BORE_ON_4
     BORE_LAUNCH_LBFGSB(4)
+#endif
+#if BORE_ON_N1
     BORE_LAUNCH_LBFGSB(-1)
+#endif
+#if BORE_ON_N2
     BORE_LAUNCH_LBFGSB(-2)
+#endif
+#if BORE_ON_N3
     BORE_LAUNCH_LBFGSB(-3)
+#endif
+#if BORE_ON_N4
     BORE_LAUNCH_LBFGSB(-4)
+#endif
     default:
+#if !BORE_ON_0
+      return fail(BORE_E_UNSUPPORTED, BORE_FLAVOUR_LEFT_OUT);
+#endif
+#if BORE_ON_0
     BORE_LAUNCH_LBFGSB(0)
+#endif
   }
 #undef BORE_LAUNCH_LBFGSB
   HIP_TRY(hipGetLastError());

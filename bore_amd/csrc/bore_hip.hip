@@ -2118,17 +2118,39 @@ extern "C" int bore_mlp_fit(const bore_mlp_desc *desc, int n_models, float *thet
     hipLaunchKernelGGL(fit_kernel<S>, dim3(n_models), dim3(BORE_THREADS), off * 4,      \
                        (hipStream_t)stream, a);                                         \
     break;
+  if (!bore_flavour_built(shape)) return fail(BORE_E_UNSUPPORTED, BORE_FLAVOUR_LEFT_OUT);
   switch (shape) {
+#if BORE_ON_1
     BORE_LAUNCH_FIT(1)
+#endif
+#if BORE_ON_2
     BORE_LAUNCH_FIT(2)
+#endif
+#if BORE_ON_3
     BORE_LAUNCH_FIT(3)
+#endif
+#if BORE_ON_4
     BORE_LAUNCH_FIT(4)
+#endif
+#if BORE_ON_N1
     BORE_LAUNCH_FIT(-1)
+#endif
+#if BORE_ON_N2
     BORE_LAUNCH_FIT(-2)
+#endif
+#if BORE_ON_N3
     BORE_LAUNCH_FIT(-3)
+#endif
+#if BORE_ON_N4
     BORE_LAUNCH_FIT(-4)
+#endif
     default:
+#if !BORE_ON_0
+      return fail(BORE_E_UNSUPPORTED, BORE_FLAVOUR_LEFT_OUT);
+#endif
+#if BORE_ON_0
     BORE_LAUNCH_FIT(0)
+#endif
   }
 #undef BORE_LAUNCH_FIT
   HIP_TRY(hipGetLastError());
@@ -2198,12 +2220,21 @@ static int fit_bf16_impl(const bore_mlp_desc *desc, int n_models, float *theta, 
     if (rc) return rc;                                                                       \
     hipLaunchKernelGGL(KERNEL, dim3(n_models), dim3(BORE_THREADS), off, (hipStream_t)stream, a); \
   }
+  if (!bore_flavour_built(shape)) return fail(BORE_E_UNSUPPORTED, BORE_FLAVOUR_LEFT_OUT);
   if (old_form) {
+#if BORE_ON_3
     if (shape == 3) BORE_LAUNCH_BF16(fit_bf16_kernel<3>)
-    else BORE_LAUNCH_BF16(fit_bf16_kernel<4>)
+#endif
+#if BORE_ON_4
+    if (shape == 4) BORE_LAUNCH_BF16(fit_bf16_kernel<4>)
+#endif
   } else {
+#if BORE_ON_3
     if (shape == 3) BORE_LAUNCH_BF16(fit_bf16_mfma_kernel<3>)
-    else BORE_LAUNCH_BF16(fit_bf16_mfma_kernel<4>)
+#endif
+#if BORE_ON_4
+    if (shape == 4) BORE_LAUNCH_BF16(fit_bf16_mfma_kernel<4>)
+#endif
   }
 #undef BORE_LAUNCH_BF16
   HIP_TRY(hipGetLastError());
@@ -2241,34 +2272,50 @@ static int row_launch(bool with_grad, int n_models, RowArgs &a, void *stream) {
     hipLaunchKernelGGL((rows_kernel<G, S, true>), dim3(n_models, (unsigned)gy),                \
                        dim3(BORE_THREADS), off * 4, (hipStream_t)stream, a);                   \
   }
+  if (!bore_flavour_built(shape)) return fail(BORE_E_UNSUPPORTED, BORE_FLAVOUR_LEFT_OUT);
   if (a.bf16) {  // (the entry points have checked: wide static shape)
-    if (with_grad) {
-      if (shape == 3) BORE_LAUNCH_ROWS16(true, 3)
-      else BORE_LAUNCH_ROWS16(true, 4)
-    } else {
-      if (shape == 3) BORE_LAUNCH_ROWS16(false, 3)
-      else BORE_LAUNCH_ROWS16(false, 4)
-    }
-  } else if (with_grad) {
-    if (shape == 1) BORE_LAUNCH_ROWS(true, 1)
-    else if (shape == 2) BORE_LAUNCH_ROWS(true, 2)
-    else if (shape == 3) BORE_LAUNCH_ROWS(true, 3)
-    else if (shape == 4) BORE_LAUNCH_ROWS(true, 4)
-    else if (shape == -1) BORE_LAUNCH_ROWS(true, -1)
-    else if (shape == -2) BORE_LAUNCH_ROWS(true, -2)
-    else if (shape == -3) BORE_LAUNCH_ROWS(true, -3)
-    else if (shape == -4) BORE_LAUNCH_ROWS(true, -4)
-    else BORE_LAUNCH_ROWS(true, 0)
+#if BORE_ON_3
+    if (shape == 3 && with_grad) BORE_LAUNCH_ROWS16(true, 3)
+    if (shape == 3 && !with_grad) BORE_LAUNCH_ROWS16(false, 3)
+#endif
+#if BORE_ON_4
+    if (shape == 4 && with_grad) BORE_LAUNCH_ROWS16(true, 4)
+    if (shape == 4 && !with_grad) BORE_LAUNCH_ROWS16(false, 4)
+#endif
   } else {
-    if (shape == 1) BORE_LAUNCH_ROWS(false, 1)
-    else if (shape == 2) BORE_LAUNCH_ROWS(false, 2)
-    else if (shape == 3) BORE_LAUNCH_ROWS(false, 3)
-    else if (shape == 4) BORE_LAUNCH_ROWS(false, 4)
-    else if (shape == -1) BORE_LAUNCH_ROWS(false, -1)
-    else if (shape == -2) BORE_LAUNCH_ROWS(false, -2)
-    else if (shape == -3) BORE_LAUNCH_ROWS(false, -3)
-    else if (shape == -4) BORE_LAUNCH_ROWS(false, -4)
-    else BORE_LAUNCH_ROWS(false, 0)
+#define BORE_ROWS_BOTH(S)                      \
+  if (shape == (S)) {                          \
+    if (with_grad) BORE_LAUNCH_ROWS(true, S)   \
+    else BORE_LAUNCH_ROWS(false, S)            \
+  }
+#if BORE_ON_1
+    BORE_ROWS_BOTH(1)
+#endif
+#if BORE_ON_2
+    BORE_ROWS_BOTH(2)
+#endif
+#if BORE_ON_3
+    BORE_ROWS_BOTH(3)
+#endif
+#if BORE_ON_4
+    BORE_ROWS_BOTH(4)
+#endif
+#if BORE_ON_N1
+    BORE_ROWS_BOTH(-1)
+#endif
+#if BORE_ON_N2
+    BORE_ROWS_BOTH(-2)
+#endif
+#if BORE_ON_N3
+    BORE_ROWS_BOTH(-3)
+#endif
+#if BORE_ON_N4
+    BORE_ROWS_BOTH(-4)
+#endif
+#if BORE_ON_0
+    BORE_ROWS_BOTH(0)
+#endif
+#undef BORE_ROWS_BOTH
   }
 #undef BORE_LAUNCH_ROWS
 #undef BORE_LAUNCH_ROWS16

@@ -82,7 +82,7 @@ __device__ __attribute__((noinline)) void iteration_once(const IterArgs *__restr
   if (stp && threadIdx.x == 0) stp[3] = wall_clock64();
   __threadfence();
   __syncthreads();
-  lbfgsb_body<SHAPE, false, true>(a.b, slot, 0, it);  // (publishes flag[lid] = it + 1)
+  lbfgsb_body<SHAPE, false, true, true>(a.b, slot, 0, it);  // (publishes flag[lid] = it + 1)
 }
 
 // RESIDENT: the workgroup may go on to later iterations of its loop (a loop around a real call).
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(BORE_THREADS, 2) void iteration_kernel(const IterAr
     if (stp && threadIdx.x == 0) stp[3] = wall_clock64();
     __threadfence();
     __syncthreads();
-    lbfgsb_body<SHAPE, false, true>(a.b, slot, 0);  // (publishes flag[lid] = it + 1)
+    lbfgsb_body<SHAPE, false, true, true>(a.b, slot, 0);  // (publishes flag[lid] = it + 1)
     // not the loop's last iteration: leave the next one to a later launch.  (Any wave may say so,
     // and before the others are done: the host reacts to `parked` only after the flag.)
     if (a.targets && threadIdx.x == 0 && it + 1 < a.targets[slot])

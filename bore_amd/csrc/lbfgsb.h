@@ -30,6 +30,8 @@
 #include <math.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #if defined(__HIPCC__)
 #define LB_HD __host__ __device__ __forceinline__
 #define LB_HDN __host__ __device__ __forceinline__  // (real calls measured slower: +20 % kernel time)
@@ -77,6 +79,9 @@ struct State {
   // driver
   int stage, task, msg, nit, nfev, status;
   double flast;
+#if defined(BORE_STAMPS)
+  long long lb_last;  // (diagnostic builds: time of the previous mark, LB_MARK)
+#endif
 };
 
 // Every sub-array starts on a 16-byte boundary (vectors are padded to an even length) and the
@@ -155,29 +160,37 @@ struct Coop {
 
 // -DBORE_STAMPS: per-phase cycle accumulators, diagnostics only.  g_lb_phase: workgroup 0,
 // thread 0.  g_lb_pp[q][i]: every problem q = 4*blockIdx.x + wave of a one-problem-per-wave launch
-// (i < 7: cycles in phase i, 8 + i: calls; 7 / 15: whole advance / f-g cycles, added by the kernel).
+// (i < 16: cycles in phase i, 16 + i: calls; 13 / 14: whole advance / f-g cycles, added by the kernel;
+// phases: 0 cauchy 1 formk 2 cmprlb 3 subsm 4 lnsrlb 5 matupd 6 formt 7 head of advance (saves of the
+// evaluated point) 8 freev 9 accept (projgr + tests) 10 cache check 11 BFGS pair (r, rr, d) 12 d = z - x).
 #if defined(BORE_STAMPS) && defined(__HIPCC__)
 __device__ long long g_lb_phase[16];
 #define LB_PP_MAX 4096
-__device__ unsigned long long g_lb_pp[LB_PP_MAX][16];
+__device__ unsigned long long g_lb_pp[LB_PP_MAX][64];
+// Accumulated per wave in LDS (ds_add without return: no round trip in the optimiser's chain; the
+// r2 form added to global memory with returning atomics, ~2 k cycles per stamped phase); the kernel
+// flushes a wave's row to g_lb_pp when its problem ends.
+__shared__ unsigned g_lb_lds[8][64];
 #endif
 #if defined(BORE_STAMPS) && defined(__HIP_DEVICE_COMPILE__)
-#define LB_PHASE_BEGIN() const long long lb_t0_ = clock64()
-#define LB_PHASE_END(i)                                                                   \
+// Every cycle of lbfgsb_advance lands in exactly one bucket: LB_PHASE_BEGIN(g) charges the time
+// since the previous mark to the GAP bucket g (what precedes the phase: control flow, copies between
+// register assignments, ...), LB_PHASE_END(i) charges the time since then to phase i.
+#define LB_MARK(s_, i)                                                                    \
   do {                                                                                    \
-    const long long lb_dt_ = clock64() - lb_t0_;                                          \
-    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {                         \
-      g_lb_phase[i] += lb_dt_;                                                            \
-      g_lb_phase[8 + (i)] += 1;                                                           \
-    }                                                                                     \
-    const unsigned lb_q_ = 4u * blockIdx.x + (threadIdx.x >> 6);                          \
-    if ((threadIdx.x & 63) == 0 && lb_q_ < LB_PP_MAX) {                                   \
-      atomicAdd(&g_lb_pp[lb_q_][i], (unsigned long long)lb_dt_);                          \
-      atomicAdd(&g_lb_pp[lb_q_][8 + (i)], 1ull);                                          \
+    const long long lb_now_ = clock64();                                                  \
+    const unsigned lb_dt_ = (unsigned)(lb_now_ - (s_).lb_last);                           \
+    (s_).lb_last = lb_now_;                                                               \
+    if ((threadIdx.x & 63) == 0) {                                                        \
+      __hip_atomic_fetch_add(&g_lb_lds[(threadIdx.x >> 6) & 7][i], lb_dt_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
+      __hip_atomic_fetch_add(&g_lb_lds[(threadIdx.x >> 6) & 7][32 + (i)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
     }                                                                                     \
   } while (0)
+#define LB_PHASE_BEGIN(g) LB_MARK(s, g)
+#define LB_PHASE_END(i) LB_MARK(s, i)
 #else
-#define LB_PHASE_BEGIN() ((void)0)
+#define LB_MARK(s_, i) ((void)0)
+#define LB_PHASE_BEGIN(g) ((void)0)
 #define LB_PHASE_END(i) ((void)0)
 #endif
 
@@ -1577,20 +1590,37 @@ LB_HD void lbfgsb_init(State &s, const Work &w, int n, int m, const double *x0, 
 // s.nfev, s.status, s.task, s.msg).
 // `coop`: {0, 1} for a thread that owns its problem alone; {lane, 64} when the 64 lanes of a
 // wave run ONE problem together (every lane calls with identical State; see struct Coop).
-template <bool VL = true>
+//
+// DIRECT form: with an evaluation functor `fg(State &, const Work &)` -- which leaves f in s.f and
+// g in w.g for the point in w.x -- the routine does not return for evaluations; it calls fg where
+// the reverse-communication form returns LB_NEED_FG and goes on exactly where a re-entry would
+// (same operations in the same order: the two forms give the same bits, tested).  What it saves
+// is the way out of and back into a state machine that the device compiler has inlined into its
+// caller's loop: ~2 k cycles per evaluation of exits through nested loops, re-dispatch on the
+// stage and copies between register assignments (profiles/r3/lbfgsb_gap_stamps.txt).  For a
+// caller whose lanes all work on ONE problem (Coop) -- divergent callers need the returning form.
+struct ReverseCommunication {};
+template <bool VL = true, class FG = ReverseCommunication>
 LB_HD int lbfgsb_advance(State &s, const Work &w, const double *l, const double *u,
-                         const int *nbd, const Options &opt, const Coop coop = Coop{0, 1}) {
+                         const int *nbd, const Options &opt, const Coop coop = Coop{0, 1},
+                         FG fg = FG{}) {
+  constexpr bool DIRECT = !std::is_same<FG, ReverseCommunication>::value;
   const int n = s.n, m = s.m;
   bool first_ls = false;
   bool resume_ls = (s.stage == S_FG_LNSRCH);
 
   if (s.stage == S_FINISHED) return LB_DONE;
+  LB_MARK(s, 15);  // (everything since the previous return: the evaluation)
 
-  if (s.stage == S_FG_START || s.stage == S_FG_LNSRCH) {  // fresh f, g at w.x have arrived
+  // fresh f, g at w.x have arrived: remember the point (SciPy's ScalarFunction cache)
+  auto save_evaluated_point = [&]() {
+    LB_PHASE_BEGIN(20);
     for (int i = coop.lane; i < n; i += coop.nl) { w.xlast[i] = w.x[i]; w.glast[i] = w.g[i]; }
     LB_LANES_SYNC();
     s.flast = s.f;
-  }
+    LB_PHASE_END(7);
+  };
+  if (s.stage == S_FG_START || s.stage == S_FG_LNSRCH) save_evaluated_point();
 
   if (s.stage == S_INIT) {
     s.col = 0; s.head = 0; s.theta = 1.0; s.iupdat = 0; s.updatd = 0;
@@ -1656,7 +1686,14 @@ LB_HD int lbfgsb_advance(State &s, const Work &w, const double *l, const double 
     s.stage = S_FG_START;
     s.task = T_FG;
     ++s.nfev;
-    return LB_NEED_FG;
+    if constexpr (DIRECT) {
+      LB_MARK(s, 18);
+      fg(s, w);
+      LB_MARK(s, 15);
+      save_evaluated_point();
+    } else {
+      return LB_NEED_FG;
+    }
   }
 
   if (s.stage == S_FG_START) {
@@ -1682,7 +1719,7 @@ LB_HD int lbfgsb_advance(State &s, const Work &w, const double *l, const double 
       } else {
         const IterArgs ia{n, m, s.col, s.head, s.nfree, s.nenter, s.ileave, s.updatd, s.iupdat,
                           s.theta, s.sbgnrm, coop};
-        LB_PHASE_BEGIN();
+        LB_PHASE_BEGIN(21);
         const int rc = cauchy<VL>(ia, w, l, u, nbd);
         LB_PHASE_END(0);
         s.nseg = rc >> 8;
@@ -1690,42 +1727,50 @@ LB_HD int lbfgsb_advance(State &s, const Work &w, const double *l, const double 
           refresh_memory(s);
           continue;
         }
-        freev<VL>(s, w, coop);
+        {
+          LB_PHASE_BEGIN(22);
+          freev<VL>(s, w, coop);
+          LB_PHASE_END(8);
+        }
         s.nact = n - s.nfree;
       }
       if (s.nfree != 0 && s.col != 0) {
         const IterArgs ia{n, m, s.col, s.head, s.nfree, s.nenter, s.ileave, s.updatd, s.iupdat,
                           s.theta, s.sbgnrm, coop};
         if (s.wrk) {
-          LB_PHASE_BEGIN();
+          LB_PHASE_BEGIN(23);
           const int fk = formk(ia, w);
           LB_PHASE_END(1);
           if (fk) { refresh_memory(s); continue; }
         }
         int rc;
         {
-          LB_PHASE_BEGIN();
+          LB_PHASE_BEGIN(24);
           const int cm = cmprlb(s, w, coop);
           LB_PHASE_END(2);
           if (cm) { refresh_memory(s); continue; }
         }
         {
-          LB_PHASE_BEGIN();
+          LB_PHASE_BEGIN(25);
           rc = subsm<VL>(ia, w, l, u, nbd);
           LB_PHASE_END(3);
         }
         s.iword = rc >> 8;
         if (rc & 0xff) { refresh_memory(s); continue; }
       }
-      for (int i = coop.lane; i < n; i += coop.nl) w.d[i] = w.z[i] - w.x[i];
-      LB_LANES_SYNC();
+      {
+        LB_PHASE_BEGIN(26);
+        for (int i = coop.lane; i < n; i += coop.nl) w.d[i] = w.z[i] - w.x[i];
+        LB_LANES_SYNC();
+        LB_PHASE_END(12);
+      }
       first_ls = true;
     }
 
     s.info = 0;
     int ls_rc;
     {
-      LB_PHASE_BEGIN();
+      LB_PHASE_BEGIN(27);
       ls_rc = lnsrlb<VL>(s, w, l, u, nbd, first_ls ? 1 : 0, coop);
       LB_PHASE_END(4);
     }
@@ -1733,9 +1778,11 @@ LB_HD int lbfgsb_advance(State &s, const Work &w, const double *l, const double 
       if (s.iback < opt.maxls) {
         // SciPy's ScalarFunction serves a request at the point it evaluated last from its
         // cache (no call, nfev unchanged); a collapsed bracket asks for such points.
+        LB_PHASE_BEGIN(28);
         bool differs = false;
         for (int i = coop.lane; i < n; i += coop.nl) differs = differs || (w.x[i] != w.xlast[i]);
         const bool cached = coop.nl > 1 ? !lanes_any(differs) : !differs;
+        LB_PHASE_END(10);
         if (cached) {
           s.f = s.flast;
           for (int i = coop.lane; i < n; i += coop.nl) w.g[i] = w.glast[i];
@@ -1746,7 +1793,16 @@ LB_HD int lbfgsb_advance(State &s, const Work &w, const double *l, const double 
         s.stage = S_FG_LNSRCH;
         s.task = T_FG;
         ++s.nfev;
-        return LB_NEED_FG;
+        LB_MARK(s, 18);
+        if constexpr (DIRECT) {
+          fg(s, w);
+          LB_MARK(s, 15);
+          save_evaluated_point();
+          resume_ls = true;  // (what a re-entry in stage S_FG_LNSRCH does)
+          continue;
+        } else {
+          return LB_NEED_FG;
+        }
       }
       // maxls trial points used up: handled like a failed search (the trial x is dropped)
     }
@@ -1767,7 +1823,11 @@ LB_HD int lbfgsb_advance(State &s, const Work &w, const double *l, const double 
     }
     // new iterate accepted
     ++s.iter;
-    s.sbgnrm = projgr(n, l, u, nbd, w.x, w.g, coop);
+    {
+      LB_PHASE_BEGIN(29);
+      s.sbgnrm = projgr(n, l, u, nbd, w.x, w.g, coop);
+      LB_PHASE_END(9);
+    }
     // --- what the SciPy driver does on NEW_X ---
     ++s.nit;
     if (s.nit >= opt.maxiter) { finish(s, T_STOP, M_MAXITER); return LB_DONE; }
@@ -1783,6 +1843,7 @@ LB_HD int lbfgsb_advance(State &s, const Work &w, const double *l, const double 
       }
     }
     // --- BFGS update: r = g - g_old (y), d = step (s) ---
+    LB_PHASE_BEGIN(30);
     for (int i = coop.lane; i < n; i += coop.nl) w.r[i] = w.g[i] - w.r[i];
     LB_LANES_SYNC();
     {
@@ -1803,14 +1864,15 @@ LB_HD int lbfgsb_advance(State &s, const Work &w, const double *l, const double 
       }
       s.updatd = 1;
       ++s.iupdat;
+      LB_PHASE_END(11);
       {
-        LB_PHASE_BEGIN();
+        LB_PHASE_BEGIN(31);
         matupd<VL>(s, w, rr, dr, coop);
         LB_PHASE_END(5);
       }
       int ft;
       {
-        LB_PHASE_BEGIN();
+        LB_PHASE_BEGIN(19);
         ft = formt(m, w, s.col, s.theta, coop);
         LB_PHASE_END(6);
       }

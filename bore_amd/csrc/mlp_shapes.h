@@ -11,6 +11,24 @@
 
 #define BORE_N_SHAPES 4  // ids 1..BORE_N_SHAPES
 
+// Which kernel flavours a build instantiates (experiment builds only: tools/build_variant.sh fast1
+// -DBORE_SHAPE_MASK=0x2 compiles the 2->16-16-1 kernels alone in a fifth of the time; a request for
+// a flavour that was left out is refused with BORE_E_UNSUPPORTED).  Bit 0: the generic flavour 0,
+// bits 1..4: static shapes 1..4, bits 5..8: flavours -1..-4.  The shipped library has them all.
+#ifndef BORE_SHAPE_MASK
+#define BORE_SHAPE_MASK 0x1ff
+#endif
+#define BORE_ON_0 ((BORE_SHAPE_MASK) & 0x001)
+#define BORE_ON_1 ((BORE_SHAPE_MASK) & 0x002)
+#define BORE_ON_2 ((BORE_SHAPE_MASK) & 0x004)
+#define BORE_ON_3 ((BORE_SHAPE_MASK) & 0x008)
+#define BORE_ON_4 ((BORE_SHAPE_MASK) & 0x010)
+#define BORE_ON_N1 ((BORE_SHAPE_MASK) & 0x020)
+#define BORE_ON_N2 ((BORE_SHAPE_MASK) & 0x040)
+#define BORE_ON_N3 ((BORE_SHAPE_MASK) & 0x080)
+#define BORE_ON_N4 ((BORE_SHAPE_MASK) & 0x100)
+#define BORE_FLAVOUR_LEFT_OUT "this build of the library leaves the kernel flavour out (BORE_SHAPE_MASK)"
+
 struct ShapeSpec {
   int D, n_layers;
   int units[4];
@@ -77,4 +95,10 @@ static inline int bore_kernel_flavour(const bore_mlp_desc *d, bool full_tile) {
   const int s = full_tile ? bore_match_shape(d) : 0;
   if (s) return s;
   return d->n_layers <= 4 ? -d->n_layers : 0;
+}
+
+// (experiment builds: was this flavour compiled in?)
+static inline bool bore_flavour_built(int flavour) {
+  const int bit = flavour >= 0 ? flavour : 4 - flavour;
+  return ((BORE_SHAPE_MASK) >> bit) & 1;
 }
