@@ -901,13 +901,13 @@ __global__ __launch_bounds__(BORE_THREADS) void lbfgsb_kernel(const LbfgsbArgs a
 // with many more workgroups than the device has CUs.
 template <int SHAPE, bool BF16 = false>
 __global__ __launch_bounds__(BORE_THREADS, 2) void lbfgsb_kernel_occ2(const LbfgsbArgs a) {
-  lbfgsb_body<SHAPE, BF16, true>(a, blockIdx.x, blockIdx.y);
+  lbfgsb_body<SHAPE, BF16, true, true>(a, blockIdx.x, blockIdx.y);
 }
 // The same for the wide shapes, whose weights take too much LDS for two workgroups: ONE workgroup of
 // up to eight waves (two per SIMD), one problem per wave, the weights staged once for all of them.
 template <int SHAPE, bool BF16 = false>
 __global__ __launch_bounds__(2 * BORE_THREADS) void lbfgsb_kernel_w8(const LbfgsbArgs a) {
-  lbfgsb_body<SHAPE, BF16, true>(a, blockIdx.x, blockIdx.y);
+  lbfgsb_body<SHAPE, BF16, true, true>(a, blockIdx.x, blockIdx.y);
 }
 
 static int lbfgsb_build(const bore_mlp_desc *desc, int n_models, const float *theta,
@@ -1095,7 +1095,8 @@ extern "C" int bore_lbfgsb_minimize(const bore_mlp_desc *desc, int n_models, con
     const int forced = getenv("BORE_LBFGSB_OCC2") ? atoi(getenv("BORE_LBFGSB_OCC2")) : -1;
     const bool many = (long long)n_models * blocks > device_cus();
 #if BORE_ON_2
-    if (flavour == 2 && off * 4 <= BORE_LDS_BYTES / 2 && (forced < 0 ? many : forced != 0)) {
+    // (one problem per wave only: the kernel does not carry the lane-per-problem loop)
+    if (flavour == 2 && a.PB <= 4 && off * 4 <= BORE_LDS_BYTES / 2 && (forced < 0 ? many : forced != 0)) {
       rc = allow_lds(lbfgsb_kernel_occ2<2>, off * 4);
       if (rc) return rc;
       hipLaunchKernelGGL(lbfgsb_kernel_occ2<2>, dim3(n_models, blocks), dim3(BORE_THREADS), off * 4,

@@ -154,8 +154,10 @@ struct Coop {
 };
 #if defined(__HIP_DEVICE_COMPILE__)
 #define LB_LANES_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#define LB_OPAQUE_LANE(x) asm volatile("" : "+v"(x))
 #else
 #define LB_LANES_SYNC() ((void)0)
+#define LB_OPAQUE_LANE(x) ((void)0)
 #endif
 
 // -DBORE_STAMPS: per-phase cycle accumulators, diagnostics only.  g_lb_phase: workgroup 0,
@@ -1602,9 +1604,10 @@ LB_HD void lbfgsb_init(State &s, const Work &w, int n, int m, const double *x0, 
 struct ReverseCommunication {};
 template <bool VL = true, class FG = ReverseCommunication>
 LB_HD int lbfgsb_advance(State &s, const Work &w, const double *l, const double *u,
-                         const int *nbd, const Options &opt, const Coop coop = Coop{0, 1},
+                         const int *nbd, const Options &opt, const Coop coop_in = Coop{0, 1},
                          FG fg = FG{}) {
   constexpr bool DIRECT = !std::is_same<FG, ReverseCommunication>::value;
+  Coop coop = coop_in;
   const int n = s.n, m = s.m;
   bool first_ls = false;
   bool resume_ls = (s.stage == S_FG_LNSRCH);
@@ -1706,6 +1709,10 @@ LB_HD int lbfgsb_advance(State &s, const Work &w, const double *l, const double 
   // otherwise S_FG_LNSRCH: f and g at the trial point have arrived; resume the line search
 
   for (;;) {
+    // The lane number is made opaque once per pass: every per-lane address below derives from it, and
+    // computed from a loop-invariant they are all hoisted out of this loop and kept live around it --
+    // 340 spilled registers in the 128-wide restart kernels (profiles/r3/resource_usage.txt).
+    LB_OPAQUE_LANE(coop.lane);
     if (resume_ls) {
       resume_ls = false;
       first_ls = false;

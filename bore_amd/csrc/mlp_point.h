@@ -25,6 +25,34 @@
 
 namespace bore {
 
+// Activations picked at run time (shapes whose widths alone are static), as REAL calls: inlined, the
+// four activation bodies (exp, expm1, tanh ...) at each of a dozen sites made the 128-wide restart
+// kernel spill 320 registers (668 B of scratch per lane; 156 B with relu alone inlined).  Leaf
+// functions of a dozen registers: the call costs ~50 cycles, a layer of 128 units takes thousands.
+// Same expressions as act_fwd / act_grad inlined: same bits.
+static __device__ __attribute__((noinline)) float point_act_call(int a, float x) {
+  switch (a) {
+    case BORE_ACT_RELU: return act_fwd(BORE_ACT_RELU, x);
+    case BORE_ACT_ELU: return act_fwd(BORE_ACT_ELU, x);
+    case BORE_ACT_SIGMOID: return act_fwd(BORE_ACT_SIGMOID, x);
+    case BORE_ACT_TANH: return act_fwd(BORE_ACT_TANH, x);
+    default: return x;
+  }
+}
+static __device__ __attribute__((noinline)) float point_grad_call(int a, float v, float hh) {
+  switch (a) {
+    case BORE_ACT_RELU: return v * act_grad(BORE_ACT_RELU, hh);
+    case BORE_ACT_ELU: return v * act_grad(BORE_ACT_ELU, hh);
+    case BORE_ACT_SIGMOID: return v * act_grad(BORE_ACT_SIGMOID, hh);
+    case BORE_ACT_TANH: return v * act_grad(BORE_ACT_TANH, hh);
+    default: return v;  // linear: derivative 1
+  }
+}
+
+#ifndef BORE_POINT_KB
+#define BORE_POINT_KB(U) ((U) > 1 ? 8 : 16)
+#endif
+
 template <int SHAPE, bool BF16 = false>
 struct PointNet {
   using R = RegNet<SHAPE, 2, BF16>;
@@ -39,7 +67,9 @@ struct PointNet {
     return s;
   }
   static constexpr int U = max_slots();
-  static constexpr int KB = 16;  // terms whose operands are in flight together
+  // terms whose operands are in flight together (two slots per lane double the registers a batch
+  // takes: 128-wide layers batch 8 terms)
+  static constexpr int KB = BORE_POINT_KB(U);
   float h[n + 1][U];  // h[l][s] = A_l[unit lane + 64 s]
   float d[n + 1][U];
   int acts[n + 1];
@@ -56,22 +86,10 @@ struct PointNet {
   // act_fwd / act_grad with a wave-uniform run-time id: one scalar branch, then the same
   // constant-id code the matrix path runs (act_tiles / grad_tiles)
   static __device__ __forceinline__ float act_rt(int a, float x) {
-    switch (__builtin_amdgcn_readfirstlane(a)) {
-      case BORE_ACT_RELU: return act_fwd(BORE_ACT_RELU, x);
-      case BORE_ACT_ELU: return act_fwd(BORE_ACT_ELU, x);
-      case BORE_ACT_SIGMOID: return act_fwd(BORE_ACT_SIGMOID, x);
-      case BORE_ACT_TANH: return act_fwd(BORE_ACT_TANH, x);
-      default: return x;
-    }
+    return point_act_call(__builtin_amdgcn_readfirstlane(a), x);
   }
   static __device__ __forceinline__ float grad_rt(int a, float v, float hh) {
-    switch (__builtin_amdgcn_readfirstlane(a)) {
-      case BORE_ACT_RELU: return v * act_grad(BORE_ACT_RELU, hh);
-      case BORE_ACT_ELU: return v * act_grad(BORE_ACT_ELU, hh);
-      case BORE_ACT_SIGMOID: return v * act_grad(BORE_ACT_SIGMOID, hh);
-      case BORE_ACT_TANH: return v * act_grad(BORE_ACT_TANH, hh);
-      default: return v;  // linear: derivative 1
-    }
+    return point_grad_call(__builtin_amdgcn_readfirstlane(a), v, hh);
   }
   static __device__ __forceinline__ float lane_value(float v, int src) {  // src: compile-time after unrolling
     return __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), src));
