@@ -198,7 +198,9 @@ __device__ __forceinline__ void screen_body(const ScreenArgs &a, const long long
   extern __shared__ float smem[];
   constexpr MlpLayout Lc = bore_static_layout(SHAPE > 0 ? SHAPE : 0, 0, BORE_BATCH_MAX);
   const MlpLayout &L = begin_kernel<SHAPE>(Lc, a.L, smem, a.total, a.o_layout);
-  const int tid = threadIdx.x, nthr = blockDim.x;
+  int tid = threadIdx.x;
+  BORE_OPAQUE_TID(tid);
+  const int nthr = blockDim.x;
   // `model` is the output slot
   const long long lid = a.ids ? a.ids[model] : model;        // whose weights and stream
   const int n = layer_count<SHAPE>(L), D = L.w[0];
@@ -581,6 +583,7 @@ extern "C" int bore_debug_lpp(unsigned long long *out) {  // [LB_PP_MAX][64]
 #define BORE_POINT_SHAPE(S) ((S) != 1)
 #endif
 
+
 // LEAN: the network's weight operands are re-requested from LDS for every evaluation instead of
 // living in registers across the optimiser (the fused iteration kernel is held to 256 VGPRs).
 // ALWAYS_COOP: the caller's launches never give a wave more than one problem at a time (the fused
@@ -593,7 +596,8 @@ __device__ __forceinline__ void lbfgsb_body(const LbfgsbArgs &a, const long long
   const long long c_enter = BORE_LCLOCK();
   const MlpLayout &L = begin_kernel<SHAPE>(Lc, a.L, smem, a.total, a.o_layout);
   const long long c_begun = BORE_LCLOCK();
-  const int tid = threadIdx.x;
+  int tid = threadIdx.x;
+  BORE_OPAQUE_TID(tid);
   const int wv = tid >> 6, lane = tid & 63;
   // `model` is the slot: it indexes x0 / x / fun / jac / info
   const long long lid = a.ids ? a.ids[model] : model;  // whose weights (and record, and result)
@@ -724,7 +728,31 @@ __device__ __forceinline__ void lbfgsb_body(const LbfgsbArgs &a, const long long
         ++n_rounds;
       };
       const long long c0 = BORE_LCLOCK();
-      lbfgsb::lbfgsb_advance<SHAPE != 1>(st, wk, blo, bhi, bnbd, a.opt, cp, evaluate);
+      if constexpr (SHAPE == 1 && !BORE_POINT_SHAPE(SHAPE) && !BF16) {
+        // two inputs: the line search keeps its vectors in registers (lbfgsb.h, TWO-VARIABLE form) and
+        // hands the point over in registers as well
+        auto evaluate2 = [&](lbfgsb::State &s, double x0, double x1, double &g0, double &g1) {
+          const long long c1 = BORE_LCLOCK();
+          if constexpr (LEAN) {
+            net.load_fwd(thw);
+            net.template load_bwd<Net::n, 1>(thw);
+          }
+          static_assert(Net::KC0 == 1, "two inputs: one k-chunk");
+          float xin[Net::KC0];
+          xin[0] = q4 == 0 ? (float)x0 : (q4 == 1 ? (float)x1 : 0.f);  // Keras autocast fp64 -> fp32
+          __builtin_amdgcn_sched_barrier(0);
+          const float Tv = net.fg(thw, xin, a.transform, a.sign);
+          s.f = (double)__uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(Tv)));
+          // lane 0 (row 0, inputs 0..3) holds d T / d x_0, d T / d x_1
+          g0 = (double)__uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(net.d[0][0][0])));
+          g1 = (double)__uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(net.d[0][0][1])));
+          t_fg += BORE_LCLOCK() - c1;
+          ++n_rounds;
+        };
+        lbfgsb::lbfgsb_advance<SHAPE != 1>(st, wk, blo, bhi, bnbd, a.opt, cp, evaluate, evaluate2);
+      } else {
+        lbfgsb::lbfgsb_advance<SHAPE != 1>(st, wk, blo, bhi, bnbd, a.opt, cp, evaluate);
+      }
       t_adv = BORE_LCLOCK() - c0 - t_fg;
       done = true;
     }
@@ -808,13 +836,17 @@ __device__ __forceinline__ void lbfgsb_body(const LbfgsbArgs &a, const long long
     }
 #endif
 
+  // (the result addresses below depend on the problem number alone: an opaque copy keeps them from
+  // being formed before the optimisation and held -- spilled -- across it)
+  int myq = myp;
+  BORE_OPAQUE_TID(myq);
   if (myp >= 0 && st.stage != lbfgsb::S_FINISHED) {  // round cap hit (cannot happen with a sane cap)
     st.status = 2;
     st.task = lbfgsb::T_STOP;
     st.msg = lbfgsb::M_MAXFUN;
   }
   if (myp >= 0 && (!coop || lane == 0)) {  // (coop: one lane reports the shared problem)
-    const long long q = model * a.R + p0 + myp;
+    const long long q = model * a.R + p0 + myq;
     for (int d = 0; d < D; ++d) {
       a.x[q * D + d] = wk.x[d];
       a.jac[q * D + d] = wk.g[d];
@@ -827,7 +859,7 @@ __device__ __forceinline__ void lbfgsb_body(const LbfgsbArgs &a, const long long
   // ---- batch mode: the loop's pick (bore_select_best's rule), published by whichever of its
   // waves finishes the loop's last problem, while other loops of the launch are still optimising ----
   if (lane == 0) {
-    double *r = res + myp * (D + 3);
+    double *r = res + myq * (D + 3);
     r[0] = st.f;
     r[1] = (double)st.status;
     r[2] = (double)st.nfev;

@@ -848,7 +848,9 @@ __device__ __forceinline__ void fit_body(const FitArgs &a, const long long slot,
     TileOrder<WIDE ? SHAPE : 1>::convert(a.av + mdl * Lc.P, smem, true);
   }
   const MlpLayout &L = begin_kernel<SHAPE>(Lc, a.L, smem, a.total, a.o_layout);
-  const int tid = threadIdx.x, nthr = blockDim.x;
+  int tid = threadIdx.x;
+  BORE_OPAQUE_TID(tid);
+  const int nthr = blockDim.x;
   const int wv = tid >> 6, lane = tid & 63, m16 = lane & 15, q4 = lane >> 4;
   const long long model = a.ids ? a.ids[slot] : slot;  // the loop this workgroup fits
   const int P = L.P, n = layer_count<SHAPE>(L), D = L.w[0];

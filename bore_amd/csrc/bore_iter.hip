@@ -45,12 +45,22 @@ __device__ __forceinline__ double load_host_f64(const double *p) {
   return __longlong_as_double(v);
 }
 
-// One iteration of the loop in `slot`.  NOT inlined into the kernel's loop: inlined, the compiler
-// hoists the phases' argument loads and address arithmetic out of the loop and keeps them live
-// around it (307 SGPR + 109 VGPR spills, 420 B of scratch per lane against 24 B for this body on
-// its own); the call costs a few dozen cycles once per BO iteration.
+// One iteration of the loop in `slot`.  Round 2 made this a real (noinline) call from the resident
+// kernel's loop: inlined, the compiler hoisted the phases' argument loads and per-lane address
+// arithmetic out of the loop and kept them live around it (420 B of scratch per lane) -- but the call
+// parks the callee-saved half of the register file in the private segment (568 - 784 B per lane,
+// ~300 KB of HBM traffic per loop-iteration, profiles/r2/pmc_traffic.json).  Round 3 inlines it again
+// and takes the loop-invariants away instead: the argument block's address is opaque per iteration
+// and every phase body derives its lane numbers from an opaque copy of the work-item id
+// (BORE_OPAQUE_TID), so what the loop carries is the slot, the iteration count and a dozen lane
+// constants of the register network (100 B of scratch, spilled once per BO iteration; same speed:
+// profiles/r3/resident_inline_vs_call.txt).  -DBORE_ITER_ONCE_ATTR='__attribute__((noinline))'
+// restores the call (A/B builds).
+#ifndef BORE_ITER_ONCE_ATTR
+#define BORE_ITER_ONCE_ATTR __forceinline__
+#endif
 template <int SHAPE>
-__device__ __attribute__((noinline)) void iteration_once(const IterArgs *__restrict__ pa,
+__device__ BORE_ITER_ONCE_ATTR void iteration_once(const IterArgs *__restrict__ pa,
                                                          const long long slot, const int it,
                                                          const bool staged) {
   const IterArgs &a = *pa;
@@ -85,10 +95,9 @@ __device__ __attribute__((noinline)) void iteration_once(const IterArgs *__restr
   lbfgsb_body<SHAPE, false, true, true>(a.b, slot, 0, it);  // (publishes flag[lid] = it + 1)
 }
 
-// RESIDENT: the workgroup may go on to later iterations of its loop (a loop around a real call).
-// Otherwise ONE iteration, inlined -- the launch for loops that do not wait on their CU (more loops
-// than the device holds at once, wait_ticks = 0): no call, no callee-saved registers to park in the
-// private segment (24 B of scratch per lane against 792).
+// RESIDENT: the workgroup may go on to later iterations of its loop.  Otherwise ONE iteration -- the
+// launch for loops that do not wait on their CU (more loops than the device holds at once,
+// wait_ticks = 0): no loop, no scratch at all.
 template <int SHAPE, bool RESIDENT>
 __global__ __launch_bounds__(BORE_THREADS, 2) void iteration_kernel(const IterArgs *__restrict__ pa) {
   const long long slot = blockIdx.x;
@@ -132,6 +141,9 @@ __global__ __launch_bounds__(BORE_THREADS, 2) void iteration_kernel(const IterAr
   __shared__ __attribute__((aligned(16))) int s_go4[4];  // (16 B: the dynamic LDS keeps its alignment)
   const int target = pa->targets ? pa->targets[slot] : it_first + 1;
   for (int it = it_first;;) {
+    // (the argument block's address is made opaque per iteration, so that nothing read through it
+    // is hoisted out of the loop and kept live around it)
+    asm volatile("" : "+s"(pa));
     iteration_once<SHAPE>(pa, slot, it, it == it_first);
     __syncthreads();  // the waves leave the restart phase one by one: LDS is reused below
     ++it;

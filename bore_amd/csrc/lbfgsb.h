@@ -1601,12 +1601,24 @@ LB_HD void lbfgsb_init(State &s, const Work &w, int n, int m, const double *x0, 
 // caller's loop: ~2 k cycles per evaluation of exits through nested loops, re-dispatch on the
 // stage and copies between register assignments (profiles/r3/lbfgsb_gap_stamps.txt).  For a
 // caller whose lanes all work on ONE problem (Coop) -- divergent callers need the returning form.
+//
+// TWO-VARIABLE form of the line search (DIRECT callers may add `fg2(State &, double x0, double x1,
+// double &g0, double &g1)`): from a search's second call on, the trial point, the direction, the
+// gradient and the cache of the point evaluated last live in REGISTERS (the same values in every
+// lane) instead of the workspace -- per evaluation that is the trial point written, read back for the
+// cache check and again for the evaluation, the gradient written and read, and both copied to the
+// cache: half a dozen LDS round trips on a chain that one wave walks alone.  The first call of a
+// search (step bound, saves) keeps the workspace form; the registers go back to the workspace when
+// the search ends.  Same operations on the same values in the same order: same bits (tested against
+// the other two forms on the host, tests/test_lbfgsb_host.py, and on the device).
 struct ReverseCommunication {};
-template <bool VL = true, class FG = ReverseCommunication>
+struct NoTwoVariableForm {};
+template <bool VL = true, class FG = ReverseCommunication, class FG2 = NoTwoVariableForm>
 LB_HD int lbfgsb_advance(State &s, const Work &w, const double *l, const double *u,
                          const int *nbd, const Options &opt, const Coop coop_in = Coop{0, 1},
-                         FG fg = FG{}) {
+                         FG fg = FG{}, FG2 fg2 = FG2{}) {
   constexpr bool DIRECT = !std::is_same<FG, ReverseCommunication>::value;
+  constexpr bool TWO = DIRECT && !std::is_same<FG2, NoTwoVariableForm>::value;
   Coop coop = coop_in;
   const int n = s.n, m = s.m;
   bool first_ls = false;
@@ -1712,7 +1724,7 @@ LB_HD int lbfgsb_advance(State &s, const Work &w, const double *l, const double 
     // The lane number is made opaque once per pass: every per-lane address below derives from it, and
     // computed from a loop-invariant they are all hoisted out of this loop and kept live around it --
     // 340 spilled registers in the 128-wide restart kernels (profiles/r3/resource_usage.txt).
-    LB_OPAQUE_LANE(coop.lane);
+    if (VL) LB_OPAQUE_LANE(coop.lane);
     if (resume_ls) {
       resume_ls = false;
       first_ls = false;
@@ -1780,6 +1792,76 @@ LB_HD int lbfgsb_advance(State &s, const Work &w, const double *l, const double 
       LB_PHASE_BEGIN(27);
       ls_rc = lnsrlb<VL>(s, w, l, u, nbd, first_ls ? 1 : 0, coop);
       LB_PHASE_END(4);
+    }
+    if constexpr (TWO) {
+      if (ls_rc && n == 2) {
+        // ---- the rest of this search in registers (see the header of this function) ----
+        const double ftol_ls = 1e-3, gtol_ls = 0.9, xtol_ls = 0.1;   // (lnsrlb's constants)
+        double x0 = w.x[0], x1 = w.x[1];
+        const double d0 = w.d[0], d1 = w.d[1], t0 = w.t[0], t1 = w.t[1], z0 = w.z[0], z1 = w.z[1];
+        double g0 = w.g[0], g1 = w.g[1];
+        double xl0 = w.xlast[0], xl1 = w.xlast[1], gl0 = w.glast[0], gl1 = w.glast[1];
+        while (s.iback < opt.maxls) {
+          // SciPy's ScalarFunction cache: a request at the point evaluated last is served from it
+          const bool differs = (x0 != xl0) || (x1 != xl1);
+          if (!differs) {
+            s.f = s.flast;
+            g0 = gl0;
+            g1 = gl1;
+          } else {
+            s.stage = S_FG_LNSRCH;
+            s.task = T_FG;
+            ++s.nfev;
+            LB_MARK(s, 18);
+            fg2(s, x0, x1, g0, g1);
+            LB_MARK(s, 15);
+            xl0 = x0; xl1 = x1; gl0 = g0; gl1 = g1;
+            s.flast = s.f;
+            LB_MARK(s, 7);
+          }
+          // lnsrlb, not the first call of the search
+          s.info = 0;
+          {
+            double sum = 0.0;
+            sum += g0 * d0;
+            sum += g1 * d1;
+            s.gd = sum;
+          }
+          if (s.ifun == 0) {
+            s.gdold = s.gd;
+            if (s.gd >= 0.0) {
+              s.info = -4;
+              ls_rc = 0;
+              break;
+            }
+          }
+          dcsrch(s, s.f, s.gd, s.stp, ftol_ls, gtol_ls, xtol_ls, 0.0, s.stpmx);
+          s.xstep = s.stp * s.dnorm;
+          if (s.ls_task != LS_CONV && s.ls_task != LS_WARN) {
+            ++s.ifun;
+            ++s.nfgv;
+            s.iback = s.ifun - 1;
+            if (s.stp == 1.0) {
+              x0 = z0;
+              x1 = z1;
+            } else {
+              x0 = s.stp * d0 + t0;
+              x1 = s.stp * d1 + t1;
+            }
+            ls_rc = 1;
+          } else {
+            ls_rc = 0;
+            break;
+          }
+          LB_MARK(s, 4);
+        }
+        // (every lane holds the same values: redundant stores of identical data)
+        w.x[0] = x0; w.x[1] = x1;
+        w.g[0] = g0; w.g[1] = g1;
+        w.xlast[0] = xl0; w.xlast[1] = xl1;
+        w.glast[0] = gl0; w.glast[1] = gl1;
+        LB_LANES_SYNC();
+      }
     }
     if (ls_rc) {
       if (s.iback < opt.maxls) {

@@ -18,8 +18,11 @@
 // build of the optimiser is fed through bore_mlp_value_and_input_grad and must reproduce the
 // device run bit for bit).  Measured (profiles/r2/lbfgsb_phase_stamps.txt): cycles per evaluation
 // 17.6 k -> 9.5 k (16->64-64-64-1), 52 k -> 33 k (32->128-128-1 bf16), 5.8 k -> 6.3 k (6->32-32-1).
-// The 2->16-16-1 net keeps the matrix path: its operands live in registers across the
-// optimisation, and in the fused iteration kernel the vector form measured 4 % slower (A/B).
+// The 2->16-16-1 net keeps the matrix path: in the fused iteration kernel the vector form measured
+// 4 % slower (A/B, round 2); round 3 tried it again with every layer's operands requested before
+// the first term (one LDS round trip instead of six, 70 registers): restart phase 399.8 against
+// 398.9 us per loop-iteration, same bits -- a 16-term readlane + fmac chain per layer is as long as
+// the matrix path's four dependent matrix instructions plus transposes.  Not kept.
 #pragma once
 #include "mlp_regs.h"
 
@@ -232,5 +235,6 @@ struct PointNet {
     return Tv;
   }
 };
+
 
 }  // namespace bore

@@ -23,12 +23,15 @@ def lib():
                             SRC, "-o", SO], check=True)
         _lib = C.CDLL(SO)
         _lib.lbfgsb_host_minimize.restype = C.c_int
+        _lib.lbfgsb_host_minimize_form.restype = C.c_int
     return _lib
 
 
 def minimize(fun, x0, bounds, maxcor=10, ftol=2.2204460492503131e-09, gtol=1e-5, maxfun=15000,
-             maxiter=15000, maxls=20):
-    """fun(x) -> (f, g).  bounds: (lb, ub) arrays with +-inf for open sides."""
+             maxiter=15000, maxls=20, form=0):
+    """fun(x) -> (f, g).  bounds: (lb, ub) arrays with +-inf for open sides.
+    form: 0 reverse communication, 1 the routine calls the evaluation (DIRECT), 2 DIRECT with the
+    two-variable line search in registers (lbfgsb.h)."""
     x0 = np.ascontiguousarray(x0, dtype=np.float64)
     n = x0.size
     lb, ub = (np.broadcast_to(np.asarray(b, dtype=np.float64), n).copy() for b in bounds)
@@ -51,7 +54,7 @@ def minimize(fun, x0, bounds, maxcor=10, ftol=2.2204460492503131e-09, gtol=1e-5,
     fo = C.c_double()
     oi = np.zeros(5, dtype=np.int32)
     dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
-    lib().lbfgsb_host_minimize(n, maxcor, dp(x0), dp(l), dp(u), nbd.ctypes.data_as(C.POINTER(C.c_int)),
+    lib().lbfgsb_host_minimize_form(int(form), n, maxcor, dp(x0), dp(l), dp(u), nbd.ctypes.data_as(C.POINTER(C.c_int)),
                                C.c_double(ftol / np.finfo(float).eps), C.c_double(gtol), maxiter,
                                maxfun, maxls, _CB(cb), dp(xo), C.byref(fo), dp(go),
                                oi.ctypes.data_as(C.POINTER(C.c_int)))

@@ -144,3 +144,45 @@ def test_host_build_is_clean_under_asan_and_ubsan(tmp_path):
     run = subprocess.run([sys.executable, os.path.join(here, "native", "sanitized_run.py"), so],
                          capture_output=True, text=True, env=env, timeout=600)
     assert run.returncode == 0 and "sanitized runs ok: 256" in run.stdout, run.stderr[-2000:]
+
+
+def test_the_three_forms_of_the_routine_give_the_same_bits():
+    """lbfgsb_advance as a reverse-communication state machine (form 0), calling the evaluation
+    itself (form 1, what a wave that owns one problem runs on the device) and with the two-variable
+    line search in registers (form 2, the fused iteration kernel): same operations in the same
+    order -- x, fun, jac, nit, nfev, status, task bit for bit, on smooth problems and on the float32
+    classifier objective whose line searches collapse, hit the evaluation cache and end abnormally."""
+    def same(a, b):
+        return (np.array_equal(a.x, b.x) and a.fun == b.fun and np.array_equal(a.jac, b.jac)
+                and (a.nit, a.nfev, a.status, a.task) == (b.nit, b.nfev, b.status, b.task))
+    rs = np.random.RandomState(11)
+    n_cases = n_abnormal = 0
+    for n in (2, 5):
+        for box in range(3):
+            x0 = rs.uniform(-2, 2, size=n)
+            lb = np.full(n, -1.5) if box != 2 else np.full(n, -np.inf)
+            ub = np.full(n, 0.8 if box == 1 else 2.0) if box != 2 else np.full(n, np.inf)
+            f = lambda x: (rosen(x), rosen_der(x))
+            for kw in (OPTS, dict(maxls=2), dict(maxiter=3), dict(maxfun=7)):
+                r0 = H.minimize(f, x0, (lb, ub), form=0, **kw)
+                for form in (1, 2):
+                    assert same(r0, H.minimize(f, x0, (lb, ub), form=form, **kw)), (n, box, kw, form)
+                n_cases += 1
+    # the classifier objective in float32 (bore/mixins.py:20: transform(-f(x))), two variables
+    acts = ["relu", "relu", "sigmoid"]
+    for seed in range(12):
+        rs = np.random.RandomState(100 + seed)
+        p = O.glorot_uniform_params(2, [16, 16, 1], rs)
+        for q in p:
+            q *= 3.0          # saturating nets: flat regions, abnormal line searches
+        def f(x):
+            v, g = O.value_and_input_grad(p, acts, x, "identity")
+            return float(v), np.asarray(g, dtype=np.float64)
+        for _ in range(4):
+            x0 = rs.uniform(size=2)
+            r0 = H.minimize(f, x0, (np.zeros(2), np.ones(2)), form=0, **OPTS)
+            for form in (1, 2):
+                assert same(r0, H.minimize(f, x0, (np.zeros(2), np.ones(2)), form=form, **OPTS)), (seed, form)
+            n_cases += 1
+            n_abnormal += r0.status == 2
+    assert n_cases >= 70 and n_abnormal >= 3      # (the abnormal endings are exercised)
