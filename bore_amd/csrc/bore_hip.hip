@@ -34,6 +34,39 @@ __device__ int g_stamp_on;
 #define BORE_TSTAMP(i)
 #endif
 
+// -DBORE_FIT_MARKS: where an Adam step of the static-shape fit spends its cycles, summed over EVERY step
+// of every workgroup (tools/fit_marks.py).  Each wave keeps the time of its previous mark in a
+// register and adds the interval to a per-wave LDS row (ds_add without return); the rows go to
+// global memory once, at the end of the fit.  Buckets: 0 gather + operand requests, 1 forward,
+// 2 loss + delta, 3 backward + A / D copies, 4 wait at the mid-step barrier, 5 weight gradients +
+// Adam (whole phase), 6 wait at the step's last barrier, 7 between steps (shuffles, epoch
+// bookkeeping); inside a weight-gradient task: 8 operand requests, 9 matrix chain, 10 Adam + stores.
+#ifdef BORE_FIT_MARKS
+__device__ unsigned long long g_fit_acc[4][32];
+__shared__ unsigned g_fit_lds[4][32];
+#define FIT_MARK_DECL long long fm_last = clock64()
+#define FIT_MARK(i)                                                                                    \
+  do {                                                                                                 \
+    const long long fm_now = clock64();                                                                \
+    if ((threadIdx.x & 63) == 0) {                                                                     \
+      __hip_atomic_fetch_add(&g_fit_lds[(threadIdx.x >> 6) & 3][i], (unsigned)(fm_now - fm_last), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
+      __hip_atomic_fetch_add(&g_fit_lds[(threadIdx.x >> 6) & 3][16 + (i)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
+    }                                                                                                  \
+    fm_last = fm_now;                                                                                  \
+  } while (0)
+extern "C" int bore_debug_fit_marks(unsigned long long *out, int reset) {
+  int rc = (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fit_acc), sizeof(unsigned long long) * 128);
+  if (reset) {
+    unsigned long long z[128] = {0};
+    rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(g_fit_acc), z, sizeof(z));
+  }
+  return rc;
+}
+#else
+#define FIT_MARK_DECL
+#define FIT_MARK(i)
+#endif
+
 // -DBORE_WIDE_STAMPS: cycles per phase of the wide fits' Adam step, summed over the launch by
 // every wave's lane 0 of workgroup 0 (diagnostic builds only; tools/wide_stamps.py)
 #ifdef BORE_WIDE_STAMPS
@@ -135,6 +168,7 @@ __device__ __forceinline__ void dw_task(const MlpLayout &L, float *smem, int o_t
   const float *ap = tile + L.aoff[l - 1] + q4 * lda_p + kb * 16 + m16;
   const float *bp = tile + L.doff[l] + q4 * ldd + cb * 16 + m16;
   float av[4 * (BORE_BATCH_MAX / 16)], bv[4 * (BORE_BATCH_MAX / 16)];
+  FIT_MARK_DECL;
   BORE_TSTAMP(8);
 #pragma unroll
   for (int kc = 0; kc < kch; ++kc) {
@@ -171,6 +205,7 @@ __device__ __forceinline__ void dw_task(const MlpLayout &L, float *smem, int o_t
   // latency kch / 2 times)
   __builtin_amdgcn_sched_barrier(0);
   BORE_TSTAMP(9);
+  FIT_MARK(8);
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   float bsum = 0.f;
 #pragma unroll
@@ -181,6 +216,7 @@ __device__ __forceinline__ void dw_task(const MlpLayout &L, float *smem, int o_t
   }
   float g[5] = {acc[0], acc[1], acc[2], acc[3], 0.f};
   BORE_TSTAMP(10);
+  FIT_MARK(9);
   if (want_bias) {
     const float gb = rows_sum4(bsum);  // column sums of D_l (every lane of the column)
     if (transposed) g[0] = lane == 16 ? gb : g[0];
@@ -205,6 +241,7 @@ __device__ __forceinline__ void dw_task(const MlpLayout &L, float *smem, int o_t
     sv[li[r]] = vv[r];
   }
   BORE_TSTAMP(11);
+  FIT_MARK(10);
 }
 
 template <int SHAPE, int NBLK>
@@ -903,6 +940,12 @@ __device__ __forceinline__ void fit_body(const FitArgs &a, const long long slot,
   double b2p = pow((double)a.beta2, (double)t0);
   const float omb1 = 1.f - a.beta1, omb2 = 1.f - a.beta2;
   const int steps = (N + a.B - 1) / a.B;
+  // Shuffles off the step chain: when the LAST step of an epoch leaves the fourth wave without rows
+  // (at most 48 rows in it; static shapes whose waves own their row-blocks), that wave draws and
+  // ranks the NEXT epoch's permutation during the step (make_perm_wave) into the other of two
+  // buffers; the step's closing barrier publishes it.  Same permutations as the group form below.
+  const bool pipe_perm = SHAPE > 0 && !WIDE && !a.perm && PG >= 2 && blockDim.x == BORE_THREADS &&
+                         N - (steps - 1) * a.B <= 16 * (BORE_THREADS / 64 - 1);
   // Step size of Adam step t: lr * sqrt(1 - beta2^t) / (1 - beta1^t).  Every wave forms the
   // first one; after that the last wave computes the NEXT step's while it waits at the end of
   // the weight-gradient phase and leaves it in misc[5] (one sqrt + divide per step per
@@ -912,12 +955,24 @@ __device__ __forceinline__ void fit_body(const FitArgs &a, const long long slot,
   const float alpha_first = a.lr * sqrtf(1.f - (float)b2p) / (1.f - (float)b1p);
   bool first_step = true;
   __syncthreads();
+#ifdef BORE_FIT_MARKS
+  if (lane < 32) g_fit_lds[wv & 3][lane] = 0;
+#endif
+  FIT_MARK_DECL;
 
   for (int e = 0; e < a.epochs; ++e) {
-    if (a.perm) {
+#ifdef BORE_FIT_MARKS_CAL
+    FIT_MARK(12);
+#endif
+    if (__builtin_expect(pipe_perm && e > 0, 1)) {  // (first: the test every step of the headline run takes)
+      perm_s = perm_all + (e & 1) * N;
+    } else if (a.perm) {
       const int *pg = a.perm + (model * a.epochs + e) * (long long)N;
       for (int i = tid; i < N; i += nthr) perm_s[i] = pg[i];
       __syncthreads();
+    } else if (pipe_perm) {  // (the first one by everybody; ends with a barrier)
+      make_perm(shuffle_base(a.seed, a.model0 + model, epoch0), N, keys, perm_all);
+      perm_s = perm_all;
     } else if (PG > 1) {  // small data set: the shuffles of PG consecutive epochs at once
       const int eg = e & (PG - 1);  // PG is 2 or 4
       if (eg == 0)
@@ -928,8 +983,14 @@ __device__ __forceinline__ void fit_body(const FitArgs &a, const long long slot,
       make_perm(shuffle_base(a.seed, a.model0 + model, epoch0 + e), N, keys, perm_s);
     }
     float eloss = 0.f;  // per lane: sum over the epoch of the losses of its row slot
+#ifdef BORE_FIT_MARKS_CAL
+    FIT_MARK(13);
+#endif
 
     for (int s = 0; s < steps; ++s) {
+#ifdef BORE_FIT_MARKS_CAL
+      FIT_MARK(14);
+#endif
       const int row0 = s * a.B;
       const int nb = min(a.B, N - row0);
       const float alpha = first_step ? alpha_first : misc[5];
@@ -947,6 +1008,10 @@ __device__ __forceinline__ void fit_body(const FitArgs &a, const long long slot,
       const bool first_sub = sub == 0, last_sub = sub + 1 == nsub;
       // ---- forward / loss / backward: wave wv owns rows [16 wv, 16 wv + 16), no barriers ----
       BORE_STAMP(0);
+      FIT_MARK(7);
+#ifdef BORE_FIT_MARKS_CAL
+      FIT_MARK(11);  // (two marks back to back: bucket 11 = what a mark costs)
+#endif
       BORE_WSTAMP_DECL;
       int src = 0;  // static path: this lane's mini-batch row, requested ahead of the arithmetic below
       if constexpr (SHAPE > 0) {
@@ -993,9 +1058,11 @@ __device__ __forceinline__ void fit_body(const FitArgs &a, const long long slot,
             }
           __builtin_amdgcn_sched_barrier(0);  // every operand load is in flight before the chain
           BORE_STAMP(1);
+          FIT_MARK(0);
           BORE_WSTAMP(0);
           net.forward(th, xin, /*keep_logits=*/true);
           BORE_STAMP(2);
+          FIT_MARK(1);
           BORE_WSTAMP(1);
           if constexpr (ROUNDS) {  // (the rows stay in registers until their round: wide_rounds_f32)
           } else if constexpr (bore_shape_is_wide(SHAPE)) {
@@ -1022,6 +1089,7 @@ __device__ __forceinline__ void fit_body(const FitArgs &a, const long long slot,
           }
           net.set_output_delta(delta);
           BORE_STAMP(3);
+          FIT_MARK(2);
           BORE_WSTAMP(2);
           net.template backward<Net::n, 2>(th);
           BORE_WSTAMP(3);
@@ -1038,6 +1106,7 @@ __device__ __forceinline__ void fit_body(const FitArgs &a, const long long slot,
             net.template store_D<1, Net::n - 1>(tile, rb);
           }
           BORE_STAMP(4);
+          FIT_MARK(3);
           BORE_WSTAMP(4);
         } else {
         {  // gather the mini-batch rows of this row-block (rows past the sub-tile: zeros)
@@ -1080,6 +1149,13 @@ __device__ __forceinline__ void fit_body(const FitArgs &a, const long long slot,
           eloss += misc[0] * (float)nb;
           misc[0] = 0.f;  // consumed; re-accumulated from the updated weights below
         }
+      } else if (pipe_perm && wv == BORE_THREADS / 64 - 1 && s == steps - 1 && e + 1 < a.epochs) {
+        // (an opaque copy keeps the epoch's hash in THIS wave's branch: wave-uniform scalar code is
+        // otherwise hoisted in front of every wave's step)
+        long long next_epoch = epoch0 + e + 1;
+        asm volatile("" : "+v"(next_epoch));
+        make_perm_wave(shuffle_base(a.seed, a.model0 + model, next_epoch), N,
+                       reinterpret_cast<unsigned long long *>(keys), perm_all + ((e + 1) & 1) * N);
       }
       __syncthreads();
 #ifdef BORE_STAMPS
@@ -1087,6 +1163,7 @@ __device__ __forceinline__ void fit_body(const FitArgs &a, const long long slot,
       __syncthreads();
 #endif
       BORE_STAMP(5);
+      FIT_MARK(4);
 
       // ---- weight gradients (sums over all rows) + Adam, one 16x16 tile per wave at a time ----
       const int kch = (nr + 3) >> 2;
@@ -1244,8 +1321,10 @@ __device__ __forceinline__ void fit_body(const FitArgs &a, const long long slot,
         if (lane == 0) misc[5] = an;
       }
       BORE_STAMP(6);
+      FIT_MARK(5);
       __syncthreads();
       BORE_STAMP(7);
+      FIT_MARK(6);
     }
     if (a.epoch_loss) {
       eloss = wave_sum(eloss);
@@ -1268,6 +1347,9 @@ __device__ __forceinline__ void fit_body(const FitArgs &a, const long long slot,
     TileOrder<WIDE ? SHAPE : 1>::convert(v_g, smem, false);
   }
   if (tid == 0) a.at[model] = t0 + (long long)a.epochs * steps;
+#ifdef BORE_FIT_MARKS
+  if (lane < 32) atomicAdd(&g_fit_acc[wv & 3][lane], (unsigned long long)g_fit_lds[wv & 3][lane]);
+#endif
 }
 
 template <int SHAPE>
@@ -1340,6 +1422,10 @@ __global__ __launch_bounds__(BORE_THREADS) void fit_bf16_kernel(const FitBf16Arg
   const float alpha_first = a.lr * sqrtf(1.f - (float)b2p) / (1.f - (float)b1p);
   bool first_step = true;
   __syncthreads();
+#ifdef BORE_FIT_MARKS
+  if (lane < 32) g_fit_lds[wv & 3][lane] = 0;
+#endif
+  FIT_MARK_DECL;
 
   for (int e = 0; e < a.epochs; ++e) {
     if (a.perm) {
@@ -1488,6 +1574,10 @@ __global__ __launch_bounds__(BORE_THREADS) void fit_bf16_mfma_kernel(const FitBf
   const float alpha_first = a.lr * sqrtf(1.f - (float)b2p) / (1.f - (float)b1p);
   bool first_step = true;
   __syncthreads();
+#ifdef BORE_FIT_MARKS
+  if (lane < 32) g_fit_lds[wv & 3][lane] = 0;
+#endif
+  FIT_MARK_DECL;
 
   for (int e = 0; e < a.epochs; ++e) {
     if (a.perm) {

@@ -450,4 +450,36 @@ __device__ __forceinline__ void make_perm_group(unsigned long long seed, long lo
   __syncthreads();
 }
 
+
+// ONE epoch's permutation by ONE wave (N <= 128), no workgroup barrier: what the fit's idle wave
+// does for the NEXT epoch while the other waves run the current step's forward / backward (a
+// static-shape fit of at most 48 rows per last step leaves its fourth wave without rows; formed by
+// the whole workgroup between two steps, the shuffles were a sixth of an Adam step of the
+// 2->16-16-1 fit: profiles/r3/fit_marks.txt).  Same keys, same ranking rule as make_perm: the same
+// permutation.  k64: round_up(N, 16) words of scratch that only this wave touches.
+__device__ __forceinline__ void make_perm_wave(unsigned long long base, int N,
+                                               unsigned long long *k64, int *perm_out) {
+  const int lane = threadIdx.x & 63;
+  const int N16 = (N + 15) & ~15;
+  for (int i = lane; i < N16; i += 64)  // the padding words (all ones) are never below a key
+    k64[i] = i < N ? ((unsigned long long)shuffle_key(base, i) << 32) | (unsigned)i : ~0ULL;
+  wave_lds_sync();
+  const ulonglong2 *kk = reinterpret_cast<const ulonglong2 *>(k64);
+  for (int i = lane; i < N; i += 64) {
+    const unsigned long long ki = k64[i];
+    int r = 0;
+    for (int b = 0; b < (N16 >> 4); ++b) {
+      ulonglong2 k[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) k[j] = kk[b * 8 + j];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        r += k[j].x < ki;
+        r += k[j].y < ki;
+      }
+    }
+    perm_out[r] = i;
+  }
+}
+
 }  // namespace bore
