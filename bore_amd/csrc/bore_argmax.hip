@@ -1016,7 +1016,11 @@ static int lbfgsb_build(const bore_mlp_desc *desc, int n_models, const float *th
     // points (A_0) and gradients (D_0) of waves that run several problems: 2 x 64 rows
     const int rows = shape ? 16 : 16 * (PB < 4 ? PB : 4);
     if (bore_make_layout(desc, 2, rows, &a.L)) return fail(BORE_E_INVALID, "bad bore_mlp_desc");
-    off = a.L.P_lds;
+    // (a bfloat16 image holds 2-byte elements at the float image's indices: half its bytes.  Round 2
+    // reserved the float size, which left BASELINE config 5 -- 128-128-1 -- room for three problems per
+    // workgroup and kept it out of the eight-wave kernel; with the true size six fit.)
+    off = desc->compute == BORE_COMPUTE_BF16 ? ((size_t)a.L.P_lds + 1) / 2 : (size_t)a.L.P_lds;
+    off = (off + 3) & ~(size_t)3;
     a.o_tile = (int)off;
     // (one problem per wave -- up to 4 problems, 8 in the eight-wave kernel, 16 in batch mode -- reads
     // its point straight from the optimiser's vector: no staging region at all)
