@@ -39,8 +39,10 @@ __device__ int g_stamp_on;
 // register and adds the interval to a per-wave LDS row (ds_add without return); the rows go to
 // global memory once, at the end of the fit.  Buckets: 0 gather + operand requests, 1 forward,
 // 2 loss + delta, 3 backward + A / D copies, 4 wait at the mid-step barrier, 5 weight gradients +
-// Adam (whole phase), 6 wait at the step's last barrier, 7 between steps (shuffles, epoch
-// bookkeeping); inside a weight-gradient task: 8 operand requests, 9 matrix chain, 10 Adam + stores.
+// Adam (whole phase), 6 wait at the step's last barrier, 7 step loop top -> first instruction of the
+// step; inside a weight-gradient task: 8 operand requests, 9 matrix chain, 10 Adam + stores; 11 two
+// marks back to back (what a mark costs: ~85 cycles, included in every bucket); 12 end of a step ->
+// top of the next epoch, 13 -> shuffle chosen, 14 -> step loop top.
 #ifdef BORE_FIT_MARKS
 __device__ unsigned long long g_fit_acc[4][32];
 __shared__ unsigned g_fit_lds[4][32];
@@ -961,9 +963,7 @@ __device__ __forceinline__ void fit_body(const FitArgs &a, const long long slot,
   FIT_MARK_DECL;
 
   for (int e = 0; e < a.epochs; ++e) {
-#ifdef BORE_FIT_MARKS_CAL
     FIT_MARK(12);
-#endif
     if (__builtin_expect(pipe_perm && e > 0, 1)) {  // (first: the test every step of the headline run takes)
       perm_s = perm_all + (e & 1) * N;
     } else if (a.perm) {
@@ -983,14 +983,10 @@ __device__ __forceinline__ void fit_body(const FitArgs &a, const long long slot,
       make_perm(shuffle_base(a.seed, a.model0 + model, epoch0 + e), N, keys, perm_s);
     }
     float eloss = 0.f;  // per lane: sum over the epoch of the losses of its row slot
-#ifdef BORE_FIT_MARKS_CAL
     FIT_MARK(13);
-#endif
 
     for (int s = 0; s < steps; ++s) {
-#ifdef BORE_FIT_MARKS_CAL
       FIT_MARK(14);
-#endif
       const int row0 = s * a.B;
       const int nb = min(a.B, N - row0);
       const float alpha = first_step ? alpha_first : misc[5];
@@ -1009,9 +1005,7 @@ __device__ __forceinline__ void fit_body(const FitArgs &a, const long long slot,
       // ---- forward / loss / backward: wave wv owns rows [16 wv, 16 wv + 16), no barriers ----
       BORE_STAMP(0);
       FIT_MARK(7);
-#ifdef BORE_FIT_MARKS_CAL
-      FIT_MARK(11);  // (two marks back to back: bucket 11 = what a mark costs)
-#endif
+      FIT_MARK(11);  // (two marks back to back: what a mark costs)
       BORE_WSTAMP_DECL;
       int src = 0;  // static path: this lane's mini-batch row, requested ahead of the arithmetic below
       if constexpr (SHAPE > 0) {
