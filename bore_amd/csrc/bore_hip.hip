@@ -128,6 +128,7 @@ struct FitArgs {
   int N, epochs, B;
   float lr, beta1, beta2, eps;
   int state_in_lds, data_in_lds;
+  int perm_in_lds;  // 0: an explicit perm too long for LDS is read from memory per step (generic flavours)
   // LDS carve (float offsets)
   int o_tile, o_zt, o_misc, o_m, o_v, o_perm, o_keys, o_X, o_z, o_g, o_layout, total;
   // batch mode (bore_set_batch): slot -> loop ids[slot] at iteration its[slot]; N above is the
@@ -967,9 +968,11 @@ __device__ __forceinline__ void fit_body(const FitArgs &a, const long long slot,
     if (__builtin_expect(pipe_perm && e > 0, 1)) {  // (first: the test every step of the headline run takes)
       perm_s = perm_all + (e & 1) * N;
     } else if (a.perm) {
-      const int *pg = a.perm + (model * a.epochs + e) * (long long)N;
-      for (int i = tid; i < N; i += nthr) perm_s[i] = pg[i];
-      __syncthreads();
+      if (a.perm_in_lds) {
+        const int *pg = a.perm + (model * a.epochs + e) * (long long)N;
+        for (int i = tid; i < N; i += nthr) perm_s[i] = pg[i];
+        __syncthreads();
+      }
     } else if (pipe_perm) {  // (the first one by everybody; ends with a barrier)
       make_perm(shuffle_base(a.seed, a.model0 + model, epoch0), N, keys, perm_all);
       perm_s = perm_all;
@@ -1106,7 +1109,11 @@ __device__ __forceinline__ void fit_body(const FitArgs &a, const long long slot,
         {  // gather the mini-batch rows of this row-block (rows past the sub-tile: zeros)
           float *A0 = tile + L.aoff[0] + (rb * 16 + m16) * L.lda[0];
           const int row = rb * 16 + m16;
-          const int src = row < nr ? perm_s[r0 + row] : 0;
+          // (a data set whose shuffle does not fit in LDS: the explicit permutation is read from
+          // memory, 64 indices per step)
+          const int src = row < nr ? (a.perm_in_lds ? perm_s[r0 + row]
+                                                    : a.perm[(model * a.epochs + e) * (long long)N + r0 + row])
+                                   : 0;
           if (a.data_in_lds) {  // (two branches: a selected pointer would make these flat loads)
             for (int d = q4; d < D; d += 4) A0[d] = row < nr ? smem[a.o_X + src * D + d] : 0.f;
             if (q4 == 0) zt[row] = row < nr ? smem[a.o_z + src] : 0.f;
@@ -2069,7 +2076,7 @@ static int fit_build(const bore_mlp_desc *desc, int n_models, float *theta, floa
                      int64_t model_index0, int64_t epoch0, const bore_adam_cfg *adam,
                      float *epoch_loss, FitArgs &a, size_t &lds_floats, int &shape_out) {
   if (batch_size < 1) return fail(BORE_E_INVALID, "fit: batch_size must be positive (got %d)", batch_size);
-  if (N < 1 || N > (1 << 20)) return fail(BORE_E_INVALID, "fit: N=%lld out of range", (long long)N);
+  if (N < 1 || N > (1 << 24)) return fail(BORE_E_INVALID, "fit: N=%lld out of range", (long long)N);
   // a mini-batch of up to 64 rows is one tile (larger ones: 64-row sub-tiles, fit_body); perm
   // (+ keys) and the batch targets ride along
   const int tile_rows = batch_size < BORE_BATCH_MAX ? batch_size : BORE_BATCH_MAX;
@@ -2095,13 +2102,23 @@ static int fit_build(const bore_mlp_desc *desc, int n_models, float *theta, floa
   } else
   rc = check_common(desc, n_models, 1, tile_rows, false, fixed_extra + (size_t)N * (perm ? 1 : 3),
                     &a.L);
+  a.perm_in_lds = 1;
   if (rc == BORE_E_UNSUPPORTED && !check_common(desc, n_models, 1, tile_rows, false, fixed_extra, &a.L)) {
-    // the network fits, the epoch's shuffle (drawn and ranked in LDS) does not: say how far N goes
-    const size_t avail = BORE_LDS_BYTES / 4 - ((size_t)a.L.P_lds + a.L.tile_floats + fixed_extra);
-    return fail(BORE_E_UNSUPPORTED,
-                "fit: N=%lld rows exceed what one workgroup's LDS holds beside this network (the "
-                "epoch's shuffle lives there): at most %zu rows",
-                (long long)N, avail / (perm ? 1 : 3));
+    // the network fits, the epoch's shuffle (drawn and ranked in LDS) does not
+    if (perm && !g_batch) {
+      // an EXPLICIT permutation of any length is read from memory step by step (round 3: the
+      // reference's fit takes whatever the record holds; bore_amd.models draws such shuffles with
+      // the host statement of the stream and passes them here)
+      a.perm_in_lds = 0;
+      rc = 0;
+    } else {
+      const size_t avail = BORE_LDS_BYTES / 4 - ((size_t)a.L.P_lds + a.L.tile_floats + fixed_extra);
+      return fail(BORE_E_UNSUPPORTED,
+                  "fit: N=%lld rows exceed what one workgroup's LDS holds beside this network when the "
+                  "epoch's shuffle is drawn on the device (at most %zu rows): pass explicit shuffles "
+                  "(`perm`, e.g. from bore_amd.shuffle.permutations) -- any N then",
+                  (long long)N, avail / 3);
+    }
   }
   if (rc) return rc;
   const MlpLayout &L = a.L;
@@ -2132,7 +2149,7 @@ static int fit_build(const bore_mlp_desc *desc, int n_models, float *theta, floa
   a.o_zt = (int)off; off += BORE_BATCH_MAX;
   a.o_misc = (int)off; off += 8;
   const int PG = perm ? 1 : perm_group(N, BORE_THREADS);  // epochs shuffled together (N <= 128)
-  size_t perm_f = (size_t)PG * N, keys_f = perm ? 0 : (size_t)perm_group_scratch_floats(N, PG);
+  size_t perm_f = a.perm_in_lds ? (size_t)PG * N : 0, keys_f = perm ? 0 : (size_t)perm_group_scratch_floats(N, PG);
   if (g_batch)  // a slot's own N (<= this N) may shuffle more epochs together: room for each case
     for (long long nn : {(long long)(N < 64 ? N : 64), (long long)(N < 128 ? N : 128)}) {
       const int pg = perm_group(nn, BORE_THREADS);
@@ -2168,6 +2185,11 @@ static int fit_build(const bore_mlp_desc *desc, int n_models, float *theta, floa
   // the constexpr-layout instantiation needs the layout it was compiled for (64-row tile)
   // (and keeps the Adam slots in LDS unconditionally)
   int shape = bore_kernel_flavour(desc, batch_size == BORE_BATCH_MAX);
+  if (!a.perm_in_lds && shape > 0) {  // (only the generic flavours read the permutation from memory)
+    if (bore_shape_is_wide(shape))
+      return fail(BORE_E_UNSUPPORTED, "fit: N=%lld rows with this wide network: the shuffle must fit in LDS", (long long)N);
+    shape = -desc->n_layers;
+  }
   if (shape > 0 && !rounds && (!bore_shape_has_static_fit(shape) || (!a.state_in_lds && !bore_shape_is_wide(shape))))
     shape = -desc->n_layers;
   if (shape > 0 && bore_shape_is_wide(shape)) {

@@ -10,6 +10,7 @@ import numpy as np
 import torch
 
 from . import _lib, ops
+from . import shuffle as _shuffle
 from .layers import Adam, BinaryCrossentropy, Dense, resolve_loss, resolve_optimizer
 from .mixins import BatchMaximizableMixin, MaximizableMixin
 
@@ -178,11 +179,27 @@ class Sequential:
         o = self._optimizer
 
         def launch(e0, n_epochs):
-            loss = ops.mlp_fit(self._desc, self.theta, self.adam_m, self.adam_v, self.adam_t, X, z,
-                               n_epochs, batch_size,
-                               perm=None if perm is None else perm[:, e0:e0 + n_epochs].contiguous(),
-                               seed=self._shuffle_seed, epoch0=self._epochs_seen,
-                               lr=o.learning_rate, beta1=o.beta_1, beta2=o.beta_2, eps=o.epsilon)
+            kw = dict(seed=self._shuffle_seed, epoch0=self._epochs_seen, lr=o.learning_rate,
+                      beta1=o.beta_1, beta2=o.beta_2, eps=o.epsilon)
+            try:
+                loss = ops.mlp_fit(self._desc, self.theta, self.adam_m, self.adam_v, self.adam_t, X, z,
+                                   n_epochs, batch_size,
+                                   perm=None if perm is None else perm[:, e0:e0 + n_epochs].contiguous(), **kw)
+            except _lib.UnsupportedError as err:
+                if perm is not None or "pass explicit shuffles" not in str(err):
+                    raise
+                # A data set too long for the device to draw its shuffles in LDS (the reference's fit
+                # takes whatever the record holds, README.rst:93): the SAME stream from its host
+                # statement (bore_amd.shuffle), a few epochs per launch, read from memory by the kernel.
+                chunk = max(1, min(n_epochs, (64 << 20) // (4 * N)))
+                parts = []
+                for c0 in range(0, n_epochs, chunk):
+                    ne = min(chunk, n_epochs - c0)
+                    pc = _shuffle.permutations(self._shuffle_seed, 1, ne, N, epoch0=self._epochs_seen + c0)
+                    pc = torch.from_numpy(pc).to(self.theta.device)
+                    parts.append(ops.mlp_fit(self._desc, self.theta, self.adam_m, self.adam_v, self.adam_t,
+                                             X, z, ne, batch_size, perm=pc, **kw))
+                loss = torch.cat(parts, dim=1)
             self._epochs_seen += n_epochs
             return loss[0].cpu().numpy()
 

@@ -25,10 +25,21 @@ def shuffle_base(seed, model, epoch):
     return _mix64((h + _C_EPOCH * (epoch + 1)) & _M)
 
 
+def _mix64_array(z):
+    """_mix64 on a uint64 array (numpy's unsigned arithmetic wraps modulo 2**64)."""
+    z = z ^ (z >> np.uint64(30))
+    z = z * np.uint64(0xBF58476D1CE4E5B9)
+    z = z ^ (z >> np.uint64(27))
+    z = z * np.uint64(0x94D049BB133111EB)
+    return z ^ (z >> np.uint64(31))
+
+
 def shuffle_keys(seed, model, epoch, N):
     base = shuffle_base(seed, model, epoch)
-    return np.array([_mix64((base + _C_ROW * (i + 1)) & _M) >> 32 for i in range(N)],
-                    dtype=np.uint32)
+    i = np.arange(1, N + 1, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        z = np.uint64(base) + np.uint64(_C_ROW) * i
+        return (_mix64_array(z) >> np.uint64(32)).astype(np.uint32)
 
 
 def epoch_permutation(seed, model, epoch, N):

@@ -134,9 +134,13 @@ int bore_mlp_value_and_input_grad(const bore_mlp_desc *desc, int n_models,
  *   X        device fp32 [n_models][N][D];  z device fp32 [n_models][N] in {0,1}
  *   perm     device int32 [n_models][epochs][N] explicit shuffles, or NULL to
  *            draw them in-kernel from (seed, model_index0+model, epoch0+epoch)
- *            -- the same stream bore_shuffle_perm() writes out
+ *            -- the same stream bore_shuffle_perm() writes out.  In-kernel shuffles are
+ *            drawn and ranked in LDS: N up to what a workgroup's LDS holds beside the
+ *            network (BORE_E_UNSUPPORTED beyond, the message gives the bound); an
+ *            explicit perm may have any length N <= 2^24 (read from memory step by step
+ *            when it does not fit in LDS)
  *   epoch_loss  device fp32 [n_models][epochs] or NULL: Keras' logged loss
- *   batch_size  1..BORE_BATCH_MAX
+ *   batch_size  >= 1 (more than BORE_BATCH_MAX rows: 64-row sub-tiles of one Adam step)
  */
 int bore_mlp_fit(const bore_mlp_desc *desc, int n_models, float *theta,
                  float *adam_m, float *adam_v, int64_t *adam_t, const float *X,

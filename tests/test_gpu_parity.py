@@ -546,3 +546,48 @@ def test_fp32_fit_of_128_128_1_in_rounds_against_oracle(gpu, N, acts):
         np.testing.assert_allclose(theta.cpu().numpy()[l], pack(p64), rtol=2e-4, atol=1e-5)
         np.testing.assert_allclose(m.cpu().numpy()[l], pack(st.m), rtol=1e-3, atol=1e-7)
         np.testing.assert_allclose(v.cpu().numpy()[l], pack(st.v), rtol=1e-3, atol=1e-10)
+
+
+def test_fit_of_a_data_set_whose_shuffle_does_not_fit_in_lds(gpu):
+    """The reference's fit takes whatever the record holds (README.rst:93,
+    bore/plugins/hpbandster/base.py:184).  Beyond ~12 k rows (2 -> 16-16-1) the device cannot draw and
+    rank an epoch's shuffle in LDS: an explicit permutation of any length is then read from memory
+    step by step (bore_mlp_fit), and `Sequential.fit` draws such shuffles from the host statement of
+    the same stream.  Against the float64 oracle on 30 000 rows, and: the model-level fit of a long
+    data set equals the explicit-permutation launch bit for bit."""
+    from bore_amd import shuffle
+    from bore_amd.layers import Dense
+    from bore_amd.models import Sequential
+    rs = np.random.RandomState(77)
+    D, units, acts = 2, [16, 16, 1], ["relu", "relu", "sigmoid"]
+    N, E, B = 30000, 2, 64
+    p = rand_model(rs, D, units)
+    X = rs.uniform(size=(N, D))
+    z = (np.sum((X - 0.4) ** 2, axis=1) < 0.1)
+    perms = shuffle.permutations(9, 1, E, N)[0]
+    p64 = [a.astype(np.float64) for a in p]
+    st = O.AdamState(p64)
+    hist = O.fit(p64, acts, st, X.astype(np.float32), z, perms, batch_size=B, dtype=np.float64)
+    desc = _lib.make_desc(D, units, acts)
+    theta = dev(pack(p)).reshape(1, -1)
+    m, v = torch.zeros_like(theta), torch.zeros_like(theta)
+    t = torch.zeros(1, dtype=torch.int64, device="cuda")
+    Xd, zd = dev(X, torch.float32).reshape(1, N, D), dev(z.astype(np.float32)).reshape(1, N)
+    with pytest.raises(_lib.UnsupportedError, match="pass explicit shuffles"):
+        ops.mlp_fit(desc, theta, m, v, t, Xd, zd, E, B, seed=9)          # (device-drawn shuffle: refused, says why)
+    h = ops.mlp_fit(desc, theta, m, v, t, Xd, zd, E, B, perm=dev(perms.astype(np.int32)).reshape(1, E, N))
+    assert int(t[0]) == st.t == E * O.steps_per_epoch(N, B) == 938
+    np.testing.assert_allclose(h.cpu().numpy()[0], hist, rtol=2e-4)
+    # 938 chained fp32 Adam steps: the tolerance of the 400-step fits (DESIGN.md "Stated tolerances")
+    np.testing.assert_allclose(theta.cpu().numpy()[0], pack(p64), rtol=5e-3, atol=2e-4)
+    # the model API: same stream (seed 9), shuffles from the host statement, two launches of one epoch
+    model = Sequential(seed=0)
+    for u, a in zip(units, acts):
+        model.add(Dense(u, activation=a))
+    model.compile(optimizer="adam", loss="binary_crossentropy")
+    model.build(D)
+    model.set_weights([q.copy() for q in p])
+    model._shuffle_seed = 9
+    hm = model.fit(X, z, epochs=E, batch_size=B)
+    np.testing.assert_array_equal(np.asarray(hm.history["loss"], dtype=np.float32), h.cpu().numpy()[0])
+    np.testing.assert_array_equal(model.theta.cpu().numpy()[0], theta.cpu().numpy()[0])

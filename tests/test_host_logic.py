@@ -147,3 +147,17 @@ def test_no_cpu_fallback_without_gpu():
     m.add(Dense(1, activation="sigmoid"))
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         m.predict(np.zeros((3, 2)))
+
+
+def test_vectorised_shuffle_keys_equal_the_scalar_statement():
+    """bore_amd.shuffle draws an epoch's keys with numpy's wrapping uint64 arithmetic (the host
+    fallback of `fit` for data sets whose shuffle the device cannot draw in LDS uses it for 10^5+
+    rows): the same numbers as the scalar Python statement of mlp_device.h's mix64 chain."""
+    from bore_amd import shuffle as S
+    for seed, model, epoch, N in [(0, 0, 0, 17), (5, 100, 7, 1000), (2 ** 63 + 11, 3, 999, 5000)]:
+        base = S.shuffle_base(seed, model, epoch)
+        ref = np.array([S._mix64((base + S._C_ROW * (i + 1)) & S._M) >> 32 for i in range(N)], dtype=np.uint32)
+        assert np.array_equal(S.shuffle_keys(seed, model, epoch, N), ref)
+        perm = S.epoch_permutation(seed, model, epoch, N)
+        assert np.array_equal(np.sort(perm), np.arange(N))
+        assert np.all(np.diff(ref[perm].astype(np.int64)) >= 0)          # ascending keys, ties by row index
