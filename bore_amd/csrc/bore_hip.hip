@@ -42,7 +42,8 @@ __device__ int g_stamp_on;
 // Adam (whole phase), 6 wait at the step's last barrier, 7 step loop top -> first instruction of the
 // step; inside a weight-gradient task: 8 operand requests, 9 matrix chain, 10 Adam + stores; 11 two
 // marks back to back (what a mark costs: ~85 cycles, included in every bucket); 12 end of a step ->
-// top of the next epoch, 13 -> shuffle chosen, 14 -> step loop top.
+// top of the next epoch, 13 -> shuffle chosen, 14 -> step loop top; 15 mid-step barrier -> the wave's
+// weight-gradient task done (5 then holds what follows it: the next step size, the l2 sums).
 #ifdef BORE_FIT_MARKS
 __device__ unsigned long long g_fit_acc[4][32];
 __shared__ unsigned g_fit_lds[4][32];
@@ -256,7 +257,10 @@ __device__ __forceinline__ void dw_adam_static(const FitArgs &a, float *smem, fl
 #pragma unroll
   for (int l = 1; l <= L.n_layers; ++l) n_tiles += (L.Np[l - 1] >> 4) * (L.Np[l] >> 4);
   const bool split = n_tiles < BORE_THREADS / 64;
-  const int wv = threadIdx.x >> 6;
+  // (the wave number as a SCALAR: the task tests below are then scalar compares and branches, not
+  // vector compares that narrow the execution mask -- the way from the mid-step barrier to the
+  // wave's task was ~380 cycles of an Adam step, profiles/r3/fit_marks_dispatch.txt)
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   int t = 0;
 #pragma unroll
   for (int l = 1; l <= L.n_layers; ++l) {
@@ -1185,6 +1189,7 @@ __device__ __forceinline__ void fit_body(const FitArgs &a, const long long slot,
           case 3: dw_adam_static<SHAPE, 3>(a, smem, alpha, omb1, omb2); break;
           default: dw_adam_static<SHAPE, 4>(a, smem, alpha, omb1, omb2); break;
         }
+        FIT_MARK(15);  // (bucket 15: the mid-step barrier -> the wave's task done)
       } else
 #pragma unroll
       for (int l = 1; l <= n; ++l) {

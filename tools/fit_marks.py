@@ -26,7 +26,7 @@ st = eng.take_stats()
 lib.bore_debug_fit_marks(buf, 0)
 a = np.array(buf, dtype=np.float64).reshape(4, 32)
 names = ["gather+requests", "forward", "loss+delta", "backward+copies", "wait mid barrier", "dW+Adam phase", "wait end barrier",
-         "step loop top -> step", "  task: requests", "  task: matrix chain", "  task: Adam+stores", "(a mark itself)", "(end barrier -> epoch top)", "(epoch top -> shuffle chosen)", "(-> step loop top)"]
+         "step loop top -> step", "  task: requests", "  task: matrix chain", "  task: Adam+stores", "(a mark itself)", "(end barrier -> epoch top)", "(epoch top -> shuffle chosen)", "(-> step loop top)", "(mid barrier -> own task done)"]
 n_steps = a[:, 16 + 5].max()          # every wave passes mark 5 once per Adam step
 print(f"{L} loops x {steps} steps (marks build): {L * steps / dt:.0f} it/s; fit {1e-3 * st['phase_ns_fit'] / max(st['phase_iterations'], 1):.1f} us per loop-iteration; "
       f"{n_steps:.0f} Adam steps marked, N {eng.N - steps}..{eng.N - 1}")
