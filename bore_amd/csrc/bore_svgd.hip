@@ -213,6 +213,172 @@ __global__ __launch_bounds__(BORE_THREADS) void svgd_kernel(const SvgdArgs a) {
   for (int e = tid; e < nD; e += BORE_THREADS) a.x_out[model * nD + e] = x[e];
 }
 
+
+// More than 64 particles (up to 256: one thread per particle in the interaction): the n x n kernel
+// matrix does not fit in LDS beside the rest (n = 128: 128 KB), so it is never stored -- thread i
+// walks j = 0 .. n-1, forms |x_i - x_j|^2 and exp(-gamma .) on the fly and adds particle j's drive
+// and repulsion terms to its D accumulators (8 coordinates per pass over j); the median of the n^2
+// distances is the same radix select, each of its passes recomputing the distances; the network
+// sees the particles in chunks of 64 rows.  Same sums in the same (index) order as svgd_kernel.
+__global__ __launch_bounds__(BORE_THREADS) void svgd_big_kernel(const SvgdArgs a) {
+  extern __shared__ float smem[];
+  constexpr MlpLayout Lc = bore_static_layout(0, 2, BORE_BATCH_MAX);
+  const MlpLayout &L = begin_kernel<0>(Lc, a.L, smem, a.total, a.o_layout);
+  const int tid = threadIdx.x, wv = tid >> 6;
+  const long long model = blockIdx.x;
+  const int n_lay = L.n_layers, D = L.w[0], n = a.n, nD = n * D;
+  const long long nn = (long long)n * n;
+  float *th = smem, *tile = smem + a.o_tile, *vals = smem + a.o_vals;
+  double *x = reinterpret_cast<double *>(smem + a.o_x);
+  double *fg = reinterpret_cast<double *>(smem + a.o_fg);
+  double *grad = reinterpret_cast<double *>(smem + a.o_grad);
+  double *hist = reinterpret_cast<double *>(smem + a.o_hist);
+  unsigned *hist_s = reinterpret_cast<unsigned *>(smem + a.o_sort);  // [256] bins + [8] scratch
+  int *scan_s = reinterpret_cast<int *>(hist_s + 256);               // [0..3] wave totals, [4] bin, [5] below
+  double *f = reinterpret_cast<double *>(smem + a.o_f), *zeta = f + n;
+  stage_theta<false>(L, n_lay, a.theta + model * L.P, smem);
+  for (int e = tid; e < nD; e += BORE_THREADS) x[e] = a.x_init[model * nD + e];
+  __syncthreads();
+  auto sqdist = [&](int i, int j) {
+    double s = 0.0;
+    for (int d = 0; d < D; ++d) {
+      const double t = x[i * D + d] - x[j * D + d];
+      s += t * t;
+    }
+    return s;
+  };
+
+  for (int it = 0; it < a.n_iter; ++it) {
+    double h = a.length_scale;
+    if (a.length_scale < 0.0) {
+      // np.median over all n^2 squared distances: order statistics k1 = (nn - 1) / 2 and k2 = nn / 2
+      // by a radix select on the bit patterns (svgd_kernel), 8 bits per pass from the top
+      const long long k1 = (nn - 1) >> 1, k2 = nn >> 1;
+      unsigned long long prefix = 0;
+      long long rank = k1;
+      for (int shift = 56; shift >= 0; shift -= 8) {
+        hist_s[tid] = 0u;
+        __syncthreads();
+        const unsigned long long hi_mask = shift == 56 ? 0ULL : ~0ULL << (shift + 8);
+        for (long long e = tid; e < nn; e += BORE_THREADS) {
+          const int i = (int)(e / n), j = (int)(e - (long long)i * n);
+          const unsigned long long v = (unsigned long long)__double_as_longlong(sqdist(i, j));
+          if ((v & hi_mask) == prefix) atomicAdd(&hist_s[(unsigned)(v >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        const int cnt = (int)hist_s[tid];
+        int incl = cnt;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+          const int up = __shfl_up(incl, off, 64);
+          if ((tid & 63) >= off) incl += up;
+        }
+        if ((tid & 63) == 63) scan_s[tid >> 6] = incl;
+        __syncthreads();
+        int base = 0;
+        for (int w = 0; w < (tid >> 6); ++w) base += scan_s[w];
+        incl += base;
+        if (incl - cnt <= rank && rank < incl) {  // exactly one bin holds the rank
+          scan_s[4] = tid;
+          scan_s[5] = incl - cnt;
+        }
+        __syncthreads();
+        rank -= scan_s[5];
+        prefix |= (unsigned long long)scan_s[4] << shift;
+        __syncthreads();
+      }
+      const double v1 = __longlong_as_double((long long)prefix);
+      double med = v1;
+      if (k2 != k1) {  // even count: the next entry in order = v1 again if it repeats, else min above
+        unsigned *cnt_le = hist_s;
+        unsigned long long *min_gt = reinterpret_cast<unsigned long long *>(hist_s + 2);
+        if (tid == 0) {
+          *cnt_le = 0u;
+          *min_gt = ~0ULL;
+        }
+        __syncthreads();
+        unsigned c = 0;
+        unsigned long long mg = ~0ULL;
+        for (long long e = tid; e < nn; e += BORE_THREADS) {
+          const int i = (int)(e / n), j = (int)(e - (long long)i * n);
+          const unsigned long long v = (unsigned long long)__double_as_longlong(sqdist(i, j));
+          if (v <= prefix) ++c;
+          else if (v < mg) mg = v;
+        }
+        atomicAdd(cnt_le, c);
+        atomicMin(min_gt, mg);
+        __syncthreads();
+        const double v2 = (long long)*cnt_le > k2 ? v1 : __longlong_as_double((long long)*min_gt);
+        med = (v1 + v2) / 2.0;
+        __syncthreads();
+      }
+      h = sqrt(.5 * med / log((double)(n + 1)));
+    }
+    h = fmax(h, 1e-6);
+    const double gamma = .5 / (h * h);
+    // value and input gradient of every particle, 64 rows of the tile at a time
+    for (int c0 = 0; c0 < n; c0 += BORE_BATCH_MAX) {
+      const int nc = min(BORE_BATCH_MAX, n - c0);
+      for (int e = tid; e < BORE_BATCH_MAX * D; e += BORE_THREADS) {
+        const int i = e / D, d = e - i * D;
+        tile[L.aoff[0] + i * L.lda[0] + d] = i < nc ? (float)x[(c0 + i) * D + d] : 0.f;  // Keras autocast
+      }
+      __syncthreads();
+      if (wv * 16 < nc) fg_rowblock(L, n_lay, th, tile, wv, a.transform, 1.f, vals);
+      __syncthreads();
+      for (int e = tid; e < nc * D; e += BORE_THREADS) {
+        const int i = e / D, d = e - i * D;
+        fg[(c0 + i) * D + d] = (double)tile[L.doff[0] + i * L.lda[0] + d];
+      }
+      for (int i = tid; i < nc; i += BORE_THREADS) f[c0 + i] = (double)vals[i];
+      __syncthreads();
+    }
+    for (int i = tid; i < n; i += BORE_THREADS) {  // zeta = distortion(rank(f))
+      double z = a.dparam;
+      if (a.distortion == 1) {
+        int c = 0;
+        for (int j = 0; j < n; ++j) c += f[j] <= f[i];
+        z = pow((double)c / (double)n, -a.dparam);
+      }
+      zeta[i] = z;
+    }
+    __syncthreads();
+    if (tid < n) {  // particle i = tid: drive and repulsion, 8 coordinates per pass over the others
+      const int i = tid;
+      for (int d0 = 0; d0 < D; d0 += 8) {
+        double drive[8], rep[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) drive[q] = rep[q] = 0.0;
+        for (int j = 0; j < n; ++j) {
+          const double kij = exp(-gamma * sqdist(i, j));
+          const double zj = zeta[j];
+#pragma unroll
+          for (int q = 0; q < 8; ++q)
+            if (d0 + q < D) {
+              drive[q] += kij * (zj * fg[j * D + d0 + q]);
+              rep[q] += gamma * (x[i * D + d0 + q] - x[j * D + d0 + q]) * kij;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+          if (d0 + q < D) grad[i * D + d0 + q] = (drive[q] + a.tau * (2.0 * rep[q])) / (double)n;
+      }
+    }
+    __syncthreads();
+    for (int e = tid; e < nD; e += BORE_THREADS) {
+      const int d = e % D;
+      const double g = grad[e];
+      const double hs = it == 0 ? g * g : a.alpha * hist[e] + (1.0 - a.alpha) * (g * g);
+      hist[e] = hs;
+      double xn = x[e] + a.step * (g / (a.eps + sqrt(hs)));
+      if (a.clip) xn = fmin(fmax(xn, a.lo[d]), a.hi[d]);
+      x[e] = xn;
+    }
+    __syncthreads();
+  }
+  for (int e = tid; e < nD; e += BORE_THREADS) a.x_out[model * nD + e] = x[e];
+}
+
 extern "C" int bore_svgd_optimize(const bore_mlp_desc *desc, int n_models, const float *theta,
                                   int transform, const double *x_init, int n_particles,
                                   const double *lb, const double *ub, const bore_svgd_opts *opts,
@@ -223,15 +389,16 @@ extern "C" int bore_svgd_optimize(const bore_mlp_desc *desc, int n_models, const
     return fail(BORE_E_UNSUPPORTED, "svgd_optimize: float32 networks only");
   const int D = desc->input_dim, n = n_particles;
   if (D < 1 || D > BORE_DIM_MAX) return fail(BORE_E_UNSUPPORTED, "svgd_optimize: input_dim must be 1..%d", BORE_DIM_MAX);
-  if (n < 1 || n > BORE_BATCH_MAX)
-    return fail(BORE_E_UNSUPPORTED, "svgd_optimize: 1..%d particles per launch", BORE_BATCH_MAX);
+  if (n < 1 || n > BORE_THREADS)
+    return fail(BORE_E_UNSUPPORTED, "svgd_optimize: 1..%d particles per launch", BORE_THREADS);
+  const bool big = n > BORE_BATCH_MAX;  // (no kernel matrix in LDS: svgd_big_kernel)
   if (transform < BORE_T_IDENTITY || transform > BORE_T_EXP)
     return fail(BORE_E_INVALID, "svgd_optimize: unknown transform %d", transform);
   if (opts->n_iter < 0 || (opts->distortion != 0 && opts->distortion != 1))
     return fail(BORE_E_INVALID, "svgd_optimize: bad options");
   if ((lb == nullptr) != (ub == nullptr)) return fail(BORE_E_INVALID, "svgd_optimize: lb and ub go together");
   SvgdArgs a;
-  if (bore_make_layout(desc, 2, 16 * ((n + 15) / 16), &a.L)) return fail(BORE_E_INVALID, "bad bore_mlp_desc");
+  if (bore_make_layout(desc, 2, big ? BORE_BATCH_MAX : 16 * ((n + 15) / 16), &a.L)) return fail(BORE_E_INVALID, "bad bore_mlp_desc");
   if (a.L.w[a.L.n_layers] != 1) return fail(BORE_E_INVALID, "svgd_optimize: the last Dense layer must have 1 unit");
   a.clip = lb != nullptr;
   for (int d = 0; d < D; ++d) {
@@ -254,9 +421,9 @@ extern "C" int bore_svgd_optimize(const bore_mlp_desc *desc, int n_models, const
   a.o_fg = (int)off; off += nD2;
   a.o_grad = (int)off; off += nD2;
   a.o_hist = (int)off; off += nD2;
-  a.o_K = (int)off; off += 2 * (size_t)n * n + 2;
+  a.o_K = (int)off; off += big ? 0 : 2 * (size_t)n * n + 2;
   off = (off + 3) & ~(size_t)3;
-  a.o_sort = (int)off; off += opts->length_scale < 0.0 ? 2 * (size_t)ns + 256 + 8 : 0;
+  a.o_sort = (int)off; off += big ? 256 + 8 : (opts->length_scale < 0.0 ? 2 * (size_t)ns + 256 + 8 : 0);
   a.o_f = (int)off; off += 4 * (size_t)n + 4;
   a.total = (int)off;
   off = (off + 3) & ~(size_t)3;
@@ -264,9 +431,12 @@ extern "C" int bore_svgd_optimize(const bore_mlp_desc *desc, int n_models, const
   if (off * 4 > BORE_LDS_BYTES)
     return fail(BORE_E_UNSUPPORTED, "svgd_optimize: %d particles in %d dimensions need %zu B of LDS (> %d)",
                 n, D, off * 4, BORE_LDS_BYTES);
-  int rc = allow_lds(svgd_kernel, off * 4);
+  int rc = big ? allow_lds(svgd_big_kernel, off * 4) : allow_lds(svgd_kernel, off * 4);
   if (rc) return rc;
-  hipLaunchKernelGGL(svgd_kernel, dim3(n_models), dim3(BORE_THREADS), off * 4, (hipStream_t)stream, a);
+  if (big)
+    hipLaunchKernelGGL(svgd_big_kernel, dim3(n_models), dim3(BORE_THREADS), off * 4, (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL(svgd_kernel, dim3(n_models), dim3(BORE_THREADS), off * 4, (hipStream_t)stream, a);
   HIP_TRY(hipGetLastError());
   return 0;
 }

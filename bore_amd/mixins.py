@@ -164,7 +164,8 @@ class BatchMaximizableMixin(MaximizableMixin):
 
     ``svgd_mode`` chooses where the particle interaction runs:
       "device"  (default) all iterations in ONE launch (``bore_svgd_optimize``: particles, kernel
-                matrix and history in LDS); float32 networks, <= 64 particles -- anything else
+                matrix and history in LDS; beyond 64 particles, up to 256, the matrix entries are formed on
+                the fly); float32 networks -- anything else
                 falls back to "host" with a warning;
       "host"    the checker of the device kernel: ``_func_max`` -- value + input gradient of
                 ``transform(f(x))`` for all particles -- is one HIP launch per SVGD iteration;

@@ -134,7 +134,39 @@ def test_device_svgd_tracks_the_host_statement(gpu, n, D, units, ls, lambd, tr):
     with pytest.raises(RuntimeError, match="LDS"):
         ops.svgd_optimize(big, thb, dev(rs.uniform(size=(1, 64, 16))), n_iter=1)
     with pytest.raises(RuntimeError, match="particles"):
-        ops.svgd_optimize(desc, th, dev(rs.uniform(size=(L, 65, D))), n_iter=1)
+        ops.svgd_optimize(desc, th, dev(rs.uniform(size=(L, 257, D))), n_iter=1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,D,ls,lambd", [(65, 2, None, None), (100, 6, None, 0.5), (130, 3, 0.2, None),
+                                          (256, 2, None, None), (96, 11, None, None)])
+def test_device_svgd_with_more_than_64_particles(gpu, n, D, ls, lambd):
+    """Beyond 64 particles the n x n kernel matrix does not fit in LDS: svgd_big_kernel forms its
+    entries on the fly (one thread per particle, up to 256), the median heuristic's radix select
+    recomputes the distances per pass, the network sees the particles 64 rows at a time.  Same
+    sums in the same order as the small kernel: against the host statement (bit-equal to the
+    reference's SVGD) driven by the same device f/g operator, to rounding."""
+    import torch
+    from bore_amd import _lib, ops
+    from test_gpu_parity import dev, pack, rand_model
+    rs = np.random.RandomState(n * 7 + D)
+    units = [16, 16, 1]
+    acts = ["tanh", "relu", "linear"]
+    desc = _lib.make_desc(D, units, acts)
+    th = dev(pack(rand_model(rs, D, units))[None])
+    x0 = rs.uniform(size=(1, n, D))
+    kw = dict(n_iter=60, step_size=1e-2, alpha=.9, eps=1e-6, tau=1.)
+    out = ops.svgd_optimize(desc, th, dev(x0), np.zeros(D), np.ones(D), "sigmoid", length_scale=ls,
+                            lambd=lambd, **kw).cpu().numpy()
+    assert ((out >= 0) & (out <= 1)).all() and (np.abs(out - x0) > 1e-4).any()
+
+    def func(X):
+        v, g = ops.mlp_value_and_input_grad(desc, th, dev(X[None]), "sigmoid", False)
+        return v.cpu().numpy()[0].astype(np.float64), g.cpu().numpy()[0]
+    dist = DistortionConstant() if lambd is None else DistortionExpDecay(lambd=lambd)
+    ref = SVGD(kernel=RadialBasis(length_scale=ls), distortion=dist, **kw).optimize_from_init(
+        func, x0[0], bounds=[(0.0, 1.0)] * D)
+    np.testing.assert_allclose(out[0], ref, rtol=0, atol=1e-9 if lambd is None else 1e-6)
 
 
 @pytest.mark.gpu
