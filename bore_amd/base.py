@@ -15,7 +15,7 @@ import torch
 from scipy.stats import truncnorm
 
 from . import ops
-from .transforms import resolve
+from .transforms import CallableTransform, resolve
 
 
 def convert(model, transform=None):
@@ -33,9 +33,16 @@ def convert(model, transform=None):
         X = np.ascontiguousarray(np.atleast_2d(x))
         model._ensure_built(X)
         Xd = torch.from_numpy(X).to(model.theta.device).reshape(1, X.shape[0], X.shape[1])
-        val, grad = ops.mlp_value_and_input_grad(model._desc, model.theta, Xd, tr.name, tr.negate)
-        val = val[0].cpu().numpy()
-        grad = grad[0].cpu().numpy()
+        if isinstance(tr, CallableTransform):
+            # f and d f / d x from the kernel; the callable and its derivative on the host (float32
+            # value, float64 gradient, like numpy_io / value_and_gradient: bore/decorators.py:51-77)
+            f, gf = ops.mlp_value_and_input_grad(model._desc, model.theta, Xd, "identity", False)
+            val, dT = tr.value_and_derivative(f[0].cpu().numpy())
+            grad = dT[:, None] * gf[0].cpu().numpy()
+        else:
+            val, grad = ops.mlp_value_and_input_grad(model._desc, model.theta, Xd, tr.name, tr.negate)
+            val = val[0].cpu().numpy()
+            grad = grad[0].cpu().numpy()
         if single:
             return [val[0], grad[0]]
         return [val, grad]

@@ -93,6 +93,7 @@ class NativeEngine:
         self.desc = _lib.make_desc(D, self.units, self.acts)
         self.P = ops.param_count(self.desc)
         tr = resolve(transform).negated()
+        assert tr.name is not None, "the replica engine runs on the device only: a named transform ('identity', 'sigmoid', 'exp')"
         assert tr.negate, "the engine minimises transform(-f(x)) (bore/mixins.py:20)"
         self.objective = objective
         self.low, self.high = np.zeros(D), np.ones(D)
@@ -224,6 +225,7 @@ class ReplicaEngine:
         self.desc = _lib.make_desc(D, self.units, self.acts)
         self.P = ops.param_count(self.desc)
         self.transform = resolve(transform)
+        assert self.transform.name is not None, "the replica engine runs on the device only: a named transform"
         self.gamma, self.epochs, self.batch_size = gamma, int(epochs), int(batch_size)
         self.num_starts, self.num_samples = int(num_starts), int(num_samples)
         self.objective = objective

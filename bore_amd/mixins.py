@@ -108,6 +108,8 @@ class MaximizableMixin:
         if method == "L-BFGS-B" and self.restart_mode == "device":
             from ._lib import UnsupportedError
             try:
+                if self._func_min.transform.name is None:
+                    raise UnsupportedError("a callable transform runs on the host")
                 return self._minimize_on_device(X0, bounds, dict(options or {}))
             except UnsupportedError as e:
                 import warnings
@@ -196,6 +198,8 @@ class BatchMaximizableMixin(MaximizableMixin):
             x_init = random_state.uniform(low=low, high=high, size=(batch_size, dims))
             self._ensure_built(x_init)
             try:
+                if self.transform.name is None:
+                    raise UnsupportedError("a callable transform runs on the host")
                 out = ops.svgd_optimize(
                     self._desc, self.theta,
                     torch.from_numpy(np.ascontiguousarray(x_init[None])).to(self.theta.device), low,

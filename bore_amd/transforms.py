@@ -3,8 +3,16 @@
 The reference passes TensorFlow callables (``tf.identity``, ``tf.sigmoid``, ``tf.exp``:
 TRANSFORMS, bore/plugins/hpbandster/base.py:18) and composes the minimisation form
 as ``lambda u: transform(-u)`` (bore/mixins.py:20).  A Python callable cannot run
-inside a HIP kernel, so transforms are named records; ``negated()`` is the
-composition with ``-u``.
+inside a HIP kernel, so the three transforms the reference names are records the kernels
+know (``Transform``); ``negated()`` is the composition with ``-u``.
+
+ANY other elementwise callable (the reference takes any TF callable, bore/mixins.py:16) is a
+``CallableTransform``: it must take and return a torch tensor and be differentiable by
+torch.autograd (``lambda u: torch.nn.functional.softplus(u)``).  The network's value and input
+gradient still come from the HIP kernel; the callable and its derivative are applied to them
+on the host (float32, like the reference's TF graph), which the host-driven restart modes
+("lockstep", "sequential") and the host SVGD use -- the one-launch device modes need a named
+transform and fall back with a warning.
 """
 from __future__ import annotations
 
@@ -37,6 +45,39 @@ class Transform:
         return f"Transform({self.name!r}, negate={self.negate})"
 
 
+class CallableTransform:
+    """``transform`` given as a torch-differentiable elementwise callable (see the module docstring)."""
+    __slots__ = ("fn", "negate")
+    name = None          # (no kernel-side name: the device-only modes check for this)
+
+    def __init__(self, fn, negate=False):
+        if not callable(fn):
+            raise TypeError(f"transform {fn!r} is not callable")
+        self.fn = fn
+        self.negate = bool(negate)
+
+    def negated(self):
+        return CallableTransform(self.fn, not self.negate)
+
+    def value_and_derivative(self, f):
+        """(T(s f), d T(s f) / d f) for the float32 network outputs ``f``, s = -1 when negated."""
+        import torch
+        sign = -1.0 if self.negate else 1.0
+        u = torch.tensor(sign * np.asarray(f, dtype=np.float32), dtype=torch.float32, requires_grad=True)
+        t = self.fn(u)
+        if not isinstance(t, torch.Tensor) or t.shape != u.shape:
+            raise TypeError("a callable transform must map a torch tensor to a torch tensor of the same "
+                            "shape (elementwise); named transforms: 'identity', 'sigmoid', 'exp'")
+        (dT,) = torch.autograd.grad(t.sum(), u)
+        return t.detach().numpy().astype(np.float32), sign * dT.numpy().astype(np.float64)
+
+    def __call__(self, u):
+        return self.value_and_derivative(np.asarray(u))[0]
+
+    def __repr__(self):
+        return f"CallableTransform({self.fn!r}, negate={self.negate})"
+
+
 identity = Transform("identity")
 sigmoid = Transform("sigmoid")
 exp = Transform("exp")
@@ -47,7 +88,7 @@ TRANSFORMS = dict(identity=identity, sigmoid=sigmoid, exp=exp)
 def resolve(t):
     if t is None:
         return identity
-    if isinstance(t, Transform):
+    if isinstance(t, (Transform, CallableTransform)):
         return t
     if isinstance(t, str):
         if t not in TRANSFORMS:
@@ -56,5 +97,7 @@ def resolve(t):
     name = getattr(t, "__name__", None)
     if name in TRANSFORMS:          # e.g. np.exp, a function called sigmoid/identity
         return TRANSFORMS[name]
-    raise TypeError(f"transform {t!r}: pass 'identity', 'sigmoid', 'exp' or a bore_amd.transforms "
-                    "object; arbitrary callables cannot run inside the HIP kernel")
+    if callable(t):                 # any other elementwise, torch-differentiable callable
+        return CallableTransform(t)
+    raise TypeError(f"transform {t!r}: pass 'identity', 'sigmoid', 'exp', a bore_amd.transforms "
+                    "object or a torch-differentiable elementwise callable")

@@ -244,3 +244,55 @@ def test_fit_callbacks_and_large_batches(gpu):
     hc = c.fit(X, z, epochs=6, batch_size=100, callbacks=[stop])
     assert len(hc.history["loss"]) == 3
     np.testing.assert_allclose(hc.history["loss"], ha.history["loss"][:3], rtol=1e-6)
+
+
+def test_callable_transform_drives_the_host_restart_modes(gpu):
+    """`transform` as a callable (bore/mixins.py:16 takes any TF callable; here any
+    torch-differentiable elementwise one): f and df/dx come from the HIP kernel, the callable and
+    its derivative are applied on the host.  A callable that spells a named transform gives the
+    named transform's objective; a custom one (softplus) passes a finite-difference check against
+    the float64 oracle forward; argmax runs SciPy around the kernel (the device-only mode falls
+    back with a warning) and returns a maximiser of the transformed classifier output."""
+    import torch
+    import warnings
+    rs = np.random.RandomState(4)
+    D = 3
+    weights = None
+    vals = {}
+    for name, tr in [("named", "sigmoid"), ("callable", lambda u: torch.sigmoid(u)),
+                     ("softplus", lambda u: torch.nn.functional.softplus(u))]:
+        model = MaximizableSequential(tr, seed=1)
+        model.add(Dense(8, activation="tanh", input_dim=D))
+        model.add(Dense(1))
+        model.build()
+        if weights is None:
+            weights = model.get_weights()
+        model.set_weights(weights)
+        Xb = np.random.RandomState(1).uniform(size=(7, D))
+        v, g = model._func_min(Xb)
+        assert v.dtype == np.float32 and v.shape == (7,) and g.dtype == np.float64 and g.shape == (7, D)
+        vals[name] = (v, g, model)
+    np.testing.assert_allclose(vals["callable"][0], vals["named"][0], rtol=1e-6)
+    np.testing.assert_allclose(vals["callable"][1], vals["named"][1], rtol=1e-5, atol=1e-8)
+    # softplus(-f): against the float64 oracle forward and central differences
+    acts = ["tanh", "linear"]
+    Xb = np.random.RandomState(1).uniform(size=(7, D))
+    f64 = lambda X: np.log1p(np.exp(-O.predict(weights, acts, X, dtype=np.float64)[:, 0]))
+    v, g, model = vals["softplus"]
+    np.testing.assert_allclose(v, f64(Xb), rtol=2e-5)
+    for d in range(D):
+        e = np.zeros(D); e[d] = 1e-5
+        np.testing.assert_allclose(g[:, d], (f64(Xb + e) - f64(Xb - e)) / 2e-5, rtol=2e-3, atol=1e-6)
+    b = Bounds(np.zeros(D), np.ones(D))
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        res = model.argmax(b, num_starts=4, num_samples=128, print_fn=lambda s: None,
+                           random_state=np.random.RandomState(2))
+    assert any("callable transform" in str(x.message) for x in w)        # device mode said why it stepped aside
+    assert res is not None and np.all(res.x >= 0) and np.all(res.x <= 1)
+    grid = np.random.RandomState(3).uniform(size=(2048, D))
+    assert res.fun <= f64(grid).min() + 1e-4                              # a minimiser of softplus(-f) over the box
+    model.restart_mode = "lockstep"
+    res2 = model.argmax(b, num_starts=4, num_samples=128, print_fn=lambda s: None,
+                        random_state=np.random.RandomState(2))
+    assert np.array_equal(res.x, res2.x) and res.fun == res2.fun

@@ -53,8 +53,10 @@ def test_transforms_registry():
     np.testing.assert_allclose(transforms.exp.negated()(1.0), np.exp(-1.0))
     with pytest.raises(ValueError):
         transforms.resolve("softplus")
+    doubled = transforms.resolve(lambda u: u * 2)          # any other callable: applied on the host (round 3)
+    assert isinstance(doubled, transforms.CallableTransform) and doubled.name is None
     with pytest.raises(TypeError):
-        transforms.resolve(lambda u: u * 2)
+        transforms.resolve(3)
 
 
 def test_dense_descriptor_and_compile_arguments():
@@ -161,3 +163,29 @@ def test_vectorised_shuffle_keys_equal_the_scalar_statement():
         perm = S.epoch_permutation(seed, model, epoch, N)
         assert np.array_equal(np.sort(perm), np.arange(N))
         assert np.all(np.diff(ref[perm].astype(np.int64)) >= 0)          # ascending keys, ties by row index
+
+
+def test_callable_transforms_are_applied_on_the_host():
+    """The reference takes any TF callable as `transform` (bore/mixins.py:16); here any
+    torch-differentiable elementwise callable: value and derivative by torch.autograd in float32,
+    composed with -u as bore/mixins.py:20 does."""
+    import torch
+    from bore_amd.transforms import CallableTransform, Transform, resolve
+    assert resolve(np.exp).name == "exp" and resolve("sigmoid").name == "sigmoid"     # names still resolve to kernels
+    sp = resolve(lambda u: torch.nn.functional.softplus(u))
+    assert isinstance(sp, CallableTransform) and sp.name is None and not sp.negate and sp.negated().negate
+    f = np.array([0.1, 0.5, 0.93], dtype=np.float32)
+    val, d = sp.negated().value_and_derivative(f)
+    assert val.dtype == np.float32 and d.dtype == np.float64
+    np.testing.assert_allclose(val, np.log1p(np.exp(-f.astype(np.float64))), rtol=1e-6)
+    np.testing.assert_allclose(d, -1.0 / (1.0 + np.exp(f.astype(np.float64))), rtol=1e-6)   # d/df softplus(-f)
+    # a callable that spells a named transform agrees with the named one
+    sg = CallableTransform(torch.sigmoid, negate=True)
+    v2, d2 = sg.value_and_derivative(f)
+    s = Transform("sigmoid", negate=True)(f)
+    np.testing.assert_allclose(v2, s, rtol=1e-6)
+    np.testing.assert_allclose(d2, -s * (1 - s), rtol=1e-5)
+    with pytest.raises(TypeError):
+        CallableTransform(lambda u: 3.0).value_and_derivative(f)
+    with pytest.raises(TypeError):
+        resolve(3)
