@@ -611,7 +611,6 @@ def run_rank(args):
     t_eff_done = time.perf_counter()
 
     if rank == 0:
-        total_iters = total * args.steps
         try:
             with open(os.path.join(ROOT, TRAFFIC_FILE)) as f:
                 pmc = json.load(f)
