@@ -131,7 +131,7 @@ struct FitArgs {
   int state_in_lds, data_in_lds;
   int perm_in_lds;  // 0: an explicit perm too long for LDS is read from memory per step (generic flavours)
   // LDS carve (float offsets)
-  int o_tile, o_zt, o_misc, o_m, o_v, o_perm, o_keys, o_X, o_z, o_g, o_layout, total;
+  int o_tile, o_zt, o_misc, o_stage, o_m, o_v, o_perm, o_keys, o_X, o_z, o_g, o_layout, total;
   // batch mode (bore_set_batch): slot -> loop ids[slot] at iteration its[slot]; N above is the
   // largest of the batch and the data buffers are `cap`-strided per loop
   const int *ids, *its;
@@ -947,12 +947,32 @@ __device__ __forceinline__ void fit_body(const FitArgs &a, const long long slot,
   double b2p = pow((double)a.beta2, (double)t0);
   const float omb1 = 1.f - a.beta1, omb2 = 1.f - a.beta2;
   const int steps = (N + a.B - 1) / a.B;
-  // Shuffles off the step chain: when the LAST step of an epoch leaves the fourth wave without rows
-  // (at most 48 rows in it; static shapes whose waves own their row-blocks), that wave draws and
-  // ranks the NEXT epoch's permutation during the step (make_perm_wave) into the other of two
-  // buffers; the step's closing barrier publishes it.  Same permutations as the group form below.
+  // Shuffles and row gathers off the step chain: when the LAST step of an epoch leaves the fourth wave
+  // without rows (at most 48 rows in it; static shapes whose waves own their row-blocks), that wave
+  // draws and ranks the permutation of the epoch AFTER the next during the step (make_perm_wave) into
+  // the buffer of the current epoch's, which nobody reads any more: every step requests the NEXT
+  // step's rows (permutation entry -> row of X, z) beside its own weight operands and parks each
+  // lane's share in that lane's slot of `stage`, so that a step starts from one LDS round trip with
+  // loop-invariant addresses instead of the perm -> row -> operand chain.  (The slot is private to
+  // its lane: no synchronisation; LDS rather than a register carried around the loop, which the
+  // compiler rotated with copies that waited for the request at once.)  Same permutations, same rows.
   const bool pipe_perm = SHAPE > 0 && !WIDE && !a.perm && PG >= 2 && blockDim.x == BORE_THREADS &&
-                         N - (steps - 1) * a.B <= 16 * (BORE_THREADS / 64 - 1);
+                         a.data_in_lds && N - (steps - 1) * a.B <= 16 * (BORE_THREADS / 64 - 1);
+  constexpr int PRE_KC = RegNet<(SHAPE > 0 ? SHAPE : 1), 1>::KC0;
+  static_assert(WIDE || SHAPE <= 0 || (PRE_KC + 1) * BORE_THREADS <= BORE_FIT_STAGE_FLOATS, "stage region");
+  float *stage = smem + a.o_stage + tid;  // [PRE_KC + 1][BORE_THREADS]: inputs 4 kc + q4, then the label
+  // (pipe_perm) request this lane's share of row `srow`: every address valid, dead shares zeroed at the store
+  auto request_row = [&](float (&gx)[PRE_KC], float &gz, const int srow) {  // (pipe_perm: the data is in LDS)
+#pragma unroll
+    for (int kc = 0; kc < PRE_KC; ++kc) gx[kc] = smem[a.o_X + srow * D + min(4 * kc + q4, D - 1)];
+    gz = smem[a.o_z + srow];
+  };
+  auto park_row = [&](const float (&gx)[PRE_KC], const float gz, const bool live_row) {
+#pragma unroll
+    for (int kc = 0; kc < PRE_KC; ++kc)
+      stage[kc * BORE_THREADS] = (4 * kc + q4 < D && live_row) ? gx[kc] : 0.f;
+    stage[PRE_KC * BORE_THREADS] = (q4 == 0 && live_row) ? gz : 0.f;
+  };
   // Step size of Adam step t: lr * sqrt(1 - beta2^t) / (1 - beta1^t).  Every wave forms the
   // first one; after that the last wave computes the NEXT step's while it waits at the end of
   // the weight-gradient phase and leaves it in misc[5] (one sqrt + divide per step per
@@ -967,9 +987,21 @@ __device__ __forceinline__ void fit_body(const FitArgs &a, const long long slot,
 #endif
   FIT_MARK_DECL;
 
+  if (pipe_perm) {  // the first two epochs' shuffles by everybody (ends with a barrier); the first step's rows
+    make_perm_group(a.seed, a.model0 + model, epoch0, min(2, a.epochs), N, keys, perm_all);
+    const bool live0 = wv * 16 + m16 < min(a.B, N);
+    float gx[PRE_KC], gz;
+    request_row(gx, gz, perm_all[live0 ? wv * 16 + m16 : 0]);
+    park_row(gx, gz, live0);
+  }
+
+  // (the epochs in two instantiations -- rows parked ahead or gathered in the step -- chosen once: tested
+  // inside the step, the two forms met in blocks where the compiler waited for every pending request)
+  auto run_epochs = [&](auto pipe_c) {
+  constexpr bool PIPE = decltype(pipe_c)::value;
   for (int e = 0; e < a.epochs; ++e) {
     FIT_MARK(12);
-    if (__builtin_expect(pipe_perm && e > 0, 1)) {  // (first: the test every step of the headline run takes)
+    if constexpr (PIPE) {  // (first: the test every step of the headline run takes)
       perm_s = perm_all + (e & 1) * N;
     } else if (a.perm) {
       if (a.perm_in_lds) {
@@ -977,9 +1009,6 @@ __device__ __forceinline__ void fit_body(const FitArgs &a, const long long slot,
         for (int i = tid; i < N; i += nthr) perm_s[i] = pg[i];
         __syncthreads();
       }
-    } else if (pipe_perm) {  // (the first one by everybody; ends with a barrier)
-      make_perm(shuffle_base(a.seed, a.model0 + model, epoch0), N, keys, perm_all);
-      perm_s = perm_all;
     } else if (PG > 1) {  // small data set: the shuffles of PG consecutive epochs at once
       const int eg = e & (PG - 1);  // PG is 2 or 4
       if (eg == 0)
@@ -1015,8 +1044,22 @@ __device__ __forceinline__ void fit_body(const FitArgs &a, const long long slot,
       FIT_MARK(11);  // (two marks back to back: what a mark costs)
       BORE_WSTAMP_DECL;
       int src = 0;  // static path: this lane's mini-batch row, requested ahead of the arithmetic below
+      bool live_n = false;  // (PIPE: src is the NEXT step's row of this lane, live_n whether it has one)
+      float cx[PRE_KC], cz = 0.f;  // (PIPE) this step's row, parked during the last step
       if constexpr (SHAPE > 0) {
-        if (wv * 16 + m16 < nb) src = perm_s[row0 + wv * 16 + m16];
+        if constexpr (PIPE) {
+#pragma unroll
+          for (int kc = 0; kc < PRE_KC; ++kc) cx[kc] = stage[kc * BORE_THREADS];
+          cz = stage[PRE_KC * BORE_THREADS];
+          const bool last_s = s == steps - 1;
+          const int *perm_n = last_s ? perm_all + ((e + 1) & 1) * N : perm_s;
+          const int row0n = last_s ? 0 : row0 + a.B;
+          const int nbn = last_s && e + 1 >= a.epochs ? 0 : min(a.B, N - row0n);
+          live_n = wv * 16 + m16 < nbn;
+          src = perm_n[live_n ? row0n + wv * 16 + m16 : 0];
+        } else if (wv * 16 + m16 < nb) {
+          src = perm_s[row0 + wv * 16 + m16];
+        }
       }
       // (wide shapes: every wave runs, rows past the batch are dead -- x = 0, delta = 0 -- so
       // that the weight-gradient tiles can always sum over all 64 rows)
@@ -1034,11 +1077,23 @@ __device__ __forceinline__ void fit_body(const FitArgs &a, const long long slot,
           net.template load_bwd<Net::n, 2>(th);
           const int row = rb * 16 + m16;
           const bool live = row < nb;
+          static_assert(Net::KC0 == PRE_KC, "the parked row has the first layer's k-chunks");
           float xin[Net::KC0];
           float *A0 = tile + L.aoff[0] + row * L.lda[0];
 #pragma unroll
           for (int kc = 0; kc < Net::KC0; ++kc) xin[kc] = 0.f;
           float zz = 0.f;
+          float nx[PRE_KC], nz = 0.f;  // (PIPE) the next step's row, on its way
+          if constexpr (PIPE) {  // this step's row was parked during the last one; request the next step's
+#pragma unroll
+            for (int kc = 0; kc < Net::KC0; ++kc) xin[kc] = cx[kc];
+            zz = cz;
+            // (opaque here: the row's address is the same expression in the branch of the waves without
+            // rows, and hoisted in front of both it waited for `src` before the weight requests above)
+            int srow = src;
+            asm volatile("" : "+v"(srow));
+            request_row(nx, nz, srow);
+          } else
           if (a.data_in_lds) {  // (two branches: a selected pointer would make these flat loads)
 #pragma unroll
             for (int kc = 0; kc < Net::KC0; ++kc)
@@ -1106,6 +1161,7 @@ __device__ __forceinline__ void fit_body(const FitArgs &a, const long long slot,
           } else {
             net.template store_D<1, Net::n - 1>(tile, rb);
           }
+          if constexpr (PIPE) park_row(nx, nz, live_n);
           BORE_STAMP(4);
           FIT_MARK(3);
           BORE_WSTAMP(4);
@@ -1154,13 +1210,18 @@ __device__ __forceinline__ void fit_body(const FitArgs &a, const long long slot,
           eloss += misc[0] * (float)nb;
           misc[0] = 0.f;  // consumed; re-accumulated from the updated weights below
         }
-      } else if (pipe_perm && wv == BORE_THREADS / 64 - 1 && s == steps - 1 && e + 1 < a.epochs) {
-        // (an opaque copy keeps the epoch's hash in THIS wave's branch: wave-uniform scalar code is
-        // otherwise hoisted in front of every wave's step)
-        long long next_epoch = epoch0 + e + 1;
-        asm volatile("" : "+v"(next_epoch));
-        make_perm_wave(shuffle_base(a.seed, a.model0 + model, next_epoch), N,
-                       reinterpret_cast<unsigned long long *>(keys), perm_all + ((e + 1) & 1) * N);
+      } else if constexpr (PIPE) {  // a wave without rows in this step may have some in the next
+        float gx[PRE_KC], gz;
+        request_row(gx, gz, src);
+        park_row(gx, gz, live_n);
+        if (wv == BORE_THREADS / 64 - 1 && s == steps - 1 && e + 2 < a.epochs) {
+          // (an opaque copy keeps the epoch's hash in THIS wave's branch: wave-uniform scalar code is
+          // otherwise hoisted in front of every wave's step)
+          long long draw_epoch = epoch0 + e + 2;
+          asm volatile("" : "+v"(draw_epoch));
+          make_perm_wave(shuffle_base(a.seed, a.model0 + model, draw_epoch), N,
+                         reinterpret_cast<unsigned long long *>(keys), perm_all + (e & 1) * N);
+        }
       }
       __syncthreads();
 #ifdef BORE_STAMPS
@@ -1339,6 +1400,13 @@ __device__ __forceinline__ void fit_body(const FitArgs &a, const long long slot,
       if (tid == 0)
         a.epoch_loss[model * a.epochs + e] = (misc[1] + misc[2] + misc[3] + misc[4]) / (float)N;
     }
+  }
+  };
+  if constexpr (SHAPE > 0 && !WIDE) {
+    if (pipe_perm) run_epochs(std::true_type{});
+    else run_epochs(std::false_type{});
+  } else {
+    run_epochs(std::false_type{});
   }
 
   __syncthreads();
@@ -2085,7 +2153,10 @@ static int fit_build(const bore_mlp_desc *desc, int n_models, float *theta, floa
   // a mini-batch of up to 64 rows is one tile (larger ones: 64-row sub-tiles, fit_body); perm
   // (+ keys) and the batch targets ride along
   const int tile_rows = batch_size < BORE_BATCH_MAX ? batch_size : BORE_BATCH_MAX;
-  const size_t fixed_extra = BORE_BATCH_MAX + 8 + BORE_LAYOUT_FLOATS + 12;
+  // (the parked-row slots of fit_body: the narrow static shapes only -- a wide one has no LDS to spare)
+  const int flavour_early = desc ? bore_kernel_flavour(desc, batch_size == BORE_BATCH_MAX) : 0;
+  const size_t stage_f = flavour_early > 0 && !bore_shape_is_wide(flavour_early) ? BORE_FIT_STAGE_FLOATS : 0;
+  const size_t fixed_extra = BORE_BATCH_MAX + 8 + stage_f + BORE_LAYOUT_FLOATS + 12;
   // 32->128-128-1 in float32 with 64-row batches: theta and the 64-row images do not share the LDS;
   // the weight gradients are formed in four rounds over 16-row images instead (wide_rounds_f32)
   const bool rounds = desc && desc->compute != BORE_COMPUTE_BF16 && batch_size == BORE_BATCH_MAX && !g_batch &&
@@ -2147,12 +2218,13 @@ static int fit_build(const bore_mlp_desc *desc, int n_models, float *theta, floa
     a.ids = g_batch->ids; a.its = g_batch->its; a.n_init = g_batch->n_init; a.cap = g_batch->cap;
   }
 
-  // LDS carve: theta | tile | zt | misc | perm | keys | [m v] | [X z]
+  // LDS carve: theta | tile | zt | misc | stage | perm | keys | [m v] | [X z]
   size_t off = 0;
   off += L.P_lds;
   a.o_tile = (int)off; off += L.tile_floats;
   a.o_zt = (int)off; off += BORE_BATCH_MAX;
   a.o_misc = (int)off; off += 8;
+  a.o_stage = (int)off; off += stage_f;  // each lane's share of its next-step row (fit_body)
   const int PG = perm ? 1 : perm_group(N, BORE_THREADS);  // epochs shuffled together (N <= 128)
   size_t perm_f = a.perm_in_lds ? (size_t)PG * N : 0, keys_f = perm ? 0 : (size_t)perm_group_scratch_floats(N, PG);
   if (g_batch)  // a slot's own N (<= this N) may shuffle more epochs together: room for each case

@@ -174,6 +174,9 @@ __device__ __forceinline__ const MlpLayout &stage_layout(const MlpLayout &Lk, fl
 }
 
 #define BORE_LAYOUT_FLOATS ((int)((sizeof(MlpLayout) + 15) / 16 * 4))
+// fit_body's `stage`: one slot per work-item and k-chunk of the first layer (static shapes 1, 2: at most two)
+// plus one for the label -- each lane's share of its next-step row (bore_hip.hip, pipe_perm)
+#define BORE_FIT_STAGE_FLOATS (3 * BORE_THREADS)
 
 // Start of every kernel: zero the LDS, then hand out the layout.  Three kernel flavours:
 //   SHAPE > 0   a shape of mlp_shapes.h: the caller holds a constexpr layout (everything folds)
