@@ -124,6 +124,7 @@ struct Async {
   int stream_concurrency = 0;  // worker streams the device ran at once in the creation probe
   // diagnostics (BORE_ASYNC_DEBUG): waits between a loop's states
   std::vector<double> launched_at;
+  std::vector<double> loop_acc;  // per loop: fit ns, restart ns, evaluations, rounds, launch->result s, iterations
   double sum_wait = 0, sum_flight = 0;
   long long n_wait = 0, n_batches = 0, n_slots = 0;
 };
@@ -629,6 +630,11 @@ int async_run(bore_engine *e, int n_steps) {
       e->st.phase_ns_screen += r[D + 5] * A.ns_per_tick;
       e->st.phase_ns_lbfgsb += r[D + 6] * A.ns_per_tick;
       ++e->st.phase_iterations;
+      if (A.loop_acc.size() == (size_t)L * 6) {
+        double *la = &A.loop_acc[(size_t)l * 6];
+        la[0] += r[D + 4] * A.ns_per_tick; la[1] += r[D + 6] * A.ns_per_tick;
+        la[2] += r[D + 1]; la[3] += r[D + 2]; la[4] += t0 - A.launched_at[l]; la[5] += 1.0;
+      }
       if (r[D] < 0.0) {  // reference: fall back to a random point of this loop's stream
         ++e->st.none_results;
         Mt19937 &rs = e->rs[l];
@@ -970,6 +976,18 @@ extern "C" int bore_engine_state(bore_engine *e, float *theta, float *adam_m, fl
   if (adam_m) HIP_TRY(hipMemcpy(adam_m, e->adam_m, n * 4, hipMemcpyDeviceToHost));
   if (adam_v) HIP_TRY(hipMemcpy(adam_v, e->adam_v, n * 4, hipMemcpyDeviceToHost));
   if (adam_t) HIP_TRY(hipMemcpy(adam_t, e->adam_t, (size_t)e->cfg.n_loops * 8, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+// Diagnostic (tools/loop_tail.py; not part of include/bore_hip.h): per-loop sums since the last reset --
+// out[L][6] = fit ns, restart ns, evaluations, rounds of the slowest restart, launch -> result s, iterations.
+// reset != 0 also (re)starts the accumulation.  Asynchronous engines only.
+extern "C" int bore_debug_engine_loop_stats(bore_engine *e, double *out, int reset) {
+  if (!e || !e->as) return fail(BORE_E_INVALID, "loop_stats: an asynchronous engine is needed");
+  Async &A = *e->as;
+  const size_t n = (size_t)e->cfg.n_loops * 6;
+  if (out && A.loop_acc.size() == n) std::memcpy(out, A.loop_acc.data(), n * 8);
+  if (reset) A.loop_acc.assign(n, 0.0);
   return 0;
 }
 
