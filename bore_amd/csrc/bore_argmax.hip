@@ -29,8 +29,8 @@ __device__ __forceinline__ void labels_body(const double *y, int N, double vi, f
   double *ys = reinterpret_cast<double *>(smem);  // [N] + 2 (a, b)
   long long stride = N;
   if (ids) {
-    N = n_init + (it_now >= 0 ? it_now : its[model]);
-    model = ids[model];
+    N = n_init + (it_now >= 0 ? it_now : uniform_i32(its[model]));
+    model = uniform_i64(ids[model]);
     stride = cap;
     vi = (double)(N - 1) * gamma;  // numpy's virtual index for this slot's N
   }
@@ -202,7 +202,7 @@ __device__ __forceinline__ void screen_body(const ScreenArgs &a, const long long
   BORE_OPAQUE_TID(tid);
   const int nthr = blockDim.x;
   // `model` is the output slot
-  const long long lid = a.ids ? a.ids[model] : model;        // whose weights and stream
+  const long long lid = a.ids ? uniform_i64(a.ids[model]) : model;        // whose weights and stream
   const int n = layer_count<SHAPE>(L), D = L.w[0];
   const int Ns = (int)a.n_samples;
   float *th = smem, *tile = smem + a.o_tile;
@@ -217,7 +217,7 @@ __device__ __forceinline__ void screen_body(const ScreenArgs &a, const long long
   }
   const unsigned long long cbase =
       a.sampled ? candidate_base(a.seed, a.model0 + lid,
-                                 a.ids ? (long long)(it_now >= 0 ? it_now : a.its[model]) : a.draw)
+                                 a.ids ? (long long)(it_now >= 0 ? it_now : uniform_i32(a.its[model])) : a.draw)
                 : 0ULL;
   auto xval = [&](long long row, int d) -> double {
     if (a.sampled) {
@@ -600,7 +600,7 @@ __device__ __forceinline__ void lbfgsb_body(const LbfgsbArgs &a, const long long
   BORE_OPAQUE_TID(tid);
   const int wv = tid >> 6, lane = tid & 63;
   // `model` is the slot: it indexes x0 / x / fun / jac / info
-  const long long lid = a.ids ? a.ids[model] : model;  // whose weights (and record, and result)
+  const long long lid = a.ids ? uniform_i64(a.ids[model]) : model;  // whose weights (and record, and result)
   const int n_lay = layer_count<SHAPE>(L), D = L.w[0];
   const int p0 = block_y * a.PB;                  // first problem of this workgroup
   const int np = min(a.PB, a.R - p0);             // problems here (>= 1 by grid construction)
@@ -871,7 +871,7 @@ __device__ __forceinline__ void lbfgsb_body(const LbfgsbArgs &a, const long long
   last = __shfl(last, 0, 64);
   if (!last) continue;
   wave_lds_sync();
-  const int it_done = it_now >= 0 ? it_now : a.its[model];
+  const int it_done = it_now >= 0 ? it_now : uniform_i32(a.its[model]);
   const int N = a.n_init + it_done;
   const double *Xs = a.dedup ? a.X_seen + lid * a.cap * D : nullptr;
   int best = -1;

@@ -887,7 +887,7 @@ __device__ __forceinline__ void fit_body(const FitArgs &a, const long long slot,
   constexpr bool WIDE = bore_shape_is_wide(SHAPE > 0 ? SHAPE : 0);
   constexpr bool ROUNDS = bore_shape_fit_in_rounds(SHAPE > 0 ? SHAPE : 0);  // (wide_rounds_f32)
   if constexpr (WIDE) {  // m / v (in HBM for a wide net) go to tile order for the launch (TileOrder)
-    const long long mdl = a.ids ? a.ids[slot] : slot;
+    const long long mdl = a.ids ? uniform_i64(a.ids[slot]) : slot;
     TileOrder<WIDE ? SHAPE : 1>::convert(a.am + mdl * Lc.P, smem, true);
     TileOrder<WIDE ? SHAPE : 1>::convert(a.av + mdl * Lc.P, smem, true);
   }
@@ -896,9 +896,9 @@ __device__ __forceinline__ void fit_body(const FitArgs &a, const long long slot,
   BORE_OPAQUE_TID(tid);
   const int nthr = blockDim.x;
   const int wv = tid >> 6, lane = tid & 63, m16 = lane & 15, q4 = lane >> 4;
-  const long long model = a.ids ? a.ids[slot] : slot;  // the loop this workgroup fits
+  const long long model = a.ids ? uniform_i64(a.ids[slot]) : slot;  // the loop this workgroup fits
   const int P = L.P, n = layer_count<SHAPE>(L), D = L.w[0];
-  const int it_cur = a.ids ? (it_now >= 0 ? it_now : a.its[slot]) : 0;
+  const int it_cur = a.ids ? (it_now >= 0 ? it_now : uniform_i32(a.its[slot])) : 0;
   const int N = a.ids ? a.n_init + it_cur : a.N;
   const long long epoch0 = a.ids ? (long long)it_cur * a.epochs : a.epoch0;
 

@@ -68,7 +68,7 @@ __device__ BORE_ITER_ONCE_ATTR void iteration_once(const IterArgs *__restrict__ 
                                                          const long long slot, const int it,
                                                          const bool staged) {
   const IterArgs &a = *pa;
-  const long long lid = a.f.ids[slot], cap = a.f.cap;
+  const long long lid = uniform_i64(a.f.ids[slot]), cap = a.f.cap;
   long long *stp = a.stamps ? a.stamps + lid * 4 : nullptr;  // read back by the restart phase's epilogue
   if (stp && threadIdx.x == 0) stp[0] = wall_clock64();
   if (it > 0) {  // append (append_kernel's batch branch)
@@ -105,10 +105,10 @@ __device__ BORE_ITER_ONCE_ATTR void iteration_once(const IterArgs *__restrict__ 
 template <int SHAPE, bool RESIDENT>
 __global__ __launch_bounds__(BORE_THREADS, 2) void iteration_kernel(const IterArgs *__restrict__ pa) {
   const long long slot = blockIdx.x;
-  const int it_first = pa->f.its[slot];
+  const int it_first = uniform_i32(pa->f.its[slot]);
   if constexpr (!RESIDENT) {
     const IterArgs &a = *pa;
-    const long long lid = a.f.ids[slot], cap = a.f.cap;
+    const long long lid = uniform_i64(a.f.ids[slot]), cap = a.f.cap;
     const int it = it_first;
     long long *stp = a.stamps ? a.stamps + lid * 4 : nullptr;
     if (stp && threadIdx.x == 0) stp[0] = wall_clock64();
@@ -143,12 +143,22 @@ __global__ __launch_bounds__(BORE_THREADS, 2) void iteration_kernel(const IterAr
     return;
   }
   __shared__ __attribute__((aligned(16))) int s_go4[4];  // (16 B: the dynamic LDS keeps its alignment)
-  const int target = pa->targets ? pa->targets[slot] : it_first + 1;
+  const int target = pa->targets ? uniform_i32(pa->targets[slot]) : it_first + 1;
   for (int it = it_first;;) {
     // (the argument block's address is made opaque per iteration, so that nothing read through it
     // is hoisted out of the loop and kept live around it)
+#ifndef BORE_ITER_ARGS_LAUNDERED
+    // (the block is written by the host before the launch and never by a kernel: read through the
+    // constant address space its fields are scalar loads -- uniform values in scalar registers, loops
+    // over them scalar loops -- instead of vector loads that a store earlier in the loop might clobber)
+    unsigned long long pa_bits = reinterpret_cast<unsigned long long>(pa);
+    asm volatile("" : "+s"(pa_bits));
+    typedef const __attribute__((address_space(4))) IterArgs *IterArgsConst;
+    iteration_once<SHAPE>((const IterArgs *)(IterArgsConst)pa_bits, slot, it, it == it_first);
+#else
     asm volatile("" : "+s"(pa));
     iteration_once<SHAPE>(pa, slot, it, it == it_first);
+#endif
     __syncthreads();  // the waves leave the restart phase one by one: LDS is reused below
     ++it;
     if (it >= target) break;
@@ -172,7 +182,7 @@ __global__ __launch_bounds__(BORE_THREADS, 2) void iteration_kernel(const IterAr
       s_go4[0] = go;
     }
     __syncthreads();
-    const int go = s_go4[0];
+    const int go = uniform_i32(s_go4[0]);
     __syncthreads();
     if (!go) break;
   }

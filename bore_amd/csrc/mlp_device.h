@@ -174,6 +174,17 @@ __device__ __forceinline__ const MlpLayout &stage_layout(const MlpLayout &Lk, fl
 }
 
 #define BORE_LAYOUT_FLOATS ((int)((sizeof(MlpLayout) + 15) / 16 * 4))
+// A value every lane of the wave holds alike, moved to scalar registers (v_readfirstlane): what is read
+// through a pointer into ordinary global memory -- a loop's id, its iteration count -- arrives in vector
+// registers, and everything derived from it (data-set size, trip counts, base addresses) then stays
+// there: loops over it become execution-mask loops, tests vector compares.
+__device__ __forceinline__ int uniform_i32(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ long long uniform_i64(long long v) {
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((unsigned long long)v & 0xffffffffULL));
+  const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((unsigned long long)v >> 32));
+  return (long long)(((unsigned long long)hi << 32) | lo);
+}
+
 // fit_body's `stage`: one slot per work-item and k-chunk of the first layer (static shapes 1, 2: at most two)
 // plus one for the label -- each lane's share of its next-step row (bore_hip.hip, pipe_perm)
 #define BORE_FIT_STAGE_FLOATS (3 * BORE_THREADS)
