@@ -632,7 +632,9 @@ __device__ __forceinline__ void lbfgsb_body(const LbfgsbArgs &a, const long long
   const bool coop = np <= NW || multi;
   const int passes = multi ? (np + 3) / 4 : 1;
   const int myrow = coop ? wv * 16 : wv * 16 + lane;
-  const lbfgsb::Coop cp = coop ? lbfgsb::Coop{lane, 64} : lbfgsb::Coop{0, 1};
+  // (ALWAYS_COOP kernels run one problem per wave or nothing: the lane count is a compile-time 64
+  // there, which is what lets lbfgsb.h's LB_UNI move the optimiser's integers to scalar registers)
+  const lbfgsb::Coop cp = (ALWAYS_COOP || coop) ? lbfgsb::Coop{lane, 64} : lbfgsb::Coop{0, 1};
   __syncthreads();  // weights staged; from here on the waves are independent
   const long long c_staged = BORE_LCLOCK();
   if (wv >= np) return;  // wave without problems (np < 4)

@@ -152,6 +152,17 @@ LB_HD Work make_work(double *dw, int *iw, int n, int m) {
 struct Coop {
   int lane, nl;
 };
+// LB_UNI: an integer of the State that every lane of a cooperating wave holds alike (c.nl > 1: ONE
+// problem per wave), moved to a scalar register.  The State lives in vector registers and is updated
+// under tests on fp64 values, which the compiler must take for lane-dependent: without the hint every
+// loop over col / nfree / ... is an execution-mask loop with its counter and bounds in vector registers.
+// (Tried beside it and dropped: the line search's own tests as scalar branches -- the compare's lane mask
+// against zero -- instead of execution-mask regions: no change, profiles/r3/ab_headline.txt.)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define LB_UNI(v, c) ((c).nl > 1 ? __builtin_amdgcn_readfirstlane(v) : (v))
+#else
+#define LB_UNI(v, c) (v)
+#endif
 #if defined(__HIP_DEVICE_COMPILE__)
 #define LB_LANES_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 #define LB_OPAQUE_LANE(x) asm volatile("" : "+v"(x))
@@ -1085,17 +1096,18 @@ LB_HDN int formk(const IterArgs s, const Work w) {
 
 // r = -Z'B(xcp - x) - Z'g   (uses c = wa[2m..4m) from cauchy; p = wa[0..2m) as scratch)
 LB_HD int cmprlb(State &s, const Work &w, const Coop c) {
-  const int n = s.n, m = s.m, col = s.col;
+  const int n = LB_UNI(s.n, c), m = LB_UNI(s.m, c), col = LB_UNI(s.col, c);
+  const int nfree = LB_UNI(s.nfree, c), head = LB_UNI(s.head, c);
   if (!s.cnstnd && col > 0) {
     for (int i = c.lane; i < n; i += c.nl) w.r[i] = -w.g[i];
     LB_LANES_SYNC();
     return 0;
   }
   if (bmv(m, w, col, w.wa + 2 * m, w.wa, c)) return -8;
-  for (int i = c.lane; i < s.nfree; i += c.nl) {  // each r[i]: its terms in the order j = 0, 1, ...
+  for (int i = c.lane; i < nfree; i += c.nl) {  // each r[i]: its terms in the order j = 0, 1, ...
     const int k = w.index[i] - 1;
     double ri = -s.theta * (w.z[k] - w.x[k]) - w.g[k];
-    int p0 = s.head;
+    int p0 = head;
     int j = 0;
     for (; j + 2 <= col; j += 2) {  // operands of two terms in flight
       const int p1 = p0 + 1 == m ? 0 : p0 + 1;
@@ -1490,7 +1502,11 @@ LB_HD int lnsrlb(State &s, const Work &w, const double *l, const double *u, cons
 // ---- BFGS matrix update -----------------------------------------------------------------------
 template <bool VL = true>
 LB_HD void matupd(State &s, const Work &w, double rr, double dr, const Coop c = Coop{0, 1}) {
-  const int n = s.n, m = s.m;
+  const int n = LB_UNI(s.n, c), m = LB_UNI(s.m, c);
+  s.iupdat = LB_UNI(s.iupdat, c);
+  s.head = LB_UNI(s.head, c);
+  s.itail = LB_UNI(s.itail, c);
+  s.col = LB_UNI(s.col, c);
   if (s.iupdat <= m) {
     s.col = s.iupdat;
     s.itail = wrap(s.head + s.iupdat - 1, m);
@@ -1620,7 +1636,7 @@ LB_HD int lbfgsb_advance(State &s, const Work &w, const double *l, const double 
   constexpr bool DIRECT = !std::is_same<FG, ReverseCommunication>::value;
   constexpr bool TWO = DIRECT && !std::is_same<FG2, NoTwoVariableForm>::value;
   Coop coop = coop_in;
-  const int n = s.n, m = s.m;
+  const int n = LB_UNI(s.n, coop_in), m = LB_UNI(s.m, coop_in);
   bool first_ls = false;
   bool resume_ls = (s.stage == S_FG_LNSRCH);
 
@@ -1736,8 +1752,9 @@ LB_HD int lbfgsb_advance(State &s, const Work &w, const double *l, const double 
         s.wrk = s.updatd;
         s.nseg = 0;
       } else {
-        const IterArgs ia{n, m, s.col, s.head, s.nfree, s.nenter, s.ileave, s.updatd, s.iupdat,
-                          s.theta, s.sbgnrm, coop};
+        const IterArgs ia{n, m, LB_UNI(s.col, coop), LB_UNI(s.head, coop), LB_UNI(s.nfree, coop),
+                          LB_UNI(s.nenter, coop), LB_UNI(s.ileave, coop), LB_UNI(s.updatd, coop),
+                          LB_UNI(s.iupdat, coop), s.theta, s.sbgnrm, coop};
         LB_PHASE_BEGIN(21);
         const int rc = cauchy<VL>(ia, w, l, u, nbd);
         LB_PHASE_END(0);
@@ -1754,8 +1771,9 @@ LB_HD int lbfgsb_advance(State &s, const Work &w, const double *l, const double 
         s.nact = n - s.nfree;
       }
       if (s.nfree != 0 && s.col != 0) {
-        const IterArgs ia{n, m, s.col, s.head, s.nfree, s.nenter, s.ileave, s.updatd, s.iupdat,
-                          s.theta, s.sbgnrm, coop};
+        const IterArgs ia{n, m, LB_UNI(s.col, coop), LB_UNI(s.head, coop), LB_UNI(s.nfree, coop),
+                          LB_UNI(s.nenter, coop), LB_UNI(s.ileave, coop), LB_UNI(s.updatd, coop),
+                          LB_UNI(s.iupdat, coop), s.theta, s.sbgnrm, coop};
         if (s.wrk) {
           LB_PHASE_BEGIN(23);
           const int fk = formk(ia, w);
@@ -1962,7 +1980,7 @@ LB_HD int lbfgsb_advance(State &s, const Work &w, const double *l, const double 
       int ft;
       {
         LB_PHASE_BEGIN(19);
-        ft = formt(m, w, s.col, s.theta, coop);
+        ft = formt(m, w, LB_UNI(s.col, coop), s.theta, coop);
         LB_PHASE_END(6);
       }
       if (ft) {
