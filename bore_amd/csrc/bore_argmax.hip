@@ -687,6 +687,24 @@ __device__ __forceinline__ void lbfgsb_body(const LbfgsbArgs &a, const long long
       auto evaluate = [&](lbfgsb::State &s, const lbfgsb::Work &w) {
         wave_lds_sync();  // (x was written by the lanes that own its components)
         const long long c1 = BORE_LCLOCK();
+        // (the image shortcut of evaluate2 below for a bfloat16 network, which reads the point's bfloat16
+        // image: the point evaluated last, its gradient and its value are the optimiser's own cache --
+        // from the second evaluation on.  BASELINE config 5, 256 loops: restarts 111 -> 91 ms.  Not for
+        // float32 networks of more than two inputs: configs 2 / 3 hardly ever repeat an image and paid
+        // 1 - 2 % for the test, profiles/r3/ab_headline.txt)
+        static_assert(BORE_DIM_MAX <= 64, "one input per lane");
+        if (BF16 && s.nfev > 1) {
+          bool other = false;
+          if (lane < D)
+            other = __float_as_uint(Net::rnd((float)w.x[lane])) != __float_as_uint(Net::rnd((float)w.xlast[lane]));
+          if (!__any(other)) {
+            s.f = s.flast;
+            if (lane < D) w.g[lane] = w.glast[lane];
+            wave_lds_sync();
+            ++n_rounds;
+            return;
+          }
+        }
         if constexpr (LEAN) {
           if (!BORE_POINT_SHAPE(SHAPE)) {
             net.load_fwd(thw);
@@ -733,8 +751,25 @@ __device__ __forceinline__ void lbfgsb_body(const LbfgsbArgs &a, const long long
       if constexpr (SHAPE == 1 && !BORE_POINT_SHAPE(SHAPE) && !BF16) {
         // two inputs: the line search keeps its vectors in registers (lbfgsb.h, TWO-VARIABLE form) and
         // hands the point over in registers as well
-        auto evaluate2 = [&](lbfgsb::State &s, double x0, double x1, double &g0, double &g1) {
+        auto evaluate2 = [&](lbfgsb::State &s, double x0, double x1, double &g0, double &g1,
+                             const double xl0, const double xl1, const double gl0, const double gl1) {
           const long long c1 = BORE_LCLOCK();
+          // The network reads the point's float32 image (Keras autocast): a trial point whose image has
+          // the bits of the last evaluated point's gets that point's value and gradient -- what the
+          // network would return -- without the evaluation.  A line search that fails in float32 noise
+          // shrinks its step below the float32 spacing of x long before it gives up: a fifth of all
+          // requests (scratch/fp32_cache_hits.py; counted as evaluations all the same: SciPy's cache
+          // compares the float64 points).
+          if (__float_as_uint((float)x0) == __float_as_uint((float)xl0) &&
+              __float_as_uint((float)x1) == __float_as_uint((float)xl1)) {
+            s.f = s.flast;
+            g0 = gl0;
+            g1 = gl1;
+            ++n_rounds;
+            return;
+          }
+          // (tried and dropped: the search's base point as a second entry -- another 7 % of the requests,
+          // no gain over its compare and four more registers in the loop, profiles/r3/ab_headline.txt)
           if constexpr (LEAN) {
             net.load_fwd(thw);
             net.template load_bwd<Net::n, 1>(thw);

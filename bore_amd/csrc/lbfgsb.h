@@ -1619,8 +1619,9 @@ LB_HD void lbfgsb_init(State &s, const Work &w, int n, int m, const double *x0, 
 // caller whose lanes all work on ONE problem (Coop) -- divergent callers need the returning form.
 //
 // TWO-VARIABLE form of the line search (DIRECT callers may add `fg2(State &, double x0, double x1,
-// double &g0, double &g1)`): from a search's second call on, the trial point, the direction, the
-// gradient and the cache of the point evaluated last live in REGISTERS (the same values in every
+// double &g0, double &g1, double xlast0, double xlast1, double glast0, double glast1)` -- the point
+// evaluated last with its gradient; its value is s.flast): from a search's second call on, the trial
+// point, the direction, the gradient and the cache of the point evaluated last live in REGISTERS (the same values in every
 // lane) instead of the workspace -- per evaluation that is the trial point written, read back for the
 // cache check and again for the evaluation, the gradient written and read, and both copied to the
 // cache: half a dozen LDS round trips on a chain that one wave walks alone.  The first call of a
@@ -1831,7 +1832,10 @@ LB_HD int lbfgsb_advance(State &s, const Work &w, const double *l, const double 
             s.task = T_FG;
             ++s.nfev;
             LB_MARK(s, 18);
-            fg2(s, x0, x1, g0, g1);
+            // (the functor also sees the point evaluated last, its value in s.flast and its gradient: an
+            // evaluation that depends on LESS than the fp64 point -- the network reads its float32 image --
+            // may answer from them, bore_argmax.hip)
+            fg2(s, x0, x1, g0, g1, xl0, xl1, gl0, gl1);
             LB_MARK(s, 15);
             xl0 = x0; xl1 = x1; gl0 = g0; gl1 = g1;
             s.flast = s.f;

@@ -32,7 +32,7 @@ int lbfgsb_host_minimize_form(int form, int n, int m, const double *x0, const do
     st.f = f;
     ++rounds;
   };
-  auto eval2 = [&](State &st, double a, double b, double &ga, double &gb) {
+  auto eval2 = [&](State &st, double a, double b, double &ga, double &gb, double, double, double, double) {
     double xx[2] = {a, b}, gg[2], f;
     fg(2, xx, &f, gg);
     st.f = f;
