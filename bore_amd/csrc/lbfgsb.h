@@ -199,12 +199,27 @@ __shared__ unsigned g_lb_lds[8][64];
       __hip_atomic_fetch_add(&g_lb_lds[(threadIdx.x >> 6) & 7][32 + (i)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
     }                                                                                     \
   } while (0)
+#ifdef BORE_STAMPS_FORMK
+// (-DBORE_STAMPS_FORMK: the gaps are lumped into bucket 15 and their buckets 19..27 take the stages of
+// formk instead: new rows, old parts, assembly, first factorisation, triangular solves, (2,2) block,
+// second factorisation; tools/engine_phases.py formk)
+#define LB_PHASE_BEGIN(g) LB_MARK(s, 15)
+struct LbLocalClock { long long lb_last; };
+#define FK_MARK_DECL LbLocalClock fk_clock{clock64()}
+#define FK_MARK(i) LB_MARK(fk_clock, i)
+#else
 #define LB_PHASE_BEGIN(g) LB_MARK(s, g)
+#endif
 #define LB_PHASE_END(i) LB_MARK(s, i)
 #else
 #define LB_MARK(s_, i) ((void)0)
 #define LB_PHASE_BEGIN(g) ((void)0)
 #define LB_PHASE_END(i) ((void)0)
+#endif
+
+#ifndef FK_MARK
+#define FK_MARK_DECL ((void)0)
+#define FK_MARK(i) ((void)0)
 #endif
 
 // The value `v` holds in lane `src` (wave-uniform), in every lane of the wave.
@@ -960,6 +975,7 @@ LB_HDN int formk(const IterArgs s, const Work w) {
 #define WS(k, p) w.ws[(p) * n + (k)]
 #define WY(k, p) w.wy[(p) * n + (k)]
   int upcl;
+  FK_MARK_DECL;
   if (s.updatd) {
     if (s.iupdat > m) {  // shift the old part of WN1 (overlapping moves: kept sequential)
       for (int jy = 0; jy < m - 1; ++jy) {
@@ -1013,6 +1029,7 @@ LB_HDN int formk(const IterArgs s, const Work w) {
   } else {
     upcl = col;
   }
+  FK_MARK(19);
   // old parts of blocks (1,1), (2,2) and (2,1): variables that entered / left the free set.
   // Each (iy, jy) entry is independent.
   for (int e = c.lane; e < upcl * upcl; e += c.nl) {
@@ -1052,6 +1069,7 @@ LB_HDN int formk(const IterArgs s, const Work w) {
     }
   }
   LB_LANES_SYNC();
+  FK_MARK(20);
   // upper triangle of WN = [D+Y'ZZ'Y/theta   -L_a'+R_z'] [-L_a+R_z   S'AA'S*theta]
   // (each iy writes its own columns iy and col+iy)
   const double theta = s.theta, rtheta = 1.0 / s.theta;
@@ -1067,9 +1085,11 @@ LB_HDN int formk(const IterArgs s, const Work w) {
     WN(iy, iy) += w.sy[iy * m + iy];
   }
   LB_LANES_SYNC();
+  FK_MARK(21);
   // Cholesky of the (1,1) block, then L^-1(-L_a'+R_z') in the (1,2) block (one right-hand
   // side per lane)
   if (dpofa(wn, m2, col, w.rwn, c)) return -1;
+  FK_MARK(22);
   const int col2 = 2 * col;
   if (c.nl > 1 && c.nl >= col) {
     if (lanes_any(c.lane < col && wn[(c.lane < col ? c.lane : 0) * (m2 + 1)] == 0.0)) return -1;
@@ -1080,13 +1100,16 @@ LB_HDN int formk(const IterArgs s, const Work w) {
   for (int js = col + c.lane; js < col2; js += c.nl)
     dtrsl_lower_rhs(wn, m2, col, wn + js * m2, w.rwn);
   LB_LANES_SYNC();
+  FK_MARK(23);
   // (2,2) block: S'AA'S*theta + (L^-1(-L_a'+R_z'))'(L^-1(-L_a'+R_z')), then its Cholesky
   for (int e = c.lane; e < col * col; e += c.nl) {
     const int is = col + e / col, js = col + e % col;
     if (js >= is) WN(is, js) += ddot(col, wn + is * m2, wn + js * m2);
   }
   LB_LANES_SYNC();
+  FK_MARK(24);
   if (dpofa(wn + col * m2 + col, m2, col, w.rwn + col, c)) return -2;
+  FK_MARK(25);
   return 0;
 #undef WN
 #undef WN1
@@ -1246,6 +1269,10 @@ LB_HDN int subsm(const IterArgs s, const Work w, const double *l, const double *
 }
 
 // ---- More'-Thuente line search -------------------------------------------------------------
+// (Tried and dropped, round 3: the quotients of dcstep written out as LLVM's fp64 division sequence for
+// three or four operands in lockstep -- same bits, the instructions interleaved in the ISA as intended,
+// restart phase 331.0 -> 329.8 us: the chain is not what bounds it.  profiles/r3/ab_headline.txt,
+// lbfgsb_formk_dcsrch_stages.txt: dcstep ~1.0 k of dcsrch's ~1.9 k cycles per call.)
 LB_HD void dcstep(double &stx, double &fx, double &dx, double &sty, double &fy, double &dy,
                   double &stp, double fp, double dp, int &brackt, double stpmin, double stpmax) {
   const double p66 = 0.66;
@@ -1326,6 +1353,7 @@ enum { LS_START = 0, LS_FG = 1, LS_CONV = 2, LS_WARN = 3, LS_ERROR = 4 };
 LB_HD void dcsrch(State &s, double f, double g, double &stp, double ftol, double gtol,
                   double xtol, double stpmin, double stpmax) {
   const double xtrapl = 1.1, xtrapu = 4.0, p5 = 0.5, p66 = 0.66;
+  FK_MARK_DECL;
   if (s.ls_task == LS_START) {
     if (stp < stpmin || stp > stpmax || g >= 0.0 || ftol < 0.0 || gtol < 0.0 || xtol < 0.0 ||
         stpmin < 0.0 || stpmax < stpmin) {
@@ -1373,7 +1401,9 @@ LB_HD void dcsrch(State &s, double f, double g, double &stp, double ftol, double
       gx = s.gx - s.gtest;
       gy = s.gy - s.gtest;
     }
+    FK_MARK(26);
     dcstep(stx, fx, gx, sty, fy, gy, stp, fp, gp, brackt, s.stmin, s.stmax);
+    FK_MARK(27);
     if (modified) {
       fx = fx + stx * s.gtest;
       fy = fy + sty * s.gtest;
@@ -1857,7 +1887,9 @@ LB_HD int lbfgsb_advance(State &s, const Work &w, const double *l, const double 
               break;
             }
           }
+          LB_MARK(s, 16);
           dcsrch(s, s.f, s.gd, s.stp, ftol_ls, gtol_ls, xtol_ls, 0.0, s.stpmx);
+          LB_MARK(s, 17);
           s.xstep = s.stp * s.dnorm;
           if (s.ls_task != LS_CONV && s.ls_task != LS_WARN) {
             ++s.ifun;

@@ -2,7 +2,7 @@
 problem of a bench-shaped run (diagnostic build libbore_hip_stamps.so = -DBORE_STAMPS; GPU box):
 per-routine cycles and calls (LDS accumulators, flushed per problem), the whole advance / f-g time,
 per-problem totals (mean, p90, max) and the slowest problem of each loop.
-usage: python tools/engine_phases.py [loops] [steps] [warmup]"""
+usage: python tools/engine_phases.py [loops] [steps] [warmup] [formk]"""
 import ctypes as C, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -28,9 +28,14 @@ pp = (C.c_ulonglong * (4096 * 64))()
 lib.bore_debug_lpp(pp)
 pp = np.array(pp, dtype=np.float64).reshape(4096, 64)[:4 * L].reshape(L, 4, 64)[:, :3]   # 3 restarts per loop
 names = ["cauchy", "formk", "cmprlb", "subsm", "lnsrlb", "matupd", "formt", "head", "freev", "accept", "cachechk", "bfgspair", "d=z-x"]
-GAPS = {15: "outside advance (evaluation + kernel loop)", 18: "tail before return", 19: "gap before formt", 20: "gap entry->head", 21: "gap before cauchy", 22: "gap before freev",
+GAPS = {16: "two-variable search: evaluation -> dcsrch", 17: "two-variable search: dcsrch", 15: "outside advance (evaluation + kernel loop)", 18: "tail before return", 19: "gap before formt", 20: "gap entry->head", 21: "gap before cauchy", 22: "gap before freev",
         23: "gap before formk", 24: "gap before cmprlb", 25: "gap before subsm", 26: "gap before d=z-x", 27: "gap before lnsrlb",
         28: "gap before cachechk", 29: "gap before accept", 30: "gap before bfgspair", 31: "gap before matupd"}
+if len(sys.argv) > 4 and sys.argv[4] == "formk":   # libbore_hip_stamps.so built with -DBORE_STAMPS_FORMK
+    GAPS = {16: GAPS[16], 17: GAPS[17], 15: "outside advance + all gaps", 18: GAPS[18],
+            19: "formk: new rows / column (after an update)", 20: "formk: old parts (entered / left variables)", 21: "formk: assembly of WN",
+            22: "formk: Cholesky of block (1,1)", 23: "formk: diagonal check + triangular solves", 24: "formk: block (2,2)",
+            25: "formk: Cholesky of block (2,2)", 26: "dcsrch: entry -> dcstep", 27: "dcsrch: dcstep"}
 n_prob = L * 3 * steps
 tot_adv, tot_fg = pp[..., 13].sum(), pp[..., 14].sum()
 print(f"{L} loops x {steps} steps (stamps build): {L * steps / dt:.0f} it/s; device us per loop-iteration: "
