@@ -107,7 +107,12 @@ __global__ __launch_bounds__(BORE_THREADS, 2) void iteration_kernel(const IterAr
   const long long slot = blockIdx.x;
   const int it_first = uniform_i32(pa->f.its[slot]);
   if constexpr (!RESIDENT) {
+#ifndef BORE_ITER_ARGS_LAUNDERED
+    typedef const __attribute__((address_space(4))) IterArgs *IterArgsConst1;  // (scalar loads: see below)
+    const IterArgs &a = *(const IterArgs *)(IterArgsConst1) reinterpret_cast<unsigned long long>(pa);
+#else
     const IterArgs &a = *pa;
+#endif
     const long long lid = uniform_i64(a.f.ids[slot]), cap = a.f.cap;
     const int it = it_first;
     long long *stp = a.stamps ? a.stamps + lid * 4 : nullptr;
