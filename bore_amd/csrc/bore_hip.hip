@@ -272,12 +272,19 @@ __device__ __forceinline__ void dw_adam_static(const FitArgs &a, float *smem, fl
         const bool transposed = L.w[l] == 1;
         const bool two = !transposed && split && L.w[l - 1] - kb * 16 > 2;
         if ((t & 3) == wv)
-          dw_task(L, smem, a.o_tile, a.o_m, a.o_v, l, kb, cb, 0, two ? 2 : 4, kb == 0, transposed,
+          // (registers past the layer's inputs hold padding: a 2-input layer updates two, not four; a tile
+          // split into two tasks: the bias rides with the SECOND half -- the first half's wave was the
+          // heavier one: fit 392.7 -> 385.8 us per loop-iteration.  Tried beyond that and dropped: the bias
+          // of a narrow layer in the idle lanes of register 0, the split tile's bias as second register of
+          // the transposed task -- an unpaired register costs ~340 cycles, but the fused kernel paid for the
+          // extra operands in spills: profiles/r3/ab_headline.txt)
+          dw_task(L, smem, a.o_tile, a.o_m, a.o_v, l, kb, cb, 0,
+                  two ? 2 : (L.w[l - 1] - kb * 16 < 4 ? L.w[l - 1] - kb * 16 : 4), kb == 0 && !two, transposed,
                   KCH, alpha, omb1, omb2, a.eps);
         ++t;
         if (two) {
           if ((t & 3) == wv)
-            dw_task(L, smem, a.o_tile, a.o_m, a.o_v, l, kb, cb, 2, 4, false, false, KCH, alpha,
+            dw_task(L, smem, a.o_tile, a.o_m, a.o_v, l, kb, cb, 2, 4, kb == 0, false, KCH, alpha,
                     omb1, omb2, a.eps);
           ++t;
         }
