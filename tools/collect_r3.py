@@ -32,9 +32,10 @@ out = {"_source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passe
                   "--warmup 5 --cpu-seconds 0 --no-configs --repeats 1 --survey-steps 0` (tools/profile_r3.sh, tools/collect_r3.py).  HBM bytes = "
                   "(2*FETCH_SIZE + WRITE_SIZE)*1024: gfx950's FETCH_SIZE reports half of a wide coalesced read (MI355X_MICROARCH.md, HBM "
                   "section).  Resident workgroups: the run is TWO launches of iteration_kernel (warm-up steps, timed steps) that together "
-                  "carry loops x (warm-up + steps) loop-iterations.  Round 3: the resident kernel's body is inlined again (140 B of scratch "
-                  "per lane, spilled once per BO iteration, instead of the 568 - 784 B a real call parked).",
-       "build": "r3 (direct L-BFGS-B form, two-variable line search in registers, inlined resident body, pipelined shuffles)"}
+                  "carry loops x (warm-up + steps) loop-iterations.  Round 3: the resident kernel's body is inlined again and its "
+                  "arguments are scalar loads (12 B of scratch per lane instead of the 568 - 784 B a real call parked).",
+       "build": "r3 final (direct L-BFGS-B form, two-variable line search in registers, scalar arguments / loop ids / optimiser integers, "
+                "parked rows + shuffles two epochs ahead, image shortcut of the evaluation)"}
 f, w = table("headline_pmc_fetch_per_launch_mean.csv"), table("headline_pmc_write_per_launch_mean.csv")
 k = [x for x in f if x.startswith("iteration_kernel")][0]
 n, its = int(f[k]["launches"]), L * (steps + warm)
