@@ -229,6 +229,42 @@ def test_shuffle_stream_is_bit_exact_and_drives_fit(gpu):
         assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1]), N
 
 
+@pytest.mark.parametrize("D,units,acts,N,B,E", [
+    (2, [16, 16, 1], ["relu", "relu", "sigmoid"], 24, 64, 1),     # one epoch: nothing to draw ahead
+    (2, [16, 16, 1], ["relu", "relu", "sigmoid"], 24, 64, 2),     # two: both drawn before the loop
+    (2, [16, 16, 1], ["relu", "relu", "sigmoid"], 48, 64, 7),     # the last step just leaves the fourth wave idle
+    (2, [16, 16, 1], ["relu", "relu", "sigmoid"], 49, 64, 7),     # ... and just does not (no pipeline)
+    (2, [16, 16, 1], ["relu", "relu", "sigmoid"], 112, 64, 6),    # two steps per epoch, 64 + 48 rows
+    (2, [16, 16, 1], ["relu", "relu", "sigmoid"], 40, 32, 5),     # batch of 32: steps of 32 + 8 rows
+    (2, [16, 16, 1], ["relu", "relu", "sigmoid"], 100, 16, 3),    # seven steps per epoch, the last of 4 rows
+    (4, [16, 16, 1], ["tanh", "relu", "linear"], 33, 64, 9),      # four inputs (one k-chunk, all of it live)
+    (6, [32, 32, 1], ["elu", "elu", "linear"], 40, 64, 5),        # static shape 2: two k-chunks per parked row
+    (8, [32, 32, 1], ["relu", "relu", "sigmoid"], 90, 64, 4),
+])
+def test_parked_rows_and_shuffles_two_epochs_ahead_equal_explicit_shuffles(gpu, D, units, acts, N, B, E):
+    """Round 3: with device-drawn shuffles a static-shape fit whose last step leaves the fourth wave
+    idle parks every step's rows one step ahead and draws shuffles two epochs ahead (fit_body, pipe_perm).
+    An explicit permutation takes the step-by-step path: same stream, so the same bits -- weights, Adam
+    slots and the epoch losses -- at every boundary of the pipeline."""
+    rs = np.random.RandomState(N * 31 + B + E)
+    desc = _lib.make_desc(D, units, acts)
+    L = 3
+    th0 = np.stack([pack(rand_model(rs, D, units)) for _ in range(L)])
+    X = dev(rs.uniform(size=(L, N, D)), torch.float32)
+    z = dev((rs.uniform(size=(L, N)) < 0.3).astype(np.float32))
+    outs = []
+    for explicit in (False, True):
+        th = dev(th0)
+        m, v = torch.zeros_like(th), torch.zeros_like(th)
+        t = torch.zeros(L, dtype=torch.int64, device="cuda")
+        perm = ops.shuffle_perm(7, L, E, N, model_index0=1, epoch0=11) if explicit else None
+        loss = ops.mlp_fit(desc, th, m, v, t, X, z, E, B, perm=perm, seed=7, model_index0=1, epoch0=11)
+        outs.append([a.cpu().numpy() for a in (th, m, v, loss, t)])
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)
+    assert int(outs[0][4][0]) == E * O.steps_per_epoch(N, B)
+
+
 def test_replicas_are_independent_and_equal_single_model_runs(gpu):
     """The leading n_models dimension: L models in one launch == L launches of one."""
     rs = np.random.RandomState(1)
