@@ -758,7 +758,7 @@ __device__ __forceinline__ void lbfgsb_body(const LbfgsbArgs &a, const long long
           // the bits of the last evaluated point's gets that point's value and gradient -- what the
           // network would return -- without the evaluation.  A line search that fails in float32 noise
           // shrinks its step below the float32 spacing of x long before it gives up: a fifth of all
-          // requests (scratch/fp32_cache_hits.py; counted as evaluations all the same: SciPy's cache
+          // requests (tools/fp32_image_hits.py; counted as evaluations all the same: SciPy's cache
           // compares the float64 points).
           if (__float_as_uint((float)x0) == __float_as_uint((float)xl0) &&
               __float_as_uint((float)x1) == __float_as_uint((float)xl1)) {

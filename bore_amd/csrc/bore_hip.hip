@@ -14,7 +14,7 @@
 
 using namespace bore;
 
-// -DBORE_STAMPS: cycle stamps of one Adam step's phases (diagnostic builds only; scratch/stamps.py)
+// -DBORE_STAMPS: cycle stamps of one Adam step's phases (diagnostic builds only)
 #ifdef BORE_STAMPS
 __device__ long long g_stamps[64];
 #define BORE_STAMP(i)                                                                  \
