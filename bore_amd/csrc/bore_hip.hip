@@ -965,6 +965,16 @@ __device__ __forceinline__ void fit_body(const FitArgs &a, const long long slot,
   // compiler rotated with copies that waited for the request at once.)  Same permutations, same rows.
   const bool pipe_perm = SHAPE > 0 && !WIDE && !a.perm && PG >= 2 && blockDim.x == BORE_THREADS &&
                          a.data_in_lds && N - (steps - 1) * a.B <= 16 * (BORE_THREADS / 64 - 1);
+  // who draws the shuffles of the pipelined form: the fourth wave, two epochs ahead, while one pass
+  // ranks all keys (N <= 64); otherwise the whole workgroup, two epochs at the top of every odd epoch
+  // (see the epoch header).  (Tried: the pipelined form also for last steps of 49..64 rows, drawn by the
+  // workgroup -- 623 against 593 us per fit at N 48..67, profiles/r3/ab_headline.txt: those keep the
+  // four-epoch groups and the gather in the step.)
+#ifdef BORE_WAVE_DRAWS_ALWAYS  // (A/B builds: the mid-round-3 form)
+  const bool wave_draws = true;
+#else
+  const bool wave_draws = N <= 64;
+#endif
   constexpr int PRE_KC = RegNet<(SHAPE > 0 ? SHAPE : 1), 1>::KC0;
   static_assert(WIDE || SHAPE <= 0 || (PRE_KC + 1) * BORE_THREADS <= BORE_FIT_STAGE_FLOATS, "stage region");
   float *stage = smem + a.o_stage + tid;  // [PRE_KC + 1][BORE_THREADS]: inputs 4 kc + q4, then the label
@@ -1006,10 +1016,20 @@ __device__ __forceinline__ void fit_body(const FitArgs &a, const long long slot,
   // inside the step, the two forms met in blocks where the compiler waited for every pending request)
   auto run_epochs = [&](auto pipe_c) {
   constexpr bool PIPE = decltype(pipe_c)::value;
+  const int pmask = wave_draws ? 1 : 3;  // (PIPE) shuffle buffers in use: see the epoch header
   for (int e = 0; e < a.epochs; ++e) {
     FIT_MARK(12);
     if constexpr (PIPE) {  // (first: the test every step of the headline run takes)
-      perm_s = perm_all + (e & 1) * N;
+      // More than 64 rows: one wave cannot rank an epoch's keys inside a step's front half (~6 k cycles
+      // for 100 rows against 2.5 k: the row-block waves stood 5 k cycles per epoch at the mid-step
+      // barrier, fit marks at N = 100).  There the WHOLE workgroup draws two epochs' shuffles at the top
+      // of every odd epoch (make_perm_group, ~1 k cycles per epoch) for the two epochs that follow -- four
+      // buffers, epoch e in buffer e & 3 -- so that the next epoch's is always there for the rows parked
+      // during an epoch's last step.
+      if (!wave_draws && (e & 1) && e + 1 < a.epochs)
+        make_perm_group(a.seed, a.model0 + model, epoch0 + e + 1, min(2, a.epochs - e - 1), N, keys,
+                        perm_all + ((e + 1) & 2) * N);
+      perm_s = perm_all + (e & pmask) * N;
     } else if (a.perm) {
       if (a.perm_in_lds) {
         const int *pg = a.perm + (model * a.epochs + e) * (long long)N;
@@ -1059,7 +1079,7 @@ __device__ __forceinline__ void fit_body(const FitArgs &a, const long long slot,
           for (int kc = 0; kc < PRE_KC; ++kc) cx[kc] = stage[kc * BORE_THREADS];
           cz = stage[PRE_KC * BORE_THREADS];
           const bool last_s = s == steps - 1;
-          const int *perm_n = last_s ? perm_all + ((e + 1) & 1) * N : perm_s;
+          const int *perm_n = last_s ? perm_all + ((e + 1) & pmask) * N : perm_s;
           const int row0n = last_s ? 0 : row0 + a.B;
           const int nbn = last_s && e + 1 >= a.epochs ? 0 : min(a.B, N - row0n);
           live_n = wv * 16 + m16 < nbn;
@@ -1221,7 +1241,7 @@ __device__ __forceinline__ void fit_body(const FitArgs &a, const long long slot,
         float gx[PRE_KC], gz;
         request_row(gx, gz, src);
         park_row(gx, gz, live_n);
-        if (wv == BORE_THREADS / 64 - 1 && s == steps - 1 && e + 2 < a.epochs) {
+        if (wave_draws && wv == BORE_THREADS / 64 - 1 && s == steps - 1 && e + 2 < a.epochs) {
           // (an opaque copy keeps the epoch's hash in THIS wave's branch: wave-uniform scalar code is
           // otherwise hoisted in front of every wave's step)
           long long draw_epoch = epoch0 + e + 2;
@@ -2234,6 +2254,8 @@ static int fit_build(const bore_mlp_desc *desc, int n_models, float *theta, floa
   a.o_stage = (int)off; off += stage_f;  // each lane's share of its next-step row (fit_body)
   const int PG = perm ? 1 : perm_group(N, BORE_THREADS);  // epochs shuffled together (N <= 128)
   size_t perm_f = a.perm_in_lds ? (size_t)PG * N : 0, keys_f = perm ? 0 : (size_t)perm_group_scratch_floats(N, PG);
+  // (the pipelined fit of 65..128 rows keeps four epochs' shuffles: fit_body, pipe_perm)
+  if (!perm && stage_f && N <= 128 && perm_f < 4 * (size_t)N) perm_f = 4 * (size_t)N;
   if (g_batch)  // a slot's own N (<= this N) may shuffle more epochs together: room for each case
     for (long long nn : {(long long)(N < 64 ? N : 64), (long long)(N < 128 ? N : 128)}) {
       const int pg = perm_group(nn, BORE_THREADS);
@@ -2241,6 +2263,10 @@ static int fit_build(const bore_mlp_desc *desc, int n_models, float *theta, floa
       if ((size_t)perm_group_scratch_floats(nn, pg) > keys_f)
         keys_f = (size_t)perm_group_scratch_floats(nn, pg);
     }
+  if (g_batch && stage_f) {  // (a slot of up to 128 rows in pipelined form: four shuffles)
+    const size_t nn = N < 128 ? (size_t)N : 128;
+    if (perm_f < 4 * nn) perm_f = 4 * nn;
+  }
   a.o_perm = (int)off; off += perm_f;
   off = (off + 3) & ~(size_t)3;  // keys: 64-bit words fetched two at a time
   a.o_keys = (int)off; off += keys_f;

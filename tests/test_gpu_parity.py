@@ -234,6 +234,10 @@ def test_shuffle_stream_is_bit_exact_and_drives_fit(gpu):
     (2, [16, 16, 1], ["relu", "relu", "sigmoid"], 24, 64, 2),     # two: both drawn before the loop
     (2, [16, 16, 1], ["relu", "relu", "sigmoid"], 48, 64, 7),     # the last step just leaves the fourth wave idle
     (2, [16, 16, 1], ["relu", "relu", "sigmoid"], 49, 64, 7),     # ... and just does not (no pipeline)
+    (2, [16, 16, 1], ["relu", "relu", "sigmoid"], 64, 64, 8),
+    (2, [16, 16, 1], ["relu", "relu", "sigmoid"], 120, 64, 5),    # 64 + 56 rows: no pipeline
+    (2, [16, 16, 1], ["relu", "relu", "sigmoid"], 128, 64, 2),
+    (2, [16, 16, 1], ["relu", "relu", "sigmoid"], 129, 64, 3),    # more than 128 rows: no pipeline
     (2, [16, 16, 1], ["relu", "relu", "sigmoid"], 112, 64, 6),    # two steps per epoch, 64 + 48 rows
     (2, [16, 16, 1], ["relu", "relu", "sigmoid"], 40, 32, 5),     # batch of 32: steps of 32 + 8 rows
     (2, [16, 16, 1], ["relu", "relu", "sigmoid"], 100, 16, 3),    # seven steps per epoch, the last of 4 rows
