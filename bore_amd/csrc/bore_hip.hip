@@ -1023,7 +1023,7 @@ __device__ __forceinline__ void fit_body(const FitArgs &a, const long long slot,
       // More than 64 rows: one wave cannot rank an epoch's keys inside a step's front half (~6 k cycles
       // for 100 rows against 2.5 k: the row-block waves stood 5 k cycles per epoch at the mid-step
       // barrier, fit marks at N = 100).  There the WHOLE workgroup draws two epochs' shuffles at the top
-      // of every odd epoch (make_perm_group, ~1 k cycles per epoch) for the two epochs that follow -- four
+      // of every odd epoch (make_perm_group, ~2.2 k cycles per epoch at 100 rows) for the two that follow -- four
       // buffers, epoch e in buffer e & 3 -- so that the next epoch's is always there for the rows parked
       // during an epoch's last step.
       if (!wave_draws && (e & 1) && e + 1 < a.epochs)
