@@ -189,3 +189,20 @@ def test_callable_transforms_are_applied_on_the_host():
         CallableTransform(lambda u: 3.0).value_and_derivative(f)
     with pytest.raises(TypeError):
         resolve(3)
+
+
+def test_tools_and_committed_measurements_are_readable():
+    """The GPU-box scripts under tools/ at least compile, and the judged measurement files of the current
+    round parse (a bench.py run reads profiles/r3/pmc_traffic.json and loops_sweep.json)."""
+    import glob, json, os, py_compile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    scripts = glob.glob(os.path.join(root, "tools", "*.py"))
+    assert len(scripts) >= 10
+    for path in scripts:
+        py_compile.compile(path, doraise=True)
+    traffic = json.load(open(os.path.join(root, "profiles", "r3", "pmc_traffic.json")))
+    assert traffic["iteration_kernel"]["hbm_bytes_per_model"] > 0
+    sweep = json.load(open(os.path.join(root, "profiles", "r3", "loops_sweep.json")))
+    assert set(sweep["it_per_s"]) >= {"64", "512"}
+    line = json.loads(open(os.path.join(root, "profiles", "r3", "bench_driver_form.json")).read().strip().splitlines()[-1])
+    assert line["unit"] == "BO-iterations/s" and line["roofline"]["frac"] > 0 and line["cpu_baseline"]["value"] > 0
