@@ -238,7 +238,11 @@ def test_shuffle_stream_is_bit_exact_and_drives_fit(gpu):
     (2, [16, 16, 1], ["relu", "relu", "sigmoid"], 120, 64, 5),    # 64 + 56 rows: no pipeline
     (2, [16, 16, 1], ["relu", "relu", "sigmoid"], 128, 64, 2),
     (2, [16, 16, 1], ["relu", "relu", "sigmoid"], 129, 64, 3),    # more than 128 rows: no pipeline
-    (2, [16, 16, 1], ["relu", "relu", "sigmoid"], 112, 64, 6),    # two steps per epoch, 64 + 48 rows
+    (2, [16, 16, 1], ["relu", "relu", "sigmoid"], 112, 64, 6),    # two steps per epoch, 64 + 48 rows: the workgroup draws
+    (2, [16, 16, 1], ["relu", "relu", "sigmoid"], 100, 64, 1),    # ... one epoch, two, three (an odd epoch without successors)
+    (2, [16, 16, 1], ["relu", "relu", "sigmoid"], 100, 64, 2),
+    (2, [16, 16, 1], ["relu", "relu", "sigmoid"], 65, 64, 3),
+    (2, [16, 16, 1], ["relu", "relu", "sigmoid"], 90, 64, 11),
     (2, [16, 16, 1], ["relu", "relu", "sigmoid"], 40, 32, 5),     # batch of 32: steps of 32 + 8 rows
     (2, [16, 16, 1], ["relu", "relu", "sigmoid"], 100, 16, 3),    # seven steps per epoch, the last of 4 rows
     (4, [16, 16, 1], ["tanh", "relu", "linear"], 33, 64, 9),      # four inputs (one k-chunk, all of it live)
