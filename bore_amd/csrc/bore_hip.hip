@@ -11,6 +11,7 @@
 #include "mlp_device.h"
 #include "mlp_regs.h"
 #include "fit_bf16_mfma.h"
+#include "arg_bf16_mfma.h"
 
 using namespace bore;
 
@@ -139,12 +140,32 @@ struct FitArgs {
   long long cap;
 };
 
+// The fit's arithmetic is "at most 1 ulp per operation", not IEEE-correctly-rounded: square root,
+// reciprocal and exp2 are the hardware's v_sqrt_f32 / v_rcp_f32 / v_exp_f32 (1 ulp each).  TensorFlow's
+// own Eigen kernels are not correctly rounded either; the parity gate is the oracle
+// tolerance of tests/test_gpu_parity.py, not the bits of a previous build.  The correctly rounded forms
+// (ocml expf, IEEE division and sqrt: ~30 dependent instructions per updated register) were 0.8 - 1.2 k
+// cycles of a 3.3 - 3.7 k-cycle Adam step (profiles/r3/fit_marks_final.txt).  The L-BFGS-B (fp64,
+// lbfgsb.h) and the objective evaluation keep their IEEE forms.
+__device__ __forceinline__ float fit_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float fit_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+// exp(x) for x <= 0: 2^(x log2 e) with the product's rounding error fed back (the argument's error
+// would otherwise be |x| 2^-24 in the exponent); flushes to zero below 2^-126 like the result's use
+// (1 + e) does not notice
+__device__ __forceinline__ float fit_exp_neg(float x) {
+  const float L2E = 1.442695040888963f, L2E_LO = 1.925963033500e-8f;  // log2(e) = hi + lo
+  const float t = x * L2E;
+  const float r = fmaf(x, L2E_LO, fmaf(x, L2E, -t));                 // exact remainder of the product
+  const float e = __builtin_amdgcn_exp2f(t);
+  return fmaf(e, r * 0.6931471805599453f, e);                          // 2^(t + r) = 2^t (1 + r ln 2)
+}
+
 // Adam update of one parameter (ResourceApplyAdam, non-nesterov); returns the new weight.
 __device__ __forceinline__ float adam_update(float w, float g, float &m, float &v, float alpha,
                                              float omb1, float omb2, float eps) {
   m += (g - m) * omb1;
   v += (g * g - v) * omb2;
-  return w - (m * alpha) / (sqrtf(v) + eps);
+  return fmaf(-(m * alpha), fit_rcp(fit_sqrt(v) + eps), w);
 }
 
 // Weight gradients + Adam for a static shape, NBLK = row-blocks of the batch that hold live
@@ -1052,6 +1073,7 @@ __device__ __forceinline__ void fit_body(const FitArgs &a, const long long slot,
       FIT_MARK(14);
       const int row0 = s * a.B;
       const int nb = min(a.B, N - row0);
+      const float inv_nb = fit_rcp((float)nb);  // (wave-uniform; the mean over the step's rows as a multiply)
       const float alpha = first_step ? alpha_first : misc[5];
       first_step = false;
       float reg = 0.f;
@@ -1159,11 +1181,11 @@ __device__ __forceinline__ void fit_body(const FitArgs &a, const long long slot,
           float delta = 0.f;
           if (lane < 16 && live) {
             const float x = net.h[Net::n][0][0];
-            const float ex = expf(-fabsf(x));
-            const float den = 1.f + ex;
-            const float sig = x >= 0.f ? 1.f / den : ex / den;
+            const float ex = fit_exp_neg(-fabsf(x));
+            const float rden = fit_rcp(1.f + ex);
+            const float sig = x >= 0.f ? rden : ex * rden;
             if (a.epoch_loss) eloss += fmaxf(x, 0.f) - x * zz + log1pf(ex);
-            delta = (sig - zz) / (float)nb;
+            delta = (sig - zz) * inv_nb;
           }
           if (lane < 16) {
             if constexpr (ROUNDS) {
@@ -1217,12 +1239,12 @@ __device__ __forceinline__ void fit_body(const FitArgs &a, const long long slot,
           if (row < nr) {
             const float x = tile[L.aoff[n] + row * L.lda[n]];
             const float zz = zt[row];
-            const float ex = expf(-fabsf(x));  // shared by the loss and the sigmoid
-            const float den = 1.f + ex;
-            const float sig = x >= 0.f ? 1.f / den : ex / den;
+            const float ex = fit_exp_neg(-fabsf(x));  // shared by the loss and the sigmoid
+            const float rden = fit_rcp(1.f + ex);
+            const float sig = x >= 0.f ? rden : ex * rden;
             if (a.epoch_loss)  // per-lane; reduced once per epoch
               eloss += fmaxf(x, 0.f) - x * zz + log1pf(ex);
-            delta = (sig - zz) / (float)nb;
+            delta = (sig - zz) * inv_nb;
           }
           tile[L.doff[n] + row * L.lda[n]] = delta;
         }
@@ -1546,6 +1568,7 @@ __global__ __launch_bounds__(BORE_THREADS) void fit_bf16_kernel(const FitBf16Arg
     for (int s = 0; s < steps; ++s) {
       const int row0 = s * a.B;
       const int nb = min(a.B, N - row0);
+      const float inv_nb = fit_rcp((float)nb);  // (wave-uniform; the mean over the step's rows as a multiply)
       const float alpha = first_step ? alpha_first : misc[5];
       first_step = false;
       BORE_WSTAMP_DECL;
@@ -1574,11 +1597,11 @@ __global__ __launch_bounds__(BORE_THREADS) void fit_bf16_kernel(const FitBf16Arg
         float delta = 0.f;
         if (lane < 16 && live) {
           const float x = net.h[n][0][0];
-          const float ex = expf(-fabsf(x));
-          const float den = 1.f + ex;
-          const float sig = x >= 0.f ? 1.f / den : ex / den;
+          const float ex = fit_exp_neg(-fabsf(x));
+          const float rden = fit_rcp(1.f + ex);
+          const float sig = x >= 0.f ? rden : ex * rden;
           if (a.epoch_loss) eloss += fmaxf(x, 0.f) - x * zz + log1pf(ex);
-          delta = bf16_round((sig - zz) / (float)nb);
+          delta = bf16_round((sig - zz) * inv_nb);
         }
         if (lane < 16) tile16[L.doff[n] + row * L.lda[n]] = f32_to_bf16(delta);
         net.set_output_delta(delta);
@@ -1698,6 +1721,7 @@ __global__ __launch_bounds__(BORE_THREADS) void fit_bf16_mfma_kernel(const FitBf
     for (int s = 0; s < steps; ++s) {
       const int row0 = s * a.B;
       const int nb = min(a.B, N - row0);
+      const float inv_nb = fit_rcp((float)nb);  // (wave-uniform; the mean over the step's rows as a multiply)
       const float alpha = first_step ? alpha_first : misc[5];
       first_step = false;
       BORE_WSTAMP_DECL;
@@ -1740,11 +1764,11 @@ __global__ __launch_bounds__(BORE_THREADS) void fit_bf16_mfma_kernel(const FitBf
         float delta = 0.f;
         if (lane < 16 && live) {
           const float x = net.h[n][0][0];
-          const float ex = expf(-fabsf(x));
-          const float den = 1.f + ex;
-          const float sig = x >= 0.f ? 1.f / den : ex / den;
+          const float ex = fit_exp_neg(-fabsf(x));
+          const float rden = fit_rcp(1.f + ex);
+          const float sig = x >= 0.f ? rden : ex * rden;
           if (a.epoch_loss) eloss += fmaxf(x, 0.f) - x * zz + log1pf(ex);
-          delta = bf16_round_hw((sig - zz) / (float)nb);
+          delta = bf16_round_hw((sig - zz) * inv_nb);
         }
 #pragma unroll
         for (int t = 0; t < Net::TM; ++t)
@@ -2010,13 +2034,49 @@ __global__ __launch_bounds__(BORE_THREADS) void rows_kernel(const RowArgs a) {
   const long long model = blockIdx.x;
   const int n = layer_count<SHAPE>(L), D = L.w[0];
   float *th = smem, *tile = smem + a.o_tile, *vals = smem + a.o_vals;
-  stage_theta<BF16>(L, n, a.theta + model * L.P, smem);
+  if constexpr (BF16) arg_bf16_stage<SHAPE>(a.theta + model * L.P, smem);
+  else stage_theta<false>(L, n, a.theta + model * L.P, smem);
   __syncthreads();
-  const int waves = L.tbp >> 4;  // waves that own a 16-row slice of the tile buffers
+  // waves that own a 16-row slice of the tile buffers (the bf16-MFMA form has no tile: all four)
+  const int waves = BF16 ? BORE_THREADS / 64 : L.tbp >> 4;
   if (wv >= waves) return;
   const long long xoff = a.x_shared ? 0 : model * a.n_rows * D;
   float *out = a.out + model * a.n_rows;
   const long long n_blocks = (a.n_rows + 15) >> 4;
+  if constexpr (BF16) {  // a bfloat16 model: the bf16 matrix cores (arg_bf16_mfma.h)
+    static_assert(!BF16 || bore_shape_is_wide(SHAPE), "bfloat16: wide static shapes");
+    using ANet = ArgBf16Net<SHAPE>;
+    const ArgBf16Images im = arg_bf16_images<SHAPE>(smem);
+    ANet net;
+    net.set_acts(a.L);
+    for (long long g = (long long)blockIdx.y * waves + wv; g < n_blocks;
+         g += (long long)gridDim.y * waves) {
+      const long long row = g * 16 + m16;
+      bf16x8_t xf[ANet::CF1];
+      ANet::make_xfrag(xf, [&](int d) -> float {
+        if (d >= D || row >= a.n_rows) return 0.f;
+        return WITH_GRAD ? (float)a.Xd[xoff + row * D + d] : a.Xf[xoff + row * D + d];  // Keras autocast
+      });
+      if (WITH_GRAD) {
+        const float Tv = net.fg(im, xf, a.transform, a.sign);
+        if (lane < 16 && row < a.n_rows) out[row] = Tv;
+        double *grad = a.grad + (model * a.n_rows) * D;
+        if (row < a.n_rows) {
+#pragma unroll
+          for (int t = 0; t < ANet::T0; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int d = 16 * t + 4 * q4 + r;
+              if (d < D) grad[row * D + d] = (double)net.d[0][t][r];
+            }
+        }
+      } else {
+        net.predict(im.wf, im.bias, xf);
+        if (lane < 16 && row < a.n_rows) out[row] = net.h[ANet::n][0][0];
+      }
+    }
+    return;
+  }
   using Net = RegNet<(SHAPE > 0 ? SHAPE : 1), WITH_GRAD ? 2 : 0, BF16>;
   const typename Net::WT *thw = reinterpret_cast<const typename Net::WT *>(smem);
   Net net;  // static shapes: the weights stay in this lane's registers for every row-block
@@ -2462,12 +2522,14 @@ static int fit_bf16_impl(const bore_mlp_desc *desc, int n_models, float *theta, 
 static int row_launch(bool with_grad, int n_models, RowArgs &a, void *stream) {
   const MlpLayout &L = a.L;
   size_t off = L.P_lds;
-  a.o_tile = (int)off; off += L.tile_floats;
+  // (a bfloat16 model: the fragment-order weight images of arg_bf16_mfma.h, and no tile)
+  if (a.bf16) off = a.shape == 3 ? ArgBf16Plan<3>::floats : ArgBf16Plan<4>::floats;
+  a.o_tile = (int)off; off += a.bf16 ? 0 : L.tile_floats;
   a.o_vals = (int)off; off += BORE_BATCH_MAX;  // objective values of the tile rows
   a.total = (int)off;
   off = (off + 3) & ~(size_t)3;
   a.o_layout = (int)off; off += BORE_LAYOUT_FLOATS;
-  const int waves = L.tbp >> 4;
+  const int waves = a.bf16 ? BORE_THREADS / 64 : L.tbp >> 4;
   const long long n_blocks = (a.n_rows + 15) / 16;
   // enough workgroups to fill 256 CUs a few times over, never more than there is work
   long long gy = (n_blocks + waves - 1) / waves;
