@@ -12,6 +12,7 @@
 #include "mlp_device.h"
 #include "mlp_regs.h"
 #include "mlp_point.h"
+#include "arg_bf16_mfma.h"
 
 using namespace bore;
 
@@ -208,7 +209,10 @@ __device__ __forceinline__ void screen_body(const ScreenArgs &a, const long long
   float *th = smem, *tile = smem + a.o_tile;
   unsigned long long *keys = reinterpret_cast<unsigned long long *>(smem + a.o_keys);
   const int wv = tid >> 6, lane = tid & 63, m16 = lane & 15, q4 = lane >> 4;
-  if constexpr (MODE != 2) stage_theta<BF16>(L, n, a.theta + lid * L.P, smem);
+  if constexpr (MODE != 2) {
+    if constexpr (BF16) arg_bf16_stage<SHAPE>(a.theta + lid * L.P, smem);  // (arg_bf16_mfma.h)
+    else stage_theta<false>(L, n, a.theta + lid * L.P, smem);
+  }
   const double *X = a.sampled ? nullptr : a.X + (a.x_shared ? 0 : model * a.n_samples * D);
   double *blo = reinterpret_cast<double *>(smem + a.o_box), *bhi = blo + D;
   if (a.sampled && tid < D) {  // the box is indexed per lane: LDS copy
@@ -236,17 +240,26 @@ __device__ __forceinline__ void screen_body(const ScreenArgs &a, const long long
   using Net = RegNet<(SHAPE > 0 ? SHAPE : 1), 0, BF16>;
   const typename Net::WT *thw = reinterpret_cast<const typename Net::WT *>(smem);
   Net net;  // static shapes: the weights stay in this lane's registers for every row-block
-  if constexpr (SHAPE > 0 && MODE != 2) {
+  if constexpr (SHAPE > 0 && MODE != 2 && !BF16) {
     if constexpr (Net::RT_ACT) net.set_acts(a.L);
     net.load_fwd(thw);
   }
+  using ANet = ArgBf16Net<(BF16 ? SHAPE : 3)>;  // a bfloat16 model: the bf16 matrix cores
+  ANet anet;
+  if constexpr (BF16 && MODE != 2) anet.set_acts(a.L);
   const int g0 = MODE == 1 ? wv + waves * (int)blockIdx.y : wv;
   const int gs = MODE == 1 ? waves * (int)gridDim.y : waves;
   if (MODE != 2 && wv < waves)
     for (int g = g0; g < n_blocks; g += gs) {
       const int row = g * 16 + m16;
       float p;  // prediction of row g*16 + lane, in the lanes < 16
-      if constexpr (SHAPE > 0) {  // activations in registers (mlp_regs.h)
+      if constexpr (BF16) {
+        static_assert(!BF16 || bore_shape_is_wide(SHAPE), "bfloat16: wide static shapes");
+        bf16x8_t xf[ANet::CF1];
+        ANet::make_xfrag(xf, [&](int d) -> float { return (d < D && row < Ns) ? (float)xval(row, d) : 0.f; });
+        anet.predict(arg_bf16_images<SHAPE>(smem).wf, arg_bf16_images<SHAPE>(smem).bias, xf);
+        p = anet.h[ANet::n][0][0];
+      } else if constexpr (SHAPE > 0) {  // activations in registers (mlp_regs.h)
         float xin[Net::KC0];
 #pragma unroll
         for (int kc = 0; kc < Net::KC0; ++kc) {
@@ -376,7 +389,11 @@ static int screen_build(const bore_mlp_desc *desc, int n_models, const float *th
     }
   }
   size_t off = a.L.P_lds;
-  a.o_tile = (int)off; off += a.L.tile_floats;
+  const int flav = bore_kernel_flavour(desc, true);
+  const bool bf_img = desc->compute == BORE_COMPUTE_BF16 && bore_shape_is_wide(flav);
+  // (a bfloat16 model: the fragment-order images of arg_bf16_mfma.h, activations in registers)
+  if (bf_img) off = flav == 3 ? ArgBf16Plan<3>::floats : ArgBf16Plan<4>::floats;
+  a.o_tile = (int)off; off += bf_img ? 0 : a.L.tile_floats;
   off = (off + 3) & ~(size_t)3;
   a.o_box = (int)off; off += 4 * (size_t)desc->input_dim;
   off = (off + 1) & ~(size_t)1;
@@ -540,6 +557,9 @@ struct LbfgsbArgs {
   int nbd[BORE_DIM_MAX];
   lbfgsb::Options opt;
   int R, PB, transform, max_rounds;  // PB = problems per workgroup
+  // queue != 0: one problem per wave at a time, PB may exceed the waves: a wave that finishes a problem
+  // draws the workgroup's next one from a counter in LDS (o_queue) and reuses its workspace slot
+  int queue, o_queue;
   float sign;
   // LDS carve (float offsets; the fp64 regions are 8-byte aligned)
   int o_tile, o_vals, o_box, o_prob, prob_floats, o_state, o_dw, o_iw, o_layout, total;
@@ -613,7 +633,8 @@ __device__ __forceinline__ void lbfgsb_body(const LbfgsbArgs &a, const long long
     bhi[tid] = a.box.hi[tid];
     bnbd[tid] = a.nbd[tid];
   }
-  stage_theta<BF16>(L, n_lay, a.theta + lid * L.P, smem);
+  if constexpr (BF16) arg_bf16_stage<SHAPE>(a.theta + lid * L.P, smem);  // (arg_bf16_mfma.h)
+  else stage_theta<false>(L, n_lay, a.theta + lid * L.P, smem);
   __syncthreads();
 
   // Which problem this thread works on.  With at most one problem per wave (np <= 4: the
@@ -629,8 +650,18 @@ __device__ __forceinline__ void lbfgsb_body(const LbfgsbArgs &a, const long long
 #endif
   const int NW = (int)(blockDim.x >> 6);
   const bool multi = a.result && np > 4 && np <= 16;
-  const bool coop = np <= NW || multi;
-  const int passes = multi ? (np + 3) / 4 : 1;
+  // Many problems per workgroup, one per wave at a time (a.queue, round 4).  Round 3 launched one
+  // workgroup per 4 (8) restarts: every workgroup zeroed its LDS and staged the model's weights for
+  // four problems, and lived as long as the SLOWEST of them while the other waves idled.  Now a model's
+  // restarts go to a few workgroups with hundreds of problems each, and a wave that finishes one draws
+  // the next from a counter in LDS: the weights are staged once per workgroup, the waves stay busy
+  // until the workgroup's problems run out.  Same results (a problem's arithmetic does not depend on
+  // the wave or the order).
+  const bool queue = a.queue != 0;
+  const bool coop = np <= NW || multi || queue;
+  const int passes = multi ? (np + 3) / 4 : (queue ? 0x7fffffff : 1);
+  int *qnext = reinterpret_cast<int *>(smem + a.o_queue);
+  if (queue && tid == 0) *qnext = NW;  // (the first NW problems go to the waves in order)
   const int myrow = coop ? wv * 16 : wv * 16 + lane;
   // (ALWAYS_COOP kernels run one problem per wave or nothing: the lane count is a compile-time 64
   // there, which is what lets lbfgsb.h's LB_UNI move the optimiser's integers to scalar registers)
@@ -641,8 +672,18 @@ __device__ __forceinline__ void lbfgsb_body(const LbfgsbArgs &a, const long long
   double *res = reinterpret_cast<double *>(smem + a.o_res);  // batch mode: [np][D + 3] fun, status, nfev, x
   int *cnt = reinterpret_cast<int *>(res + (multi ? np : 4) * (D + 3));
   for (int pass = 0; pass < passes; ++pass) {
-  const int myp = coop ? (wv + 4 * pass < np ? wv + 4 * pass : -1)
-                       : ((lane < 16 && lane * 4 + wv < np) ? lane * 4 + wv : -1);
+  int myp;
+  if (queue) {
+    int nxt = wv;
+    if (pass > 0) {
+      if (lane == 0) nxt = atomicAdd(qnext, 1);
+      nxt = __builtin_amdgcn_readfirstlane(nxt);
+    }
+    myp = nxt < np ? nxt : -1;
+  } else {
+    myp = coop ? (wv + 4 * pass < np ? wv + 4 * pass : -1)
+               : ((lane < 16 && lane * 4 + wv < np) ? lane * 4 + wv : -1);
+  }
   if (coop && myp < 0) break;
   // The scalar state of the optimiser stays in this thread's REGISTERS for the whole launch
   // (its vectors and matrices are in LDS): kept in memory, every store to a workspace array
@@ -650,7 +691,12 @@ __device__ __forceinline__ void lbfgsb_body(const LbfgsbArgs &a, const long long
   lbfgsb::State st;
   lbfgsb::Work wk;
   if (myp >= 0) {
-    float *base = smem + a.o_prob + (size_t)myp * a.prob_floats;
+    float *base = smem + a.o_prob + (size_t)(queue ? wv : myp) * a.prob_floats;  // (queue: the wave's slot)
+    if (queue && pass > 0) {  // a reused slot starts as the zeroed LDS a first problem finds (prob_floats % 4 == 0)
+      float4 *b4 = reinterpret_cast<float4 *>(base);
+      for (int i = lane; i < a.prob_floats / 4; i += 64) b4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      wave_lds_sync();
+    }
     wk = lbfgsb::make_work(reinterpret_cast<double *>(base + a.o_dw),
                            reinterpret_cast<int *>(base + a.o_iw), D, a.opt.m);
     const double *x0 = a.x0 + (model * a.R + p0 + myp) * (long long)D;
@@ -666,7 +712,7 @@ __device__ __forceinline__ void lbfgsb_body(const LbfgsbArgs &a, const long long
   using Net = RegNet<(SHAPE > 0 ? SHAPE : 1), 2, BF16>;
   const typename Net::WT *thw = reinterpret_cast<const typename Net::WT *>(smem);
   Net net;
-  if constexpr (SHAPE > 0) {
+  if constexpr (SHAPE > 0 && !BF16) {
     if constexpr (Net::RT_ACT) net.set_acts(a.L);
     if constexpr (!LEAN) {
       if (!(coop && BORE_POINT_SHAPE(SHAPE))) {  // (one point per wave goes through PointNet: no matrix operands)
@@ -675,6 +721,13 @@ __device__ __forceinline__ void lbfgsb_body(const LbfgsbArgs &a, const long long
       }
     }
   }
+  // A bfloat16 model: every evaluation -- one point per wave included -- is a 16-row pass over the bf16
+  // matrix cores (arg_bf16_mfma.h): 84 matrix instructions for 32->128-128-1 where the vector-ALU chain
+  // of mlp_point.h took 25 k cycles.
+  static_assert(!BF16 || bore_shape_is_wide(SHAPE), "bfloat16: wide static shapes");
+  using ANet = ArgBf16Net<(BF16 ? SHAPE : 3)>;
+  ANet anet;
+  if constexpr (BF16) anet.set_acts(a.L);
   bool done = (myp < 0);
   const long long c_init = BORE_LCLOCK();
   long long t_adv = 0, t_fg = 0, n_rounds = 0;
@@ -705,13 +758,29 @@ __device__ __forceinline__ void lbfgsb_body(const LbfgsbArgs &a, const long long
             return;
           }
         }
-        if constexpr (LEAN) {
+        if constexpr (LEAN && !BF16) {
           if (!BORE_POINT_SHAPE(SHAPE)) {
             net.load_fwd(thw);
             net.template load_bwd<Net::n, 1>(thw);
           }
         }
-        if constexpr (BORE_POINT_SHAPE(SHAPE)) {
+        if constexpr (BF16) {
+          // every row of the wave's block is the point, read from the optimiser's fp64 x (autocast)
+          bf16x8_t xf[ANet::CF1];
+          ANet::make_xfrag(xf, [&](int d) -> float { return d < D ? (float)w.x[d] : 0.f; });
+          __builtin_amdgcn_sched_barrier(0);
+          const float Tv = anet.fg(arg_bf16_images<SHAPE>(smem), xf, a.transform, a.sign);
+          s.f = (double)__uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(Tv)));
+          if (m16 == 0) {
+#pragma unroll
+            for (int t = 0; t < ANet::T0; ++t)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const int d = 16 * t + 4 * q4 + r;
+                if (d < D) w.g[d] = (double)anet.d[0][t][r];
+              }
+          }
+        } else if constexpr (BORE_POINT_SHAPE(SHAPE)) {
           // one point per wave, on the vector ALU (mlp_point.h: the same k-ordered fmaf chains as the
           // matrix path, 1 / 16 of its arithmetic); x straight from the optimiser's fp64 vector (Keras
           // autocast fp64 -> fp32)
@@ -819,16 +888,25 @@ __device__ __forceinline__ void lbfgsb_body(const LbfgsbArgs &a, const long long
       // s < 16 owns row s (a wave's single problem takes the DIRECT form above)
       const int m16 = lane & 15, q4 = lane >> 4;
       float xin[Net::KC0];
-      if constexpr (LEAN) {
+      if constexpr (LEAN && !BF16) {
         net.load_fwd(thw);
         net.template load_bwd<Net::n, 1>(thw);
       }
       const float *A0 = tile + L.aoff[0] + (wv * 16 + m16) * L.lda[0];
+      float Tv;
+      if constexpr (BF16) {
+        bf16x8_t xf[ANet::CF1];
+        ANet::make_xfrag(xf, [&](int d) -> float { return d < D ? A0[d] : 0.f; });
+        __builtin_amdgcn_sched_barrier(0);
+        Tv = anet.fg(arg_bf16_images<SHAPE>(smem), xf, a.transform, a.sign);
+        Net::template store_rows_f32<0>(anet.d[0], tile + BORE_BATCH_MAX * L.lda[0], wv);
+      } else {
 #pragma unroll
-      for (int kc = 0; kc < Net::KC0; ++kc) xin[kc] = Net::rnd(A0[4 * kc + q4]);
-      __builtin_amdgcn_sched_barrier(0);
-      const float Tv = net.fg(thw, xin, a.transform, a.sign);
-      Net::template store_rows_f32<0>(net.d[0], tile + BORE_BATCH_MAX * L.lda[0], wv);
+        for (int kc = 0; kc < Net::KC0; ++kc) xin[kc] = Net::rnd(A0[4 * kc + q4]);
+        __builtin_amdgcn_sched_barrier(0);
+        Tv = net.fg(thw, xin, a.transform, a.sign);
+        Net::template store_rows_f32<0>(net.d[0], tile + BORE_BATCH_MAX * L.lda[0], wv);
+      }
       wave_lds_sync();
       if (pending) {  // lane s < 16 owns row s: its value is already in this lane
         st.f = (double)Tv;
@@ -1060,6 +1138,10 @@ static int lbfgsb_build(const bore_mlp_desc *desc, int n_models, const float *th
     // reserved the float size, which left BASELINE config 5 -- 128-128-1 -- room for three problems per
     // workgroup and kept it out of the eight-wave kernel; with the true size six fit.)
     off = desc->compute == BORE_COMPUTE_BF16 ? ((size_t)a.L.P_lds + 1) / 2 : (size_t)a.L.P_lds;
+    // (round 4: wide static shapes in bfloat16 hold the fragment-order images of arg_bf16_mfma.h -- forward
+    // and backward operands of the bf16 matrix instructions, about twice the plain bfloat16 image)
+    if (desc->compute == BORE_COMPUTE_BF16 && bore_shape_is_wide(flavour))
+      off = flavour == 3 ? ArgBf16Plan<3>::floats : ArgBf16Plan<4>::floats;
     off = (off + 3) & ~(size_t)3;
     a.o_tile = (int)off;
     // (one problem per wave -- up to 4 problems, 8 in the eight-wave kernel, 16 in batch mode -- reads
@@ -1074,13 +1156,30 @@ static int lbfgsb_build(const bore_mlp_desc *desc, int n_models, const float *th
     off = (off + 3) & ~(size_t)3;
     a.o_res = (int)off;  // batch mode: [max(R, 4)][D + 3] fp64 + the finished-problem counter
     off += g_batch ? 2 * (size_t)(num_starts > 4 ? num_starts : 4) * ((size_t)D + 3) + 4 : 0;
+    a.o_queue = (int)off; off += 4;  // (the queue's next-problem counter)
     a.total = (int)off;
     off = (off + 3) & ~(size_t)3;
     a.o_layout = (int)off; off += BORE_LAYOUT_FLOATS;
     if (off * 4 <= BORE_LDS_BYTES) break;
   }
+  // One problem per wave and many restarts per model: a few workgroups per model, each drawing its
+  // share of the restarts from a queue (lbfgsb_body).  About four workgroups per CU over the launch;
+  // BORE_LBFGSB_QUEUE = 0 keeps one workgroup per PB restarts, = n > 0 asks for n workgroups in all
+  // (A/B, tests).
+  const int slots = PB;  // workspaces = waves with a problem
+  a.queue = 0;
+  const long long q_env = getenv("BORE_LBFGSB_QUEUE") ? atoll(getenv("BORE_LBFGSB_QUEUE")) : -1;
+  if (!g_batch && PB <= (w8 ? 8 : 4) && num_starts > PB && q_env != 0) {
+    const long long want = q_env > 0 ? q_env : 4LL * device_cus();
+    long long per_model = (want + n_models - 1) / n_models;
+    const long long most = (num_starts + slots - 1) / slots;
+    if (per_model > most) per_model = most;
+    if (per_model < 1) per_model = 1;
+    PB = (int)((num_starts + per_model - 1) / per_model);
+    a.queue = PB > slots;
+  }
   a.PB = PB;
-  if (waves_out) *waves_out = w8 && PB > 4 ? PB : 4;
+  if (waves_out) *waves_out = w8 && slots > 4 ? slots : 4;
   if (a.L.w[a.L.n_layers] != 1)
     return fail(BORE_E_INVALID, "lbfgsb_minimize: the last Dense layer must have 1 unit");
   a.theta = theta; a.x0 = x0; a.x = x; a.fun = fun; a.jac = jac; a.info = info;
@@ -1172,7 +1271,7 @@ extern "C" int bore_lbfgsb_minimize(const bore_mlp_desc *desc, int n_models, con
     const bool many = (long long)n_models * blocks > device_cus();
 #if BORE_ON_2
     // (one problem per wave only: the kernel does not carry the lane-per-problem loop)
-    if (flavour == 2 && a.PB <= 4 && off * 4 <= BORE_LDS_BYTES / 2 && (forced < 0 ? many : forced != 0)) {
+    if (flavour == 2 && (a.PB <= 4 || a.queue) && off * 4 <= BORE_LDS_BYTES / 2 && (forced < 0 ? many : forced != 0)) {
       rc = allow_lds(lbfgsb_kernel_occ2<2>, off * 4);
       if (rc) return rc;
       hipLaunchKernelGGL(lbfgsb_kernel_occ2<2>, dim3(n_models, blocks), dim3(BORE_THREADS), off * 4,

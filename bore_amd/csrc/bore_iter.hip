@@ -36,6 +36,11 @@ struct IterArgs {
   int *parked;               // pinned [n_loops]: the iteration this workgroup left to a later launch
   const int *abort_flag;     // pinned [1]: non-zero = stop waiting
   long long wait_ticks;
+  // Resident launches: loop-iterations finished by the whole grid since the launch (zeroed by the
+  // upload of this block; device copy only, touched with agent-scope atomics and never through the
+  // constant-address-space view of the block).  A loop behind the grid's mean raises its waves'
+  // priority, one ahead lowers it (iteration_kernel).
+  int progress;
 };
 
 // 64-bit load from host memory that the host may have written since the kernel started
@@ -62,6 +67,9 @@ __device__ __forceinline__ double load_host_f64(const double *p) {
 #endif
 #ifndef BORE_ITER_ONCE_ATTR
 #define BORE_ITER_ONCE_ATTR __forceinline__
+#endif
+#ifndef BORE_LAG_PRIO
+#define BORE_LAG_PRIO 1
 #endif
 template <int SHAPE>
 __device__ BORE_ITER_ONCE_ATTR void iteration_once(const IterArgs *__restrict__ pa,
@@ -149,7 +157,30 @@ __global__ __launch_bounds__(BORE_THREADS, 2) void iteration_kernel(const IterAr
   }
   __shared__ __attribute__((aligned(16))) int s_go4[4];  // (16 B: the dynamic LDS keeps its alignment)
   const int target = pa->targets ? uniform_i32(pa->targets[slot]) : it_first + 1;
+#if BORE_LAG_PRIO
+  // Two loops share a CU (512 loops on 256 CUs) and their waves share the SIMDs' issue slots.  The
+  // timed region of K iterations ends with the SLOWEST loop -- loops whose restarts need twice the
+  // evaluations, 1.45x the mean loop's time (profiles/r3/loop_tail.txt) -- so a loop that is behind
+  // the grid's mean progress runs its waves at priority 3, one that is ahead at 0: the laggard gets
+  // the issue slots first (alone on a CU a loop is ~10 % faster), its partner pays with slack it has.
+  int *prog;
+  {
+    unsigned long long pb = reinterpret_cast<unsigned long long>(pa) + offsetof(IterArgs, progress);
+    asm volatile("" : "+s"(pb));
+    prog = reinterpret_cast<int *>(pb);
+  }
+#endif
   for (int it = it_first;;) {
+#if BORE_LAG_PRIO
+    {
+      const int total = __hip_atomic_load(prog, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int n_wg = (int)gridDim.x;
+      const int lead = uniform_i32((it - it_first) * n_wg - total);  // > 0: ahead of the mean, in 1 / n_wg iterations
+      if (lead < -(n_wg >> 1)) __builtin_amdgcn_s_setprio(3);
+      else if (lead > (n_wg >> 1)) __builtin_amdgcn_s_setprio(0);
+      else __builtin_amdgcn_s_setprio(1);
+    }
+#endif
     // (the argument block's address is made opaque per iteration, so that nothing read through it
     // is hoisted out of the loop and kept live around it)
 #ifndef BORE_ITER_ARGS_LAUNDERED
@@ -166,6 +197,9 @@ __global__ __launch_bounds__(BORE_THREADS, 2) void iteration_kernel(const IterAr
 #endif
     __syncthreads();  // the waves leave the restart phase one by one: LDS is reused below
     ++it;
+#if BORE_LAG_PRIO
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(prog, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
     if (it >= target) break;
     // ---- the next row: delivered while we were busy, or within wait_ticks, or not our business ----
     if (threadIdx.x == 0) {
@@ -240,6 +274,7 @@ static int iteration_launch(const bore_mlp_desc *desc, int n_slots, float *theta
   h->wait_ticks = resident ? g_batch->wait_ticks : 0;
   h->gamma = gamma;
   h->D = desc->input_dim;
+  h->progress = 0;
   size_t floats = lf > ls ? lf : ls;
   floats = floats > lb ? floats : lb;
   const size_t labels_floats = 2 * ((size_t)cap + 2);

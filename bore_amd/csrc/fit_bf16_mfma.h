@@ -45,6 +45,7 @@ template <int SHAPE>
 struct Bf16Plan {
   static constexpr MlpLayout L = bore_static_layout(SHAPE, 1, BORE_BATCH_MAX);
   static constexpr int n = L.n_layers;
+  static constexpr bool TIGHT = false;  // (see Bf16Net: the fit leaves the operand loads to the scheduler)
   static constexpr int RS = 64;  // row pitch of the transposed A / D images, in elements (128 B)
   // element (unit, row) of a transposed image: the row's 16-byte chunk (8 rows) is XOR-ed with
   // bits 1..3 of the unit -- a fragment read (16 consecutive units, one chunk) then touches 64
@@ -284,9 +285,11 @@ __device__ __forceinline__ void bf16_put(unsigned short *wf, unsigned short *wb,
   }
 }
 
-template <int SHAPE>
+// PLAN: where the weight images live -- Bf16Plan (the fit: no input gradient, backward images of
+// layers 2..n-1) or ArgBf16Plan (arg_bf16_mfma.h: value + input gradient, backward images 1..n-1).
+template <int SHAPE, typename PLAN = Bf16Plan<SHAPE>>
 struct Bf16Net {
-  using Pl = Bf16Plan<SHAPE>;
+  using Pl = PLAN;
   static constexpr MlpLayout L = Pl::L;
   static constexpr int n = Pl::n;
   static constexpr int TM = RegNet<SHAPE, 1, true>::T;  // widest layer, in tiles
@@ -332,6 +335,9 @@ struct Bf16Net {
         for (int c = 0; c < CFl; ++c) wfr[(t + 1) & 1][c] = lds_frag(wp + ((t + 1) * CFl + c) * 512);
         br[(t + 1) & 1] = *reinterpret_cast<const float4 *>(bp + 16 * (t + 1));
       }
+      // (TIGHT plans -- kernels that share their registers with an optimiser: the operand loads stay ONE
+      // tile ahead instead of being hoisted, all tiles at once, to the top of the layer)
+      if constexpr (Pl::TIGHT) __builtin_amdgcn_sched_barrier(0);
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int c = 0; c < CFl; ++c)
@@ -339,6 +345,7 @@ struct Bf16Net {
       const float b4[4] = {br[t & 1].x, br[t & 1].y, br[t & 1].z, br[t & 1].w};
 #pragma unroll
       for (int r = 0; r < 4; ++r) h[l][t][r] = acc[r] + b4[r];
+      if constexpr (Pl::TIGHT) __builtin_amdgcn_sched_barrier(0);
     }
     const int a = (keep_logits && l == n) ? BORE_ACT_LINEAR : acts[l];
     RegNet<SHAPE, 1, true>::template act_tiles_rt<Tl>(a, h[l]);
@@ -349,11 +356,13 @@ struct Bf16Net {
         h[l][t][r] = 16 * t + 4 * q + r < L.w[l] ? bf16_round_hw(h[l][t][r]) : 0.f;  // padding stays zero
   }
 
-  // D_{l-1} = (D_l W_l^T) .* act'_{l-1}(A_{l-1}), l >= 2
+  // D_{l-1} = (D_l W_l^T) .* act'_{l-1}(A_{l-1}), l >= 2;  l = 1 (plans with a backward image of
+  // layer 1): D_0 = D_1 W_1^T, the input gradient, left in float32
   template <int l>
   __device__ __forceinline__ void bwd_layer(const unsigned short *wb, const float *bias) {
     const int lane = threadIdx.x & 63, q = lane >> 4;
     constexpr int CBl = Pl::CB(l), Tp = Pl::T(l - 1);
+    static_assert(n >= 2, "one hidden layer at least");
     if constexpr (l == n) {  // one output unit: D_{n-1}[row][k] = delta[row] * W_n[k][0] (exact in float32)
       static_assert(L.w[n] == 1, "the classifier's last layer has one unit");
       const float dl = __shfl(d[n][0][0], lane & 15, 64);  // row m's delta sits in lane m
@@ -384,18 +393,22 @@ struct Bf16Net {
 #pragma unroll
         for (int c = 0; c < CBl; ++c) wfr[(t + 1) & 1][c] = lds_frag(wp + ((t + 1) * CBl + c) * 512);
       }
+      if constexpr (Pl::TIGHT) __builtin_amdgcn_sched_barrier(0);
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int c = 0; c < CBl; ++c)
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfr[t & 1][c], bfr[c], acc, 0, 0, 0);
 #pragma unroll
       for (int r = 0; r < 4; ++r) d[l - 1][t][r] = 16 * t + 4 * q + r < L.w[l - 1] ? acc[r] : 0.f;
+      if constexpr (Pl::TIGHT) __builtin_amdgcn_sched_barrier(0);
     }
-    RegNet<SHAPE, 1, true>::template grad_tiles_rt<Tp>(acts[l - 1], d[l - 1], h[l - 1]);
+    if constexpr (l >= 2) {
+      RegNet<SHAPE, 1, true>::template grad_tiles_rt<Tp>(acts[l - 1], d[l - 1], h[l - 1]);
 #pragma unroll
-    for (int t = 0; t < Tp; ++t)
+      for (int t = 0; t < Tp; ++t)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) d[l - 1][t][r] = bf16_round_hw(d[l - 1][t][r]);
+        for (int r = 0; r < 4; ++r) d[l - 1][t][r] = bf16_round_hw(d[l - 1][t][r]);
+    }
   }
 
   template <int l = 1>
@@ -406,11 +419,20 @@ struct Bf16Net {
       forward<l + 1>(wf, bias, xfrag);
     }
   }
-  template <int l = n>
+  // (the acquisition side: the last layer's activation applied -- predictions, not logits)
+  template <int l = 1>
+  __device__ __forceinline__ void predict(const unsigned short *wf, const float *bias,
+                                          const bf16x8_t (&xfrag)[Pl::CF(1)]) {
+    if constexpr (l <= n) {
+      fwd_layer<l>(wf, bias, xfrag, false);
+      predict<l + 1>(wf, bias, xfrag);
+    }
+  }
+  template <int l = n, int to = 2>
   __device__ __forceinline__ void backward(const unsigned short *wb, const float *bias) {
-    if constexpr (l >= 2) {
+    if constexpr (l >= to) {
       bwd_layer<l>(wb, bias);
-      backward<l - 1>(wb, bias);
+      backward<l - 1, to>(wb, bias);
     }
   }
 

@@ -12,7 +12,8 @@ Neither ``hpbandster`` nor ``ConfigSpace`` is in this image.  The generator is t
 duck-typed: it derives from ``hpbandster.core.base_config_generator`` when that imports and from a
 stand-in with the same two members (``logger``, ``new_result`` logging a job's exception)
 otherwise, and ``config_space`` is a ``bore_amd.plugins.types.DenseSpace`` (the ConfigSpace-free
-dense one-hot encoding).  Everything between the two calls -- when a random configuration is
+dense one-hot encoding) or a ``ConfigSpace.ConfigurationSpace``, whose hyperparameters are taken over
+by class name (``types.dense_space_from``; float / integer / categorical, as types.py:76-88).  Everything between the two calls -- when a random configuration is
 returned, what is fitted with which defaults, how the suggestion is picked, filtered and distorted
 -- is ``ClassifierSuggester`` (classifier.py), i.e. the kernels of the hot path.
 
@@ -26,7 +27,7 @@ import logging
 import numpy as np
 
 from .classifier import ClassifierSuggester
-from .types import DenseSpace
+from .types import DenseSpace, dense_space_from
 
 try:                                                    # pragma: no cover  (not in this image)
     from hpbandster.core.base_config_generator import base_config_generator as _GeneratorBase
@@ -52,10 +53,9 @@ class ClassifierConfigGenerator(_GeneratorBase):
     def __init__(self, config_space, gamma, num_random_init, random_rate, retrain, classifier_kws,
                  fit_kws, optimizer_kws, seed, **kwargs):
         super().__init__(**kwargs)
-        assert isinstance(config_space, DenseSpace), \
-            "`config_space` must be a bore_amd.plugins.types.DenseSpace (ConfigSpace is not in this image)"
-        # DenseConfigurationSpace(config_space, seed=seed) (:100): the space's own seeded stream
-        self.config_space = DenseSpace(config_space.hyperparameters, seed=seed)
+        # DenseConfigurationSpace(config_space, seed=seed) (:100): the hyperparameters of a DenseSpace or
+        # of a ConfigSpace.ConfigurationSpace (types.dense_space_from), the space's own seeded stream
+        self.config_space = DenseSpace(dense_space_from(config_space).hyperparameters, seed=seed)
         # same defaults as the reference reads out of the three dictionaries (:105-138)
         self._suggester = ClassifierSuggester(
             space=self.config_space, gamma=gamma, num_random_init=num_random_init,

@@ -149,3 +149,40 @@ def array_from_dict(space, dct):
 def dict_from_array(space, array):
     """bore/plugins/hpbandster/types.py:12-14."""
     return space.from_array(array)
+
+
+def dense_space_from(configspace, seed=None):
+    """A ``DenseSpace`` from a ``ConfigSpace.ConfigurationSpace`` (or anything shaped like one), as
+    ``DenseConfigurationSpace(other, seed=...)`` takes one (bore/plugins/hpbandster/types.py:17-35):
+    only the hyperparameters are carried over -- "conditions, clauses, seed, and other metadata
+    ignored" (types.py:22-23).  Duck-typed, because ConfigSpace is not in this image: the space must
+    offer ``get_hyperparameters()`` (or ``values()``), and every hyperparameter is recognised by its
+    CLASS NAME -- ``UniformFloatHyperparameter`` (``lower``, ``upper``, ``log``),
+    ``UniformIntegerHyperparameter`` (same), ``CategoricalHyperparameter`` (``choices``) -- anything
+    else raises the reference's NotImplementedError (types.py:83-88).  A ``DenseSpace`` passes through."""
+    if isinstance(configspace, DenseSpace):
+        return configspace
+    if hasattr(configspace, "get_hyperparameters"):
+        hps = list(configspace.get_hyperparameters())
+    elif hasattr(configspace, "values"):          # ConfigSpace >= 0.7: a Mapping name -> hyperparameter
+        hps = list(configspace.values())
+    else:
+        raise TypeError(f"not a configuration space: {type(configspace).__name__} has neither "
+                        "get_hyperparameters() nor values()")
+    out = []
+    for hp in hps:
+        if isinstance(hp, (UniformFloat, Categorical)):       # already ours (UniformInteger is a UniformFloat)
+            out.append(hp)
+            continue
+        kind = type(hp).__name__
+        if kind == "CategoricalHyperparameter":
+            out.append(Categorical(hp.name, list(hp.choices)))
+        elif kind == "UniformIntegerHyperparameter":
+            out.append(UniformInteger(hp.name, hp.lower, hp.upper, bool(getattr(hp, "log", False))))
+        elif kind == "UniformFloatHyperparameter":
+            out.append(UniformFloat(hp.name, hp.lower, hp.upper, bool(getattr(hp, "log", False))))
+        else:
+            raise NotImplementedError("Only hyperparameters of types `CategoricalHyperparameter`, "
+                                      "`UniformIntegerHyperparameter`, `UniformFloatHyperparameter` "
+                                      f"are supported! (got {kind} for {getattr(hp, 'name', '?')!r})")
+    return DenseSpace(out, seed=seed)

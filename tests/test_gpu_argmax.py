@@ -680,6 +680,35 @@ def test_lbfgsb_eight_waves_per_workgroup_give_the_same_bits(gpu, monkeypatch, D
         assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize("D,units,compute,R,opts", [
+    (2, [16, 16, 1], "float32", 37, dict(maxiter=1000, ftol=1e-9)),
+    (6, [32, 32, 1], "float32", 70, dict(maxiter=1000, ftol=1e-9)),
+    (16, [64, 64, 64, 1], "float32", 45, dict(maxiter=200, ftol=1e-9)),
+    (16, [64, 64, 64, 1], "bfloat16", 21, dict(maxiter=200, ftol=1e-9)),
+    (32, [128, 128, 1], "bfloat16", 29, dict(maxiter=200, ftol=1e-9, maxcor=4))])
+def test_lbfgsb_problem_queue_gives_the_same_bits(gpu, monkeypatch, D, units, compute, R, opts):
+    """Many restarts per model: a workgroup's waves draw problem after problem from a queue in LDS
+    (weights staged once, workspace slots reused) instead of one workgroup per four (eight)
+    restarts.  BORE_LBFGSB_QUEUE = 0 / n forces one workgroup per PB restarts / n workgroups in all:
+    same results bit for bit -- incl. workgroups with fewer problems than waves, a ragged last
+    workgroup, the two-per-CU and eight-wave kernels, and reused workspaces of every size."""
+    rs = np.random.RandomState(31 + D)
+    acts = ["relu"] * (len(units) - 1) + ["sigmoid"]
+    desc = _lib.make_desc(D, units, acts, compute=compute)
+    th = dev(np.stack([pack(rand_model(rs, D, units)) for _ in range(3)]))
+    X0 = dev(rs.uniform(size=(3, R, D)))
+    lo, hi = np.zeros(D), np.ones(D)
+    outs = []
+    for q, extra in (("0", {}), ("3", {}), ("7", {}), ("7", {"BORE_LBFGSB_W8": "1", "BORE_LBFGSB_OCC2": "1"})):
+        monkeypatch.setenv("BORE_LBFGSB_QUEUE", q)
+        for k, v in extra.items():
+            monkeypatch.setenv(k, v)
+        outs.append([t.cpu().numpy() for t in ops.lbfgsb_minimize(desc, th, X0, lo, hi, "identity", True, **opts)])
+    for other in outs[1:]:
+        for a, b in zip(outs[0], other):
+            assert np.array_equal(a, b)
+
+
 @pytest.mark.parametrize("D,units,compute,Ns,R", [(16, [64, 64, 64, 1], "float32", 1024, 1024),
                                                   (16, [64, 64, 64, 1], "bfloat16", 2048, 7),
                                                   (32, [128, 128, 1], "bfloat16", 4096, 4096)])

@@ -130,6 +130,66 @@ def test_dense_encoding_reproduces_the_reference_test_vector():
     assert isinstance(cs.sample_configuration(), dict)
 
 
+class _FakeHp:
+    """A ConfigSpace hyperparameter as far as the converter looks at one: class name + attributes."""
+    def __init__(self, name, **kw):
+        self.name = name
+        self.__dict__.update(kw)
+
+
+def _fake_configspace_classes():
+    mk = lambda cls: type(cls, (_FakeHp,), {})
+    return (mk("UniformIntegerHyperparameter"), mk("UniformFloatHyperparameter"),
+            mk("CategoricalHyperparameter"), mk("NormalFloatHyperparameter"))
+
+
+def test_configspace_bridge_takes_a_configuration_space_by_duck_typing():
+    """DenseConfigurationSpace(other, seed) (bore/plugins/hpbandster/types.py:17-35) wraps a real
+    ConfigSpace.ConfigurationSpace; ConfigSpace is not in this image, so the bridge goes by class name
+    and attributes.  A fake space with the reference's own test hyperparameters
+    (tests/test_types.py:17-33, insertion order as there) must give the dense encoding of the
+    reference's test vector; old (get_hyperparameters) and new (Mapping) ConfigSpace surfaces;
+    unsupported types raise the reference's NotImplementedError."""
+    from bore_amd.plugins.types import DenseSpace, dense_space_from
+    from bore_amd.plugins.hpbandster import ClassifierConfigGenerator
+    UI, UF, Cat, Normal = _fake_configspace_classes()
+    hps = [UI("n_units_1", lower=0, upper=5, log=False), UI("n_units_2", lower=0, upper=5, log=False),
+           UF("dropout_1", lower=0, upper=0.9, log=False), UF("dropout_2", lower=0, upper=0.9, log=False),
+           Cat("activation_fn_1", choices=("tanh", "relu")), Cat("activation_fn_2", choices=("tanh", "relu")),
+           UI("init_lr", lower=0, upper=5, log=False), Cat("lr_schedule", choices=("cosine", "const")),
+           UI("batch_size", lower=0, upper=3, log=False)]
+
+    class OldSpace:                       # ConfigSpace < 0.7
+        def get_hyperparameters(self):
+            return list(hps)
+
+    class NewSpace(dict):                 # ConfigSpace >= 0.7: Mapping name -> hyperparameter
+        pass
+
+    want = _reference_space()
+    dct = {'activation_fn_1': 'relu', 'activation_fn_2': 'tanh', 'batch_size': 2,
+           'dropout_1': 0.39803953082292726, 'dropout_2': 0.022039062686389176, 'init_lr': 0,
+           'lr_schedule': 'cosine', 'n_units_1': 5, 'n_units_2': 1}
+    for space in (OldSpace(), NewSpace((hp.name, hp) for hp in hps)):
+        cs = dense_space_from(space, seed=8888)
+        assert isinstance(cs, DenseSpace)
+        assert cs.get_dimensions(sparse=True) == 9 and cs.get_dimensions(sparse=False) == 12
+        assert cs.get_hyperparameter_by_idx(0) == "activation_fn_1"
+        assert np.array_equal(cs.to_array(dct), want.to_array(dct))
+        assert cs.from_array(cs.to_array(dct)) == dct
+        assert cs.sample_configuration(size=3) == _reference_space().sample_configuration(size=3)
+    assert dense_space_from(want) is want
+    with pytest.raises(NotImplementedError, match="Only hyperparameters of types"):
+        dense_space_from(NewSpace(x=Normal("x", mu=0.0, sigma=1.0)))
+    with pytest.raises(TypeError, match="not a configuration space"):
+        dense_space_from(object())
+    # the HpBandSter generator accepts the ConfigSpace object itself (reference: base.py:100)
+    gen = ClassifierConfigGenerator(OldSpace(), gamma=0.25, num_random_init=3, random_rate=None, retrain=False,
+                                    classifier_kws={}, fit_kws={}, optimizer_kws={}, seed=8888)
+    cfg, info = gen.get_config(budget=1.0)          # fewer than num_random_init observations: a random draw
+    assert set(cfg) == set(dct) and info == {}
+
+
 def test_dense_encoding_log_scales_and_integer_edges():
     from bore_amd.plugins.types import DenseSpace, UniformFloat, UniformInteger, array_from_dict, dict_from_array
     cs = DenseSpace([UniformFloat("lr", 1e-5, 1e-1, log=True), UniformInteger("width", 16, 1024, log=True),
