@@ -57,8 +57,32 @@ HBM_PEAK_GBS = 8000.0    # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
 FP32_PEAK_TF = 157.3     # fp32 vector / MFMA peak, same guide
 BF16_PEAK_TF = 2500.0    # dense bf16 MFMA peak
 TOTAL_LOOPS = 512        # BASELINE.json config 4
-TRAFFIC_FILE = os.path.join("profiles", "r3", "pmc_traffic.json")
-SWEEP_FILE = os.path.join("profiles", "r3", "loops_sweep.json")   # T(1, L) measured on one GPU
+def _latest(name):
+    """profiles/rN/<name> of the newest round that has it."""
+    for rnd in ("r4", "r3"):
+        if os.path.exists(os.path.join(ROOT, "profiles", rnd, name)):
+            return os.path.join("profiles", rnd, name)
+    return os.path.join("profiles", "r4", name)
+
+
+TRAFFIC_FILE = _latest("pmc_traffic.json")
+SWEEP_FILE = _latest("loops_sweep.json")   # T(1, L) measured on one GPU
+
+
+def csrc_digest():
+    """sha256 over the kernel sources (bore_amd/csrc/*.hip, *.h and include/bore_hip.h, names and
+    contents in sorted order): what a committed PMC pass was collected on (tools/collect_r4.py stores
+    it in pmc_traffic.json) against what this run times -- `traffic_stale` in the line."""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "bore_amd", "csrc")
+    files = sorted(os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".h")))
+    files.append(os.path.join(ROOT, "include", "bore_hip.h"))
+    for f in files:
+        h.update(os.path.basename(f).encode() + b"\0")
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
 
 
 def predicted_efficiency(world, total):
@@ -141,6 +165,54 @@ def spawn_ranks(n, argv):
     sys.stdout.write(out0.decode())
     sys.stdout.flush()
     return rc
+
+
+def pin_rank_cores(rank, world):
+    """Give this rank its own slice of the host cores the container may use: the ranks of one node
+    share a cgroup quota (16 cores for 8 ranks on the driver's box) and every rank runs a Python
+    main thread plus the engine's service thread(s).  Returns the cores, or None when nothing was
+    pinned (one rank, or an affinity mask that cannot be changed).  The slice is taken from the
+    affinity mask in order, `usable / world` cores per rank where usable = min(mask, cgroup quota)."""
+    if world <= 1:
+        return None
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+        n_mask, quota = _cpu_quota()
+        usable = n_mask
+        if quota:
+            parts = quota.split()
+            if parts[0] != "max" and int(parts[0]) > 0:
+                period = int(parts[1]) if len(parts) > 1 else 100000
+                usable = max(1, min(n_mask, int(parts[0]) // period))
+        per = max(1, usable // world)
+        start = (rank * per) % len(allowed)
+        cores = [allowed[(start + i) % len(allowed)] for i in range(per)]
+        os.sched_setaffinity(0, cores)
+        return cores
+    except (OSError, ValueError, AttributeError):
+        return None
+
+
+def rank_census(rank, world, local, backend, dry, cores):
+    """What the backend itself says about the job: its world size, and every rank's device -- the
+    proof in the N > 1 line that the collective backend (RCCL) saw N ranks on N different GPUs."""
+    import torch
+    import torch.distributed as dist
+    me = {"rank": rank, "local_rank": local, "pid": os.getpid(), "host_cores": cores,
+          "device": None if dry else torch.cuda.get_device_name(local),
+          "device_index": None if dry else int(torch.cuda.current_device())}
+    if not dry:
+        try:
+            pr = torch.cuda.get_device_properties(local)
+            me["device_uuid"] = str(getattr(pr, "uuid", "")) or None
+            me["pci_bus_id"] = getattr(pr, "pci_bus_id", None)
+        except Exception:
+            pass
+    if world == 1:
+        return {"backend": None, "backend_world_size": 1, "ranks": [me]}
+    everyone = [None] * world
+    dist.all_gather_object(everyone, me)
+    return {"backend": dist.get_backend(), "backend_world_size": dist.get_world_size(), "ranks": everyone}
 
 
 def resolve_loops(args, world):
@@ -282,7 +354,7 @@ class _DryEngine:
 
     def take_stats(self, reset=True):
         z = dict.fromkeys(("fit_ms", "fit_bytes", "host_enqueue_s", "host_finalize_s"), 0.0)
-        z.update(dict.fromkeys(("fit_launches", "n_fg_rows", "n_rounds", "none_results"), 0))
+        z.update(dict.fromkeys(("fit_launches", "n_fg_rows", "n_fg_requests", "n_rounds", "none_results"), 0))
         z.update(argmax_ms=1.0, argmax_bytes=1.0, argmax_launches=1)
         return z
 
@@ -411,8 +483,9 @@ def config_gpu(name, c, loops, epochs=200, batch=64, reps=3):
         e[4].record()
         infos.append(info)
     torch.cuda.synchronize()
-    ph = np.array([[ev[k][i].elapsed_time(ev[k][i + 1]) for i in range(4)]
-                   for k in range(1, reps + 1)]).mean(axis=0)             # ms per phase
+    per_rep = np.array([[ev[k][i].elapsed_time(ev[k][i + 1]) for i in range(4)]
+                        for k in range(1, reps + 1)])                     # [rep][phase] ms
+    ph = np.median(per_rep, axis=0)                                       # ms per phase: the median rep
     nfev = np.stack([i.cpu().numpy()[:, :, 1] for i in infos[1:]]).astype(np.float64)
     rows = float(nfev.sum() / reps)                                      # f/g rows per iteration
     rounds = float(nfev.max(axis=2).sum() / reps)                        # rounds, summed over loops
@@ -430,6 +503,12 @@ def config_gpu(name, c, loops, epochs=200, batch=64, reps=3):
         "loops": loops, "it_per_s": loops / (total_ms * 1e-3),
         "ms": {"fit": float(ph[0]), "screen": float(ph[1]), "lbfgsb": float(ph[2]),
                "pick": float(ph[3]), "iteration": total_ms},
+        # (the driver's box and the builder's differ by up to 20 % on these launches: every phase is
+        # the median of `reps` repetitions -- each a new fit on top of the last, new starts -- with
+        # the spread beside it)
+        "ms_reps": {"n": int(reps), "value_is": "median",
+                    "min": {k: float(per_rep[:, i].min()) for i, k in enumerate(("fit", "screen", "lbfgsb", "pick"))},
+                    "max": {k: float(per_rep[:, i].max()) for i, k in enumerate(("fit", "screen", "lbfgsb", "pick"))}},
         "us_per_adam_step": 1e3 * float(ph[0]) / S,
         "fg_rows_per_iteration": rows, "restarts_ok_frac": float(np.mean(status <= 1)),
         "algorithmic_bytes": {k: float(x) for k, x in by.items()},
@@ -495,7 +574,7 @@ def all_configs(args, barrier, cpu):
     for name, c in WIDE_CONFIGS.items():
         try:
             one = config_gpu(name, c, loops=1)
-            many = config_gpu(name, c, loops=256, reps=2)
+            many = config_gpu(name, c, loops=256, reps=5)
             out[name] = dict(one, many_loops=many)
             if cpu:
                 out[name]["cpu_baseline"] = config_cpu(c)
@@ -523,6 +602,7 @@ def run_rank(args):
         raise SystemExit(f"bench.py: rank {rank} told to fail (BORE_BENCH_FAIL_RANK)")
     if os.environ.get("BORE_BENCH_ONE_DEVICE") == "1":     # rehearsal: every rank on cuda:0
         local = 0
+    cores = pin_rank_cores(rank, world)     # (before the engine starts its threads: they inherit the mask)
     if not dry:
         torch.cuda.set_device(local)
     if world > 1:
@@ -530,6 +610,7 @@ def run_rank(args):
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
             dist.init_process_group("gloo")
+    census = rank_census(rank, world, local, args.backend, dry, cores)
     loops, total, scaling = resolve_loops(args, world)
 
     def barrier():
@@ -616,6 +697,7 @@ def run_rank(args):
                 pmc = json.load(f)
         except Exception:
             pmc = {}
+        digest = csrc_digest()
         models_per_launch = (loops / r["n_groups"] if st["fit_ms"]
                              else loops * args.steps / max(st["argmax_launches"], 1))
 
@@ -630,6 +712,8 @@ def run_rank(args):
                     "traffic_source": None if per_model is None else
                     f"{TRAFFIC_FILE} ({pmc.get('build', '?')}; rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
                     "passes, committed; NOT collected in this run)",
+                    # the committed pass belongs to THESE kernel sources (hash stored at collection)?
+                    "traffic_stale": None if per_model is None else pmc.get("csrc_sha256") != digest,
                     "avg_launch_ms": float(ms_sum / launches),
                     "algorithmic_bytes_per_launch": float(bytes_sum / launches),
                     "launches": int(launches),
@@ -643,7 +727,10 @@ def run_rank(args):
         if st["fit_ms"] == 0.0:        # asynchronous schedule: fit + argmax are ONE kernel per launch
             kernels = [roof("iteration_kernel", st["argmax_ms"], st["fit_bytes"] + st["argmax_bytes"],
                             st["argmax_launches"])]
-            if st.get("phase_iterations"):
+            # (only while every loop of the launch is RESIDENT -- a handful of launches per region: with more
+            # loops than the device holds at once workgroups queue behind each other, busy time per launch
+            # is no longer the sum / loops and the figures would overstate the rate)
+            if st.get("phase_iterations") and st["argmax_launches"] <= 4:
                 # A resident launch spans the host's turn-around as well: its workgroups wait on their
                 # CUs for the objective values.  `achieved` / `frac` above are per the contract (a
                 # launch's algorithmic bytes / its HIP-event duration, = the rocprofv3 duration); the
@@ -681,7 +768,9 @@ def run_rank(args):
                      "achieved": flops / dt / 1e12, "peak": FP32_PEAK_TF, "unit": "TFLOP/s",
                      "frac": flops / dt / 1e12 / FP32_PEAK_TF,
                      "algorithmic_flops_per_iteration": flops / (loops * args.steps)}
-        phases = {"fg_rows_per_step": st["n_fg_rows"] / args.steps,
+        phases = {"fg_rows_per_step": st["n_fg_rows"] / args.steps,          # evaluations that ran the network
+                  # (the optimisers' nfev: also counts trial points the image shortcut served)
+                  "fg_requests_per_step": st.get("n_fg_requests", st["n_fg_rows"]) / args.steps,
                   "fg_rounds_per_step": st["n_rounds"] / args.steps,
                   "none_results": int(st["none_results"]),
                   "host_enqueue_ms_per_step": 1e3 * st["host_enqueue_s"] / args.steps,
@@ -737,6 +826,8 @@ def run_rank(args):
                                  "between barriers"},
             "best_y_median": float(np.median(results[:, -1])),
             "tf_keras": tf_keras_probe(),
+            # the collective backend's own count of ranks and every rank's device and host cores
+            "ranks": census,
         }
         out["flow_wall_s"] = {"repeated_timed_regions": t_repeats_done - t_flow0,
                               "efficiency_reference_runs": t_eff_done - t_repeats_done,

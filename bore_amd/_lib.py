@@ -86,7 +86,7 @@ class EngineStats(C.Structure):
                 ("ready_to_launch_s", C.c_double), ("launch_to_result_s", C.c_double),
                 ("result_to_ready_s", C.c_double), ("phase_iterations", C.c_int64),
                 ("batches", C.c_int64), ("worker_streams", C.c_int64),
-                ("stream_concurrency", C.c_int64)]
+                ("stream_concurrency", C.c_int64), ("n_fg_requests", C.c_int64)]
 
 
 OBJECTIVE_FN = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_double), C.c_int64, C.c_int32,
@@ -196,9 +196,14 @@ class UnsupportedError(RuntimeError):
     """BORE_E_UNSUPPORTED: the request does not fit this build's kernels (shape, LDS budget, ...)."""
 
 
+class NeedsPermError(UnsupportedError):
+    """BORE_E_NEEDS_PERM: bore_mlp_fit cannot draw the shuffles of this many rows in LDS; the same call
+    with explicit permutations works (bore_amd.models passes them)."""
+
+
 def check(rc):
     if rc != 0:
-        cls = UnsupportedError if rc == -2 else RuntimeError
+        cls = {-2: UnsupportedError, -5: NeedsPermError}.get(rc, RuntimeError)
         raise cls(f"libbore_hip: {lib().bore_last_error().decode()} (code {rc})")
 
 

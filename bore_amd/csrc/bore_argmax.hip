@@ -731,6 +731,7 @@ __device__ __forceinline__ void lbfgsb_body(const LbfgsbArgs &a, const long long
   bool done = (myp < 0);
   const long long c_init = BORE_LCLOCK();
   long long t_adv = 0, t_fg = 0, n_rounds = 0;
+  int n_exec = 0;  // evaluations that RAN the network (nfev also counts requests served by the image shortcut)
   // ---- one problem per wave, static shape: the optimiser calls the evaluation (lbfgsb.h, DIRECT form) ----
   bool direct = false;
   if constexpr (SHAPE > 0) {
@@ -758,6 +759,7 @@ __device__ __forceinline__ void lbfgsb_body(const LbfgsbArgs &a, const long long
             return;
           }
         }
+        ++n_exec;
         if constexpr (LEAN && !BF16) {
           if (!BORE_POINT_SHAPE(SHAPE)) {
             net.load_fwd(thw);
@@ -839,6 +841,7 @@ __device__ __forceinline__ void lbfgsb_body(const LbfgsbArgs &a, const long long
           }
           // (tried and dropped: the search's base point as a second entry -- another 7 % of the requests,
           // no gain over its compare and four more registers in the loop, profiles/r3/ab_headline.txt)
+          ++n_exec;
           if constexpr (LEAN) {
             net.load_fwd(thw);
             net.template load_bwd<Net::n, 1>(thw);
@@ -864,7 +867,9 @@ __device__ __forceinline__ void lbfgsb_body(const LbfgsbArgs &a, const long long
     }
   }
   if constexpr (ALWAYS_COOP) {
-    if (!direct) return;  // (cannot happen: the fused kernel's launches keep np <= 16)
+    // (cannot happen: these kernels' launches give a wave one problem at a time -- engine_create,
+    // lbfgsb_build.  If a caller ever breaks that, the problems are REPORTED, unoptimised, with status 2
+    // below -- every flag is published, no host waits -- instead of being dropped silently.)
   } else {
   for (int round = 0; !direct && round < a.max_rounds; ++round) {
     int pending = 0;
@@ -976,7 +981,7 @@ __device__ __forceinline__ void lbfgsb_body(const LbfgsbArgs &a, const long long
   if (lane == 0) {
     double *r = res + myq * (D + 3);
     r[0] = st.f;
-    r[1] = (double)st.status;
+    r[1] = (double)(st.status + 8 * n_exec);  // (status 0..2 | executed evaluations: unpacked below)
     r[2] = (double)st.nfev;
     for (int d = 0; d < D; ++d) r[3 + d] = wk.x[d];
   }
@@ -990,12 +995,13 @@ __device__ __forceinline__ void lbfgsb_body(const LbfgsbArgs &a, const long long
   const int N = a.n_init + it_done;
   const double *Xs = a.dedup ? a.X_seen + lid * a.cap * D : nullptr;
   int best = -1;
-  double best_fun = 0.0, nfev_sum = 0.0, nfev_max = 0.0;
+  double best_fun = 0.0, nfev_sum = 0.0, nfev_max = 0.0, exec_sum = 0.0;
   for (int r = 0; r < np; ++r) {
     const double *rr = res + r * (D + 3);
     nfev_sum += rr[2];
     nfev_max = fmax(nfev_max, rr[2]);
-    const int status = (int)rr[1];
+    const int status = (int)rr[1] & 7;
+    exec_sum += (double)((int)rr[1] >> 3);
     if (status != 0 && status != 1) continue;  // res.success or res.status == 1
     bool dup = false;
     if (a.dedup) {  // any(np.allclose(x_prev, x) for x_prev in record): rows dealt to lanes
@@ -1032,7 +1038,7 @@ __device__ __forceinline__ void lbfgsb_body(const LbfgsbArgs &a, const long long
     } else {
       out[D + 3] = out[D + 4] = out[D + 5] = out[D + 6] = 0.0;
     }
-    out[D + 7] = 0.0;
+    out[D + 7] = exec_sum;  // evaluations that ran the network (<= nfev_sum: the image shortcut serves the rest)
     __threadfence_system();
     __hip_atomic_store(a.flag + lid, it_done + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }

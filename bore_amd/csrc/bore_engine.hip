@@ -273,6 +273,7 @@ int finalize(bore_engine *e, Group &g) {
     rounds_max = mx > rounds_max ? mx : rounds_max;
   }
   e->st.n_fg_rows += rows;
+  e->st.n_fg_requests += rows;
   e->st.n_rounds += rounds_max;
   e->st.argmax_bytes += rows * 4.0 * (2 * D + 1) + rounds_sum * 4.0 * e->P;
   for (int l = 0; l < Lg; ++l) {
@@ -642,9 +643,12 @@ int async_run(bore_engine *e, int n_steps) {
       } else {
         std::memcpy(xn, r, (size_t)D * 8);
       }
-      e->st.n_fg_rows += (int64_t)r[D + 1];
+      // (r[D + 7]: evaluations that ran the network; r[D + 1] = nfev also counts the trial points the
+      // image shortcut served -- the algorithmic bytes are those of the evaluations that ran)
+      e->st.n_fg_rows += (int64_t)r[D + 7];
+      e->st.n_fg_requests += (int64_t)r[D + 1];
       e->st.n_rounds += (int64_t)r[D + 2];
-      e->st.argmax_bytes += r[D + 1] * 4.0 * (2 * D + 1) + r[D + 2] * 4.0 * e->P;
+      e->st.argmax_bytes += r[D + 7] * 4.0 * (2 * D + 1) + r[D + 2] * 4.0 * e->P;
       const double N = c.n_init + A.it[l], steps = std::ceil(N / c.batch_size);
       e->st.fit_bytes += c.epochs * (4.0 * N * (D + 1) + steps * 24.0 * e->P);
       A.done_ids[n_done++] = l;

@@ -2276,7 +2276,7 @@ static int fit_build(const bore_mlp_desc *desc, int n_models, float *theta, floa
       rc = 0;
     } else {
       const size_t avail = BORE_LDS_BYTES / 4 - ((size_t)a.L.P_lds + a.L.tile_floats + fixed_extra);
-      return fail(BORE_E_UNSUPPORTED,
+      return fail(g_batch ? BORE_E_UNSUPPORTED : BORE_E_NEEDS_PERM,
                   "fit: N=%lld rows exceed what one workgroup's LDS holds beside this network when the "
                   "epoch's shuffle is drawn on the device (at most %zu rows): pass explicit shuffles "
                   "(`perm`, e.g. from bore_amd.shuffle.permutations) -- any N then",

@@ -71,6 +71,9 @@ __device__ __forceinline__ double load_host_f64(const double *p) {
 #ifndef BORE_LAG_PRIO
 #define BORE_LAG_PRIO 1
 #endif
+#ifndef BORE_LAG_SHIFT
+#define BORE_LAG_SHIFT 1  // "behind" / "ahead" = by more than 2^-SHIFT of an iteration
+#endif
 template <int SHAPE>
 __device__ BORE_ITER_ONCE_ATTR void iteration_once(const IterArgs *__restrict__ pa,
                                                          const long long slot, const int it,
@@ -176,8 +179,8 @@ __global__ __launch_bounds__(BORE_THREADS, 2) void iteration_kernel(const IterAr
       const int total = __hip_atomic_load(prog, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const int n_wg = (int)gridDim.x;
       const int lead = uniform_i32((it - it_first) * n_wg - total);  // > 0: ahead of the mean, in 1 / n_wg iterations
-      if (lead < -(n_wg >> 1)) __builtin_amdgcn_s_setprio(3);
-      else if (lead > (n_wg >> 1)) __builtin_amdgcn_s_setprio(0);
+      if (lead < -(n_wg >> BORE_LAG_SHIFT)) __builtin_amdgcn_s_setprio(3);
+      else if (lead > (n_wg >> BORE_LAG_SHIFT)) __builtin_amdgcn_s_setprio(0);
       else __builtin_amdgcn_s_setprio(1);
     }
 #endif

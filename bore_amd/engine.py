@@ -93,7 +93,7 @@ class NativeEngine:
         self.desc = _lib.make_desc(D, self.units, self.acts)
         self.P = ops.param_count(self.desc)
         tr = resolve(transform).negated()
-        assert tr.name is not None, "the replica engine runs on the device only: a named transform ('identity', 'sigmoid', 'exp')"
+        assert tr.name is not None, "the native engine runs on the device only: a named transform ('identity', 'sigmoid', 'exp')"
         assert tr.negate, "the engine minimises transform(-f(x)) (bore/mixins.py:20)"
         self.objective = objective
         self.low, self.high = np.zeros(D), np.ones(D)

@@ -185,8 +185,8 @@ class Sequential:
                 loss = ops.mlp_fit(self._desc, self.theta, self.adam_m, self.adam_v, self.adam_t, X, z,
                                    n_epochs, batch_size,
                                    perm=None if perm is None else perm[:, e0:e0 + n_epochs].contiguous(), **kw)
-            except _lib.UnsupportedError as err:
-                if perm is not None or "pass explicit shuffles" not in str(err):
+            except _lib.NeedsPermError:         # (BORE_E_NEEDS_PERM: a code, not a message)
+                if perm is not None:
                     raise
                 # A data set too long for the device to draw its shuffles in LDS (the reference's fit
                 # takes whatever the record holds, README.rst:93): the SAME stream from its host

@@ -64,11 +64,19 @@ class CallableTransform:
         import torch
         sign = -1.0 if self.negate else 1.0
         u = torch.tensor(sign * np.asarray(f, dtype=np.float32), dtype=torch.float32, requires_grad=True)
-        t = self.fn(u)
+        what = ("a callable transform must map a torch tensor to a torch tensor of the same shape "
+                "(elementwise, differentiable by torch); named transforms: 'identity', 'sigmoid', 'exp'")
+        try:                       # (a numpy function such as np.tanh fails inside with torch's own message)
+            t = self.fn(u)
+        except Exception as err:
+            raise TypeError(f"{what} -- {self.fn!r} raised {type(err).__name__}: {err}") from err
         if not isinstance(t, torch.Tensor) or t.shape != u.shape:
-            raise TypeError("a callable transform must map a torch tensor to a torch tensor of the same "
-                            "shape (elementwise); named transforms: 'identity', 'sigmoid', 'exp'")
-        (dT,) = torch.autograd.grad(t.sum(), u)
+            raise TypeError(what)
+        try:
+            (dT,) = torch.autograd.grad(t.sum(), u)
+        except RuntimeError as err:
+            raise TypeError(f"{what} -- the result of {self.fn!r} does not depend differentiably on its "
+                            f"input ({err})") from err
         return t.detach().numpy().astype(np.float32), sign * dT.numpy().astype(np.float64)
 
     def __call__(self, u):
@@ -85,6 +93,22 @@ exp = Transform("exp")
 TRANSFORMS = dict(identity=identity, sigmoid=sigmoid, exp=exp)
 
 
+def _KNOWN_OBJECTS():
+    """Functions that ARE one of the named transforms: numpy's / torch's exp and sigmoid, scipy's expit."""
+    known = [np.exp]
+    try:
+        import torch
+        known += [torch.exp, torch.sigmoid]
+    except Exception:                # pragma: no cover
+        pass
+    try:
+        from scipy.special import expit
+        known.append(expit)
+    except Exception:                # pragma: no cover
+        pass
+    return known
+
+
 def resolve(t):
     if t is None:
         return identity
@@ -94,9 +118,10 @@ def resolve(t):
         if t not in TRANSFORMS:
             raise ValueError(f"`transform` must be one of {tuple(TRANSFORMS)}")
         return TRANSFORMS[t]
-    name = getattr(t, "__name__", None)
-    if name in TRANSFORMS:          # e.g. np.exp, a function called sigmoid/identity
-        return TRANSFORMS[name]
+    # Known objects only: a user function that merely happens to be CALLED exp / sigmoid / identity is
+    # applied as the callable it is, not silently replaced by the kernel transform of that name.
+    if t in _KNOWN_OBJECTS():
+        return TRANSFORMS[t.__name__ if t.__name__ != "expit" else "sigmoid"]
     if callable(t):                 # any other elementwise, torch-differentiable callable
         return CallableTransform(t)
     raise TypeError(f"transform {t!r}: pass 'identity', 'sigmoid', 'exp', a bore_amd.transforms "

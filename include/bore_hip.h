@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define BORE_ABI_VERSION 8
+#define BORE_ABI_VERSION 9
 #define BORE_MAX_LAYERS 8
 #define BORE_BATCH_MAX 64 /* rows per tile == wavefront width */
 #define BORE_DIM_MAX 64   /* largest input dimension for the by-value bound arrays */
@@ -41,7 +41,11 @@ enum bore_status {
   BORE_E_INVALID = -1,   /* bad argument */
   BORE_E_UNSUPPORTED = -2, /* shape does not fit this build's kernels (e.g. LDS budget) */
   BORE_E_HIP = -3,       /* HIP runtime error (message has hipGetErrorString) */
-  BORE_E_CALLBACK = -4   /* a host callback asked to stop (bore_engine_run) */
+  BORE_E_CALLBACK = -4,  /* a host callback asked to stop (bore_engine_run) */
+  /* bore_mlp_fit without `perm`: the network fits, but N rows are too many for the epoch's shuffle to be
+   * drawn in LDS; the same call WITH explicit permutations (any N) works.  Callers test this code,
+   * not the message (a kind of BORE_E_UNSUPPORTED: bore_amd raises a subclass of its error). */
+  BORE_E_NEEDS_PERM = -5
 };
 
 /* Keras activation names accepted by Dense(activation=...) on this path
@@ -315,7 +319,7 @@ int bore_shuffle_perm(uint64_t seed, int64_t model_index0, int n_models,
  *     are done: result[ids[b]] = {x_best[D], best, sum nfev, max nfev, then the device-clock
  *     ticks (hipDeviceAttributeWallClockRate) the loop-iteration spent in labels, fit, sample +
  *     screen and restarts + pick -- zeros unless `stamps` is given and the launch is the fused
- *     iteration kernel --, one spare} (D + 8 doubles), then, after a system-scope fence,
+ *     iteration kernel --, the restarts' evaluations that ran the network} (D + 8 doubles), then, after a system-scope fence,
  *     flag[ids[b]] = its[b] + 1.  result and flag must be host-visible (pinned) memory.
  * bore_set_batch(NULL) returns to the plain meaning.  The struct is copied.
  */
@@ -406,6 +410,11 @@ typedef struct bore_engine_stats {
    * means streams share hardware queues -- GPU_MAX_HW_QUEUES was below worker_streams + 2 when
    * the HIP runtime initialised -- and launches of different batches serialise.  Not reset. */
   int64_t worker_streams, stream_concurrency;
+  /* ABI 9: n_fg_rows counts the evaluations that RAN the network (what the roofline's algorithmic
+   * bytes are made of); n_fg_requests = the optimisers' nfev, which also counts trial points served
+   * from the image shortcut of the fused kernel (SciPy's nfev counts them too).  Launch-chain
+   * schedules only see nfev: there the two are equal. */
+  int64_t n_fg_requests;
 } bore_engine_stats;
 
 typedef struct bore_engine bore_engine;

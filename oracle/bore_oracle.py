@@ -436,10 +436,12 @@ def value_and_input_grad(params, acts, X, transform="identity", dtype=np.float32
 def maxima(params, acts, bounds, num_starts=5, num_samples=1024,
            method="L-BFGS-B", options=None, transform="identity",
            random_state=None, print_fn=lambda s: None, dtype=np.float32,
-           X_init=None):
+           X_init=None, compute="float32"):
     """bore/mixins.py:22-72, restated line for line in behaviour:
     uniform samples -> predict -> argpartition -> SEQUENTIAL scipy minimize per
-    start with one single-point f/g call per evaluation."""
+    start with one single-point f/g call per evaluation.
+    compute="bfloat16": the same loop over the mixed-precision statement of the network
+    (forward_bf16 / value_and_input_grad_bf16), the arithmetic of a mixed_bfloat16 Keras model."""
     if options is None:
         options = dict(maxiter=1000, ftol=1e-9)
     if random_state is None or isinstance(random_state, (int, np.integer)):
@@ -450,9 +452,17 @@ def maxima(params, acts, bounds, num_starts=5, num_samples=1024,
     (low, high), dim = from_bounds(bounds)
     if X_init is None:
         X_init = random_state.uniform(low=low, high=high, size=(num_samples, dim))
-    z_init = predict(params, acts, X_init, dtype=dtype).squeeze(axis=-1)
+    if compute == "bfloat16":
+        z_init = forward_bf16(params, acts, X_init).squeeze(axis=-1)
+
+        def func_min(x):
+            v, g = value_and_input_grad_bf16(params, acts, x[None, :], transform, True)
+            return [v[0], g[0]]
+    else:
+        assert compute == "float32", compute
+        z_init = predict(params, acts, X_init, dtype=dtype).squeeze(axis=-1)
+        func_min = lambda x: value_and_input_grad(params, acts, x, transform, dtype)
     f_init = -z_init
-    func_min = lambda x: value_and_input_grad(params, acts, x, transform, dtype)
     results = []
     if num_starts > 0:
         ind = np.argpartition(f_init, kth=num_starts - 1, axis=None)

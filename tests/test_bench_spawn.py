@@ -54,6 +54,14 @@ def test_eight_ranks_the_drivers_widest_launch():
     assert 1.0 < pred["gain_over_one_gpu"] < 4.0
     runs = d["runs"]
     assert runs["n"] >= 2 and runs["min"] <= runs["p25"] <= runs["p75"] <= runs["max"]
+    # the backend's own view of the job: eight ranks, each with its own slice of the host cores
+    census = d["ranks"]
+    assert census["backend_world_size"] == 8 and census["backend"] == "gloo"      # (dry run: gloo)
+    assert sorted(r["rank"] for r in census["ranks"]) == list(range(8))
+    assert len({r["pid"] for r in census["ranks"]}) == 8
+    slices = [tuple(r["host_cores"]) for r in census["ranks"] if r["host_cores"]]
+    if len(os.sched_getaffinity(0)) >= 8:          # enough cores for disjoint slices
+        assert len(slices) == 8 and len(set(c for s in slices for c in s)) == sum(len(s) for s in slices)
     flow = d["flow_wall_s"]
     # by construction: repeats are bounded by --repeat-budget-s (120 s), the reference points by
     # 2 x 21 engines of the same few steps -- far inside the driver's 600 s

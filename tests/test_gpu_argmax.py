@@ -335,8 +335,11 @@ def test_async_engine_equals_lockstep_engine(gpu, dedup):
     for u, v in zip(a.state(), b.state()):
         assert np.array_equal(u, v)
     sa, sb = a.take_stats(), b.take_stats()
-    assert sa["none_results"] == sb["none_results"] and sa["n_fg_rows"] == sb["n_fg_rows"]
-    assert sa["fit_bytes"] == sb["fit_bytes"] and sa["argmax_bytes"] == sb["argmax_bytes"]
+    # (the optimisers asked for the same evaluations; the fused kernel's image shortcut served some
+    # of them without running the network: its n_fg_rows / argmax_bytes count the ones that ran)
+    assert sa["none_results"] == sb["none_results"] and sa["n_fg_requests"] == sb["n_fg_requests"]
+    assert 0 < sa["n_fg_rows"] <= sa["n_fg_requests"] and sb["n_fg_rows"] == sb["n_fg_requests"]
+    assert sa["fit_bytes"] == sb["fit_bytes"] and 0 < sa["argmax_bytes"] <= sb["argmax_bytes"]
     # (fused kernel: one timing per launch; resident workgroups go from one iteration to the next
     # without a launch -- two run() calls need two launches, parked loops a few more)
     assert 2 <= sa["fit_launches"] and sa["argmax_ms"] > 0
@@ -571,7 +574,7 @@ def test_async_engine_with_the_reference_default_of_five_restarts(gpu):
     for u, v in zip(a.state(), b.state()):
         assert np.array_equal(u, v)
     sa, sb = a.take_stats(), b.take_stats()
-    assert sa["none_results"] == sb["none_results"] and sa["n_fg_rows"] == sb["n_fg_rows"]
+    assert sa["none_results"] == sb["none_results"] and sa["n_fg_requests"] == sb["n_fg_requests"]
 
 
 def test_resident_workgroups_park_and_resume_with_a_slow_objective(gpu, monkeypatch):
@@ -618,7 +621,8 @@ def test_resident_engine_at_full_occupancy_equals_lockstep_engine(gpu):
     for u, v in zip(a.state(), b.state()):
         assert np.array_equal(u, v)
     sa, sb = a.take_stats(), b.take_stats()
-    assert sa["n_fg_rows"] == sb["n_fg_rows"] and sa["none_results"] == sb["none_results"]
+    assert sa["n_fg_requests"] == sb["n_fg_requests"] and sa["none_results"] == sb["none_results"]
+    assert sa["n_fg_rows"] <= sa["n_fg_requests"]            # (the image shortcut: ~a fifth of the requests)
     assert sa["phase_iterations"] == 512 * 8
 
 

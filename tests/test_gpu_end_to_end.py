@@ -80,6 +80,7 @@ def test_fused_iteration_kernel_against_the_oracle_teacher_forced(gpu):
     worst_theta = 0.0
     n_iter = n_same_starts = n_pick_same = n_clean = n_clean_same = n_none_both = n_none_one = 0
     n_rest = n_rest_accept_agree = n_rest_both = n_rest_both_same = 0
+    regret64 = []
     for it in range(T):
         th_prev, m_prev, v_prev, t_prev = eng.state()
         X_prev, y_prev = eng.observations()
@@ -135,6 +136,11 @@ def test_fused_iteration_kernel_against_the_oracle_teacher_forced(gpu):
             pick_same = (best is not None and bestd[l] >= 0
                          and np.allclose(x_eng, best.x, rtol=0, atol=1e-5))
             n_pick_same += pick_same
+            if best is not None and bestd[l] >= 0:
+                # the suggestion valued by the FLOAT64 network against the oracle's own suggestion
+                v64 = lambda xx: float(O.value_and_input_grad(pe, ACTS, np.asarray(xx)[None, :], "identity",
+                                                              dtype=np.float64)[0][0])
+                regret64.append(v64(x_eng) - v64(best.x))
             if not same_starts:
                 continue
             clean = True
@@ -163,7 +169,13 @@ def test_fused_iteration_kernel_against_the_oracle_teacher_forced(gpu):
         same_starts=[int(n_same_starts), n_iter], acceptance_agrees=[int(n_rest_accept_agree), n_rest],
         accepted_within_1e5=[int(n_rest_both_same), n_rest_both],
         pick_same_overall=[int(n_pick_same), n_iter], pick_same_clean=[int(n_clean_same), n_clean],
-        none_both=int(n_none_both), none_one_side=int(n_none_one)))
+        none_both=int(n_none_both), none_one_side=int(n_none_one),
+        pick_regret_under_float64_objective_quantiles_0_50_90_100=[
+            float(q) for q in np.quantile(np.abs(regret64), [0.0, 0.5, 0.9, 1.0])]))
+    # the stated float32 tolerance for suggested candidates: valued by the float64 network, the engine's
+    # suggestion is within 1e-3 of the oracle's in at least 95 % of the iterations where both suggest one
+    # (a restart that ends on another float32 plateau of the sigmoid accounts for the rest)
+    assert np.mean(np.abs(regret64) <= 1e-3) >= 0.95, np.sort(np.abs(regret64))[-5:]
     # measured (r2, 16 loops x 5 iterations): same starts 77/80 (0.96); acceptance agrees 192/231
     # (0.83); accepted restarts within 1e-5: 166/172 (0.97); suggestion 48/50 (0.96) where all
     # acceptances agree, 64/80 (0.80) overall.  Floors = measured - 5 points.
@@ -234,7 +246,8 @@ def test_config2_fit_and_argmax_chain_against_the_oracle_teacher_forced(gpu):
     worst_theta = 0.0
     n_iter = n_same_starts = n_pick_same = n_clean = n_clean_same = 0
     n_rest = n_acc_agree = n_both = n_both_same = 0
-    dfun, regret = [], []
+    dfun, regret, regret64 = [], [], []
+    status_pairs, acc_split, other_point = {}, {}, {}
     for it in range(T):
         N = X.shape[1]
         z = np.stack([O.labels(y[l], 0.25)[0] for l in range(L)]).astype(np.float32)
@@ -285,6 +298,10 @@ def test_config2_fit_and_argmax_chain_against_the_oracle_teacher_forced(gpu):
                 # the kernels' suggestion under the ORACLE's objective against the oracle's own best
                 v_dev = float(O.value_and_input_grad(pe, A2, x_eng[None, :], "identity")[0][0])
                 regret.append(v_dev - float(best.fun))
+                # ... and under the FLOAT64 network: the stated tolerance for suggested candidates
+                v64 = lambda xx: float(O.value_and_input_grad(pe, A2, np.asarray(xx)[None, :], "identity",
+                                                              dtype=np.float64)[0][0])
+                regret64.append(v64(x_eng) - v64(best.x))
             if not same_starts:
                 continue
             clean = True
@@ -296,14 +313,33 @@ def test_config2_fit_and_argmax_chain_against_the_oracle_teacher_forced(gpu):
                 n_acc_agree += acc_o == acc_d
                 clean = clean and acc_o == acc_d
                 dfun.append(float(fund[l, r]) - float(res.fun))
+                # -- per cause --
+                key = f"{int(res.status)}/{int(infod[l, r, 2])}"          # scipy-on-the-oracle / device
+                status_pairs[key] = status_pairs.get(key, 0) + 1
                 if acc_o and acc_d:
                     n_both += 1
-                    n_both_same += np.allclose(xd[l, r], res.x, rtol=0, atol=1e-5)
+                    same_x = bool(np.allclose(xd[l, r], res.x, rtol=0, atol=1e-5))
+                    n_both_same += same_x
+                    if not same_x:
+                        # another point: of equal value (the flat part of a saturated sigmoid, or the
+                        # same basin left at another float32 plateau) or a different optimum?
+                        d = abs(float(fund[l, r]) - float(res.fun))
+                        cause = ("equal_value_2e-6" if d <= 2e-6 else "value_within_1e-3" if d <= 1e-3
+                                 else "different_optimum")
+                        other_point[cause] = other_point.get(cause, 0) + 1
+                elif acc_o != acc_d:
+                    # one side ends "abnormal termination in the line search" (status 2): on the last
+                    # bits of f (values agree to 2e-6) or at different values?
+                    d = abs(float(fund[l, r]) - float(res.fun))
+                    cause = "status2_vs_accepted_same_value_2e-6" if d <= 2e-6 else "status2_vs_accepted_other_value"
+                    acc_split[cause] = acc_split.get(cause, 0) + 1
             if clean and best is not None and bestd[l] >= 0:
                 n_clean += 1
                 n_clean_same += pick_same
         X = np.concatenate([X, x_next[:, None, :]], axis=1)
         y = np.concatenate([y, objective(x_next)[:, None]], axis=1)
+    print("[config 2] status pairs (oracle/device):", status_pairs, "| acceptance disagreements:", acc_split,
+          "| both accepted, other point:", other_point)
     print(f"\n[end-to-end, config 2, teacher-forced] {L} models x {T} iterations x {R} restarts; worst "
           f"theta error / tolerance {worst_theta:.3f}; same starts {n_same_starts}/{n_iter}; acceptance "
           f"agrees {n_acc_agree}/{n_rest}; both accepted and x within 1e-5: {n_both_same}/{n_both}; pick "
@@ -314,6 +350,9 @@ def test_config2_fit_and_argmax_chain_against_the_oracle_teacher_forced(gpu):
     record_measurement("end_to_end_teacher_forced_cfg2", dict(
         abs_dfun_q50_q90_q99_max=[float(q) for q in np.quantile(dfun, [0.5, 0.9, 0.99, 1.0])],
         pick_regret_under_oracle_objective=[float(q) for q in np.sort(regret)],
+        pick_regret_under_float64_objective=[float(q) for q in np.sort(regret64)],
+        status_pairs_oracle_device=status_pairs, acceptance_disagreements_by_cause=acc_split,
+        both_accepted_other_point_by_cause=other_point,
         models=L, iterations=T, restarts=R, worst_theta_error_over_tolerance=worst_theta,
         same_starts=[int(n_same_starts), n_iter], acceptance_agrees=[int(n_acc_agree), n_rest],
         accepted_within_1e5=[int(n_both_same), n_both], pick_same_overall=[int(n_pick_same), n_iter],
@@ -332,3 +371,179 @@ def test_config2_fit_and_argmax_chain_against_the_oracle_teacher_forced(gpu):
     assert np.median(dfun) <= 5e-6 and np.quantile(dfun, 0.9) <= 5e-3
     assert len(regret) >= 0.9 * n_iter
     assert np.all(np.abs(regret) <= 1e-3) and np.mean(np.abs(regret) <= 1e-5) >= 0.6
+    # The decomposition (round 4, recorded): every restart both sides accept but end at different points,
+    # and every acceptance disagreement, is counted under exactly one cause ...
+    assert sum(other_point.values()) == n_both - n_both_same
+    assert sum(acc_split.values()) == n_rest - n_acc_agree
+    # ... other points are mostly points of (nearly) EQUAL VALUE on a flat classifier, not other optima
+    # (measured r4: 39 within 2e-6, 85 within 1e-3, 15 beyond, of 139), and most acceptance disagreements
+    # are a line search that fails on one side at the SAME value (72 of 123 within 2e-6),
+    assert other_point.get("different_optimum", 0) <= 0.2 * max(1, n_both - n_both_same)
+    assert acc_split.get("status2_vs_accepted_same_value_2e-6", 0) >= 0.4 * max(1, n_rest - n_acc_agree)
+    # and valued by the float64 network the suggestion is within 1e-3 of the oracle's (the stated
+    # float32 tolerance for suggested candidates)
+    assert np.all(np.abs(regret64) <= 1e-3)
+
+
+def _wide_chain_teacher_forced(name, D2, U2, A2, compute, L, T, R, NS, E, N0, seed):
+    """fit -> sample + screen -> restarts -> pick through the launch chain of a wide model, iteration
+    by iteration against the oracle (float32 or mixed-bfloat16 statement), teacher-forced: every
+    iteration starts from the kernels' state; the record grows by the kernels' suggestion.  Returns
+    the measurements (also recorded into parity_measured.json)."""
+    import torch
+    from bore_amd import _lib, ops
+    bf = compute == "bfloat16"
+    lo, hi = np.zeros(D2), np.ones(D2)
+    bounds = Bounds(lo, hi)
+    desc = _lib.make_desc(D2, U2, A2, compute=compute)
+    rs = np.random.RandomState(seed)
+    th0 = np.stack([pack(O.glorot_uniform_params(D2, U2, rs)) for _ in range(L)])
+    c = rs.uniform(0.2, 0.8, size=D2)
+
+    def objective(X):
+        return np.sum((X - c) ** 2, axis=-1) + 0.1 * np.sin(5.0 * X.sum(axis=-1))
+
+    def oracle_value64(pe, x):
+        """T(-f(x)) of the network in FLOAT64 arithmetic: the yardstick for "how good is this
+        suggestion", free of either side's float32 / bfloat16 noise."""
+        return float(O.value_and_input_grad(pe, A2, x[None, :], "identity", dtype=np.float64)[0][0])
+
+    X = rs.uniform(size=(L, N0, D2))
+    y = objective(X)
+    theta = torch.from_numpy(th0).cuda()
+    m, v = torch.zeros_like(theta), torch.zeros_like(theta)
+    t = torch.zeros(L, dtype=torch.int64, device=theta.device)
+    worst_theta = 0.0
+    n_iter = n_same_starts = n_pick_same = n_none_dev = n_none_ora = 0
+    n_rest = n_acc_agree = n_both = n_both_same = 0
+    start_overlap, dfun, regret, regret64, theta_within, fit_loss_rel = [], [], [], [], [], []
+    # why an accepted-by-one restart is not accepted by the other: (oracle status, device status)
+    status_pairs = {}
+    for it in range(T):
+        N = X.shape[1]
+        z = np.stack([O.labels(y[l], 0.25)[0] for l in range(L)]).astype(np.float32)
+        th_prev, m_prev, v_prev, t_prev = (a.cpu().numpy().copy() for a in (theta, m, v, t))
+        ops.mlp_fit(desc, theta, m, v, t, torch.from_numpy(X.astype(np.float32)).cuda(),
+                    torch.from_numpy(z).cuda(), E, 64, seed=5, model_index0=100, epoch0=it * E,
+                    want_loss=False)
+        x0d, _ = ops.sample_screen_topk(desc, theta, 5, NS, lo, hi, R, model_index0=100, draw_index=it)
+        xd, fund, _, infod = ops.lbfgsb_minimize(desc, theta, x0d, lo, hi, "identity", True,
+                                                 maxiter=1000, ftol=1e-9)
+        xbd, bestd = ops.select_best(xd, fund, infod)
+        th = theta.cpu().numpy()
+        x0d, xd, fund, infod, xbd, bestd = (a.cpu().numpy() for a in (x0d, xd, fund, infod, xbd, bestd))
+        assert np.array_equal(t.cpu().numpy(), t_prev + E * -(-N // 64))
+        x_next = np.empty((L, D2))
+        for l in range(L):
+            p = unpack(th_prev[l].copy(), D2, U2)
+            st = O.AdamState(p)
+            st.m, st.v, st.t = unpack(m_prev[l].copy(), D2, U2), unpack(v_prev[l].copy(), D2, U2), int(t_prev[l])
+            perms = shuffle.permutations(5, 1, E, N, model_index0=100 + l, epoch0=it * E)[0]
+            (O.fit_bf16 if bf else O.fit)(p, A2, st, X[l], z[l], perms, batch_size=64)
+            ref = pack(p)
+            # (bfloat16: a flipped rounding of an activation moves an update by a bf16 ulp of the
+            # gradient; stated tolerance of tests/test_gpu_parity.py's bf16 fit test)
+            tol = (2e-3 + 2e-2 * np.abs(ref)) if bf else (2e-4 + 2e-3 * np.abs(ref))
+            err = np.abs(th[l] - ref) / tol
+            worst_theta = max(worst_theta, float(err.max()))
+            pe = unpack(th[l].copy(), D2, U2)
+            if bf:
+                # E epochs of bfloat16 steps from the same state: a flipped rounding changes the sign of
+                # a near-zero gradient and with it a whole Adam step (lr) of that weight -- single
+                # weights drift apart, the fitted FUNCTION does not: nearly all weights within the
+                # stated tolerance, the two classifiers' losses on the data within 2 %
+                theta_within.append(float(np.mean(err <= 1.0)))
+                a_dev = O.forward_bf16(pe, A2[:-1] + ["linear"], X[l])
+                a_ref = O.forward_bf16(p, A2[:-1] + ["linear"], X[l])
+                l_dev = float(O.bce_with_logits(a_dev, z[l].reshape(-1, 1)).mean())
+                l_ref = float(O.bce_with_logits(a_ref, z[l].reshape(-1, 1)).mean())
+                fit_loss_rel.append(abs(l_dev - l_ref) / l_ref)
+                assert theta_within[-1] >= 0.97 and fit_loss_rel[-1] <= 0.02, (name, it, l, theta_within[-1], fit_loss_rel[-1])
+            else:
+                assert err.max() <= 1.0, (name, it, l, float(err.max()))
+            Xc = sampling.uniform_candidates(5, 1, NS, lo, hi, model_index0=100 + l, draw_index=it)[0]
+            pred = (O.forward_bf16(pe, A2, Xc) if bf else O.predict(pe, A2, Xc)).squeeze(axis=-1)
+            starts = Xc[np.argpartition(-pred, kth=R - 1, axis=None)[:R]]
+            results = O.maxima(pe, A2, bounds, num_starts=R, num_samples=NS, X_init=Xc, compute=compute)
+            n_iter += 1
+            s_o, s_d = {tuple(r) for r in starts}, {tuple(r) for r in x0d[l]}
+            start_overlap.append(len(s_o & s_d) / R)
+            n_same_starts += s_o == s_d
+            best = None
+            for res in results:
+                if (res.success or res.status == 1) and (best is None or res.fun < best.fun):
+                    best = res
+            n_none_ora += best is None
+            n_none_dev += bestd[l] < 0
+            x_eng = xbd[l] if bestd[l] >= 0 else rs.uniform(lo, hi)
+            x_next[l] = x_eng
+            if best is not None and bestd[l] >= 0:
+                n_pick_same += bool(np.allclose(x_eng, best.x, rtol=0, atol=1e-5)
+                                    or abs(fund[l, bestd[l]] - best.fun) <= 2e-6)
+                vg = O.value_and_input_grad_bf16 if bf else None
+                v_dev = (float(vg(pe, A2, x_eng[None, :], "identity", True)[0][0]) if bf else
+                         float(O.value_and_input_grad(pe, A2, x_eng[None, :], "identity")[0][0]))
+                regret.append(v_dev - float(best.fun))
+                regret64.append(oracle_value64(pe, x_eng) - oracle_value64(pe, np.asarray(best.x)))
+            by_start = {tuple(s): k for k, s in enumerate(starts)}
+            for r in range(R):              # restart by restart, where both sides have the start
+                k = by_start.get(tuple(x0d[l, r]))
+                if k is None:
+                    continue
+                res = results[k]
+                acc_o, acc_d = bool(res.success or res.status == 1), infod[l, r, 2] in (0, 1)
+                n_rest += 1
+                n_acc_agree += acc_o == acc_d
+                key = f"{int(res.status)}/{int(infod[l, r, 2])}"
+                status_pairs[key] = status_pairs.get(key, 0) + 1
+                dfun.append(float(fund[l, r]) - float(res.fun))
+                if acc_o and acc_d:
+                    n_both += 1
+                    n_both_same += bool(np.allclose(xd[l, r], res.x, rtol=0, atol=1e-5))
+        X = np.concatenate([X, x_next[:, None, :]], axis=1)
+        y = np.concatenate([y, objective(x_next)[:, None]], axis=1)
+    dfun, regret, regret64 = np.abs(dfun), np.asarray(regret), np.asarray(regret64)
+    meas = dict(
+        models=L, iterations=T, restarts=R, compute=compute, worst_theta_error_over_tolerance=worst_theta,
+        same_starts=[int(n_same_starts), n_iter], start_overlap_mean=float(np.mean(start_overlap)),
+        acceptance_agrees=[int(n_acc_agree), n_rest], accepted_within_1e5=[int(n_both_same), n_both],
+        status_pairs_oracle_device=status_pairs,
+        bf16_fit_theta_share_within_tolerance=theta_within or None, bf16_fit_loss_relative_difference=fit_loss_rel or None,
+        pick_same_or_equally_good=[int(n_pick_same), n_iter], none_device=int(n_none_dev), none_oracle=int(n_none_ora),
+        abs_dfun_q50_q90_q99_max=[float(q) for q in np.quantile(dfun, [0.5, 0.9, 0.99, 1.0])] if len(dfun) else None,
+        pick_regret_under_oracle_objective=[float(q) for q in np.sort(regret)],
+        pick_regret_under_float64_objective=[float(q) for q in np.sort(regret64)])
+    print(f"\n[end-to-end, {name}, teacher-forced]", meas)
+    record_measurement(f"end_to_end_teacher_forced_{name}", meas)
+    return meas
+
+
+def test_config3_fit_and_argmax_chain_against_the_oracle_teacher_forced(gpu):
+    """BASELINE config 3 (16-D, 64-64-64-1, float32) end to end: the launch chain
+    fit_kernel<3> (wide rounds) -> sample + screen -> lbfgsb_kernel_w8<3> / queue -> pick against
+    oracle.fit + oracle.maxima and the reference's acceptance rule (bore/mixins.py:57-89)."""
+    m = _wide_chain_teacher_forced("cfg3", 16, [64, 64, 64, 1], ["relu", "relu", "relu", "sigmoid"], "float32",
+                                   L=2, T=2, R=64, NS=1024, E=100, N0=96, seed=33)
+    n_it = m["same_starts"][1]
+    assert m["start_overlap_mean"] >= 0.9
+    assert len(m["pick_regret_under_float64_objective"]) >= 0.75 * n_it
+    # the stated float32 tolerance for suggested candidates: the device's pick, valued by the float64
+    # network, is within 1e-3 of the oracle's own pick (better or worse)
+    assert np.all(np.abs(m["pick_regret_under_float64_objective"]) <= 1e-3)
+
+
+def test_config5_bf16_fit_and_argmax_chain_against_the_bf16_oracle_teacher_forced(gpu):
+    """BASELINE config 5 (32-D, 128-128-1, bfloat16) end to end:
+    fit_bf16_mfma_kernel<4> -> screen (bf16 MFMA) -> lbfgsb_kernel<4, bf16> / queue -> pick against the
+    mixed-precision oracle (fit_bf16, forward_bf16, value_and_input_grad_bf16 under scipy).  A
+    bfloat16 prediction has 8 bits: both sides' objectives are step functions of x whose steps sit
+    in slightly different places, so restart-by-restart agreement is weak by construction; what is
+    asserted is the fit, the overlap of the screened starts and the quality of the pick."""
+    m = _wide_chain_teacher_forced("cfg5_bf16", 32, [128, 128, 1], ["relu", "relu", "sigmoid"], "bfloat16",
+                                   L=2, T=2, R=64, NS=1024, E=100, N0=96, seed=55)
+    n_it = m["same_starts"][1]
+    assert m["start_overlap_mean"] >= 0.7
+    # valued by the float64 network the device's pick is within a bfloat16 step (2^-8) of the oracle's
+    if len(m["pick_regret_under_float64_objective"]):
+        assert np.all(np.abs(m["pick_regret_under_float64_objective"]) <= 2.0 ** -7)
+    assert m["none_device"] + len(m["pick_regret_under_float64_objective"]) >= n_it - m["none_oracle"]

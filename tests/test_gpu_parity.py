@@ -617,7 +617,7 @@ def test_fit_of_a_data_set_whose_shuffle_does_not_fit_in_lds(gpu):
     m, v = torch.zeros_like(theta), torch.zeros_like(theta)
     t = torch.zeros(1, dtype=torch.int64, device="cuda")
     Xd, zd = dev(X, torch.float32).reshape(1, N, D), dev(z.astype(np.float32)).reshape(1, N)
-    with pytest.raises(_lib.UnsupportedError, match="pass explicit shuffles"):
+    with pytest.raises(_lib.NeedsPermError, match="pass explicit shuffles"):
         ops.mlp_fit(desc, theta, m, v, t, Xd, zd, E, B, seed=9)          # (device-drawn shuffle: refused, says why)
     h = ops.mlp_fit(desc, theta, m, v, t, Xd, zd, E, B, perm=dev(perms.astype(np.int32)).reshape(1, E, N))
     assert int(t[0]) == st.t == E * O.steps_per_epoch(N, B) == 938

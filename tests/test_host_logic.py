@@ -189,6 +189,20 @@ def test_callable_transforms_are_applied_on_the_host():
         CallableTransform(lambda u: 3.0).value_and_derivative(f)
     with pytest.raises(TypeError):
         resolve(3)
+    # functions that ARE a named transform resolve to the kernel; a user function that is merely CALLED
+    # exp stays the callable it is; a numpy function fails with the documented TypeError
+    from scipy.special import expit
+    assert resolve(torch.sigmoid).name == "sigmoid" and resolve(expit).name == "sigmoid" and resolve(torch.exp).name == "exp"
+
+    def exp(u):                      # not the exponential
+        return u * u
+    mine = resolve(exp)
+    assert isinstance(mine, CallableTransform) and mine.name is None
+    np.testing.assert_allclose(mine.value_and_derivative(f)[0], f * f, rtol=1e-6)
+    with pytest.raises(TypeError, match="torch tensor"):
+        resolve(np.tanh).value_and_derivative(f)
+    with pytest.raises(TypeError, match="differentiably"):
+        resolve(lambda u: torch.zeros_like(u.detach())).value_and_derivative(f)
 
 
 def test_tools_and_committed_measurements_are_readable():
