@@ -257,8 +257,8 @@ __device__ __forceinline__ void screen_body(const ScreenArgs &a, const long long
         static_assert(!BF16 || bore_shape_is_wide(SHAPE), "bfloat16: wide static shapes");
         bf16x8_t xf[ANet::CF1];
         ANet::make_xfrag(xf, [&](int d) -> float { return (d < D && row < Ns) ? (float)xval(row, d) : 0.f; });
-        anet.predict(arg_bf16_images<SHAPE>(smem).wf, arg_bf16_images<SHAPE>(smem).bias, xf);
-        p = anet.h[ANet::n][0][0];
+        anet.predict(arg_bf16_images<SHAPE>(smem), xf);
+        p = anet.out;
       } else if constexpr (SHAPE > 0) {  // activations in registers (mlp_regs.h)
         float xin[Net::KC0];
 #pragma unroll
@@ -608,7 +608,8 @@ extern "C" int bore_debug_lpp(unsigned long long *out) {  // [LB_PP_MAX][64]
 // living in registers across the optimiser (the fused iteration kernel is held to 256 VGPRs).
 // ALWAYS_COOP: the caller's launches never give a wave more than one problem at a time (the fused
 // iteration kernel): the lane-per-problem loop is not compiled.
-template <int SHAPE, bool BF16 = false, bool LEAN = false, bool ALWAYS_COOP = false>
+// MAYQ: the caller's launches may set a.queue (the fused iteration kernel's never do).
+template <int SHAPE, bool BF16 = false, bool LEAN = false, bool ALWAYS_COOP = false, bool MAYQ = true>
 __device__ __forceinline__ void lbfgsb_body(const LbfgsbArgs &a, const long long model,
                                             const int block_y, const int it_now = -1) {
   extern __shared__ float smem[];
@@ -657,7 +658,7 @@ __device__ __forceinline__ void lbfgsb_body(const LbfgsbArgs &a, const long long
   // the next from a counter in LDS: the weights are staged once per workgroup, the waves stay busy
   // until the workgroup's problems run out.  Same results (a problem's arithmetic does not depend on
   // the wave or the order).
-  const bool queue = a.queue != 0;
+  const bool queue = MAYQ && a.queue != 0;
   const bool coop = np <= NW || multi || queue;
   const int passes = multi ? (np + 3) / 4 : (queue ? 0x7fffffff : 1);
   int *qnext = reinterpret_cast<int *>(smem + a.o_queue);
@@ -731,7 +732,9 @@ __device__ __forceinline__ void lbfgsb_body(const LbfgsbArgs &a, const long long
   bool done = (myp < 0);
   const long long c_init = BORE_LCLOCK();
   long long t_adv = 0, t_fg = 0, n_rounds = 0;
-  int n_exec = 0;  // evaluations that RAN the network (nfev also counts requests served by the image shortcut)
+  // evaluations that RAN the network (nfev also counts requests served by the image shortcut): batch mode
+  // counts them per problem in LDS -- one ds_add per evaluation, no register carried through the optimiser
+  int *execs = cnt + 4;
   // ---- one problem per wave, static shape: the optimiser calls the evaluation (lbfgsb.h, DIRECT form) ----
   bool direct = false;
   if constexpr (SHAPE > 0) {
@@ -759,7 +762,7 @@ __device__ __forceinline__ void lbfgsb_body(const LbfgsbArgs &a, const long long
             return;
           }
         }
-        ++n_exec;
+        if (a.result && lane == 0) atomicAdd(execs + myp, 1);
         if constexpr (LEAN && !BF16) {
           if (!BORE_POINT_SHAPE(SHAPE)) {
             net.load_fwd(thw);
@@ -841,7 +844,7 @@ __device__ __forceinline__ void lbfgsb_body(const LbfgsbArgs &a, const long long
           }
           // (tried and dropped: the search's base point as a second entry -- another 7 % of the requests,
           // no gain over its compare and four more registers in the loop, profiles/r3/ab_headline.txt)
-          ++n_exec;
+          if (a.result && lane == 0) atomicAdd(execs + myp, 1);
           if constexpr (LEAN) {
             net.load_fwd(thw);
             net.template load_bwd<Net::n, 1>(thw);
@@ -981,7 +984,7 @@ __device__ __forceinline__ void lbfgsb_body(const LbfgsbArgs &a, const long long
   if (lane == 0) {
     double *r = res + myq * (D + 3);
     r[0] = st.f;
-    r[1] = (double)(st.status + 8 * n_exec);  // (status 0..2 | executed evaluations: unpacked below)
+    r[1] = (double)(st.status + 8 * execs[myq]);  // (status 0..2 | executed evaluations: unpacked below)
     r[2] = (double)st.nfev;
     for (int d = 0; d < D; ++d) r[3 + d] = wk.x[d];
   }
@@ -1161,7 +1164,8 @@ static int lbfgsb_build(const bore_mlp_desc *desc, int n_models, const float *th
     a.o_prob = (int)off; off += (size_t)a.prob_floats * PB;
     off = (off + 3) & ~(size_t)3;
     a.o_res = (int)off;  // batch mode: [max(R, 4)][D + 3] fp64 + the finished-problem counter
-    off += g_batch ? 2 * (size_t)(num_starts > 4 ? num_starts : 4) * ((size_t)D + 3) + 4 : 0;
+    // (+ the finished-problem counter and the per-problem counts of executed evaluations)
+    off += g_batch ? 2 * (size_t)(num_starts > 4 ? num_starts : 4) * ((size_t)D + 3) + 4 + 16 : 0;
     a.o_queue = (int)off; off += 4;  // (the queue's next-problem counter)
     a.total = (int)off;
     off = (off + 3) & ~(size_t)3;

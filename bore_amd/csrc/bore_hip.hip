@@ -2071,8 +2071,8 @@ __global__ __launch_bounds__(BORE_THREADS) void rows_kernel(const RowArgs a) {
             }
         }
       } else {
-        net.predict(im.wf, im.bias, xf);
-        if (lane < 16 && row < a.n_rows) out[row] = net.h[ANet::n][0][0];
+        net.predict(im, xf);
+        if (lane < 16 && row < a.n_rows) out[row] = net.out;
       }
     }
     return;

@@ -107,7 +107,7 @@ __device__ BORE_ITER_ONCE_ATTR void iteration_once(const IterArgs *__restrict__ 
   if (stp && threadIdx.x == 0) stp[3] = wall_clock64();
   __threadfence();
   __syncthreads();
-  lbfgsb_body<SHAPE, false, BORE_ITER_LEAN, true>(a.b, slot, 0, it);  // (publishes flag[lid] = it + 1)
+  lbfgsb_body<SHAPE, false, BORE_ITER_LEAN, true, false>(a.b, slot, 0, it);  // (publishes flag[lid] = it + 1)
 }
 
 // RESIDENT: the workgroup may go on to later iterations of its loop.  Otherwise ONE iteration -- the
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(BORE_THREADS, 2) void iteration_kernel(const IterAr
     if (stp && threadIdx.x == 0) stp[3] = wall_clock64();
     __threadfence();
     __syncthreads();
-    lbfgsb_body<SHAPE, false, BORE_ITER_LEAN, true>(a.b, slot, 0);  // (publishes flag[lid] = it + 1)
+    lbfgsb_body<SHAPE, false, BORE_ITER_LEAN, true, false>(a.b, slot, 0);  // (publishes flag[lid] = it + 1)
     // not the loop's last iteration: leave the next one to a later launch.  (Any wave may say so,
     // and before the others are done: the host reacts to `parked` only after the flag.)
     if (a.targets && threadIdx.x == 0 && it + 1 < a.targets[slot])
