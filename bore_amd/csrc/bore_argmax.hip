@@ -560,6 +560,11 @@ struct LbfgsbArgs {
   // queue != 0: one problem per wave at a time, PB may exceed the waves: a wave that finishes a problem
   // draws the workgroup's next one from a counter in LDS (o_queue) and reuses its workspace slot
   int queue, o_queue;
+  // big != NULL: the optimiser's two 2m x 2m matrices of every wave live in a slot of this device pool
+  // (host_common.h: big_pool) instead of in LDS: big_wave doubles per wave, slots of 8 waves
+  double *big;
+  int *big_locks;
+  int big_wave;
   float sign;
   // LDS carve (float offsets; the fp64 regions are 8-byte aligned)
   int o_tile, o_vals, o_box, o_prob, prob_floats, o_state, o_dw, o_iw, o_layout, total;
@@ -663,13 +668,35 @@ __device__ __forceinline__ void lbfgsb_body(const LbfgsbArgs &a, const long long
   const int passes = multi ? (np + 3) / 4 : (queue ? 0x7fffffff : 1);
   int *qnext = reinterpret_cast<int *>(smem + a.o_queue);
   if (queue && tid == 0) *qnext = NW;  // (the first NW problems go to the waves in order)
+  // (the pooled matrices are compiled into the one kernel whose launches use them: the eight-wave kernel of
+  // the 128-wide shape; lbfgsb_build decides per launch)
+  constexpr bool BIG_OK = ALWAYS_COOP && SHAPE == 4;
+  const bool use_big = BIG_OK && a.big != nullptr;
+  if (use_big && tid == 0) {
+    // a free slot of the pool: more slots than workgroups can be resident at once, so the walk ends
+    int sl = (int)((blockIdx.x * gridDim.y + blockIdx.y) % BORE_BIG_SLOTS);
+    while (__hip_atomic_exchange(a.big_locks + sl, 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 0)
+      sl = sl + 1 == BORE_BIG_SLOTS ? 0 : sl + 1;
+    qnext[1] = sl;
+    qnext[2] = 0;  // waves of this workgroup that are done with the slot
+  }
   const int myrow = coop ? wv * 16 : wv * 16 + lane;
   // (ALWAYS_COOP kernels run one problem per wave or nothing: the lane count is a compile-time 64
   // there, which is what lets lbfgsb.h's LB_UNI move the optimiser's integers to scalar registers)
   const lbfgsb::Coop cp = (ALWAYS_COOP || coop) ? lbfgsb::Coop{lane, 64} : lbfgsb::Coop{0, 1};
   __syncthreads();  // weights staged; from here on the waves are independent
+  double *my_big = nullptr;
+  int big_slot = 0;
+  if (use_big) {
+    big_slot = uniform_i32(qnext[1]);
+    my_big = a.big + ((size_t)big_slot * 8 + wv) * (size_t)a.big_wave;
+  }
   const long long c_staged = BORE_LCLOCK();
-  if (wv >= np) return;  // wave without problems (np < 4)
+  if (wv >= np) {  // wave without problems (np < 4)
+    if (use_big && lane == 0 && atomicAdd(qnext + 2, 1) == NW - 1)
+      __hip_atomic_store(a.big_locks + big_slot, 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
   double *res = reinterpret_cast<double *>(smem + a.o_res);  // batch mode: [np][D + 3] fun, status, nfev, x
   int *cnt = reinterpret_cast<int *>(res + (multi ? np : 4) * (D + 3));
   for (int pass = 0; pass < passes; ++pass) {
@@ -698,8 +725,13 @@ __device__ __forceinline__ void lbfgsb_body(const LbfgsbArgs &a, const long long
       for (int i = lane; i < a.prob_floats / 4; i += 64) b4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
       wave_lds_sync();
     }
+    if (my_big) {  // every problem finds the two matrices zeroed, as in the zeroed LDS
+      double2 *b2 = reinterpret_cast<double2 *>(my_big);
+      for (int i = lane; i < a.big_wave / 2; i += 64) b2[i] = make_double2(0.0, 0.0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     wk = lbfgsb::make_work(reinterpret_cast<double *>(base + a.o_dw),
-                           reinterpret_cast<int *>(base + a.o_iw), D, a.opt.m);
+                           reinterpret_cast<int *>(base + a.o_iw), D, a.opt.m, my_big);
     const double *x0 = a.x0 + (model * a.R + p0 + myp) * (long long)D;
     lbfgsb::lbfgsb_init(st, wk, D, a.opt.m, x0, blo, bhi, bnbd);
 #ifdef BORE_STAMPS
@@ -1046,6 +1078,11 @@ __device__ __forceinline__ void lbfgsb_body(const LbfgsbArgs &a, const long long
     __hip_atomic_store(a.flag + lid, it_done + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
   }  // passes
+  if (use_big) {  // the workgroup's last wave to get here frees the pool slot
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0 && atomicAdd(qnext + 2, 1) == NW - 1)
+      __hip_atomic_store(a.big_locks + big_slot, 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  }
 }
 
 template <int SHAPE, bool BF16 = false>
@@ -1107,12 +1144,13 @@ static int lbfgsb_build(const bore_mlp_desc *desc, int n_models, const float *th
   // per-problem LDS block: fp64 workspace | int workspace (8-byte aligned); the scalar
   // State lives in registers
   const size_t state_f = 0;
-  const size_t dw_f = 2 * (size_t)lbfgsb::dwork_size(D, m);
+  size_t dw_f = 2 * (size_t)lbfgsb::dwork_size(D, m);
   const size_t iw_f = ((size_t)lbfgsb::iwork_size(D) + 3) & ~(size_t)3;
   a.o_state = 0;
   a.o_dw = (int)state_f;
   a.o_iw = (int)(state_f + dw_f);
   a.prob_floats = (int)(state_f + dw_f + iw_f);
+  a.big = nullptr; a.big_locks = nullptr; a.big_wave = 0;
   // largest number of problems per workgroup whose state fits beside theta and the tile
   // (tile rows: one 16-row block per wave that has a problem)
   int PB = num_starts < BORE_BATCH_MAX ? num_starts : BORE_BATCH_MAX;
@@ -1171,6 +1209,36 @@ static int lbfgsb_build(const bore_mlp_desc *desc, int n_models, const float *th
     off = (off + 3) & ~(size_t)3;
     a.o_layout = (int)off; off += BORE_LAYOUT_FLOATS;
     if (off * 4 <= BORE_LDS_BYTES) break;
+  }
+  // The eight-wave kernel with fewer than eight problems beside the weights (32->128-128-1: six): with the
+  // optimiser's two 2m x 2m matrices in a slot of the device pool instead of in LDS eight fit (the matrices
+  // are touched by the subspace minimisation only -- once in a hundred evaluations of BASELINE config 5).
+  // BORE_LBFGSB_BIG = 0 / 1 forces the choice (tests, A/B).
+  if (w8 && !g_batch && flavour == 4) {  // (lbfgsb_body: BIG_OK)
+    const int forced = getenv("BORE_LBFGSB_BIG") ? atoi(getenv("BORE_LBFGSB_BIG")) : -1;
+    const size_t small_f = 2 * (size_t)lbfgsb::dwork_size(D, m, true) + iw_f;
+    const size_t fixed = off - (size_t)a.prob_floats * PB;   // everything but the problems (floats)
+    int PB2 = (int)((BORE_LDS_BYTES / 4 - fixed) / small_f);
+    if (PB2 > 8) PB2 = 8;
+    if (PB2 >= 1 && (forced < 0 ? PB2 > PB : forced != 0)) {
+      BigPool pool;
+      const int rcp = big_pool(8 * (size_t)lbfgsb::big_size(m), &pool);
+      if (rcp) return rcp;
+      a.big = pool.buf; a.big_locks = pool.locks; a.big_wave = (int)(pool.per_slot / 8);
+      // re-carve with the smaller problem blocks (same order of regions as in the loop above)
+      PB = PB2;
+      dw_f = 2 * (size_t)lbfgsb::dwork_size(D, m, true);
+      a.o_iw = (int)(state_f + dw_f);
+      a.prob_floats = (int)(state_f + dw_f + iw_f);
+      off = (size_t)a.o_prob + (size_t)a.prob_floats * PB;
+      off = (off + 3) & ~(size_t)3;
+      a.o_res = (int)off;
+      a.o_queue = (int)off; off += 4;
+      a.total = (int)off;
+      off = (off + 3) & ~(size_t)3;
+      a.o_layout = (int)off; off += BORE_LAYOUT_FLOATS;
+      if (off * 4 > BORE_LDS_BYTES) return fail(BORE_E_UNSUPPORTED, "lbfgsb_minimize: LDS carve with the pooled matrices");
+    }
   }
   // One problem per wave and many restarts per model: a few workgroups per model, each drawing its
   // share of the restarts from a queue (lbfgsb_body).  About four workgroups per CU over the launch;

@@ -73,6 +73,39 @@ inline int device_cus() {
   return cus[dev];
 }
 
+// Device scratch for the restart kernels whose optimiser keeps its two 2m x 2m matrices outside the
+// LDS (lbfgsb.h: make_work's `big`): BIG_SLOTS workgroup slots of `per_slot` doubles each plus one
+// lock word per slot (0 = free).  A workgroup takes a free slot when it starts and frees it when its
+// last wave is done, so the slots only have to outnumber the workgroups RESIDENT at once (at most one
+// per CU for these LDS-filling kernels; launches on several streams share the pool).  Per device,
+// grow-only (a request for larger slots allocates a new pool and leaves the old one to launches that
+// may still use it), the first call of a size is a blocking hipMalloc + hipMemset.
+constexpr int BORE_BIG_SLOTS = 1024;
+struct BigPool {
+  double *buf = nullptr;
+  int *locks = nullptr;
+  size_t per_slot = 0;
+};
+inline int big_pool(size_t per_slot_doubles, BigPool *out) {
+  static BigPool pools[64];
+  static std::mutex mu;
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 64) return fail(BORE_E_UNSUPPORTED, "big_pool: device index %d", dev);
+  std::lock_guard<std::mutex> lock(mu);
+  BigPool &p = pools[dev];
+  if (p.per_slot < per_slot_doubles) {
+    BigPool np;
+    np.per_slot = per_slot_doubles;
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&np.buf), (size_t)BORE_BIG_SLOTS * per_slot_doubles * 8));
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&np.locks), (size_t)BORE_BIG_SLOTS * 4));
+    HIP_TRY(hipMemset(np.locks, 0, (size_t)BORE_BIG_SLOTS * 4));
+    p = np;
+  }
+  *out = p;
+  return 0;
+}
+
 // Builds the layout with the largest tile (max_rows, then 16 rows fewer each try: a wave's
 // unit of work is a 16-row block) whose theta + tile + `extra_floats` fit the CU's LDS; the
 // tile may shrink only when `may_shrink`.

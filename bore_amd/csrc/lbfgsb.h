@@ -88,10 +88,15 @@ struct State {
 // caller must hand in a 16-byte aligned base: the device compiler merges adjacent fp64 LDS
 // loads into ds_read_b128, which returns WRONG data at 8-byte alignment on gfx950 (found as a
 // host/device mismatch for odd n; see tests/test_gpu_argmax.py).
-LB_HD int dwork_size(int n, int m) {
+// big_outside: the two 2m x 2m matrices of the subspace minimisation (wn, snd: 8 m^2 doubles, 37 % of a
+// 32-variable problem's workspace) live in a buffer of the caller's (big_size doubles, 16-byte aligned,
+// any address space -- the device kernels put it in global memory when that lets more problems share
+// the LDS) instead of inside dw.
+LB_HD int dwork_size(int n, int m, bool big_outside = false) {
   const int ne = (n + 1) & ~1, mne = (m * n + 1) & ~1, mm = (m * m + 1) & ~1;
-  return 2 * mne + 3 * mm + 8 * m * m + 8 * m + 9 * ne + 6 * m;
+  return 2 * mne + 3 * mm + (big_outside ? 0 : 8 * m * m) + 8 * m + 9 * ne + 6 * m;
 }
+LB_HD int big_size(int m) { return 8 * m * m; }
 LB_HD int iwork_size(int n) { return 3 * n; }
 
 // Views into the workspaces (all 0-based; matrices column-major like the original).
@@ -108,9 +113,10 @@ struct Work {
   double *rwn;              // 2m: 1 / diag of the two Cholesky factors in wn
   double *rsy, *rsq;        // m each: 1 / sy_ii and 1 / sqrt(sy_ii)
   int *index, *iwhere, *indx2;
+  int vm;                   // wn / snd are outside the caller's dw (global memory on the device)
 };
 
-LB_HD Work make_work(double *dw, int *iw, int n, int m) {
+LB_HD Work make_work(double *dw, int *iw, int n, int m, double *big = nullptr) {
   Work w;
   const int ne = (n + 1) & ~1, mne = (m * n + 1) & ~1, mm = (m * m + 1) & ~1;
   w.ws = dw; dw += mne;
@@ -118,8 +124,14 @@ LB_HD Work make_work(double *dw, int *iw, int n, int m) {
   w.sy = dw; dw += mm;
   w.ss = dw; dw += mm;
   w.wt = dw; dw += mm;
-  w.wn = dw; dw += 4 * m * m;
-  w.snd = dw; dw += 4 * m * m;
+  w.vm = big != nullptr;
+  if (big) {  // (dwork_size(n, m, true) + big_size(m))
+    w.wn = big;
+    w.snd = big + 4 * m * m;
+  } else {
+    w.wn = dw; dw += 4 * m * m;
+    w.snd = dw; dw += 4 * m * m;
+  }
   w.z = dw; dw += ne;
   w.r = dw; dw += ne;
   w.d = dw; dw += ne;
@@ -165,9 +177,19 @@ struct Coop {
 #endif
 #if defined(__HIP_DEVICE_COMPILE__)
 #define LB_LANES_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+// Where lanes hand entries of the 2m x 2m matrices to each other (formk, dpofa): those may live in
+// global memory (make_work's `big`, Work::vm) -- then the vector-memory counter is waited for as well.
+// (Not everywhere: a kernel with register spills has scratch stores in flight all the time, and waiting
+// for them at every hand-over cost the 32-32-1 restart kernel 30 %.)
+#define LB_LANES_SYNC_VM(vm)                                          \
+  do {                                                                \
+    if (vm) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          \
+    LB_LANES_SYNC();                                                  \
+  } while (0)
 #define LB_OPAQUE_LANE(x) asm volatile("" : "+v"(x))
 #else
 #define LB_LANES_SYNC() ((void)0)
+#define LB_LANES_SYNC_VM(vm) ((void)(vm))
 #define LB_OPAQUE_LANE(x) ((void)0)
 #endif
 
@@ -334,7 +356,7 @@ LB_HD void daxpy(int n, double alpha, const double *x, double *y) {
 // rd[k] receives 1/R_kk, formed as sqrt(d) * (1/d) from the pivot d = R_kk^2: the square root and
 // the reciprocal do not depend on each other, so a step's chain is one of them plus two
 // multiplies instead of a square root followed by a divide.  The entries R_kj are scaled by it.
-LB_HD int dpofa(double *a, int ld, int n, double *rd, const Coop c = Coop{0, 1}) {
+LB_HD int dpofa(double *a, int ld, int n, double *rd, const Coop c = Coop{0, 1}, const int vm = 0) {
   if (c.nl >= n && c.nl > 1) {
     const int j = c.lane;
     double s = 0.0;
@@ -343,7 +365,7 @@ LB_HD int dpofa(double *a, int ld, int n, double *rd, const Coop c = Coop{0, 1})
       const double dkk = lane_bcast(a[k * ld + k] - s, k);
       if (dkk <= 0.0) {  // not positive definite
         if (j == k) a[k * ld + k] = dkk;
-        LB_LANES_SYNC();
+        LB_LANES_SYNC_VM(vm);
         return k + 1;
       }
       const double rkk = sqrt(dkk);
@@ -358,7 +380,7 @@ LB_HD int dpofa(double *a, int ld, int n, double *rd, const Coop c = Coop{0, 1})
         a[j * ld + k] = t;
         s += t * t;
       }
-      LB_LANES_SYNC();
+      LB_LANES_SYNC_VM(vm);
     }
     return 0;
   }
@@ -986,7 +1008,7 @@ LB_HDN int formk(const IterArgs s, const Work w) {
         }
         for (int i = 0; i < m - 1; ++i) WN1(m + i, jy) = WN1(m + 1 + i, jy + 1);
       }
-      LB_LANES_SYNC();
+      LB_LANES_SYNC_VM(w.vm);
     }
     // new rows in blocks (1,1), (2,1), (2,2) and the new column in block (2,1): one entry
     // set per jy, independent of each other
@@ -1010,7 +1032,7 @@ LB_HDN int formk(const IterArgs s, const Work w) {
         WN1(is, js) = temp2;
         WN1(is, jy) = temp3;
       }
-      LB_LANES_SYNC();
+      LB_LANES_SYNC_VM(w.vm);
       const int jyc = col - 1;
       const int jpntr = wrap(s.head + col - 1, m);
       for (int i = c.lane; i < col; i += c.nl) {
@@ -1023,7 +1045,7 @@ LB_HDN int formk(const IterArgs s, const Work w) {
         }
         WN1(is2, jyc) = temp3;
       }
-      LB_LANES_SYNC();
+      LB_LANES_SYNC_VM(w.vm);
     }
     upcl = col - 1;
   } else {
@@ -1068,7 +1090,7 @@ LB_HDN int formk(const IterArgs s, const Work w) {
         WN1(is, jy) += -temp1 + temp3;
     }
   }
-  LB_LANES_SYNC();
+  LB_LANES_SYNC_VM(w.vm);
   FK_MARK(20);
   // upper triangle of WN = [D+Y'ZZ'Y/theta   -L_a'+R_z'] [-L_a+R_z   S'AA'S*theta]
   // (each iy writes its own columns iy and col+iy)
@@ -1084,11 +1106,11 @@ LB_HDN int formk(const IterArgs s, const Work w) {
     for (int jy = iy; jy < col; ++jy) WN(jy, is) = WN1(is1, jy);
     WN(iy, iy) += w.sy[iy * m + iy];
   }
-  LB_LANES_SYNC();
+  LB_LANES_SYNC_VM(w.vm);
   FK_MARK(21);
   // Cholesky of the (1,1) block, then L^-1(-L_a'+R_z') in the (1,2) block (one right-hand
   // side per lane)
-  if (dpofa(wn, m2, col, w.rwn, c)) return -1;
+  if (dpofa(wn, m2, col, w.rwn, c, w.vm)) return -1;
   FK_MARK(22);
   const int col2 = 2 * col;
   if (c.nl > 1 && c.nl >= col) {
@@ -1099,16 +1121,16 @@ LB_HDN int formk(const IterArgs s, const Work w) {
   }
   for (int js = col + c.lane; js < col2; js += c.nl)
     dtrsl_lower_rhs(wn, m2, col, wn + js * m2, w.rwn);
-  LB_LANES_SYNC();
+  LB_LANES_SYNC_VM(w.vm);
   FK_MARK(23);
   // (2,2) block: S'AA'S*theta + (L^-1(-L_a'+R_z'))'(L^-1(-L_a'+R_z')), then its Cholesky
   for (int e = c.lane; e < col * col; e += c.nl) {
     const int is = col + e / col, js = col + e % col;
     if (js >= is) WN(is, js) += ddot(col, wn + is * m2, wn + js * m2);
   }
-  LB_LANES_SYNC();
+  LB_LANES_SYNC_VM(w.vm);
   FK_MARK(24);
-  if (dpofa(wn + col * m2 + col, m2, col, w.rwn + col, c)) return -2;
+  if (dpofa(wn + col * m2 + col, m2, col, w.rwn + col, c, w.vm)) return -2;
   FK_MARK(25);
   return 0;
 #undef WN

@@ -703,7 +703,11 @@ def test_lbfgsb_problem_queue_gives_the_same_bits(gpu, monkeypatch, D, units, co
     X0 = dev(rs.uniform(size=(3, R, D)))
     lo, hi = np.zeros(D), np.ones(D)
     outs = []
-    for q, extra in (("0", {}), ("3", {}), ("7", {}), ("7", {"BORE_LBFGSB_W8": "1", "BORE_LBFGSB_OCC2": "1"})):
+    # (BORE_LBFGSB_BIG: the eight-wave kernel with the optimiser's two 2m x 2m matrices in the device pool)
+    for q, extra in (("0", {}), ("3", {}), ("7", {}), ("7", {"BORE_LBFGSB_W8": "1", "BORE_LBFGSB_OCC2": "1"}),
+                     ("7", {"BORE_LBFGSB_W8": "1", "BORE_LBFGSB_BIG": "1"}),
+                     ("0", {"BORE_LBFGSB_W8": "1", "BORE_LBFGSB_BIG": "1"}),
+                     ("7", {"BORE_LBFGSB_W8": "1", "BORE_LBFGSB_BIG": "0"})):
         monkeypatch.setenv("BORE_LBFGSB_QUEUE", q)
         for k, v in extra.items():
             monkeypatch.setenv(k, v)
