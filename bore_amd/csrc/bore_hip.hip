@@ -239,6 +239,8 @@ __device__ __forceinline__ void dw_task(const MlpLayout &L, float *smem, int o_t
                      : __builtin_amdgcn_mfma_f32_16x16x4f32(av[kc], bv[kc], acc, 0, 0, 0);
     bsum += bv[kc];
   }
+  // (round 4, tried and dropped: 2 - 4 interleaved partial sums instead of one chain of kch dependent
+  // matrix instructions -- fit 586 -> 582 us at N ~ 100, no change at N ~ 25, 14 spilled registers)
   float g[5] = {acc[0], acc[1], acc[2], acc[3], 0.f};
   BORE_TSTAMP(10);
   FIT_MARK(9);
@@ -986,16 +988,12 @@ __device__ __forceinline__ void fit_body(const FitArgs &a, const long long slot,
   // compiler rotated with copies that waited for the request at once.)  Same permutations, same rows.
   const bool pipe_perm = SHAPE > 0 && !WIDE && !a.perm && PG >= 2 && blockDim.x == BORE_THREADS &&
                          a.data_in_lds && N - (steps - 1) * a.B <= 16 * (BORE_THREADS / 64 - 1);
-  // who draws the shuffles of the pipelined form: the fourth wave, two epochs ahead, while one pass
-  // ranks all keys (N <= 64); otherwise the whole workgroup, two epochs at the top of every odd epoch
-  // (see the epoch header).  (Tried: the pipelined form also for last steps of 49..64 rows, drawn by the
-  // workgroup -- 623 against 593 us per fit at N 48..67, profiles/r3/ab_headline.txt: those keep the
-  // four-epoch groups and the gather in the step.)
-#ifdef BORE_WAVE_DRAWS_ALWAYS  // (A/B builds: the mid-round-3 form)
-  const bool wave_draws = true;
-#else
-  const bool wave_draws = N <= 64;
-#endif
+  // The shuffles of the pipelined form are drawn by the fourth wave, two epochs ahead, during an epoch's
+  // last step (make_perm_wave_buckets: ~1 k cycles at 100 rows; round 3's all-pairs count took ~6 k there,
+  // more than a step's front half, and the workgroup drew the shuffles of 65..112 rows at the top of every
+  // odd epoch instead -- 2.2 k cycles per epoch on the step chain).  (Tried in round 3: the pipelined form
+  // also for last steps of 49..64 rows, drawn by the workgroup -- 623 against 593 us per fit at N 48..67,
+  // profiles/r3/ab_headline.txt: those keep the four-epoch groups and the gather in the step.)
   constexpr int PRE_KC = RegNet<(SHAPE > 0 ? SHAPE : 1), 1>::KC0;
   static_assert(WIDE || SHAPE <= 0 || (PRE_KC + 1) * BORE_THREADS <= BORE_FIT_STAGE_FLOATS, "stage region");
   float *stage = smem + a.o_stage + tid;  // [PRE_KC + 1][BORE_THREADS]: inputs 4 kc + q4, then the label
@@ -1037,20 +1035,12 @@ __device__ __forceinline__ void fit_body(const FitArgs &a, const long long slot,
   // inside the step, the two forms met in blocks where the compiler waited for every pending request)
   auto run_epochs = [&](auto pipe_c) {
   constexpr bool PIPE = decltype(pipe_c)::value;
-  const int pmask = wave_draws ? 1 : 3;  // (PIPE) shuffle buffers in use: see the epoch header
   for (int e = 0; e < a.epochs; ++e) {
     FIT_MARK(12);
     if constexpr (PIPE) {  // (first: the test every step of the headline run takes)
-      // More than 64 rows: one wave cannot rank an epoch's keys inside a step's front half (~6 k cycles
-      // for 100 rows against 2.5 k: the row-block waves stood 5 k cycles per epoch at the mid-step
-      // barrier, fit marks at N = 100).  There the WHOLE workgroup draws two epochs' shuffles at the top
-      // of every odd epoch (make_perm_group, ~2.2 k cycles per epoch at 100 rows) for the two that follow -- four
-      // buffers, epoch e in buffer e & 3 -- so that the next epoch's is always there for the rows parked
-      // during an epoch's last step.
-      if (!wave_draws && (e & 1) && e + 1 < a.epochs)
-        make_perm_group(a.seed, a.model0 + model, epoch0 + e + 1, min(2, a.epochs - e - 1), N, keys,
-                        perm_all + ((e + 1) & 2) * N);
-      perm_s = perm_all + (e & pmask) * N;
+      // two shuffle buffers: epoch e reads buffer e & 1; during its last step the fourth wave draws epoch
+      // e + 2's into the same buffer, which nobody reads any more (that step's rows were parked a step ago)
+      perm_s = perm_all + (e & 1) * N;
     } else if (a.perm) {
       if (a.perm_in_lds) {
         const int *pg = a.perm + (model * a.epochs + e) * (long long)N;
@@ -1101,7 +1091,7 @@ __device__ __forceinline__ void fit_body(const FitArgs &a, const long long slot,
           for (int kc = 0; kc < PRE_KC; ++kc) cx[kc] = stage[kc * BORE_THREADS];
           cz = stage[PRE_KC * BORE_THREADS];
           const bool last_s = s == steps - 1;
-          const int *perm_n = last_s ? perm_all + ((e + 1) & pmask) * N : perm_s;
+          const int *perm_n = last_s ? perm_all + ((e + 1) & 1) * N : perm_s;
           const int row0n = last_s ? 0 : row0 + a.B;
           const int nbn = last_s && e + 1 >= a.epochs ? 0 : min(a.B, N - row0n);
           live_n = wv * 16 + m16 < nbn;
@@ -1263,13 +1253,18 @@ __device__ __forceinline__ void fit_body(const FitArgs &a, const long long slot,
         float gx[PRE_KC], gz;
         request_row(gx, gz, src);
         park_row(gx, gz, live_n);
-        if (wave_draws && wv == BORE_THREADS / 64 - 1 && s == steps - 1 && e + 2 < a.epochs) {
+        if (wv == BORE_THREADS / 64 - 1 && s == steps - 1 && e + 2 < a.epochs) {
           // (an opaque copy keeps the epoch's hash in THIS wave's branch: wave-uniform scalar code is
           // otherwise hoisted in front of every wave's step)
           long long draw_epoch = epoch0 + e + 2;
           asm volatile("" : "+v"(draw_epoch));
-          make_perm_wave(shuffle_base(a.seed, a.model0 + model, draw_epoch), N,
-                         reinterpret_cast<unsigned long long *>(keys), perm_all + (e & 1) * N);
+          // (up to 64 rows: one row per lane and N compares each -- cheaper than the buckets' fixed cost)
+          if (N <= 64)
+            make_perm_wave(shuffle_base(a.seed, a.model0 + model, draw_epoch), N,
+                           reinterpret_cast<unsigned long long *>(keys), perm_all + (e & 1) * N);
+          else
+            make_perm_wave_buckets(shuffle_base(a.seed, a.model0 + model, draw_epoch), N,
+                                   reinterpret_cast<unsigned long long *>(keys), perm_all + (e & 1) * N);
         }
       }
       __syncthreads();
@@ -2212,10 +2207,18 @@ __global__ __launch_bounds__(BORE_THREADS) void evaluate_kernel(const EvalArgs a
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(BORE_THREADS) void shuffle_kernel(unsigned long long seed,
                                                               long long model0, long long epoch0,
-                                                              int epochs, int N, int *perm) {
+                                                              int epochs, int N, int *perm,
+                                                              int wave_form) {
   extern __shared__ float smem[];
   unsigned *keys = reinterpret_cast<unsigned *>(smem);
   const long long model = blockIdx.x, e = blockIdx.y;
+  if (wave_form) {  // (tests: the one-wave bucket ranking the pipelined fit draws its shuffles with)
+    if (threadIdx.x < 64)
+      make_perm_wave_buckets(shuffle_base(seed, model0 + model, epoch0 + e), N,
+                             reinterpret_cast<unsigned long long *>(smem),
+                             perm + (model * epochs + e) * (long long)N);
+    return;
+  }
   make_perm(shuffle_base(seed, model0 + model, epoch0 + e), N, keys,
             perm + (model * epochs + e) * (long long)N);
 }
@@ -2316,6 +2319,8 @@ static int fit_build(const bore_mlp_desc *desc, int n_models, float *theta, floa
   size_t perm_f = a.perm_in_lds ? (size_t)PG * N : 0, keys_f = perm ? 0 : (size_t)perm_group_scratch_floats(N, PG);
   // (the pipelined fit of 65..128 rows keeps four epochs' shuffles: fit_body, pipe_perm)
   if (!perm && stage_f && N <= 128 && perm_f < 4 * (size_t)N) perm_f = 4 * (size_t)N;
+  // (... and its drawing wave ranks by buckets: make_perm_wave_buckets' scratch)
+  if (!perm && stage_f && keys_f < BORE_PERM_WAVE_FLOATS) keys_f = BORE_PERM_WAVE_FLOATS;
   if (g_batch)  // a slot's own N (<= this N) may shuffle more epochs together: room for each case
     for (long long nn : {(long long)(N < 64 ? N : 64), (long long)(N < 128 ? N : 128)}) {
       const int pg = perm_group(nn, BORE_THREADS);
@@ -2678,12 +2683,15 @@ extern "C" int bore_shuffle_perm(uint64_t seed, int64_t model_index0, int n_mode
     return fail(BORE_E_INVALID, "shuffle_perm: bad argument");
   if (epochs == 0) return 0;
   if (epochs > 65535) return fail(BORE_E_UNSUPPORTED, "shuffle_perm: epochs > 65535");
-  const size_t bytes = (size_t)perm_scratch_floats(N) * 4;
+  // BORE_SHUFFLE_WAVE = 1 (tests): N <= 128 rows through make_perm_wave_buckets, the form the
+  // pipelined fit uses inside its steps -- the same permutations
+  const int wave_form = N <= 128 && getenv("BORE_SHUFFLE_WAVE") && atoi(getenv("BORE_SHUFFLE_WAVE")) ? 1 : 0;
+  const size_t bytes = (wave_form ? (size_t)BORE_PERM_WAVE_FLOATS : (size_t)perm_scratch_floats(N)) * 4;
   int rc = allow_lds(shuffle_kernel, bytes);
   if (rc) return rc;
   hipLaunchKernelGGL(shuffle_kernel, dim3(n_models, epochs), dim3(BORE_THREADS), bytes,
                      (hipStream_t)stream, seed, (long long)model_index0, (long long)epoch0, epochs,
-                     (int)N, perm);
+                     (int)N, perm, wave_form);
   HIP_TRY(hipGetLastError());
   return 0;
 }

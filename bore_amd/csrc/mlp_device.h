@@ -496,4 +496,78 @@ __device__ __forceinline__ void make_perm_wave(unsigned long long base, int N,
   }
 }
 
+// The same permutation by ONE wave in a third of the cycles at 100 rows (65 <= N <= 128): bucket
+// ranking.  A row's rank = (rows in buckets below its own) + (rows of its bucket with a smaller word);
+// the bucket is the top 7 bits of the row's 32-bit key, so the 128 buckets hold about one row each.
+// Rows enter their bucket's member list through an LDS counter (the ORDER of arrival does not matter:
+// a row is compared with every member), a wave scan of the counts gives the buckets' first ranks, and
+// every row walks its own bucket (<= CAP members, predicated compares).  Members are 32-bit: inside a
+// bucket the top 7 key bits agree, so (low 25 key bits << 7 | row) orders like (key << 32 | row).
+// Exact: the same permutation as make_perm.  A bucket with more than CAP rows (~2e-4 of the shuffles
+// of 128 rows) sends the whole shuffle through make_perm_wave.
+// scratch: BORE_PERM_WAVE_FLOATS floats, 16-byte aligned, touched by this wave only.
+constexpr int BORE_PERM_BUCKETS = 128, BORE_PERM_CAP = 8;
+#define BORE_PERM_WAVE_FLOATS (BORE_PERM_BUCKETS + BORE_PERM_BUCKETS * BORE_PERM_CAP)
+// inclusive prefix sum over the 64 lanes: four DPP shifts inside each row of 16, the rows' totals by
+// v_readlane (no LDS round trips)
+__device__ __forceinline__ int wave_inclusive_scan(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);  // row_shr:1
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);  // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);  // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);  // row_shr:8
+  const int t0 = __builtin_amdgcn_readlane(v, 15), t1 = __builtin_amdgcn_readlane(v, 31),
+            t2 = __builtin_amdgcn_readlane(v, 47);
+  const int row = (threadIdx.x & 63) >> 4;
+  return v + (row > 0 ? t0 : 0) + (row > 1 ? t1 : 0) + (row > 2 ? t2 : 0);
+}
+__device__ __forceinline__ void make_perm_wave_buckets(unsigned long long base, int N,
+                                                       unsigned long long *scratch, int *perm_out) {
+  const int lane = threadIdx.x & 63;
+  int *cnt = reinterpret_cast<int *>(scratch);                            // [128] counts, then first rank | count << 16
+  unsigned *mem = reinterpret_cast<unsigned *>(scratch) + BORE_PERM_BUCKETS;  // [128][CAP] member words
+  cnt[lane] = 0;
+  cnt[lane + 64] = 0;
+  wave_lds_sync();
+  unsigned w[2];
+  int b[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int i = lane + 64 * j;
+    const unsigned key = shuffle_key(base, i);
+    w[j] = (key << 7) | (unsigned)i;  // (i < 128)
+    b[j] = (int)(key >> 25);
+  }
+  int slot[2] = {0, 0};
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+    if (lane + 64 * j < N) slot[j] = atomicAdd(&cnt[b[j]], 1);
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+    if (lane + 64 * j < N && slot[j] < BORE_PERM_CAP) mem[b[j] * BORE_PERM_CAP + slot[j]] = w[j];
+  wave_lds_sync();
+  const int2 c01 = *reinterpret_cast<const int2 *>(cnt + 2 * lane);  // this lane's two buckets
+  if (__any(c01.x > BORE_PERM_CAP || c01.y > BORE_PERM_CAP)) {       // (wave-uniform; the member area is free again)
+    make_perm_wave(base, N, scratch + BORE_PERM_BUCKETS / 2, perm_out);
+    return;
+  }
+  const int first = wave_inclusive_scan(c01.x + c01.y) - (c01.x + c01.y);
+  *reinterpret_cast<int2 *>(cnt + 2 * lane) = make_int2(first | (c01.x << 16), (first + c01.x) | (c01.y << 16));
+  wave_lds_sync();
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int i = lane + 64 * j;
+    if (i < N) {
+      const int pc = cnt[b[j]];
+      int r = pc & 0xffff;
+      const int nb = pc >> 16;
+      const uint4 *mb = reinterpret_cast<const uint4 *>(mem + b[j] * BORE_PERM_CAP);
+      const uint4 m0 = mb[0], m1 = mb[1];
+      const unsigned mm[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
+#pragma unroll
+      for (int q = 0; q < BORE_PERM_CAP; ++q) r += (q < nb && mm[q] < w[j]) ? 1 : 0;
+      perm_out[r] = i;
+    }
+  }
+}
+
 }  // namespace bore

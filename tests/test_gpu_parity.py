@@ -229,6 +229,27 @@ def test_shuffle_stream_is_bit_exact_and_drives_fit(gpu):
         assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1]), N
 
 
+def test_one_wave_bucket_ranking_draws_the_same_shuffles(gpu, monkeypatch):
+    """Round 4: the pipelined fit's fourth wave ranks an epoch's keys by buckets (make_perm_wave_buckets,
+    ~1 k cycles at 100 rows instead of ~6 k).  Through bore_shuffle_perm's test switch: the SAME
+    permutations as the all-pairs count and as the host statement, for every N <= 128 -- and over enough
+    shuffles of 128 rows that buckets overflow (more than eight rows in one of 128: ~2e-3 per shuffle)
+    and the fall-back inside runs too."""
+    monkeypatch.setenv("BORE_SHUFFLE_WAVE", "1")
+    for N in (1, 2, 17, 63, 64, 65, 100, 112, 127, 128):
+        d = ops.shuffle_perm(77, 4, 9, N, model_index0=5, epoch0=3).cpu().numpy()
+        assert np.array_equal(d, shuffle.permutations(77, 4, 9, N, model_index0=5, epoch0=3)), N
+        assert np.array_equal(np.sort(d, axis=-1), np.broadcast_to(np.arange(N), d.shape))
+    wave = ops.shuffle_perm(2024, 64, 512, 128).cpu().numpy()            # 32 768 shuffles of 128 rows
+    monkeypatch.setenv("BORE_SHUFFLE_WAVE", "0")
+    ref = ops.shuffle_perm(2024, 64, 512, 128).cpu().numpy()
+    assert np.array_equal(wave, ref)
+    # (how many of them took the fall-back: shuffles with a bucket of more than eight keys)
+    over = sum(int(np.bincount(shuffle.shuffle_keys(2024, m, e, 128) >> 25, minlength=128).max() > 8)
+               for m in range(64) for e in range(512))
+    assert over >= 3, over
+
+
 @pytest.mark.parametrize("D,units,acts,N,B,E", [
     (2, [16, 16, 1], ["relu", "relu", "sigmoid"], 24, 64, 1),     # one epoch: nothing to draw ahead
     (2, [16, 16, 1], ["relu", "relu", "sigmoid"], 24, 64, 2),     # two: both drawn before the loop
