@@ -373,7 +373,10 @@ def timed_run(args, loop_ids, barrier, steps=None, warmup=None):
         eng = _DryEngine(loop_ids)
     elif native:
         from bore_amd.engine import NativeEngine
-        eng = NativeEngine(loop_ids, groups=args.groups, async_loops=args.schedule == "async")
+        # (--objective native: the library's built-in Branin, evaluated by the engine's host loop itself;
+        # python: the same function as a numpy callback through ctypes)
+        eng = NativeEngine(loop_ids, groups=args.groups, async_loops=args.schedule == "async",
+                           **({"objective": "branin01"} if args.objective == "native" else {}))
     else:
         from bore_amd.engine import ReplicaEngine
         eng = ReplicaEngine(loop_ids, mode=args.mode, groups=args.groups)
@@ -799,6 +802,10 @@ def run_rank(args):
                                    "restarts from 1024 samples",
                        "loops_per_gpu": loops, "total_loops": total, "restarts": args.mode,
                        "host_loop": "native" if r["native"] else "python",
+                       # the synthetic objective (evaluated on the host, excluded from the metric)
+                       "objective": ("Branin-Hoo on [0, 1]^2, the library's built-in (C, inside the host loop)"
+                                     if r["native"] and args.objective == "native" else
+                                     "Branin-Hoo on [0, 1]^2, a numpy callback"),
                        "schedule": args.schedule if r["native"] else "groups",
                        "stream_groups": None if (r["native"] and args.schedule == "async") else r["n_groups"],
                        "worker_streams": st.get("worker_streams"),
@@ -910,6 +917,9 @@ def parse_args(argv=None):
     ap.add_argument("--engine", default="native", choices=["native", "python"],
                     help="host loop of the replica engine: native = bore_engine_* (C++), python = "
                          "bore_amd.engine.ReplicaEngine (the same trajectories, bit for bit)")
+    ap.add_argument("--objective", default="native", choices=["native", "python"],
+                    help="the synthetic Branin objective: the library's built-in (evaluated inside the "
+                         "engine's host loop) or the same function as a numpy callback")
     ap.add_argument("--schedule", default="async", choices=["groups", "async"],
                     help="native engine: groups = loop groups in lock-step on their own streams; "
                          "async = every loop re-enters the next launch as soon as its own restarts "

@@ -39,7 +39,7 @@ EXPORTS = [
     "bore_shuffle_perm", "bore_labels", "bore_uniform_candidates", "bore_screen_topk", "bore_sample_screen_topk",
     "bore_lbfgsb_minimize", "bore_append_observations", "bore_select_best",
     "bore_svgd_optimize", "bore_set_batch", "bore_engine_create", "bore_engine_run", "bore_engine_size", "bore_engine_observations",
-    "bore_engine_state", "bore_engine_get_stats", "bore_engine_destroy",
+    "bore_engine_state", "bore_engine_get_stats", "bore_engine_destroy", "bore_objective_branin01",
 ]
 
 

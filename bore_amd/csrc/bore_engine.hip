@@ -137,6 +137,19 @@ __global__ void bore_spin_kernel(long long ticks) {
   while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
 }
 
+extern "C" int bore_objective_branin01(const double *x, int64_t n, int32_t D, double *y, void *) {
+  if (D != 2 || !x || !y) return 1;
+  // (bore_amd/engine.py: branin01 -- numpy evaluates the same expression tree)
+  const double pi = 3.141592653589793;
+  const double a = 5.1 / (4 * (pi * pi)), b = 5 / pi, c = 10 * (1 - 1 / (8 * pi));
+  for (int64_t i = 0; i < n; ++i) {
+    const double x1 = 15.0 * x[2 * i] - 5.0, x2 = 15.0 * x[2 * i + 1];
+    const double t = x2 - a * (x1 * x1) + b * x1 - 6;
+    y[i] = t * t + c * std::cos(x1) + 10;
+  }
+  return 0;
+}
+
 struct bore_engine {
   bore_mlp_desc desc;
   bore_engine_cfg cfg;

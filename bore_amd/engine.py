@@ -95,6 +95,15 @@ class NativeEngine:
         tr = resolve(transform).negated()
         assert tr.name is not None, "the native engine runs on the device only: a named transform ('identity', 'sigmoid', 'exp')"
         assert tr.negate, "the engine minimises transform(-f(x)) (bore/mixins.py:20)"
+        # objective="branin01": the library's built-in Branin (bore_objective_branin01: the same fp64
+        # expression, evaluated by the host loop itself -- no interpreter between a result and the next
+        # row; what bench.py times).  A callable is called back through ctypes as before.
+        native = None
+        if isinstance(objective, str):
+            if objective != "branin01":
+                raise ValueError(f"built-in objectives: 'branin01' (got {objective!r}); or pass a callable")
+            assert D == 2, "branin01 is two-dimensional"
+            native, objective = "bore_objective_branin01", branin01
         self.objective = objective
         self.low, self.high = np.zeros(D), np.ones(D)
         rss, th, X0, y0 = initial_state(self.loop_ids, D, self.units, self.P, n_init, objective,
@@ -115,6 +124,8 @@ class NativeEngine:
                 return 1
 
         self._cb = _lib.OBJECTIVE_FN(_objective)
+        if native is not None:
+            self._cb = _lib_ctypes.cast(getattr(_lib.lib(), native), _lib.OBJECTIVE_FN)
         self._lo, lo_p = ops._host_f64(self.low, D, "low")
         self._hi, hi_p = ops._host_f64(self.high, D, "high")
         cfg = _lib.EngineCfg(L, max(1, min(int(groups), L)), int(self.loop_ids[0]), int(n_init),

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define BORE_ABI_VERSION 9
+#define BORE_ABI_VERSION 10
 #define BORE_MAX_LAYERS 8
 #define BORE_BATCH_MAX 64 /* rows per tile == wavefront width */
 #define BORE_DIM_MAX 64   /* largest input dimension for the by-value bound arrays */
@@ -372,6 +372,12 @@ void bore_set_batch(const bore_batch *batch);
 /* y[i] = objective(x[i]) for n points: x host fp64 [n][D], y host fp64 [n].  Returns 0, or
  * non-zero to stop: bore_engine_run then drains the work in flight and returns BORE_E_CALLBACK. */
 typedef int (*bore_objective_fn)(const double *x, int64_t n, int32_t D, double *y, void *user);
+/* A built-in objective of that type: Branin-Hoo on its native box, rescaled to [0, 1]^2 (D = 2; the
+ * synthetic objective of BASELINE.json's configs 1 and 4, bore_amd.engine.branin01 -- the same
+ * operations in the same order in fp64).  Passed to bore_engine_create it keeps the interpreter out
+ * of the host loop: a Python callback costs ~40 us per call, which at 512 loops was ALL of the host
+ * thread's time and ~50 us of every loop-iteration's turn-around.  `user` is ignored. */
+int bore_objective_branin01(const double *x, int64_t n, int32_t D, double *y, void *user);
 
 typedef struct bore_engine_cfg {
   int32_t n_loops;      /* loops on this GPU */

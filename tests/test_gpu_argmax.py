@@ -577,6 +577,35 @@ def test_async_engine_with_the_reference_default_of_five_restarts(gpu):
     assert sa["none_results"] == sb["none_results"] and sa["n_fg_requests"] == sb["n_fg_requests"]
 
 
+def test_builtin_branin_objective_equals_the_numpy_callback(gpu):
+    """bore_objective_branin01 (the host loop evaluates the synthetic objective itself: what bench.py
+    times) against the numpy callback: the same fp64 expression -- values within 2 ulp everywhere, and
+    where they are bit-equal on this host (they are, wherever libm's cos and numpy's agree) the two
+    engines' trajectories are the same bit for bit."""
+    import ctypes
+    from bore_amd.engine import NativeEngine, branin01
+    rs = np.random.RandomState(5)
+    X = np.ascontiguousarray(rs.uniform(size=(20000, 2)))
+    y = np.empty(len(X))
+    vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    f = _lib.lib().bore_objective_branin01
+    f.restype, f.argtypes = ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]
+    assert f(vp(X), len(X), 2, vp(y), None) == 0
+    ref = branin01(X)
+    np.testing.assert_allclose(y, ref, rtol=4.5e-16, atol=0)
+    assert f(vp(X), len(X), 3, vp(y), None) != 0                 # two-dimensional only
+    a = NativeEngine(np.arange(60, 90), async_loops=True, objective="branin01", epochs=20, num_samples=64)
+    b = NativeEngine(np.arange(60, 90), async_loops=True, epochs=20, num_samples=64)
+    a.run(6)
+    b.run(6)
+    assert a.X.shape == b.X.shape == (30, 16, 2)
+    assert np.array_equal(a.y, branin01(a.X)) or np.allclose(a.y, branin01(a.X), rtol=4.5e-16, atol=0)
+    if np.array_equal(y, ref):
+        assert np.array_equal(a.X, b.X) and np.array_equal(a.y, b.y)
+    with pytest.raises(ValueError, match="built-in objectives"):
+        NativeEngine(np.arange(2), objective="hartmann6")
+
+
 def test_resident_workgroups_park_and_resume_with_a_slow_objective(gpu, monkeypatch):
     """A workgroup waits a bounded time on its CU for the objective value (include/bore_hip.h,
     bore_batch residency); with an objective slower than that it parks, and the host launches the

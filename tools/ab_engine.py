@@ -15,7 +15,8 @@ def child(tag, loops, steps, warm, reps):
     from bore_amd.engine import NativeEngine
     vals, dev, digest = [], None, None
     for _ in range(reps):
-        eng = NativeEngine(np.arange(loops), async_loops=True)
+        eng = NativeEngine(np.arange(loops), async_loops=True,
+                           **({"objective": "branin01"} if os.environ.get("BORE_AB_OBJECTIVE", "native") == "native" else {}))
         eng.run(warm)
         eng.take_stats()
         torch.cuda.synchronize()
