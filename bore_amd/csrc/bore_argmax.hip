@@ -1248,7 +1248,9 @@ static int lbfgsb_build(const bore_mlp_desc *desc, int n_models, const float *th
   a.queue = 0;
   const long long q_env = getenv("BORE_LBFGSB_QUEUE") ? atoll(getenv("BORE_LBFGSB_QUEUE")) : -1;
   if (!g_batch && PB <= (w8 ? 8 : 4) && num_starts > PB && q_env != 0) {
-    const long long want = q_env > 0 ? q_env : 4LL * device_cus();
+    // (the 32-32-1 flavour stages 6 KB of weights and runs two workgroups per CU: finer shares -- 32 per CU
+    // over the launch -- measured best there, profiles/r4/ab_log.txt; the wide flavours stage 40 - 50 KB)
+    const long long want = q_env > 0 ? q_env : (flavour == 2 ? 32LL : 4LL) * device_cus();
     long long per_model = (want + n_models - 1) / n_models;
     const long long most = (num_starts + slots - 1) / slots;
     if (per_model > most) per_model = most;
