@@ -169,12 +169,13 @@ class BatchMaximizableMixin(MaximizableMixin):
                 matrix and history in LDS; beyond 64 particles, up to 256, the matrix entries are formed on
                 the fly); float32 networks -- anything else
                 falls back to "host" with a warning;
-      "host"    the checker of the device kernel: ``_func_max`` -- value + input gradient of
+      "host"    for what the device refuses: ``_func_max`` -- value + input gradient of
                 ``transform(f(x))`` for all particles -- is one HIP launch per SVGD iteration;
-                kernel matrix, repulsion and the Adagrad step are the reference's float64 numpy
-                statements (bore_amd/optimizers/svgd.py, pinned bit for bit by goldens recorded
-                from the reference); the device kernel equals it to rounding (1e-9 after 200
-                iterations, tests/test_svgd.py) and is ~an order of magnitude faster."""
+                kernel matrix, repulsion and the Adagrad step are a short float64 numpy driver
+                (bore_amd/optimizers/svgd.py).  The checker of both is oracle/svgd_oracle.py, the
+                reference's SVGD step for step, bit-equal to trajectories recorded from the reference;
+                the device kernel equals it to rounding (1e-9 after 200 iterations,
+                tests/test_svgd.py) and is ~an order of magnitude faster than the host driver."""
 
     svgd_mode = "device"
 

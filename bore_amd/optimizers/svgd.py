@@ -1,12 +1,14 @@
-"""Stein variational gradient descent for batch acquisition (behaviour of
-bore/optimizers/svgd/base.py:11-131 and bore/optimizers/svgd/kernels.py:4-28).
+"""Stein variational gradient descent for batch acquisition: the API of bore/optimizers/svgd
+(``SVGD``, ``RadialBasis``, ``DistortionConstant``, ``DistortionExpDecay``, ``rank``;
+base.py:11-131, kernels.py:4-28) for the requests the DEVICE kernels do not take.
 
-``BatchMaximizableMixin.argmax_batch`` (bore/mixins.py:100-116) moves ``batch_size``
-particles with the SVGD update, the objective being ``transform(f(x))``: value and
-input-gradient of ALL particles come from one ``bore_mlp_value_and_input_grad`` launch
-per iteration (the reference makes one TensorFlow call per iteration as well); the
-particle interaction (RBF kernel, repulsion term, Adagrad-with-momentum step, clipping)
-is O(n^2 d) float64 numpy on the host, exactly the reference's arithmetic.
+``BatchMaximizableMixin.argmax_batch`` (bore_amd/mixins.py) runs all SVGD iterations of up to
+256 particles in one launch (``bore_svgd_optimize``).  What it refuses -- bfloat16 networks, more
+particles, a callable transform, a user's own kernel object or callback -- comes here: the value
+and input gradient of all particles are still ONE HIP launch per iteration (``func``), the
+particle interaction is a short float64 numpy driver.  The step-for-step restatement of the
+reference (bit-equal to its recorded trajectories) is the checker, ``oracle/svgd_oracle.py``;
+this driver is held to it at 1e-10 (tests/test_svgd.py).
 """
 from __future__ import annotations
 
@@ -16,9 +18,15 @@ from sklearn.utils import check_random_state
 from .utils import from_bounds
 
 
-class DistortionConstant:
-    """omega(beta) = c."""
+def rank(a):
+    """Fraction of entries <= each entry (the "weak" empirical CDF the reference's doctest shows:
+    [0.453, 0.859, 0.379, 0.379, 0.762] -> [0.6, 1.0, 0.4, 0.4, 0.8])."""
+    a = np.asarray(a)
+    assert a.ndim == 1, "only support 1d arrays!"
+    return (a[None, :] <= a[:, None]).sum(axis=1) / a.size
 
+
+class DistortionConstant:
     def __init__(self, c=1.):
         self.c = c
 
@@ -27,84 +35,63 @@ class DistortionConstant:
 
 
 class DistortionExpDecay:
-    """omega(beta) = beta ** -lambd."""
-
     def __init__(self, lambd=1.):
         self.lambd = lambd
 
     def __call__(self, beta):
-        return np.power(beta, -self.lambd)
-
-
-def rank(a):
-    """Empirical CDF of the entries of a 1-d array ("weak" percentile / 100):
-
-    >>> rank(np.array([0.4532752, 0.858725, 0.3792093, 0.3792093, 0.7619765]))
-    array([0.6, 1. , 0.4, 0.4, 0.8])
-    """
-    assert a.ndim == 1, "only support 1d arrays!"
-    return np.less_equal(a, a[:, None]).mean(axis=1)
+        return beta ** (-self.lambd)
 
 
 class RadialBasis:
-    """exp(-|x - x'|^2 / (2 h^2)); ``length_scale=None`` picks h by the median heuristic
-    h^2 = median(|x - x'|^2) / (2 log(n + 1)); h is floored at 1e-6."""
+    """k(x, x') = exp(-|x - x'|^2 / 2h^2); ``length_scale=None``: the median heuristic
+    h^2 = median |x - x'|^2 / (2 log(n + 1)); h >= 1e-6."""
 
     def __init__(self, length_scale=1.0):
         self.length_scale = length_scale
 
     def value_and_grad(self, X):
-        n = X.shape[0]
-        diff = X[:, None, :] - X
-        sq = np.sum(np.square(diff), axis=-1)
+        """(K [n, n], sum_j d k(x_j, x_i) / d x_j [n, d]) -- the repulsion term of the update."""
+        delta = X[:, None, :] - X[None, :, :]
+        dist2 = np.einsum("ijd,ijd->ij", delta, delta)
         h = self.length_scale
         if h is None:
-            h = np.sqrt(.5 * np.median(sq) / np.log(n + 1))
-        h = np.maximum(h, 1e-6)
-        gamma = .5 / h ** 2
-        K = np.exp(-gamma * sq)
-        K_grad = 2. * np.sum(gamma * diff * K[..., None], axis=1)
-        return K, K_grad
+            h = np.sqrt(np.median(dist2) / (2.0 * np.log(len(X) + 1)))
+        h = max(float(h), 1e-6)
+        K = np.exp(dist2 * (-0.5 / h ** 2))
+        return K, np.einsum("ij,ijd->id", K, delta) / h ** 2
 
 
 class SVGD:
+    """n_iter updates x += step * phi / (eps + sqrt(hist)) with phi = (K (zeta * grad f) + tau * repulsion) / n
+    and hist the exponential average of phi^2 (its first value phi^2 itself)."""
 
     def __init__(self, kernel=None, n_iter=1000, step_size=1e-3, alpha=.9, eps=1e-6, tau=1.,
                  distortion=None):
-        self.kernel = RadialBasis() if kernel is None else kernel
-        self.n_iter, self.step_size = n_iter, step_size
-        self.alpha, self.eps, self.tau = alpha, eps, tau
-        self.distortion = DistortionConstant() if distortion is None else distortion
+        self.kernel = kernel if kernel is not None else RadialBasis()
+        self.distortion = distortion if distortion is not None else DistortionConstant()
+        self.n_iter, self.step_size, self.alpha, self.eps, self.tau = n_iter, step_size, alpha, eps, tau
 
     def optimize_from_init(self, func, x_init, bounds=None, callback=None):
-        """``func(X (n, d)) -> (f (n,), grad (n, d))``; returns the particles after n_iter
-        updates (clipped to ``bounds`` after every update)."""
-        if bounds is not None:
-            (low, high), _ = from_bounds(bounds)
-        n = x_init.shape[0]
+        """``func(X [n, d]) -> (f [n], grad [n, d])``; the particles after n_iter updates, clipped to
+        ``bounds`` after each."""
+        box = None if bounds is None else from_bounds(bounds)[0]
+        x = np.array(x_init, dtype=np.float64)
         hist = None
-        x = x_init.copy()
         for _ in range(self.n_iter):
-            K, K_grad = self.kernel.value_and_grad(x)
-            f, f_grad = func(x)
-            zeta = self.distortion(rank(f))
-            grad = K @ (np.expand_dims(zeta, axis=-1) * f_grad) + self.tau * K_grad
-            grad /= n
-            if hist is None:                      # Adagrad with momentum
-                hist = grad ** 2
-            else:
-                hist *= self.alpha
-                hist += (1 - self.alpha) * grad ** 2
-            x += self.step_size * np.true_divide(grad, self.eps + np.sqrt(hist))
-            if bounds is not None:
-                x = x.clip(low, high)
+            K, repulsion = self.kernel.value_and_grad(x)
+            f, grad = func(x)
+            weight = np.asarray(self.distortion(rank(f)), dtype=np.float64).reshape(-1, 1) * np.ones((len(x), 1))
+            phi = (K @ (weight * grad) + self.tau * repulsion) / len(x)
+            hist = phi * phi if hist is None else self.alpha * hist + (1.0 - self.alpha) * (phi * phi)
+            x = x + self.step_size * phi / (self.eps + np.sqrt(hist))
+            if box is not None:
+                x = np.clip(x, box[0], box[1])
             if callback is not None:
                 callback(x)
         return x
 
     def optimize(self, func, batch_size, bounds=None, callback=None, random_state=None):
-        """Start from ``batch_size`` uniform samples of the box."""
-        random_state = check_random_state(random_state)
+        """From ``batch_size`` uniform draws in the box (the draw bore/optimizers/svgd/base.py:121-129 makes)."""
         (low, high), dims = from_bounds(bounds)
-        x_init = random_state.uniform(low=low, high=high, size=(batch_size, dims))
+        x_init = check_random_state(random_state).uniform(low=low, high=high, size=(batch_size, dims))
         return self.optimize_from_init(func, x_init, bounds, callback)

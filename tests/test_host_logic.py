@@ -207,16 +207,23 @@ def test_callable_transforms_are_applied_on_the_host():
 
 def test_tools_and_committed_measurements_are_readable():
     """The GPU-box scripts under tools/ at least compile, and the judged measurement files of the current
-    round parse (a bench.py run reads profiles/r3/pmc_traffic.json and loops_sweep.json)."""
+    round parse (a bench.py run reads the newest round's pmc_traffic.json and loops_sweep.json)."""
     import glob, json, os, py_compile
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     scripts = glob.glob(os.path.join(root, "tools", "*.py"))
     assert len(scripts) >= 10
     for path in scripts:
         py_compile.compile(path, doraise=True)
-    traffic = json.load(open(os.path.join(root, "profiles", "r3", "pmc_traffic.json")))
+    import bench
+    assert bench.TRAFFIC_FILE.startswith(os.path.join("profiles", "r4")) and bench.SWEEP_FILE.startswith(os.path.join("profiles", "r4"))
+    traffic = json.load(open(os.path.join(root, bench.TRAFFIC_FILE)))
     assert traffic["iteration_kernel"]["hbm_bytes_per_model"] > 0
-    sweep = json.load(open(os.path.join(root, "profiles", "r3", "loops_sweep.json")))
-    assert set(sweep["it_per_s"]) >= {"64", "512"}
-    line = json.loads(open(os.path.join(root, "profiles", "r3", "bench_driver_form.json")).read().strip().splitlines()[-1])
+    # the PMC pass names the kernel sources it was collected on; bench.py compares with the tree it times
+    assert len(traffic["csrc_sha256"]) == 64 and len(bench.csrc_digest()) == 64
+    sweep = json.load(open(os.path.join(root, bench.SWEEP_FILE)))
+    assert set(sweep["it_per_s"]) >= {"64", "512", "1024", "4096"}
+    line = json.loads(open(os.path.join(root, "profiles", "r4", "bench_driver_form.json")).read().strip().splitlines()[-1])
+    for cfg in ("cfg2_hartmann6_32-32-1_R256", "cfg3_hpo16_64-64-64-1_R1024", "cfg5_nas32_128-128-1_bf16_R4096"):
+        reps = line["configs"][cfg]["many_loops"]["ms_reps"]
+        assert reps["n"] >= 5 and reps["min"]["lbfgsb"] <= line["configs"][cfg]["many_loops"]["ms"]["lbfgsb"] <= reps["max"]["lbfgsb"]
     assert line["unit"] == "BO-iterations/s" and line["roofline"]["frac"] > 0 and line["cpu_baseline"]["value"] > 0

@@ -7,8 +7,10 @@ import numpy as np
 import pytest
 from sklearn.metrics.pairwise import rbf_kernel
 
-from bore_amd.optimizers.svgd import (SVGD, DistortionConstant, DistortionExpDecay, RadialBasis,
-                                      rank)
+# The CHECKER: the reference's SVGD restated step for step (bit-equal to its recorded trajectories below);
+# the device kernels and the product's short host driver (bore_amd/optimizers/svgd.py) are held to it.
+from oracle.svgd_oracle import (SVGD, DistortionConstant, DistortionExpDecay, RadialBasis, rank)
+from bore_amd.optimizers import svgd as product
 from conftest import GOLDEN
 from oracle import bore_oracle as O
 
@@ -57,6 +59,40 @@ def test_trajectories_equal_the_reference_bit_for_bit(g):
         assert ((x >= 0) & (x <= 1)).all()
 
 
+def test_product_host_driver_tracks_the_checker(g):
+    """bore_amd/optimizers/svgd.py -- the API of bore.optimizers.svgd for what the device kernels refuse --
+    is its own short statement of the update (einsum distances, no step-for-step mirror of the reference):
+    the same doctest ranks, kernel values against sklearn, and the recorded reference trajectories to 1e-10
+    (another summation order; with a distortion, rank ties can flip a weight: 1e-6)."""
+    a = np.array([0.4532752, 0.858725, 0.3792093, 0.3792093, 0.7619765])
+    np.testing.assert_array_equal(product.rank(a), [0.6, 1.0, 0.4, 0.4, 0.8])
+    X = np.random.RandomState(42).rand(16, 64)
+    K, Kg = product.RadialBasis(length_scale=0.5).value_and_grad(X)
+    np.testing.assert_array_almost_equal(K, rbf_kernel(X, gamma=.5 / 0.5 ** 2), decimal=12)
+    Ko, Kgo = RadialBasis(length_scale=None).value_and_grad(X)
+    Kp, Kgp = product.RadialBasis(length_scale=None).value_and_grad(X)
+    np.testing.assert_allclose(Kp, Ko, rtol=1e-12, atol=0)
+    np.testing.assert_allclose(Kgp, Kgo, rtol=1e-10, atol=1e-13)
+    params = [g[f"p_{i}"] for i in range(6)]
+    acts = ["tanh", "relu", "linear"]
+
+    def func(X):
+        q = [p.copy() for p in params]
+        q[-2], q[-1] = -q[-2], -q[-1]
+        return O.value_and_input_grad(q, acts, X, "sigmoid", dtype=np.float64)
+
+    for k in range(4):
+        n, ls, lambd, n_iter = g[f"cfg_{k}"]
+        ls = None if ls < 0 else float(ls)
+        dist = product.DistortionConstant() if lambd < 0 else product.DistortionExpDecay(lambd=float(lambd))
+        x = product.SVGD(kernel=product.RadialBasis(length_scale=ls), n_iter=int(n_iter), step_size=1e-2,
+                         distortion=dist).optimize_from_init(func, g[f"x0_{k}"], bounds=[(0.0, 1.0)] * 3)
+        np.testing.assert_allclose(x, g[f"x_{k}"], rtol=0, atol=1e-10 if lambd < 0 else 1e-6)
+    seen = []
+    x = product.SVGD(n_iter=3).optimize(func, 5, bounds=[(0.0, 1.0)] * 3, callback=seen.append, random_state=1)
+    assert x.shape == (5, 3) and len(seen) == 3 and np.array_equal(seen[-1], x)
+
+
 @pytest.mark.gpu
 def test_argmax_batch_on_the_gpu(gpu):
     """BatchMaximizableSequential.argmax_batch (bore/mixins.py:100-116): particles stay in the
@@ -98,7 +134,7 @@ def test_argmax_batch_on_the_gpu(gpu):
     (1, 2, [16, 16, 1], None, None, "identity")])
 def test_device_svgd_tracks_the_host_statement(gpu, n, D, units, ls, lambd, tr):
     """bore_svgd_optimize (all iterations in one launch) against SVGD.optimize_from_init of
-    bore_amd/optimizers/svgd.py (bit-equal to the reference, test above) driven by the same
+    oracle/svgd_oracle.py (bit-equal to the reference, test above) driven by the same
     device f/g operator: same particles to rounding -- sums run in another order and exp() is
     the device's -- after 200 iterations, with clipping active on some coordinates."""
     import torch
@@ -184,6 +220,7 @@ def test_argmax_batch_device_mode(gpu):
     y = np.sum((X - 0.3) ** 2, 1)
     model.fit(X, y < np.quantile(y, 0.25), epochs=300, batch_size=64)
     bounds = Bounds(np.zeros(2), np.ones(2))
+    model.svgd_mode = "host"
     host = model.argmax_batch(8, bounds, n_iter=100, step_size=1e-2, random_state=5)
     model.svgd_mode = "device"
     devp = model.argmax_batch(8, bounds, n_iter=100, step_size=1e-2, random_state=5)
