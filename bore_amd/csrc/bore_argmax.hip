@@ -604,9 +604,7 @@ extern "C" int bore_debug_lpp(unsigned long long *out) {  // [LB_PP_MAX][64]
 #endif
 
 // which static shapes evaluate a wave's single point on the vector ALU (mlp_point.h)
-#ifndef BORE_POINT_SHAPE
 #define BORE_POINT_SHAPE(S) ((S) != 1)
-#endif
 
 
 // LEAN: the network's weight operands are re-requested from LDS for every evaluation instead of
@@ -1092,11 +1090,9 @@ __global__ __launch_bounds__(BORE_THREADS) void lbfgsb_kernel(const LbfgsbArgs a
 
 // Two workgroups per CU (256 registers per lane, operands re-requested per evaluation): for launches
 // with many more workgroups than the device has CUs.
-#ifndef BORE_OCC2_BLOCKS
-#define BORE_OCC2_BLOCKS 2  // (3 / 4 workgroups per CU measured slower in round 3: spills; kept for A/B builds)
-#endif
+// (3 / 4 workgroups per CU measured slower in round 3: spills)
 template <int SHAPE, bool BF16 = false>
-__global__ __launch_bounds__(BORE_THREADS, BORE_OCC2_BLOCKS) void lbfgsb_kernel_occ2(const LbfgsbArgs a) {
+__global__ __launch_bounds__(BORE_THREADS, 2) void lbfgsb_kernel_occ2(const LbfgsbArgs a) {
   lbfgsb_body<SHAPE, BF16, true, true>(a, blockIdx.x, blockIdx.y);
 }
 // The same for the wide shapes, whose weights take too much LDS for two workgroups: ONE workgroup of

@@ -386,7 +386,7 @@ int async_create(bore_engine *e, const double *X0, const double *y0) {
   A.scratch_ids.reserve(L); A.cb_x.resize(L * D); A.cb_y.resize(L);
   A.launched_at.assign(L, 0.0);
   A.done_ids.assign(L, 0);
-  A.fused = iteration_supported(&e->desc) && !(getenv("BORE_ASYNC_CHAIN") && atoi(getenv("BORE_ASYNC_CHAIN")));
+  A.fused = iteration_supported(&e->desc);
   // Residency: a loop's workgroup stays on its CU between iterations and waits this long for the
   // objective value before it gives its slot up (BORE_ASYNC_RESIDENT_US; 0 = one iteration per
   // launch).  Dropped by the launcher when the device cannot hold all loops at once.
@@ -426,7 +426,7 @@ int async_create(bore_engine *e, const double *X0, const double *y0) {
   // that touched the GPU before that variable was set gets fewer queues than streams, and streams
   // sharing a queue serialise -- half the throughput of the non-resident schedule, silently.
   // Probe: one 1 ms spinning single-wave kernel per stream, all at once.
-  if (A.workers.size() > 1 && !(getenv("BORE_ASYNC_NO_PROBE") && atoi(getenv("BORE_ASYNC_NO_PROBE")))) {
+  if (A.workers.size() > 1) {
     const long long ticks = (long long)(2e6 / A.ns_per_tick);  // 2 ms
     hipLaunchKernelGGL(bore_spin_kernel, dim3(1), dim3(64), 0, A.workers[0].stream, 1000LL);  // (code load)
     HIP_TRY(hipStreamSynchronize(A.workers[0].stream));
@@ -605,19 +605,15 @@ int async_run(bore_engine *e, int n_steps) {
   // oldest has waited `max_wait` (or nothing else is running).  With resident workgroups a loop
   // only needs a launch at the start of a run and after its workgroup gave up waiting: at once.
   const bool resident = A.fused && A.wait_ticks > 0;
-  const int min_batch = getenv("BORE_ASYNC_MIN") ? atoi(getenv("BORE_ASYNC_MIN"))
-                                                 : (resident ? 1 : (L >= 16 ? L / 8 : 1));
-  const double max_wait = getenv("BORE_ASYNC_WAIT_US") ? 1e-6 * atof(getenv("BORE_ASYNC_WAIT_US"))
-                                                       : (resident ? 0.0 : 150e-6);
+  const int min_batch = resident ? 1 : (L >= 16 ? L / 8 : 1);
+  const double max_wait = resident ? 0.0 : 150e-6;
   double last_progress = start, first_done = start;
   int n_done = 0;
   // Objective calls are bunched (a call into the interpreter costs tens of microseconds).  Resident
   // workgroups wait for the value on their CUs: call as soon as anything is there -- the results
   // that arrive during a call form the next bunch.
-  const int cb_min = getenv("BORE_ASYNC_CB_MIN") ? atoi(getenv("BORE_ASYNC_CB_MIN"))
-                                                 : (resident ? 1 : (L >= 64 ? L / 16 : 1));
-  const double cb_wait = getenv("BORE_ASYNC_CB_WAIT_US") ? 1e-6 * atof(getenv("BORE_ASYNC_CB_WAIT_US"))
-                                                         : (resident ? 0.0 : 40e-6);
+  const int cb_min = resident ? 1 : (L >= 64 ? L / 16 : 1);
+  const double cb_wait = resident ? 0.0 : 40e-6;
   while (remaining) {
     // 1. loops on the device: a result has arrived, or the workgroup has left the next iteration
     // to a later launch (parked)

@@ -59,23 +59,13 @@ __device__ __forceinline__ double load_host_f64(const double *p) {
 // and every phase body derives its lane numbers from an opaque copy of the work-item id
 // (BORE_OPAQUE_TID), so what the loop carries is the slot, the iteration count and a dozen lane
 // constants of the register network (100 B of scratch, spilled once per BO iteration; same speed:
-// profiles/r3/resident_inline_vs_call.txt).  -DBORE_ITER_ONCE_ATTR='__attribute__((noinline))'
-// restores the call (A/B builds).
-// (the restart phase re-requests the network's operands per evaluation: LEAN)
-#ifndef BORE_ITER_LEAN
-#define BORE_ITER_LEAN true
-#endif
-#ifndef BORE_ITER_ONCE_ATTR
-#define BORE_ITER_ONCE_ATTR __forceinline__
-#endif
+// profiles/r3/resident_inline_vs_call.txt).
+// (the restart phase re-requests the network's operands per evaluation: lbfgsb_body's LEAN)
 #ifndef BORE_LAG_PRIO
-#define BORE_LAG_PRIO 1
-#endif
-#ifndef BORE_LAG_SHIFT
-#define BORE_LAG_SHIFT 1  // "behind" / "ahead" = by more than 2^-SHIFT of an iteration
+#define BORE_LAG_PRIO 1  // -DBORE_LAG_PRIO=0: no wave priority for lagging loops (the A/B of profiles/r4/ab_log.txt)
 #endif
 template <int SHAPE>
-__device__ BORE_ITER_ONCE_ATTR void iteration_once(const IterArgs *__restrict__ pa,
+__device__ __forceinline__ void iteration_once(const IterArgs *__restrict__ pa,
                                                          const long long slot, const int it,
                                                          const bool staged) {
   const IterArgs &a = *pa;
@@ -107,7 +97,7 @@ __device__ BORE_ITER_ONCE_ATTR void iteration_once(const IterArgs *__restrict__ 
   if (stp && threadIdx.x == 0) stp[3] = wall_clock64();
   __threadfence();
   __syncthreads();
-  lbfgsb_body<SHAPE, false, BORE_ITER_LEAN, true, false>(a.b, slot, 0, it);  // (publishes flag[lid] = it + 1)
+  lbfgsb_body<SHAPE, false, true, true, false>(a.b, slot, 0, it);  // (publishes flag[lid] = it + 1)
 }
 
 // RESIDENT: the workgroup may go on to later iterations of its loop.  Otherwise ONE iteration -- the
@@ -118,12 +108,8 @@ __global__ __launch_bounds__(BORE_THREADS, 2) void iteration_kernel(const IterAr
   const long long slot = blockIdx.x;
   const int it_first = uniform_i32(pa->f.its[slot]);
   if constexpr (!RESIDENT) {
-#ifndef BORE_ITER_ARGS_LAUNDERED
     typedef const __attribute__((address_space(4))) IterArgs *IterArgsConst1;  // (scalar loads: see below)
     const IterArgs &a = *(const IterArgs *)(IterArgsConst1) reinterpret_cast<unsigned long long>(pa);
-#else
-    const IterArgs &a = *pa;
-#endif
     const long long lid = uniform_i64(a.f.ids[slot]), cap = a.f.cap;
     const int it = it_first;
     long long *stp = a.stamps ? a.stamps + lid * 4 : nullptr;
@@ -151,7 +137,7 @@ __global__ __launch_bounds__(BORE_THREADS, 2) void iteration_kernel(const IterAr
     if (stp && threadIdx.x == 0) stp[3] = wall_clock64();
     __threadfence();
     __syncthreads();
-    lbfgsb_body<SHAPE, false, BORE_ITER_LEAN, true, false>(a.b, slot, 0);  // (publishes flag[lid] = it + 1)
+    lbfgsb_body<SHAPE, false, true, true, false>(a.b, slot, 0);  // (publishes flag[lid] = it + 1)
     // not the loop's last iteration: leave the next one to a later launch.  (Any wave may say so,
     // and before the others are done: the host reacts to `parked` only after the flag.)
     if (a.targets && threadIdx.x == 0 && it + 1 < a.targets[slot])
@@ -179,14 +165,13 @@ __global__ __launch_bounds__(BORE_THREADS, 2) void iteration_kernel(const IterAr
       const int total = __hip_atomic_load(prog, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const int n_wg = (int)gridDim.x;
       const int lead = uniform_i32((it - it_first) * n_wg - total);  // > 0: ahead of the mean, in 1 / n_wg iterations
-      if (lead < -(n_wg >> BORE_LAG_SHIFT)) __builtin_amdgcn_s_setprio(3);
-      else if (lead > (n_wg >> BORE_LAG_SHIFT)) __builtin_amdgcn_s_setprio(0);
+      if (lead < -(n_wg >> 1)) __builtin_amdgcn_s_setprio(3);
+      else if (lead > (n_wg >> 1)) __builtin_amdgcn_s_setprio(0);
       else __builtin_amdgcn_s_setprio(1);
     }
 #endif
     // (the argument block's address is made opaque per iteration, so that nothing read through it
     // is hoisted out of the loop and kept live around it)
-#ifndef BORE_ITER_ARGS_LAUNDERED
     // (the block is written by the host before the launch and never by a kernel: read through the
     // constant address space its fields are scalar loads -- uniform values in scalar registers, loops
     // over them scalar loops -- instead of vector loads that a store earlier in the loop might clobber)
@@ -194,10 +179,6 @@ __global__ __launch_bounds__(BORE_THREADS, 2) void iteration_kernel(const IterAr
     asm volatile("" : "+s"(pa_bits));
     typedef const __attribute__((address_space(4))) IterArgs *IterArgsConst;
     iteration_once<SHAPE>((const IterArgs *)(IterArgsConst)pa_bits, slot, it, it == it_first);
-#else
-    asm volatile("" : "+s"(pa));
-    iteration_once<SHAPE>(pa, slot, it, it == it_first);
-#endif
     __syncthreads();  // the waves leave the restart phase one by one: LDS is reused below
     ++it;
 #if BORE_LAG_PRIO

@@ -52,9 +52,7 @@ static __device__ __attribute__((noinline)) float point_grad_call(int a, float v
   }
 }
 
-#ifndef BORE_POINT_KB
 #define BORE_POINT_KB(U) ((U) > 1 ? 8 : 16)
-#endif
 
 template <int SHAPE, bool BF16 = false>
 struct PointNet {
