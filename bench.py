@@ -369,14 +369,24 @@ def timed_run(args, loop_ids, barrier, steps=None, warmup=None):
     steps = args.steps if steps is None else steps
     warmup = args.warmup if warmup is None else warmup
     native = args.engine == "native" and args.mode == "device"
+    shards = 1
     if args.dry_run:
         eng = _DryEngine(loop_ids)
     elif native:
         from bore_amd.engine import NativeEngine
         # (--objective native: the library's built-in Branin, evaluated by the engine's host loop itself;
         # python: the same function as a numpy callback through ctypes)
-        eng = NativeEngine(loop_ids, groups=args.groups, async_loops=args.schedule == "async",
-                           **({"objective": "branin01"} if args.objective == "native" else {}))
+        kw = dict(groups=args.groups, async_loops=args.schedule == "async",
+                  **({"objective": "branin01"} if args.objective == "native" else {}))
+        # more loops than the device holds at once (> 512): the host side is sharded over threads
+        # (--host-shards; default one shard per 1 024 loops, at most 4; built-in objective only)
+        shards = args.host_shards if args.host_shards > 0 else min(4, len(loop_ids) // 1024)
+        if shards > 1 and args.schedule == "async" and args.objective == "native":
+            from bore_amd.engine import ShardedEngine
+            eng = ShardedEngine(loop_ids, shards=shards, **kw)
+        else:
+            shards = 1
+            eng = NativeEngine(loop_ids, **kw)
     else:
         from bore_amd.engine import ReplicaEngine
         eng = ReplicaEngine(loop_ids, mode=args.mode, groups=args.groups)
@@ -412,7 +422,7 @@ def timed_run(args, loop_ids, barrier, steps=None, warmup=None):
                   host_enqueue_s=eng.stats.get("host_enqueue_s", 0.0),
                   host_finalize_s=eng.stats.get("host_finalize_s", 0.0))
     return dict(dt=dt, st=st, eng=eng, n_start=n_start, n_end=eng.N, n_groups=n_groups,
-                native=native, loops=len(loop_ids), steps=steps)
+                native=native, loops=len(loop_ids), steps=steps, host_shards=shards)
 
 
 # ------------------------------------------------------------------------------------------
@@ -808,6 +818,8 @@ def run_rank(args):
                                      "Branin-Hoo on [0, 1]^2, a numpy callback"),
                        "schedule": args.schedule if r["native"] else "groups",
                        "stream_groups": None if (r["native"] and args.schedule == "async") else r["n_groups"],
+                       # engines (host threads) this GPU's loops are split over (> 1 only beyond 512 loops)
+                       "host_shards": r.get("host_shards", 1),
                        "worker_streams": st.get("worker_streams"),
                        # (measured by the engine at creation: streams the device ran at once)
                        "stream_concurrency": st.get("stream_concurrency"),
@@ -917,6 +929,9 @@ def parse_args(argv=None):
     ap.add_argument("--engine", default="native", choices=["native", "python"],
                     help="host loop of the replica engine: native = bore_engine_* (C++), python = "
                          "bore_amd.engine.ReplicaEngine (the same trajectories, bit for bit)")
+    ap.add_argument("--host-shards", type=int, default=0,
+                    help="host threads (engines) the loops of one GPU are split over; 0 = one per 1 024 loops, "
+                         "at most 4 (only with more than 512 loops, the asynchronous schedule and the built-in objective)")
     ap.add_argument("--objective", default="native", choices=["native", "python"],
                     help="the synthetic Branin objective: the library's built-in (evaluated inside the "
                          "engine's host loop) or the same function as a numpy callback")

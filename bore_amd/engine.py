@@ -194,6 +194,92 @@ class NativeEngine:
         return X[np.arange(self.L), i], y[np.arange(self.L), i]
 
 
+class ShardedEngine:
+    """More loops than the device holds at once (> 512 for the 2 -> 16-16-1 model): one host thread
+    serving all of them is the bound from ~2 048 loops on (result polling, bookkeeping, launches: ~1.3 us
+    per loop-iteration).  ``shards`` NativeEngines over contiguous ranges of the loop ids, each driven
+    by its own host thread (``bore_engine_run`` releases the interpreter lock; engines are independent
+    of each other, include/bore_hip.h).  Meant for the built-in objective (``objective="branin01"``): a
+    Python callback serialises the threads on the interpreter lock again.  A loop's trajectory does
+    not depend on its shard (the streams are keyed by global loop id).
+
+    The engines share one GPU: none of them may keep its workgroups resident (each would count the
+    whole device as its own), and the worker streams are divided among them."""
+
+    def __init__(self, loop_ids, shards=2, **kw):
+        import os
+        ids = np.asarray(loop_ids, dtype=np.int64)
+        shards = int(max(1, min(shards, len(ids))))
+        saved = {k: os.environ.get(k) for k in ("BORE_ASYNC_RESIDENT_US", "BORE_ASYNC_WORKERS")}
+        try:
+            if shards > 1:      # (read by bore_engine_create)
+                os.environ["BORE_ASYNC_RESIDENT_US"] = "0"
+                os.environ["BORE_ASYNC_WORKERS"] = str(max(2, 12 // shards))
+            self.engines = [NativeEngine(part, **kw) for part in np.array_split(ids, shards)]
+        finally:
+            for k, v in saved.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+        e0 = self.engines[0]
+        self.loop_ids, self.L, self.D, self.P = ids, len(ids), e0.D, e0.P
+        self.n_groups = e0.n_groups
+        self.device = e0.device
+
+    def run(self, n_steps):
+        import threading
+        errors = []
+
+        def work(eng):
+            try:
+                torch.cuda.set_device(eng.device)
+                eng.run(n_steps)
+            except BaseException as err:        # re-raised in the caller's thread
+                errors.append(err)
+
+        threads = [threading.Thread(target=work, args=(e,)) for e in self.engines[1:]]
+        for t in threads:
+            t.start()
+        work(self.engines[0])
+        for t in threads:
+            t.join()
+        if errors:
+            raise errors[0]
+
+    @property
+    def N(self):
+        return self.engines[0].N
+
+    def observations(self):
+        parts = [e.observations() for e in self.engines]
+        return np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts])
+
+    @property
+    def X(self):
+        return self.observations()[0]
+
+    @property
+    def y(self):
+        return self.observations()[1]
+
+    def state(self):
+        parts = [e.state() for e in self.engines]
+        return tuple(np.concatenate([p[i] for p in parts]) for i in range(4))
+
+    def take_stats(self, reset=True):
+        """Sums over the shards (worker_streams too; stream_concurrency: the smallest seen)."""
+        stats = [e.take_stats(reset) for e in self.engines]
+        out = {k: sum(s[k] for s in stats) for k in stats[0]}
+        out["stream_concurrency"] = min(s["stream_concurrency"] for s in stats)
+        return out
+
+    def best(self):
+        X, y = self.observations()
+        i = np.argmin(y, axis=1)
+        return X[np.arange(self.L), i], y[np.arange(self.L), i]
+
+
 class ReplicaEngine:
     """The Python statement of the replica engine (``NativeEngine`` runs the same loop in C++ and
     is what ``bench.py`` uses): kept as the readable reference and as the check of the native one."""

@@ -606,6 +606,29 @@ def test_builtin_branin_objective_equals_the_numpy_callback(gpu):
         NativeEngine(np.arange(2), objective="hartmann6")
 
 
+def test_sharded_engine_equals_one_engine(gpu):
+    """ShardedEngine: the loops of one GPU split over several engines, each with its own host thread (what
+    bench.py uses beyond 512 loops).  A loop's trajectory does not depend on its shard: the same
+    observations and weights as ONE engine over all the loops, bit for bit; statistics add up."""
+    from bore_amd.engine import NativeEngine, ShardedEngine
+    kw = dict(async_loops=True, objective="branin01", epochs=20, num_samples=64)
+    a = ShardedEngine(np.arange(100, 163), shards=3, **kw)
+    b = NativeEngine(np.arange(100, 163), **kw)
+    a.run(4)
+    a.run(3)
+    b.run(7)
+    assert a.N == b.N == 17 and a.L == 63
+    Xa, ya = a.observations()
+    assert np.array_equal(Xa, b.X) and np.array_equal(ya, b.y)
+    for u, v in zip(a.state(), b.state()):
+        assert np.array_equal(u, v)
+    sa, sb = a.take_stats(), b.take_stats()
+    assert sa["phase_iterations"] == sb["phase_iterations"] == 63 * 7
+    assert sa["n_fg_requests"] == sb["n_fg_requests"] and sa["none_results"] == sb["none_results"]
+    xb, yb = a.best()
+    assert xb.shape == (63, 2) and np.array_equal(yb, ya.min(axis=1))
+
+
 def test_resident_workgroups_park_and_resume_with_a_slow_objective(gpu, monkeypatch):
     """A workgroup waits a bounded time on its CU for the objective value (include/bore_hip.h,
     bore_batch residency); with an objective slower than that it parks, and the host launches the
