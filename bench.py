@@ -583,6 +583,8 @@ def all_configs(args, barrier, cpu):
         "loops": 1, "it_per_s": r["steps"] / r["dt"], "ms": {"iteration": 1e3 * r["dt"] / r["steps"]},
         "N_start": int(r["n_start"]), "N_end": int(r["n_end"]),
         "note": "chain latency of one loop: own fit + own restarts + host hand-over"}
+    if hasattr(r["eng"], "close"):
+        r["eng"].close()
     del r
     for name, c in WIDE_CONFIGS.items():
         try:
@@ -645,6 +647,8 @@ def run_rank(args):
     wall_first = float(tmax[1])                     # engine creation + warm-up + timed steps
     runs = [dict(value=total * args.steps / float(tmax[0]), dt=float(tmax[0]), r=r)]
     results = gather_results(r["eng"], world)       # the path's only collective (RCCL gather)
+    if hasattr(r["eng"], "close"):
+        r["eng"].close()
     r["eng"] = None
 
     # A timed region of K steps is tens of milliseconds here: one sample of a noisy quantity.  The
@@ -661,6 +665,8 @@ def run_rank(args):
             n_rep = int(max(1, min(n_rep, args.repeat_budget_s // max(wall_first, 1e-3))))
         for _ in range(n_rep - 1):
             rr = timed_run(args, loop_ids, barrier)
+            if hasattr(rr["eng"], "close"):
+                rr["eng"].close()
             rr["eng"] = None
             tm = torch.tensor([rr["dt"]], dtype=torch.float64,
                               device="cuda" if args.backend == "nccl" and not dry else "cpu")
@@ -685,6 +691,8 @@ def run_rank(args):
                 for _ in range(n_ref):
                     q = timed_run(args, shard_loop_ids(0, 1, n_loops), solo_barrier)
                     vs.append(n_loops * args.steps / q["dt"])
+                    if hasattr(q["eng"], "close"):
+                        q["eng"].close()
                     del q
                 return float(np.median(vs))
 
@@ -872,6 +880,8 @@ def run_rank(args):
                 for _ in range(3):
                     q = timed_run(args, loop_ids, solo_barrier, steps=args.survey_steps, warmup=3)
                     sv.append((total * args.survey_steps / q["dt"], q["dt"], q["n_start"], q["n_end"]))
+                    if hasattr(q["eng"], "close"):
+                        q["eng"].close()
                     q["eng"] = None
                 sv.sort()
                 out["survey_form"] = {"steps": args.survey_steps, "warmup": 3, "value": sv[1][0],

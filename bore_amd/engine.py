@@ -144,10 +144,16 @@ class NativeEngine:
                                                  vp(th), vp(X0), vp(y0), vp(mt), self._cb, None,
                                                  _lib_ctypes.byref(self._h)))
 
-    def __del__(self):
+    def close(self):
+        """Free the engine's device memory, pinned memory and streams now.  (The callback closure refers
+        back to the engine: without this an engine lives until the cycle collector runs, and the streams of
+        several dead engines share the process's hardware queues with the live one's.)"""
         h, self._h = getattr(self, "_h", None), None
         if h:
             _lib.lib().bore_engine_destroy(h)
+
+    def __del__(self):
+        self.close()
 
     def run(self, n_steps):
         rc = _lib.lib().bore_engine_run(self._h, int(n_steps))
@@ -246,6 +252,10 @@ class ShardedEngine:
             t.join()
         if errors:
             raise errors[0]
+
+    def close(self):
+        for e in self.engines:
+            e.close()
 
     @property
     def N(self):
