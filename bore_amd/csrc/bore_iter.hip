@@ -62,7 +62,10 @@ __device__ __forceinline__ double load_host_f64(const double *p) {
 // profiles/r3/resident_inline_vs_call.txt).
 // (the restart phase re-requests the network's operands per evaluation: lbfgsb_body's LEAN)
 #ifndef BORE_LAG_PRIO
-#define BORE_LAG_PRIO 1  // -DBORE_LAG_PRIO=0: no wave priority for lagging loops (the A/B of profiles/r4/ab_log.txt)
+#define BORE_LAG_PRIO 1  // -DBORE_LAG_PRIO=0: no wave priority for lagging loops, no yielding leaders (profiles/r4/ab_log.txt)
+#endif
+#ifndef BORE_LAG_YIELD_Q
+#define BORE_LAG_YIELD_Q 3  // a leader yields while it is more than Q / 4 iterations ahead of the mean
 #endif
 template <int SHAPE>
 __device__ __forceinline__ void iteration_once(const IterArgs *__restrict__ pa,
@@ -200,6 +203,22 @@ __global__ __launch_bounds__(BORE_THREADS, 2) void iteration_kernel(const IterAr
         if (__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) break;
         __builtin_amdgcn_s_sleep(16);
       }
+#if BORE_LAG_PRIO
+      // A loop more than 3/4 of an iteration AHEAD of the grid's mean spends its slack here, asleep, and
+      // leaves the CU's issue slots to its partner (the region ends with the slowest loop: a leader gains
+      // nothing by arriving early): until the mean has come within 3/4 of an iteration, 500 us at most per
+      // iteration.  Measured (profiles/r4/ab_log.txt): 489.0 -> 497.2 k it/s at 20 steps, 376.6 -> 387.0 k at
+      // 100; thresholds of 1/4 and 1/2 cost at 20 steps, 1 and 2 gain less.  Same trajectories.
+      if (go) {
+        const long long t1 = wall_clock64();
+        const int n_wg = (int)gridDim.x;
+        for (;;) {
+          const int total = __hip_atomic_load(prog, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (4 * ((it - it_first) * n_wg - total) <= BORE_LAG_YIELD_Q * n_wg || wall_clock64() - t1 > 50000) break;
+          __builtin_amdgcn_s_sleep(64);
+        }
+      }
+#endif
       // (after this store the workgroup touches nothing of the loop: the host may relaunch it)
       if (!go) __hip_atomic_store(pa->parked + lid, it, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
       s_go4[0] = go;
