@@ -232,6 +232,11 @@ typedef struct bore_lbfgsb_opts {
  *   info     device int32 [n_models][num_starts][5] = {nit, nfev, status, task, message}
  *            status 0 converged / 1 maxiter-or-maxfun / 2 abnormal (OptimizeResult.status);
  *            (task, message) index scipy's status_messages / task_messages
+ * Launch geometry (round 4; the results do not depend on it): one restart per wave at a time; with many
+ * restarts per model a model's restarts go to a few workgroups whose waves draw problem after problem
+ * from a queue in LDS (the weights are staged once per workgroup).  For 32 -> 128-128-1 in bfloat16 the
+ * optimiser's two 2m x 2m matrices live in a device buffer the library allocates on first use and keeps
+ * (1 024 slots x 8 waves x 8 m^2 doubles: 52 MB at maxcor 10), so that eight restarts share a CU's LDS.
  */
 int bore_lbfgsb_minimize(const bore_mlp_desc *desc, int n_models, const float *theta,
                          int transform, int negate, const double *x0, int num_starts,
