@@ -153,7 +153,10 @@ class NativeEngine:
             _lib.lib().bore_engine_destroy(h)
 
     def __del__(self):
-        self.close()
+        try:
+            self.close()
+        except Exception:       # (interpreter shutdown: the module's globals are gone; the process ends anyway)
+            pass
 
     def run(self, n_steps):
         rc = _lib.lib().bore_engine_run(self._h, int(n_steps))
