@@ -378,9 +378,10 @@ def timed_run(args, loop_ids, barrier, steps=None, warmup=None):
         # python: the same function as a numpy callback through ctypes)
         kw = dict(groups=args.groups, async_loops=args.schedule == "async",
                   **({"objective": "branin01"} if args.objective == "native" else {}))
-        # more loops than the device holds at once (> 512): the host side is sharded over threads
-        # (--host-shards; default one shard per 1 024 loops, at most 4; built-in objective only)
-        shards = args.host_shards if args.host_shards > 0 else min(4, len(loop_ids) // 1024)
+        # more loops than the device holds at once (> 512): the engine's work-queue schedule (one
+        # persistent launch fed by the host).  --host-shards n > 1: the launch-per-batch schedule
+        # instead, sharded over n engines / host threads (built-in objective only)
+        shards = args.host_shards if args.host_shards > 0 else 1
         if shards > 1 and args.schedule == "async" and args.objective == "native":
             from bore_amd.engine import ShardedEngine
             eng = ShardedEngine(loop_ids, shards=shards, **kw)
@@ -940,8 +941,8 @@ def parse_args(argv=None):
                     help="host loop of the replica engine: native = bore_engine_* (C++), python = "
                          "bore_amd.engine.ReplicaEngine (the same trajectories, bit for bit)")
     ap.add_argument("--host-shards", type=int, default=0,
-                    help="host threads (engines) the loops of one GPU are split over; 0 = one per 1 024 loops, "
-                         "at most 4 (only with more than 512 loops, the asynchronous schedule and the built-in objective)")
+                    help="n > 1: the launch-per-batch schedule sharded over n engines / host threads (more than 512 "
+                         "loops, asynchronous schedule, built-in objective); default: one engine (work queue beyond 512 loops)")
     ap.add_argument("--objective", default="native", choices=["native", "python"],
                     help="the synthetic Branin objective: the library's built-in (evaluated inside the "
                          "engine's host loop) or the same function as a numpy callback")

@@ -120,6 +120,13 @@ struct Async {
   std::vector<int> scratch_ids, done_ids;
   std::vector<double> cb_x, cb_y;
   bool fused = false;  // one kernel per launch (bore_iter.hip) instead of the five-launch chain
+  // work queue (bore_iter.hip: queue_kernel) -- the schedule for more loops than the device holds
+  // workgroups: ring of entries (pinned), ticket counter (device), entries written so far, identity index
+  bool queue = false;
+  QueueEntry *q_ring = nullptr;
+  unsigned long long *q_head = nullptr, q_tail = 0;
+  int q_mask = 0, q_wgs = 0;
+  int32_t *d_ident = nullptr;
   long long n_resident = 0, n_parked = 0;
   int stream_concurrency = 0;  // worker streams the device ran at once in the creation probe
   // diagnostics (BORE_ASYNC_DEBUG): waits between a loop's states
@@ -387,6 +394,25 @@ int async_create(bore_engine *e, const double *X0, const double *y0) {
   A.launched_at.assign(L, 0.0);
   A.done_ids.assign(L, 0);
   A.fused = iteration_supported(&e->desc);
+  // More loops than resident workgroups (two per CU for this kernel): the work-queue schedule.
+  // BORE_ASYNC_QUEUE = 0 / 1 forces the launch-per-batch schedule of round 3 / the queue (tests, A/B).
+  {
+    const int forced = getenv("BORE_ASYNC_QUEUE") ? atoi(getenv("BORE_ASYNC_QUEUE")) : -1;
+    const int resident_cap = 2 * device_cus();
+    A.queue = A.fused && (forced < 0 ? (int)L > resident_cap : forced != 0);
+    if (A.queue) {
+      A.q_wgs = (int)L < resident_cap ? (int)L : resident_cap;
+      int capq = 1;
+      while (capq < 2 * ((int)L + A.q_wgs) + 64) capq <<= 1;   // (outstanding entries <= loops + exit tokens)
+      A.q_mask = capq - 1;
+      if ((rc = pin_alloc(&A.q_ring, (size_t)capq)) || (rc = dev_alloc(&A.q_head, 1)) || (rc = dev_alloc(&A.d_ident, L)))
+        return rc;
+      std::memset(A.q_ring, 0, (size_t)capq * sizeof(QueueEntry));
+      std::vector<int32_t> ident(L);
+      for (size_t l = 0; l < L; ++l) ident[l] = (int32_t)l;
+      HIP_TRY(hipMemcpy(A.d_ident, ident.data(), L * 4, hipMemcpyHostToDevice));
+    }
+  }
   // Residency: a loop's workgroup stays on its CU between iterations and waits this long for the
   // objective value before it gives its slot up (BORE_ASYNC_RESIDENT_US; 0 = one iteration per
   // launch).  Dropped by the launcher when the device cannot hold all loops at once.
@@ -485,6 +511,9 @@ void async_destroy(bore_engine *e) {
   if (A.result) (void)hipHostFree(A.result);
   if (A.flag) (void)hipHostFree(A.flag);
   if (A.ynew) (void)hipHostFree(A.ynew);
+  if (A.q_ring) (void)hipHostFree(A.q_ring);
+  if (A.q_head) (void)hipFree(A.q_head);
+  if (A.d_ident) (void)hipFree(A.d_ident);
   delete e->as;
   e->as = nullptr;
 }
@@ -594,6 +623,156 @@ int async_drain(bore_engine *e) {
   return 0;
 }
 
+// The host has seen loop l's result (flag[l] == it[l] + 1): statistics, the suggestion (or the reference's
+// random fall-back) into the objective's input block.  Returns the new number of results waiting there.
+static int take_async_result(bore_engine *e, int l, double t0, int n_done) {
+  Async &A = *e->as;
+  const bore_engine_cfg &c = e->cfg;
+  const int L = c.n_loops, D = e->D;
+  A.state[l] = 3;  // result taken, objective pending
+  const double *r = A.result + (size_t)l * (D + 8);
+  double *xn = &A.cb_x[(size_t)n_done * D];
+  A.sum_flight += t0 - A.launched_at[l];
+  A.seen_at[l] = t0;
+  e->st.launch_to_result_s += t0 - A.launched_at[l];
+  e->st.phase_ns_labels += r[D + 3] * A.ns_per_tick;
+  e->st.phase_ns_fit += r[D + 4] * A.ns_per_tick;
+  e->st.phase_ns_screen += r[D + 5] * A.ns_per_tick;
+  e->st.phase_ns_lbfgsb += r[D + 6] * A.ns_per_tick;
+  ++e->st.phase_iterations;
+  if (A.loop_acc.size() == (size_t)L * 6) {
+    double *la = &A.loop_acc[(size_t)l * 6];
+    la[0] += r[D + 4] * A.ns_per_tick; la[1] += r[D + 6] * A.ns_per_tick;
+    la[2] += r[D + 1]; la[3] += r[D + 2]; la[4] += t0 - A.launched_at[l]; la[5] += 1.0;
+  }
+  if (r[D] < 0.0) {  // reference: fall back to a random point of this loop's stream
+    ++e->st.none_results;
+    Mt19937 &rs = e->rs[l];
+    for (int d = 0; d < D; ++d) xn[d] = e->low[d] + (e->high[d] - e->low[d]) * rs.next_double();
+  } else {
+    std::memcpy(xn, r, (size_t)D * 8);
+  }
+  // (r[D + 7]: evaluations that ran the network; r[D + 1] = nfev also counts the trial points the
+  // image shortcut served -- the algorithmic bytes are those of the evaluations that ran)
+  e->st.n_fg_rows += (int64_t)r[D + 7];
+  e->st.n_fg_requests += (int64_t)r[D + 1];
+  e->st.n_rounds += (int64_t)r[D + 2];
+  e->st.argmax_bytes += r[D + 7] * 4.0 * (2 * D + 1) + r[D + 2] * 4.0 * e->P;
+  const double N = c.n_init + A.it[l], steps = std::ceil(N / c.batch_size);
+  e->st.fit_bytes += c.epochs * (4.0 * N * (D + 1) + steps * 24.0 * e->P);
+  A.done_ids[n_done++] = l;
+  return n_done;
+}
+
+// The work-queue schedule (bore_iter.hip: queue_kernel): ONE launch of q_wgs workgroups per run; the
+// host appends a (loop, iteration) entry whenever a loop becomes ready -- all of them at the start, then
+// each again as soon as its objective value is known -- and ends the workgroups with exit entries.
+static int async_run_queue(bore_engine *e, int n_steps) {
+  Async &A = *e->as;
+  const bore_engine_cfg &c = e->cfg;
+  const int L = c.n_loops, D = e->D, R = c.num_starts;
+  Worker &w = A.workers[0];
+  std::memset(A.q_ring, 0, ((size_t)A.q_mask + 1) * sizeof(QueueEntry));
+  A.q_tail = 0;
+  HIP_TRY(hipMemsetAsync(A.q_head, 0, sizeof(unsigned long long), w.stream));
+  auto push = [&](int lid, int it) {
+    QueueEntry *en = A.q_ring + (A.q_tail & (unsigned long long)A.q_mask);
+    en->lid = lid;
+    en->it = it;
+    __atomic_store_n(&en->seq, (long long)(A.q_tail + 1), __ATOMIC_RELEASE);
+    ++A.q_tail;
+  };
+  const double start = now_s();
+  int remaining = L;
+  for (int l = 0; l < L; ++l) {
+    A.target[l] = A.it[l] + n_steps;
+    A.state[l] = 1;
+    A.launched_at[l] = start;
+    // (the row iteration it[l] appends: the previous run's last suggestion and its value)
+    double *yn = A.ynew + (size_t)l * (D + 1);
+    std::memcpy(yn, &A.x_new[(size_t)l * D], (size_t)D * 8);
+    yn[D] = A.y_new[l];
+    push(l, A.it[l]);
+  }
+  __atomic_thread_fence(__ATOMIC_SEQ_CST);
+  bore_batch bt;
+  std::memset(&bt, 0, sizeof(bt));
+  bt.ids = A.d_ident; bt.its = A.d_ident; bt.n_init = c.n_init; bt.deduplicate = c.deduplicate;
+  bt.cap = A.cap; bt.X_seen = A.X_seen; bt.result = A.result; bt.flag = A.flag; bt.stamps = A.stamps;
+  bt.ynew = A.ynew; bt.yseq = A.yseq; bt.parked = A.parked; bt.abort_flag = A.abort_flag;
+  bt.resident_loops = L;
+  bore_set_batch(&bt);
+  int rc = hipEventRecord(w.ev[2], w.stream) == hipSuccess ? 0 : fail(BORE_E_HIP, "hipEventRecord");
+  if (!rc)
+    rc = iteration_launch(&e->desc, L, e->theta, e->adam_m, e->adam_v, e->adam_t, A.X_seen, A.y_seen, A.X32,
+                          A.z, w.d_dbl, w.d_dbl + (size_t)L * D, c.gamma, c.epochs, c.batch_size, c.seed,
+                          c.loop_id0, &c.adam, c.num_samples, e->low.data(), e->high.data(), R, c.transform,
+                          &c.lbfgsb, w.x0, w.idx, w.x, w.fun, w.jac, w.info, w.h_args, w.d_args, w.stage_bytes,
+                          w.stream, A.q_wgs, A.q_ring, A.q_head, A.q_mask);
+  if (!rc && hipEventRecord(w.ev[3], w.stream) != hipSuccess) rc = fail(BORE_E_HIP, "hipEventRecord");
+  bore_set_batch(nullptr);
+  if (rc) {
+    e->poisoned = true;
+    return rc;
+  }
+  ++A.n_batches;
+  ++e->st.batches;
+  A.n_slots += L;
+  double last_progress = start;
+  int n_done = 0;
+  while (remaining) {
+    const double t0 = now_s();
+    for (int l = 0; l < L; ++l) {
+      if (A.state[l] != 1) continue;
+      if (__atomic_load_n(&A.flag[l], __ATOMIC_ACQUIRE) != A.it[l] + 1) continue;
+      n_done = take_async_result(e, l, t0, n_done);
+    }
+    if (n_done) {
+      if (e->objective(A.cb_x.data(), n_done, D, A.cb_y.data(), e->user)) {
+        async_drain(e);
+        for (int l = 0; l < L; ++l) A.state[l] = 2;
+        return fail(BORE_E_CALLBACK, "engine_run: the objective callback failed");
+      }
+      const double now = now_s();
+      for (int k = 0; k < n_done; ++k) {
+        const int l = A.done_ids[k];
+        std::memcpy(&A.x_new[(size_t)l * D], &A.cb_x[(size_t)k * D], (size_t)D * 8);
+        A.y_new[l] = A.cb_y[k];
+        e->st.result_to_ready_s += now - A.seen_at[l];
+        ++A.it[l];
+        if (A.it[l] >= A.target[l]) {
+          A.state[l] = 2;
+          --remaining;
+        } else {
+          double *yn = A.ynew + (size_t)l * (D + 1);
+          std::memcpy(yn, &A.cb_x[(size_t)k * D], (size_t)D * 8);
+          yn[D] = A.cb_y[k];
+          push(l, A.it[l]);   // (the entry's release store orders the row before it)
+          A.state[l] = 1;
+          A.launched_at[l] = now;
+          ++A.n_resident;
+        }
+      }
+      last_progress = now;
+      e->st.host_finalize_s += now - t0;
+      n_done = 0;
+    }
+    if (now_s() - last_progress > 30.0) {
+      async_drain(e);
+      return fail(BORE_E_HIP, "engine_run: no loop finished for 30 s");
+    }
+  }
+  for (int i = 0; i < A.q_wgs; ++i) push(-1, 0);  // every workgroup draws one exit entry
+  HIP_TRY(hipStreamSynchronize(w.stream));
+  float ms = 0.f;
+  HIP_TRY(hipEventElapsedTime(&ms, w.ev[2], w.ev[3]));
+  e->st.fit_launches += 1;
+  e->st.argmax_ms += ms;
+  e->st.argmax_launches += 1;
+  e->st.host_enqueue_s += 0.0;
+  return 0;
+}
+
 int async_run(bore_engine *e, int n_steps) {
   Async &A = *e->as;
   const bore_engine_cfg &c = e->cfg;
@@ -606,6 +785,7 @@ int async_run(bore_engine *e, int n_steps) {
     while (cap < c.n_init + max_it + n_steps) cap *= 2;
     if ((rc = async_alloc(e, cap))) return rc;
   }
+  if (A.queue) return async_run_queue(e, n_steps);
   const double start = now_s();
   int remaining = L;
   for (int l = 0; l < L; ++l) {
@@ -640,39 +820,8 @@ int async_run(bore_engine *e, int n_steps) {
         }
         continue;
       }
-      A.state[l] = 3;  // result taken, objective pending
       if (n_done == 0) first_done = t0;
-      const double *r = A.result + (size_t)l * (D + 8);
-      double *xn = &A.cb_x[(size_t)n_done * D];
-      A.sum_flight += t0 - A.launched_at[l];
-      A.seen_at[l] = t0;
-      e->st.launch_to_result_s += t0 - A.launched_at[l];
-      e->st.phase_ns_labels += r[D + 3] * A.ns_per_tick;
-      e->st.phase_ns_fit += r[D + 4] * A.ns_per_tick;
-      e->st.phase_ns_screen += r[D + 5] * A.ns_per_tick;
-      e->st.phase_ns_lbfgsb += r[D + 6] * A.ns_per_tick;
-      ++e->st.phase_iterations;
-      if (A.loop_acc.size() == (size_t)L * 6) {
-        double *la = &A.loop_acc[(size_t)l * 6];
-        la[0] += r[D + 4] * A.ns_per_tick; la[1] += r[D + 6] * A.ns_per_tick;
-        la[2] += r[D + 1]; la[3] += r[D + 2]; la[4] += t0 - A.launched_at[l]; la[5] += 1.0;
-      }
-      if (r[D] < 0.0) {  // reference: fall back to a random point of this loop's stream
-        ++e->st.none_results;
-        Mt19937 &rs = e->rs[l];
-        for (int d = 0; d < D; ++d) xn[d] = e->low[d] + (e->high[d] - e->low[d]) * rs.next_double();
-      } else {
-        std::memcpy(xn, r, (size_t)D * 8);
-      }
-      // (r[D + 7]: evaluations that ran the network; r[D + 1] = nfev also counts the trial points the
-      // image shortcut served -- the algorithmic bytes are those of the evaluations that ran)
-      e->st.n_fg_rows += (int64_t)r[D + 7];
-      e->st.n_fg_requests += (int64_t)r[D + 1];
-      e->st.n_rounds += (int64_t)r[D + 2];
-      e->st.argmax_bytes += r[D + 7] * 4.0 * (2 * D + 1) + r[D + 2] * 4.0 * e->P;
-      const double N = c.n_init + A.it[l], steps = std::ceil(N / c.batch_size);
-      e->st.fit_bytes += c.epochs * (4.0 * N * (D + 1) + steps * 24.0 * e->P);
-      A.done_ids[n_done++] = l;
+      n_done = take_async_result(e, l, t0, n_done);
     }
     if (n_done && (n_done >= cb_min || t0 - first_done >= cb_wait)) {
       if (e->objective(A.cb_x.data(), n_done, D, A.cb_y.data(), e->user)) {

@@ -204,9 +204,11 @@ class NativeEngine:
 
 
 class ShardedEngine:
-    """More loops than the device holds at once (> 512 for the 2 -> 16-16-1 model): one host thread
-    serving all of them is the bound from ~2 048 loops on (result polling, bookkeeping, launches: ~1.3 us
-    per loop-iteration).  ``shards`` NativeEngines over contiguous ranges of the loop ids, each driven
+    """(Round 4's first answer to more loops than the device holds at once; the engine's work-queue
+    schedule -- one persistent launch fed by the host, bore_iter.hip: queue_kernel -- has since become the
+    default there and is faster.  Kept: it shards the launch-per-batch schedule.)
+    One host thread serving all loops is the bound from ~2 048 loops on (result polling, bookkeeping,
+    launches: ~1.3 us per loop-iteration).  ``shards`` NativeEngines over contiguous ranges of the loop ids, each driven
     by its own host thread (``bore_engine_run`` releases the interpreter lock; engines are independent
     of each other, include/bore_hip.h).  Meant for the built-in objective (``objective="branin01"``): a
     Python callback serialises the threads on the interpreter lock again.  A loop's trajectory does
@@ -219,11 +221,13 @@ class ShardedEngine:
         import os
         ids = np.asarray(loop_ids, dtype=np.int64)
         shards = int(max(1, min(shards, len(ids))))
-        saved = {k: os.environ.get(k) for k in ("BORE_ASYNC_RESIDENT_US", "BORE_ASYNC_WORKERS")}
+        saved = {k: os.environ.get(k) for k in ("BORE_ASYNC_RESIDENT_US", "BORE_ASYNC_WORKERS", "BORE_ASYNC_QUEUE")}
         try:
             if shards > 1:      # (read by bore_engine_create)
                 os.environ["BORE_ASYNC_RESIDENT_US"] = "0"
                 os.environ["BORE_ASYNC_WORKERS"] = str(max(2, 12 // shards))
+                # (each engine's work-queue kernel would hold the whole device until its run ends)
+                os.environ["BORE_ASYNC_QUEUE"] = "0"
             self.engines = [NativeEngine(part, **kw) for part in np.array_split(ids, shards)]
         finally:
             for k, v in saved.items():

@@ -606,6 +606,50 @@ def test_builtin_branin_objective_equals_the_numpy_callback(gpu):
         NativeEngine(np.arange(2), objective="hartmann6")
 
 
+@pytest.mark.parametrize("dedup", [False, True])
+def test_work_queue_engine_equals_lockstep_engine(gpu, monkeypatch, dedup):
+    """The work-queue schedule (more loops than resident workgroups: ONE persistent launch, the host appends
+    (loop, iteration) entries as loops become ready; bore_iter.hip: queue_kernel), forced here for a small
+    engine: every loop's trajectory is the lock-step engine's bit for bit -- over several run() calls (the
+    first iteration of a later run appends the previous run's last row), with more loops than workgroups
+    would be natural for them (the queue, not the grid, hands out the work) and with the duplicate filter."""
+    from bore_amd.engine import NativeEngine
+    kw = dict(epochs=20, num_samples=64, deduplicate=dedup)
+    monkeypatch.setenv("BORE_ASYNC_QUEUE", "1")
+    a = NativeEngine(np.arange(3, 40), async_loops=True, objective="branin01", **kw)
+    monkeypatch.delenv("BORE_ASYNC_QUEUE")
+    b = NativeEngine(np.arange(3, 40), groups=3, **kw)
+    a.run(5)
+    a.run(1)
+    a.run(6)
+    b.run(12)
+    Xa, ya = a.observations()
+    Xb, yb = b.observations()
+    assert Xa.shape == (37, 22, 2) and np.array_equal(Xa, Xb) and np.array_equal(ya, yb)
+    for u, v in zip(a.state(), b.state()):
+        assert np.array_equal(u, v)
+    sa, sb = a.take_stats(), b.take_stats()
+    assert sa["none_results"] == sb["none_results"] and sa["n_fg_requests"] == sb["n_fg_requests"]
+    assert sa["phase_iterations"] == 37 * 12 and sa["argmax_launches"] == 3       # one launch per run()
+
+
+def test_work_queue_engine_beyond_the_resident_capacity(gpu):
+    """1 100 loops on a device that holds 512 workgroups of this kernel: the default there.  Trajectories
+    equal those of the same loops run resident in three engines of <= 512."""
+    from bore_amd.engine import NativeEngine
+    kw = dict(async_loops=True, objective="branin01", epochs=20, num_samples=64)
+    a = NativeEngine(np.arange(1100), **kw)
+    a.run(3)
+    Xa, ya = a.observations()
+    for lo, hi in ((0, 500), (500, 1000), (1000, 1100)):
+        b = NativeEngine(np.arange(lo, hi), **kw)
+        b.run(3)
+        assert np.array_equal(Xa[lo:hi], b.X) and np.array_equal(ya[lo:hi], b.y)
+        b.close()
+    st = a.take_stats()
+    assert st["phase_iterations"] == 3300 and st["argmax_launches"] == 1
+
+
 def test_sharded_engine_equals_one_engine(gpu):
     """ShardedEngine: the loops of one GPU split over several engines, each with its own host thread (what
     bench.py uses beyond 512 loops).  A loop's trajectory does not depend on its shard: the same
