@@ -207,7 +207,9 @@ __global__ __launch_bounds__(BORE_THREADS, 2) void iteration_kernel(const IterAr
       int go = 0;
       const long long t0 = wall_clock64();
       for (;;) {
-        if (__hip_atomic_load(yseq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) >= it) {
+        // (relaxed polls, one acquire once the row is there: see queue_kernel)
+        if (__hip_atomic_load(yseq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) >= it) {
+          __atomic_thread_fence(__ATOMIC_ACQUIRE);
           go = 1;
           break;
         }
@@ -262,7 +264,10 @@ __global__ __launch_bounds__(BORE_THREADS, 2) void queue_kernel(const IterArgs *
       const QueueEntry *e = ring + (t & (unsigned long long)pa->q_mask);
       int lid = -1, it = 0;
       for (;;) {
-        if (__hip_atomic_load(&e->seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) == (long long)(t + 1)) {
+        // (relaxed polls, ONE acquire when the entry is there: an acquire per poll is a cache invalidate per
+        // poll, from every waiting workgroup)
+        if (__hip_atomic_load(&e->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == (long long)(t + 1)) {
+          __atomic_thread_fence(__ATOMIC_ACQUIRE);
           lid = __hip_atomic_load(&e->lid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
           it = __hip_atomic_load(&e->it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
           break;
