@@ -862,6 +862,15 @@ def run_rank(args):
                               "bounds": f"repeats <= min({args.max_repeats}, {args.repeat_budget_s:.0f} s / "
                                         f"first run's {wall_first:.2f} s); 2 reference runs of the same "
                                         "steps on rank 0; then (N = 1 only) survey form, configs, CPU sample"}
+        # T(1, L) of the committed single-GPU sweep (tools/profile_r4.sh): what one GPU does with more loops than
+        # config 4 names -- the regime in which several GPUs pay (beyond 512 loops: the work-queue schedule)
+        try:
+            with open(os.path.join(ROOT, SWEEP_FILE)) as f:
+                sw = json.load(f)
+            out["loops_sweep_committed"] = {"it_per_s": sw["it_per_s"], "source": SWEEP_FILE,
+                                            "stale": sw.get("csrc_sha256") != digest}
+        except Exception:
+            out["loops_sweep_committed"] = None
         if eff is not None:
             out["efficiency"] = eff
         if world > 1:
