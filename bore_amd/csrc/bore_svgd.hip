@@ -17,15 +17,23 @@
 // n^2 distances is a radix select.  Sums run in plain
 // index order and exp() is the device's, so particles agree with the host statement to rounding
 // (tests: 1e-9 after 200 iterations), not bit for bit.
+//
+// BF = 0: float32 network of any shape (the LDS row-block path); BF = 3 / 4: a bfloat16 network of the wide
+// static shapes (the only ones the library has bfloat16 kernels for): value and input gradient of the
+// particles on the bf16 matrix cores (arg_bf16_mfma.h), the same arithmetic as
+// bore_mlp_value_and_input_grad gives the host driver for such a model.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
 
+#include "arg_bf16_mfma.h"
 #include "host_common.h"
 #include "mlp_device.h"
 #include "mlp_regs.h"
 
 using namespace bore;
+
+#define BORE_SVGD_MAX_PARTICLES 4096
 
 struct SvgdArgs {
   MlpLayout L;
@@ -39,10 +47,40 @@ struct SvgdArgs {
   int o_tile, o_vals, o_x, o_fg, o_grad, o_hist, o_K, o_sort, o_f, total, o_layout;
 };
 
+// value and input gradient of all n particles for a bfloat16 network: the waves take the 16-row blocks in turn
+template <int BF>
+__device__ __forceinline__ void svgd_eval_bf16(const MlpLayout &Lrt, int transform, float *smem, const double *x,
+                                               double *f, double *fg, int n, int D) {
+  using ANet = ArgBf16Net<BF>;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, m16 = lane & 15, q4 = lane >> 4;
+  const ArgBf16Images im = arg_bf16_images<BF>(smem);
+  ANet net;
+  net.set_acts(Lrt);
+  for (int rb = wv; rb * 16 < n; rb += BORE_THREADS / 64) {
+    const int row = rb * 16 + m16;
+    bf16x8_t xf[ANet::CF1];
+    ANet::make_xfrag(xf, [&](int d) -> float {
+      return d < D && row < n ? (float)x[row * D + d] : 0.f;  // Keras autocast fp64 -> fp32
+    });
+    const float Tv = net.fg(im, xf, transform, 1.f);
+    if (lane < 16 && row < n) f[row] = (double)Tv;
+    if (row < n) {
+#pragma unroll
+      for (int t = 0; t < ANet::T0; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int d = 16 * t + 4 * q4 + r;
+          if (d < D) fg[row * D + d] = (double)net.d[0][t][r];
+        }
+    }
+  }
+}
+
+template <int BF>
 __global__ __launch_bounds__(BORE_THREADS) void svgd_kernel(const SvgdArgs a) {
   extern __shared__ float smem[];
-  constexpr MlpLayout Lc = bore_static_layout(0, 2, BORE_BATCH_MAX);
-  const MlpLayout &L = begin_kernel<0>(Lc, a.L, smem, a.total, a.o_layout);
+  constexpr MlpLayout Lc = bore_static_layout(BF, 2, BORE_BATCH_MAX);
+  const MlpLayout &L = begin_kernel<BF>(Lc, a.L, smem, a.total, a.o_layout);
   const int tid = threadIdx.x, wv = tid >> 6;
   const long long model = blockIdx.x;
   const int n_lay = L.n_layers, D = L.w[0], n = a.n, nn = n * n, nD = n * D;
@@ -54,7 +92,8 @@ __global__ __launch_bounds__(BORE_THREADS) void svgd_kernel(const SvgdArgs a) {
   double *K = reinterpret_cast<double *>(smem + a.o_K);
   double *srt = reinterpret_cast<double *>(smem + a.o_sort);
   double *f = reinterpret_cast<double *>(smem + a.o_f), *zeta = f + n;
-  stage_theta<false>(L, n_lay, a.theta + model * L.P, smem);
+  if constexpr (BF) arg_bf16_stage<BF>(a.theta + model * L.P, smem);
+  else stage_theta<false>(L, n_lay, a.theta + model * L.P, smem);
   for (int e = tid; e < nD; e += BORE_THREADS) x[e] = a.x_init[model * nD + e];
   __syncthreads();
 
@@ -71,10 +110,11 @@ __global__ __launch_bounds__(BORE_THREADS) void svgd_kernel(const SvgdArgs a) {
       if (a.length_scale < 0.0) srt[e] = s;
     }
     // the particles as network inputs (Keras autocast fp64 -> fp32)
-    for (int e = tid; e < nD; e += BORE_THREADS) {
-      const int i = e / D, d = e - i * D;
-      tile[L.aoff[0] + i * L.lda[0] + d] = (float)x[e];
-    }
+    if constexpr (!BF)
+      for (int e = tid; e < nD; e += BORE_THREADS) {
+        const int i = e / D, d = e - i * D;
+        tile[L.aoff[0] + i * L.lda[0] + d] = (float)x[e];
+      }
     double h = a.length_scale;
     if (a.length_scale < 0.0 && a.n_sort <= 1024) {  // np.median, few entries: bitonic sort in LDS
       for (int e = nn + tid; e < a.n_sort; e += BORE_THREADS) srt[e] = INFINITY;
@@ -170,13 +210,17 @@ __global__ __launch_bounds__(BORE_THREADS) void svgd_kernel(const SvgdArgs a) {
     const double gamma = .5 / (h * h);
     for (int e = tid; e < nn; e += BORE_THREADS) K[e] = exp(-gamma * K[e]);
     // value and input gradient of every particle: one row-block per wave
-    if (wv * 16 < n) fg_rowblock(L, n_lay, th, tile, wv, a.transform, 1.f, vals);
-    __syncthreads();
-    for (int e = tid; e < nD; e += BORE_THREADS) {
-      const int i = e / D, d = e - i * D;
-      fg[e] = (double)tile[L.doff[0] + i * L.lda[0] + d];
+    if constexpr (BF) {
+      svgd_eval_bf16<BF>(a.L, a.transform, smem, x, f, fg, n, D);
+    } else {
+      if (wv * 16 < n) fg_rowblock(L, n_lay, th, tile, wv, a.transform, 1.f, vals);
+      __syncthreads();
+      for (int e = tid; e < nD; e += BORE_THREADS) {
+        const int i = e / D, d = e - i * D;
+        fg[e] = (double)tile[L.doff[0] + i * L.lda[0] + d];
+      }
+      for (int i = tid; i < n; i += BORE_THREADS) f[i] = (double)vals[i];
     }
-    for (int i = tid; i < n; i += BORE_THREADS) f[i] = (double)vals[i];
     __syncthreads();
     for (int i = tid; i < n; i += BORE_THREADS) {  // zeta = distortion(rank(f))
       double z = a.dparam;
@@ -214,16 +258,17 @@ __global__ __launch_bounds__(BORE_THREADS) void svgd_kernel(const SvgdArgs a) {
 }
 
 
-// More than 64 particles (up to 256: one thread per particle in the interaction): the n x n kernel
+// More than 64 particles (one thread per particle in the interaction, in turns beyond 256): the n x n kernel
 // matrix does not fit in LDS beside the rest (n = 128: 128 KB), so it is never stored -- thread i
 // walks j = 0 .. n-1, forms |x_i - x_j|^2 and exp(-gamma .) on the fly and adds particle j's drive
 // and repulsion terms to its D accumulators (8 coordinates per pass over j); the median of the n^2
 // distances is the same radix select, each of its passes recomputing the distances; the network
 // sees the particles in chunks of 64 rows.  Same sums in the same (index) order as svgd_kernel.
+template <int BF>
 __global__ __launch_bounds__(BORE_THREADS) void svgd_big_kernel(const SvgdArgs a) {
   extern __shared__ float smem[];
-  constexpr MlpLayout Lc = bore_static_layout(0, 2, BORE_BATCH_MAX);
-  const MlpLayout &L = begin_kernel<0>(Lc, a.L, smem, a.total, a.o_layout);
+  constexpr MlpLayout Lc = bore_static_layout(BF, 2, BORE_BATCH_MAX);
+  const MlpLayout &L = begin_kernel<BF>(Lc, a.L, smem, a.total, a.o_layout);
   const int tid = threadIdx.x, wv = tid >> 6;
   const long long model = blockIdx.x;
   const int n_lay = L.n_layers, D = L.w[0], n = a.n, nD = n * D;
@@ -236,7 +281,8 @@ __global__ __launch_bounds__(BORE_THREADS) void svgd_big_kernel(const SvgdArgs a
   unsigned *hist_s = reinterpret_cast<unsigned *>(smem + a.o_sort);  // [256] bins + [8] scratch
   int *scan_s = reinterpret_cast<int *>(hist_s + 256);               // [0..3] wave totals, [4] bin, [5] below
   double *f = reinterpret_cast<double *>(smem + a.o_f), *zeta = f + n;
-  stage_theta<false>(L, n_lay, a.theta + model * L.P, smem);
+  if constexpr (BF) arg_bf16_stage<BF>(a.theta + model * L.P, smem);
+  else stage_theta<false>(L, n_lay, a.theta + model * L.P, smem);
   for (int e = tid; e < nD; e += BORE_THREADS) x[e] = a.x_init[model * nD + e];
   __syncthreads();
   auto sqdist = [&](int i, int j) {
@@ -317,6 +363,10 @@ __global__ __launch_bounds__(BORE_THREADS) void svgd_big_kernel(const SvgdArgs a
     h = fmax(h, 1e-6);
     const double gamma = .5 / (h * h);
     // value and input gradient of every particle, 64 rows of the tile at a time
+    if constexpr (BF) {
+      svgd_eval_bf16<BF>(a.L, a.transform, smem, x, f, fg, n, D);
+      __syncthreads();
+    } else
     for (int c0 = 0; c0 < n; c0 += BORE_BATCH_MAX) {
       const int nc = min(BORE_BATCH_MAX, n - c0);
       for (int e = tid; e < BORE_BATCH_MAX * D; e += BORE_THREADS) {
@@ -343,8 +393,7 @@ __global__ __launch_bounds__(BORE_THREADS) void svgd_big_kernel(const SvgdArgs a
       zeta[i] = z;
     }
     __syncthreads();
-    if (tid < n) {  // particle i = tid: drive and repulsion, 8 coordinates per pass over the others
-      const int i = tid;
+    for (int i = tid; i < n; i += BORE_THREADS) {  // particle i: drive and repulsion, 8 coordinates per pass over the others
       for (int d0 = 0; d0 < D; d0 += 8) {
         double drive[8], rep[8];
 #pragma unroll
@@ -385,12 +434,14 @@ extern "C" int bore_svgd_optimize(const bore_mlp_desc *desc, int n_models, const
                                   double *x_out, void *stream) {
   if (!desc || !theta || !x_init || !x_out || !opts) return fail(BORE_E_INVALID, "svgd_optimize: NULL argument");
   if (n_models < 1) return fail(BORE_E_INVALID, "svgd_optimize: n_models must be >= 1");
-  if (desc->compute != BORE_COMPUTE_F32)
-    return fail(BORE_E_UNSUPPORTED, "svgd_optimize: float32 networks only");
+  const int flav = bore_kernel_flavour(desc, true);
+  const bool bf = desc->compute == BORE_COMPUTE_BF16;
+  if (bf && !bore_shape_is_wide(flav)) return fail(BORE_E_UNSUPPORTED, kBf16Shapes);
+  if (bf && !bore_flavour_built(flav)) return fail(BORE_E_UNSUPPORTED, BORE_FLAVOUR_LEFT_OUT);
   const int D = desc->input_dim, n = n_particles;
   if (D < 1 || D > BORE_DIM_MAX) return fail(BORE_E_UNSUPPORTED, "svgd_optimize: input_dim must be 1..%d", BORE_DIM_MAX);
-  if (n < 1 || n > BORE_THREADS)
-    return fail(BORE_E_UNSUPPORTED, "svgd_optimize: 1..%d particles per launch", BORE_THREADS);
+  if (n < 1 || n > BORE_SVGD_MAX_PARTICLES)  // (what fits is decided by the LDS check below: 32 n D bytes of state)
+    return fail(BORE_E_UNSUPPORTED, "svgd_optimize: 1..%d particles per launch", BORE_SVGD_MAX_PARTICLES);
   const bool big = n > BORE_BATCH_MAX;  // (no kernel matrix in LDS: svgd_big_kernel)
   if (transform < BORE_T_IDENTITY || transform > BORE_T_EXP)
     return fail(BORE_E_INVALID, "svgd_optimize: unknown transform %d", transform);
@@ -413,8 +464,9 @@ extern "C" int bore_svgd_optimize(const bore_mlp_desc *desc, int n_models, const
   while (ns < n * n) ns <<= 1;
   a.n_sort = ns;
   const size_t nD2 = 2 * (((size_t)n * D + 1) & ~(size_t)1);  // floats of an [n][D] fp64 array, 16-B multiple
-  size_t off = a.L.P_lds;
-  a.o_tile = (int)off; off += a.L.tile_floats;
+  // (a bfloat16 network: its image instead of the padded float32 theta, and no activation tile)
+  size_t off = bf ? (flav == 3 ? ArgBf16Plan<3>::floats : ArgBf16Plan<4>::floats) : (size_t)a.L.P_lds;
+  a.o_tile = (int)off; off += bf ? 0 : a.L.tile_floats;
   a.o_vals = (int)off; off += BORE_BATCH_MAX;
   off = (off + 3) & ~(size_t)3;
   a.o_x = (int)off; off += nD2;
@@ -431,12 +483,24 @@ extern "C" int bore_svgd_optimize(const bore_mlp_desc *desc, int n_models, const
   if (off * 4 > BORE_LDS_BYTES)
     return fail(BORE_E_UNSUPPORTED, "svgd_optimize: %d particles in %d dimensions need %zu B of LDS (> %d)",
                 n, D, off * 4, BORE_LDS_BYTES);
-  int rc = big ? allow_lds(svgd_big_kernel, off * 4) : allow_lds(svgd_kernel, off * 4);
-  if (rc) return rc;
-  if (big)
-    hipLaunchKernelGGL(svgd_big_kernel, dim3(n_models), dim3(BORE_THREADS), off * 4, (hipStream_t)stream, a);
-  else
-    hipLaunchKernelGGL(svgd_kernel, dim3(n_models), dim3(BORE_THREADS), off * 4, (hipStream_t)stream, a);
+  int rc = 0;
+#define BORE_SVGD_LAUNCH(BF)                                                                                   \
+  do {                                                                                                         \
+    rc = big ? allow_lds(svgd_big_kernel<BF>, off * 4) : allow_lds(svgd_kernel<BF>, off * 4);                  \
+    if (rc) return rc;                                                                                         \
+    if (big)                                                                                                   \
+      hipLaunchKernelGGL(svgd_big_kernel<BF>, dim3(n_models), dim3(BORE_THREADS), off * 4, (hipStream_t)stream, a); \
+    else                                                                                                       \
+      hipLaunchKernelGGL(svgd_kernel<BF>, dim3(n_models), dim3(BORE_THREADS), off * 4, (hipStream_t)stream, a); \
+  } while (0)
+  if (!bf) BORE_SVGD_LAUNCH(0);
+#if BORE_ON_3
+  else if (flav == 3) BORE_SVGD_LAUNCH(3);
+#endif
+#if BORE_ON_4
+  else if (flav == 4) BORE_SVGD_LAUNCH(4);
+#endif
+#undef BORE_SVGD_LAUNCH
   HIP_TRY(hipGetLastError());
   return 0;
 }

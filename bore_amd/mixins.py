@@ -166,9 +166,10 @@ class BatchMaximizableMixin(MaximizableMixin):
 
     ``svgd_mode`` chooses where the particle interaction runs:
       "device"  (default) all iterations in ONE launch (``bore_svgd_optimize``: particles, kernel
-                matrix and history in LDS; beyond 64 particles, up to 256, the matrix entries are formed on
-                the fly); float32 networks -- anything else
-                falls back to "host" with a warning;
+                matrix and history in LDS; beyond 64 particles the matrix entries are formed on the fly);
+                float32 networks, and bfloat16 ones of the wide static shapes; what does not fit a
+                compute unit's LDS (32 n D bytes of particle state beside the network), a callable
+                transform or a user's kernel object goes to "host" with a warning;
       "host"    for what the device refuses: ``_func_max`` -- value + input gradient of
                 ``transform(f(x))`` for all particles -- is one HIP launch per SVGD iteration;
                 kernel matrix, repulsion and the Adagrad step are a short float64 numpy driver

@@ -2,9 +2,9 @@
 (``SVGD``, ``RadialBasis``, ``DistortionConstant``, ``DistortionExpDecay``, ``rank``;
 base.py:11-131, kernels.py:4-28) for the requests the DEVICE kernels do not take.
 
-``BatchMaximizableMixin.argmax_batch`` (bore_amd/mixins.py) runs all SVGD iterations of up to
-256 particles in one launch (``bore_svgd_optimize``).  What it refuses -- bfloat16 networks, more
-particles, a callable transform, a user's own kernel object or callback -- comes here: the value
+``BatchMaximizableMixin.argmax_batch`` (bore_amd/mixins.py) runs all SVGD iterations of all
+particles in one launch (``bore_svgd_optimize``).  What it refuses -- more particles than fit a
+compute unit's LDS, a callable transform, a user's own kernel object or callback -- comes here: the value
 and input gradient of all particles are still ONE HIP launch per iteration (``func``), the
 particle interaction is a short float64 numpy driver.  The step-for-step restatement of the
 reference (bit-equal to its recorded trajectories) is the checker, ``oracle/svgd_oracle.py``;

@@ -288,8 +288,9 @@ typedef struct bore_svgd_opts {
  * SVGD.optimize_from_init (bore/optimizers/svgd/base.py:79-119) with the RadialBasis kernel
  * (bore/optimizers/svgd/kernels.py:4-28) on the objective transform(f(x)) -- every iteration of
  * every particle inside ONE launch per model (particles, kernel matrix and Adagrad history in LDS).
- *   x_init, x_out  device fp64 [n_models][n_particles][D]   (n_particles <= 256: up to BORE_BATCH_MAX with the kernel
- *                  matrix in LDS, more with its entries formed on the fly)
+ *   x_init, x_out  device fp64 [n_models][n_particles][D]   (up to BORE_BATCH_MAX particles with the kernel matrix
+ *                  in LDS, more -- as many as fit: 32 n_particles D bytes of state -- with its entries formed on the fly)
+ *   desc           float32 networks of any shape; compute = bfloat16 for the wide static shapes (as everywhere)
  *   lb, ub         HOST fp64 [D]: particles are clipped into the box after every update;
  *                  both NULL = no clipping
  * BORE_E_UNSUPPORTED when particles x dimension do not fit the LDS beside the network.

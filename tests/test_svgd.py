@@ -170,15 +170,16 @@ def test_device_svgd_tracks_the_host_statement(gpu, n, D, units, ls, lambd, tr):
     with pytest.raises(RuntimeError, match="LDS"):
         ops.svgd_optimize(big, thb, dev(rs.uniform(size=(1, 64, 16))), n_iter=1)
     with pytest.raises(RuntimeError, match="particles"):
-        ops.svgd_optimize(desc, th, dev(rs.uniform(size=(L, 257, D))), n_iter=1)
+        ops.svgd_optimize(desc, th, dev(rs.uniform(size=(L, 4097, D))), n_iter=1)
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("n,D,ls,lambd", [(65, 2, None, None), (100, 6, None, 0.5), (130, 3, 0.2, None),
-                                          (256, 2, None, None), (96, 11, None, None)])
+                                          (256, 2, None, None), (96, 11, None, None), (300, 2, None, None),
+                                          (600, 3, 0.25, 0.5), (1024, 2, None, None)])
 def test_device_svgd_with_more_than_64_particles(gpu, n, D, ls, lambd):
     """Beyond 64 particles the n x n kernel matrix does not fit in LDS: svgd_big_kernel forms its
-    entries on the fly (one thread per particle, up to 256), the median heuristic's radix select
+    entries on the fly (one thread per particle, in turns beyond 256), the median heuristic's radix select
     recomputes the distances per pass, the network sees the particles 64 rows at a time.  Same
     sums in the same order as the small kernel: against the host statement (bit-equal to the
     reference's SVGD) driven by the same device f/g operator, to rounding."""
@@ -203,6 +204,41 @@ def test_device_svgd_with_more_than_64_particles(gpu, n, D, ls, lambd):
     ref = SVGD(kernel=RadialBasis(length_scale=ls), distortion=dist, **kw).optimize_from_init(
         func, x0[0], bounds=[(0.0, 1.0)] * D)
     np.testing.assert_allclose(out[0], ref, rtol=0, atol=1e-9 if lambd is None else 1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,D,units,ls,lambd", [(24, 16, [64, 64, 64, 1], None, None), (40, 32, [128, 128, 1], 0.8, None),
+                                                (70, 16, [64, 64, 64, 1], None, None), (16, 32, [128, 128, 1], None, 0.5)])
+def test_device_svgd_of_a_bfloat16_network(gpu, n, D, units, ls, lambd):
+    """A mixed_bfloat16 model (wide static shapes, the only ones with bfloat16 kernels): the particles' value and
+    input gradient run on the bf16 matrix cores inside the SVGD launch (arg_bf16_mfma.h) -- the arithmetic
+    bore_mlp_value_and_input_grad gives the host statement for such a model, so the two track each other to
+    rounding as for float32 networks (a bfloat16 network is a step function of x, but its steps sit at the
+    bfloat16 roundings of x itself: both sides see the same inputs unless a particle lands within 1e-16 of one)."""
+    import torch
+    from bore_amd import _lib, ops
+    from test_gpu_parity import dev, pack, rand_model
+    rs = np.random.RandomState(3 * n + D)
+    acts = ["relu"] * (len(units) - 1) + ["linear"]
+    desc = _lib.make_desc(D, units, acts, compute="bfloat16")
+    th = dev(pack(rand_model(rs, D, units))[None])
+    x0 = rs.uniform(size=(1, n, D))
+    kw = dict(n_iter=60, step_size=1e-2, alpha=.9, eps=1e-6, tau=1.)
+    out = ops.svgd_optimize(desc, th, dev(x0), np.zeros(D), np.ones(D), "sigmoid", length_scale=ls,
+                            lambd=lambd, **kw).cpu().numpy()
+    assert ((out >= 0) & (out <= 1)).all() and (np.abs(out - x0) > 1e-4).any()
+
+    def func(X):
+        v, g = ops.mlp_value_and_input_grad(desc, th, dev(X[None]), "sigmoid", False)
+        return v.cpu().numpy()[0].astype(np.float64), g.cpu().numpy()[0]
+    dist = DistortionConstant() if lambd is None else DistortionExpDecay(lambd=lambd)
+    ref = SVGD(kernel=RadialBasis(length_scale=ls), distortion=dist, **kw).optimize_from_init(
+        func, x0[0], bounds=[(0.0, 1.0)] * D)
+    np.testing.assert_allclose(out[0], ref, rtol=0, atol=1e-9 if lambd is None else 1e-6)
+    # bfloat16 outside the wide static shapes has no kernels: refused, as everywhere in the library
+    small = _lib.make_desc(2, [16, 16, 1], ["relu", "relu", "linear"], compute="bfloat16")
+    with pytest.raises(RuntimeError, match="bfloat16"):
+        ops.svgd_optimize(small, dev(pack(rand_model(rs, 2, [16, 16, 1]))[None]), dev(rs.uniform(size=(1, 8, 2))), n_iter=1)
 
 
 @pytest.mark.gpu
