@@ -366,7 +366,61 @@ __host__ __device__ __forceinline__ unsigned shuffle_key(unsigned long long base
 
 // floats of LDS scratch make_perm needs: round_up(N, 16) 64-bit words + N rank counters
 __host__ __device__ __forceinline__ long long perm_scratch_floats(long long N) {
-  return 2 * ((N + 15) & ~15LL) + ((N + 3) & ~3LL);
+  return 2 * ((N + 15) & ~15LL) + ((N + 3) & ~3LL) + 8;  // (+ 8: the wave totals of make_perm_buckets' scan)
+}
+
+// More than 128 rows: rank by BUCKETS instead of all pairs (N^2 / threads compares: 8.4 k cycles per shuffle at
+// 256 rows, a sixth of the 6->32-32-1 fit's step at four steps per epoch, 134 k at 1024 rows).  NB = the largest
+// power of two <= N buckets by the top bits of the 32-bit key, about one row each.  Count the rows per bucket
+// (LDS atomics), scan the counts, drop every row's word (key << 32 | row) into its bucket's range of a second array
+// (the order inside a bucket is the order of arrival: any), then every POSITION ranks its word among the members
+// of its bucket: rank = bucket's first position + members below.  The same words and the same rule as the
+// all-pairs count: the same permutation.  Scratch: the same perm_scratch_floats(N) -- N 64-bit words, then NB <= N
+// counters, then 8 ints.  Ends with a barrier.
+__device__ __forceinline__ int wave_inclusive_scan(int v);
+__device__ __forceinline__ void make_perm_buckets(unsigned long long base, int N, unsigned *keys, int *perm_out) {
+  const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wv = tid >> 6;
+  const int N16 = (N + 15) & ~15;
+  unsigned long long *mem = reinterpret_cast<unsigned long long *>(keys);  // [N] words, bucket by bucket
+  int *cur = reinterpret_cast<int *>(mem + N16);                           // [NB] count -> first -> end
+  int *tot = cur + ((N + 3) & ~3);                                          // [8] wave totals
+  int lg = 0;
+  while ((2 << lg) <= N) ++lg;
+  const int NB = 1 << lg, sh = 32 - lg;  // (N > 128: lg >= 7)
+  for (int b = tid; b < NB; b += nthr) cur[b] = 0;
+  __syncthreads();
+  for (int i = tid; i < N; i += nthr) atomicAdd(&cur[shuffle_key(base, i) >> sh], 1);
+  __syncthreads();
+  // exclusive scan of the NB counts in place: thread t owns the `per` consecutive buckets from t * per
+  const int per = (NB + nthr - 1) / nthr, b0 = tid * per;
+  int sum = 0;
+  for (int b = b0; b < min(b0 + per, NB); ++b) sum += cur[b];
+  const int incl = wave_inclusive_scan(sum);
+  if (lane == 63) tot[wv] = incl;
+  __syncthreads();
+  int run = incl - sum;
+  for (int w = 0; w < wv; ++w) run += tot[w];
+  for (int b = b0; b < min(b0 + per, NB); ++b) {
+    const int c = cur[b];
+    cur[b] = run;
+    run += c;
+  }
+  __syncthreads();
+  // (a row's key is drawn again rather than kept: held in registers across the scan it was slower)
+  for (int i = tid; i < N; i += nthr) {
+    const unsigned key = shuffle_key(base, i);
+    mem[atomicAdd(&cur[key >> sh], 1)] = ((unsigned long long)key << 32) | (unsigned)i;
+  }
+  __syncthreads();  // (cur[b] is now the END of bucket b = the first position of bucket b + 1)
+  for (int p = tid; p < N; p += nthr) {
+    const unsigned long long w = mem[p];
+    const int b = (int)((unsigned)(w >> 32) >> sh);
+    const int lo = b ? cur[b - 1] : 0, hi = cur[b];
+    int r = lo;
+    for (int q = lo; q < hi; ++q) r += mem[q] < w;
+    perm_out[r] = (int)(unsigned)w;
+  }
+  __syncthreads();
 }
 
 // keys: LDS scratch of perm_scratch_floats(N) floats, 16-byte aligned; perm_out: [N] (LDS or
@@ -376,6 +430,10 @@ __host__ __device__ __forceinline__ long long perm_scratch_floats(long long N) {
 // (partial counts meet in an LDS counter), so that a 64-row shuffle keeps all 256 threads busy.
 __device__ __forceinline__ void make_perm(unsigned long long base, int N, unsigned *keys,
                                           int *perm_out) {
+  if (N > 128) {  // (workgroup-uniform)
+    make_perm_buckets(base, N, keys, perm_out);
+    return;
+  }
   unsigned long long *k64 = reinterpret_cast<unsigned long long *>(keys);
   // (NOT opaque here: the shuffle's per-thread constants -- a division by the padded row count among
   // them -- are wanted outside the epoch loop; made opaque the fit lost 3 %)

@@ -198,7 +198,8 @@ def test_warm_start_equals_one_long_fit(gpu):
 
 
 def test_shuffle_stream_is_bit_exact_and_drives_fit(gpu):
-    for N in (1, 10, 64, 65, 110, 300):
+    # (more than 128 rows: ranked by buckets, make_perm_buckets -- a power of two, one more, several rows per thread)
+    for N in (1, 10, 64, 65, 110, 128, 129, 256, 257, 300, 1000, 4097):
         d = ops.shuffle_perm(1234, 3, 5, N, model_index0=2, epoch0=7).cpu().numpy()
         h = shuffle.permutations(1234, 3, 5, N, model_index0=2, epoch0=7)
         assert np.array_equal(d, h), N
