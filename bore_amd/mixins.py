@@ -96,7 +96,7 @@ class MaximizableMixin:
         tr = self._func_min.transform
         x, fun, jac, info = ops.lbfgsb_minimize(self._desc, self.theta, x0, low, high, tr.name,
                                                 tr.negate, **options)
-        x, fun, jac, info = (t[0].cpu().numpy() for t in (x, fun, jac, info))
+        x, fun, jac, info = (t[0] for t in ops.lbfgsb_results_to_host(x, fun, jac, info))
         return [OptimizeResult(x=x[r], fun=float(fun[r]), jac=jac[r], nit=int(info[r, 0]),
                                nfev=int(info[r, 1]), njev=int(info[r, 1]),
                                status=int(info[r, 2]), success=bool(info[r, 2] == 0),

@@ -162,10 +162,21 @@ class Sequential:
         batch_size = 32 if batch_size is None else int(batch_size)
         if batch_size < 1:
             raise ValueError(f"batch_size must be positive, got {batch_size}")
-        X = self._to_dev(x, torch.float32).reshape(1, -1, self._input_dim)
-        N = X.shape[1]
-        z = self._to_dev(np.asarray(y).reshape(-1) if not isinstance(y, torch.Tensor)
-                         else y.reshape(-1), torch.float32).reshape(1, N)
+        if not isinstance(x, torch.Tensor) and not isinstance(y, torch.Tensor):
+            # host arrays (the reference's callers): features and labels cross PCIe in ONE copy
+            xh = np.asarray(x, dtype=np.float32).reshape(-1, self._input_dim)
+            N = xh.shape[0]
+            both = np.empty(N * (self._input_dim + 1), dtype=np.float32)
+            both[:N * self._input_dim] = xh.ravel()
+            both[N * self._input_dim:] = np.asarray(y).reshape(-1)     # (raises on a length mismatch)
+            both = torch.from_numpy(both).to(self.theta.device)
+            X = both[:N * self._input_dim].reshape(1, N, self._input_dim)
+            z = both[N * self._input_dim:].reshape(1, N)
+        else:
+            X = self._to_dev(x, torch.float32).reshape(1, -1, self._input_dim)
+            N = X.shape[1]
+            z = self._to_dev(np.asarray(y).reshape(-1) if not isinstance(y, torch.Tensor)
+                             else y.reshape(-1), torch.float32).reshape(1, N)
         epochs = int(epochs)
         if perm is None and not shuffle:
             perm = np.tile(np.arange(N, dtype=np.int32), (epochs, 1))

@@ -9,6 +9,8 @@ from __future__ import annotations
 
 import ctypes as C
 
+import numpy as np
+
 import torch
 
 from . import _lib
@@ -234,10 +236,13 @@ def lbfgsb_minimize(desc, theta, x0, low, high, transform="identity", negate=Tru
     hi, hi_p = _host_f64(high, D, "high")
     opts = _lib.LbfgsbOpts(int(maxcor), int(maxiter), int(maxfun), int(maxls), float(ftol),
                            float(gtol))
-    x = torch.empty_like(x0)
-    jac = torch.empty_like(x0)
-    fun = torch.empty((L, R), dtype=torch.float64, device=theta.device)
-    info = torch.empty((L, R, 5), dtype=torch.int32, device=theta.device)
+    # one allocation behind the four results (``lbfgsb_results_to_host`` brings them home in one copy)
+    n_xd, n_i = L * R * D, (L * R * 5 + 1) // 2
+    buf = torch.empty(2 * n_xd + L * R + n_i, dtype=torch.float64, device=theta.device)
+    x = buf[:n_xd].view(L, R, D)
+    jac = buf[n_xd:2 * n_xd].view(L, R, D)
+    fun = buf[2 * n_xd:2 * n_xd + L * R].view(L, R)
+    info = buf[2 * n_xd + L * R:].view(torch.int32)[:L * R * 5].view(L, R, 5)
     if R == 0:
         return x, fun, jac, info
     _lib.check(_lib.lib().bore_lbfgsb_minimize(
@@ -245,6 +250,17 @@ def lbfgsb_minimize(desc, theta, x0, low, high, transform="identity", negate=Tru
         _lib.ptr(x0), R, lo_p, hi_p, C.byref(opts), _lib.ptr(x), _lib.ptr(fun), _lib.ptr(jac),
         _lib.ptr(info), _lib.stream_ptr()))
     return x, fun, jac, info
+
+
+def lbfgsb_results_to_host(x, fun, jac, info):
+    """The four results of ``lbfgsb_minimize`` as numpy arrays through ONE device-to-host copy (they are views
+    of one allocation; four separate ``.cpu()`` calls are four synchronisations)."""
+    L, R, D = x.shape
+    n_xd = L * R * D
+    h = torch.as_strided(x, (2 * n_xd + L * R + (L * R * 5 + 1) // 2,), (1,), x.storage_offset()).cpu().numpy()
+    return (h[:n_xd].reshape(L, R, D), h[2 * n_xd:2 * n_xd + L * R].reshape(L, R),
+            h[n_xd:2 * n_xd].reshape(L, R, D),
+            h[2 * n_xd + L * R:].view(np.int32)[:L * R * 5].reshape(L, R, 5))
 
 
 class ObservationStore:
