@@ -1646,6 +1646,35 @@ __global__ __launch_bounds__(BORE_THREADS) void fit_bf16_kernel(const FitBf16Arg
   if (tid == 0) a.at[model] = t0 + (long long)a.epochs * steps;
 }
 
+// This lane's slots of weight-gradient tile t = wave + 4 I of the bf16-MFMA fit (layer l known at compile
+// time): kb / cb = the tile's block row / column; the index of the lane's four weights = a wave-uniform
+// part pu (scalar registers) + a lane part lb4 (bytes); pbu / 4 m16 = the same for its bias.
+template <int SHAPE, int I>
+__device__ __forceinline__ void bf16_tile_slots(int wv, int lane, int &kb, int &cb, int &pu, unsigned &lb4,
+                                                bool &ok4, int &pbu, bool &okb) {
+  using Pl = Bf16Plan<SHAPE>;
+  constexpr MlpLayout L = Pl::L;
+  constexpr int l = Pl::layer_of_tile(4 * I);
+  constexpr int K = L.w[l - 1], Nw = L.w[l], ncb = Pl::T(l);
+  constexpr bool FULL = K % 16 == 0 && Nw % 16 == 0;
+  const int m16 = lane & 15, q4 = lane >> 4;
+  const int r = wv + 4 * I - Pl::tiles_before(l);
+  kb = r / ncb;
+  cb = r - kb * ncb;
+  if constexpr (Nw == 1) {  // one column: the C layout's four rows ARE contiguous (lanes m = 0)
+    pu = L.goff_w[l] + 16 * kb;
+    lb4 = 16u * (unsigned)q4;
+    ok4 = m16 == 0 && 16 * kb + 4 * q4 < K;
+  } else {  // tile order: tile (kb, cb) = 256 consecutive floats, the lane's four at 4 * lane
+    static_assert(FULL, "a wide static shape has layer sizes that are multiples of 16");
+    pu = L.goff_w[l] + (kb * ncb + cb) * 256;
+    lb4 = 16u * (unsigned)lane;
+    ok4 = true;
+  }
+  okb = kb == 0 && q4 == 0 && (FULL || 16 * cb + m16 < Nw);
+  pbu = L.goff_b[l] + 16 * cb;
+}
+
 // The mixed-precision fit on the bf16 matrix cores (fit_bf16_mfma.h has the design).
 template <int SHAPE>
 __global__ __launch_bounds__(BORE_THREADS) void fit_bf16_mfma_kernel(const FitBf16Args a) {
@@ -1697,6 +1726,27 @@ __global__ __launch_bounds__(BORE_THREADS) void fit_bf16_mfma_kernel(const FitBf
   if (lane < 32) g_fit_lds[wv & 3][lane] = 0;
 #endif
   FIT_MARK_DECL;
+  // The float32 MASTER weights live in registers for the launch: the lane's four of each of this wave's tiles
+  // t = wave + 4 I (4 registers per tile, 88 for 32->128-128-1; a wave alone on its SIMD has 512).  Read and
+  // written in HBM every step beside m and v they were a third of the update's traffic, which at 256 loops is
+  // what the memory system delivers (profiles/r4/ab_log.txt).
+  constexpr int TPW = Pl::tiles_per_wave();
+  typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+  f4u sw[TPW];
+  float sbw[TPW];  // (only the tiles of block row 0 carry a bias: the other entries are never touched)
+  {
+    const BufF32 b_w(theta_g, P);
+    static_for<0, TPW>([&](auto ic) {
+      constexpr int I = decltype(ic)::value;
+      int kb, cb, pu, pbu;
+      unsigned lb4;
+      bool ok4, okb;
+      bf16_tile_slots<SHAPE, I>(wv, lane, kb, cb, pu, lb4, ok4, pbu, okb);
+      const f4u z4 = {0.f, 0.f, 0.f, 0.f};
+      sw[I] = ok4 ? b_w.ld4(pu, lb4) : z4;
+      if (kb == 0) sbw[I] = okb ? b_w.ld1(pbu, 4u * (unsigned)m16) : 0.f;
+    });
+  }
 
   for (int e = 0; e < a.epochs; ++e) {
     if (a.perm) {
@@ -1787,42 +1837,24 @@ __global__ __launch_bounds__(BORE_THREADS) void fit_bf16_mfma_kernel(const FitBf
         // instructions per tile, then 12 16-byte ones on half lines).  They are requested three tiles
         // ahead of use and ahead of the stores in between (loads and stores share one counter); the
         // new weights go to HBM and, rounded, into the LDS images. ----
-        constexpr int TPW = Pl::tiles_per_wave(), TOTAL = Pl::total_tiles(), AHEAD = 3;
+        constexpr int TOTAL = Pl::total_tiles(), AHEAD = 3;
         constexpr int RING = AHEAD + 2;  // (tile I - 1 is still in use when tile I + AHEAD is requested)
-        typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
         // (lane coordinates re-derived from an opaque copy of the thread id: computed from the
         // loop-invariant ones, the slot indices of all tiles are hoisted out of the step loop and
         // kept live across it -- 22 tiles x 10 registers, most of them spilled)
         const int wv = __builtin_amdgcn_readfirstlane(tid_o >> 6), lane = tid_o & 63, m16 = lane & 15, q4 = lane >> 4;
-        f4u pw[RING], pm[RING], pv[RING];
-        float bw[RING], bm[RING], bv[RING];
+        f4u pm[RING], pv[RING];
+        float bm[RING], bv[RING];
         static_assert(Pl::layers_aligned() && TOTAL % 4 == 0, "tiles of a layer must start at a multiple of 4");
         // this lane's slots of tile t = wave + 4 I (layer l known at compile time): kb / cb = the tile's
         // block row / column; the index of the lane's four weights = a wave-uniform part pu (scalar
         // registers) + a lane part lb4 (bytes); pbu / 4 m16 = the same for its bias
         auto slots = [&](auto ic, int &kb, int &cb, int &pu, unsigned &lb4, bool &ok4, int &pbu, bool &okb) {
-          constexpr int I = decltype(ic)::value, l = Pl::layer_of_tile(4 * I);
-          constexpr int K = L.w[l - 1], Nw = L.w[l], ncb = Pl::T(l);
-          constexpr bool FULL = K % 16 == 0 && Nw % 16 == 0;
-          const int r = wv + 4 * I - Pl::tiles_before(l);
-          kb = r / ncb;
-          cb = r - kb * ncb;
-          if constexpr (Nw == 1) {  // one column: the C layout's four rows ARE contiguous (lanes m = 0)
-            pu = L.goff_w[l] + 16 * kb;
-            lb4 = 16u * (unsigned)q4;
-            ok4 = m16 == 0 && 16 * kb + 4 * q4 < K;
-          } else {  // tile order: tile (kb, cb) = 256 consecutive floats, the lane's four at 4 * lane
-            static_assert(FULL, "a wide static shape has layer sizes that are multiples of 16");
-            pu = L.goff_w[l] + (kb * ncb + cb) * 256;
-            lb4 = 16u * (unsigned)lane;
-            ok4 = true;
-          }
-          okb = kb == 0 && q4 == 0 && (FULL || 16 * cb + m16 < Nw);
-          pbu = L.goff_b[l] + 16 * cb;
+          bf16_tile_slots<SHAPE, decltype(ic)::value>(wv, lane, kb, cb, pu, lb4, ok4, pbu, okb);
         };
         // buffer addressing (resource + 32-bit lane offset + scalar offset): one instruction per access
         // and no 64-bit address arithmetic (as flat pointers every access cost a 64-bit vector add)
-        const BufF32 b_th(theta_g, P), b_m(m_g, P), b_v(v_g, P);
+        const BufF32 b_m(m_g, P), b_v(v_g, P);
         const unsigned lbb = 4u * (unsigned)m16;
         auto request = [&](auto ic) {
           constexpr int I = decltype(ic)::value, l = Pl::layer_of_tile(4 * I);
@@ -1833,16 +1865,13 @@ __global__ __launch_bounds__(BORE_THREADS) void fit_bf16_mfma_kernel(const FitBf
           slots(ic, kb, cb, pu, lb4, ok4, pbu, okb);
           const f4u z4 = {0.f, 0.f, 0.f, 0.f};
           if constexpr (FULL) {
-            pw[I % RING] = b_th.ld4(pu, lb4);
             pm[I % RING] = b_m.ld4(pu, lb4);
             pv[I % RING] = b_v.ld4(pu, lb4);
           } else {
-            pw[I % RING] = ok4 ? b_th.ld4(pu, lb4) : z4;
             pm[I % RING] = ok4 ? b_m.ld4(pu, lb4) : z4;
             pv[I % RING] = ok4 ? b_v.ld4(pu, lb4) : z4;
           }
           if (kb == 0) {  // (wave-uniform: only these tiles carry a bias)
-            bw[I % RING] = okb ? b_th.ld1(pbu, lbb) : 0.f;
             bm[I % RING] = okb ? b_m.ld1(pbu, lbb) : 0.f;
             bv[I % RING] = okb ? b_v.ld1(pbu, lbb) : 0.f;
           }
@@ -1891,7 +1920,7 @@ __global__ __launch_bounds__(BORE_THREADS) void fit_bf16_mfma_kernel(const FitBf
           for (int h = 0; h < 2; ++h) {
             const f2 gg = {g[2 * h], g[2 * h + 1]};
             f2 mm = {pm[cur][2 * h], pm[cur][2 * h + 1]}, vv = {pv[cur][2 * h], pv[cur][2 * h + 1]};
-            const f2 ww = {pw[cur][2 * h], pw[cur][2 * h + 1]};
+            const f2 ww = {sw[I][2 * h], sw[I][2 * h + 1]};
             mm += (gg - mm) * omb1;
             vv += (gg * gg - vv) * omb2;
             const f2 den = {__builtin_amdgcn_sqrtf(vv.x) + a.eps, __builtin_amdgcn_sqrtf(vv.y) + a.eps};
@@ -1903,9 +1932,8 @@ __global__ __launch_bounds__(BORE_THREADS) void fit_bf16_mfma_kernel(const FitBf
           }
 #pragma unroll
           for (int r = 0; r < 4; ++r) asm volatile("" : "+v"(wn[r]));
+          sw[I] = f4u{wn[0], wn[1], wn[2], wn[3]};
           if (ok4) {
-            const f4u w4 = {wn[0], wn[1], wn[2], wn[3]};
-            b_th.st4(w4, pu, lb4);
             b_m.st4(pm[cur], pu, lb4);
             b_v.st4(pv[cur], pu, lb4);
           }
@@ -1936,9 +1964,9 @@ __global__ __launch_bounds__(BORE_THREADS) void fit_bf16_mfma_kernel(const FitBf
             float mm = bm[cur], vv = bv[cur];
             mm += (gb - mm) * omb1;
             vv += (gb * gb - vv) * omb2;
-            const float wnb = bw[cur] - (mm * alpha) * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(vv) + a.eps);
+            const float wnb = sbw[I] - (mm * alpha) * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(vv) + a.eps);
+            sbw[I] = wnb;
             if (okb) {
-              b_th.st1(wnb, pbu, lbb);
               b_m.st1(mm, pbu, lbb);
               b_v.st1(vv, pbu, lbb);
               bias[Pl::bias_off(l) + 16 * cb + m16] = bf16_round_hw(wnb);
@@ -1993,6 +2021,18 @@ __global__ __launch_bounds__(BORE_THREADS) void fit_bf16_mfma_kernel(const FitBf
       if (tid == 0)
         a.epoch_loss[model * a.epochs + e] = (misc[1] + misc[2] + misc[3] + misc[4]) / (float)N;
     }
+  }
+  {  // the master weights back to memory (tile order)
+    const BufF32 b_w(theta_g, P);
+    static_for<0, TPW>([&](auto ic) {
+      constexpr int I = decltype(ic)::value;
+      int kb, cb, pu, pbu;
+      unsigned lb4;
+      bool ok4, okb;
+      bf16_tile_slots<SHAPE, I>(wv, lane, kb, cb, pu, lb4, ok4, pbu, okb);
+      if (ok4) b_w.st4(sw[I], pu, lb4);
+      if (kb == 0 && okb) b_w.st1(sbw[I], pbu, 4u * (unsigned)m16);
+    });
   }
   // back to the packed order (the LDS images are dead by now)
   __syncthreads();
