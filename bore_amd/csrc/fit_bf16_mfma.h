@@ -4,7 +4,7 @@
 //
 // Arithmetic (the same rounding points as oracle.fit_bf16): bfloat16 weights, biases, inputs,
 // layer outputs, logits and deltas; float32 accumulation inside the MFMA, float32 loss and
-// d loss / d logit; float32 master weights + Adam slots in HBM, updated every step.
+// d loss / d logit; float32 master weights (in registers for the launch) + Adam slots (in HBM), updated every step.
 //
 // The fp32-MFMA form this replaces spent, per Adam step of 32->128-128-1, 163 k cycles: 968
 // v_mfma_f32_16x16x4_f32 per wave (31 k cycles of matrix-core time alone), each fed by its own
@@ -28,9 +28,9 @@
 //    16x16 tile of dW_l are 16-byte reads too: 2 MFMAs per tile instead of 16;
 //  * the last layer has ONE unit: its backward product is an outer product, formed elementwise
 //    from a float32 copy of its weights (no Wb image for it);
-//  * the update walks the packed parameter vector with all 256 threads (coalesced m / v / master
-//    loads, the next batch requested before this batch's stores), the gradients parked in LDS over
-//    the dead activation images, layer group by layer group.
+//  * the update runs tile by tile in the MFMA's own result layout (TileOrder below): a wave's lanes hold the
+//    float32 master weights of its tiles in registers for the whole launch; m / v stream from HBM as 16-byte
+//    loads three tiles ahead of use.
 #pragma once
 #include "mlp_device.h"
 #include "mlp_regs.h"
