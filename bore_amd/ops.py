@@ -257,7 +257,13 @@ def lbfgsb_results_to_host(x, fun, jac, info):
     of one allocation; four separate ``.cpu()`` calls are four synchronisations)."""
     L, R, D = x.shape
     n_xd = L * R * D
-    h = torch.as_strided(x, (2 * n_xd + L * R + (L * R * 5 + 1) // 2,), (1,), x.storage_offset()).cpu().numpy()
+    total = 2 * n_xd + L * R + (L * R * 5 + 1) // 2
+    packed = (x.dtype == torch.float64 and x.is_contiguous() and x.storage_offset() == 0
+              and x.untyped_storage().nbytes() == 8 * total
+              and all(t.untyped_storage().data_ptr() == x.untyped_storage().data_ptr() for t in (fun, jac, info)))
+    if not packed:      # (not the views lbfgsb_minimize returns: one copy each)
+        return tuple(t.cpu().numpy() for t in (x, fun, jac, info))
+    h = torch.as_strided(x, (total,), (1,), 0).cpu().numpy()
     return (h[:n_xd].reshape(L, R, D), h[2 * n_xd:2 * n_xd + L * R].reshape(L, R),
             h[n_xd:2 * n_xd].reshape(L, R, D),
             h[2 * n_xd + L * R:].view(np.int32)[:L * R * 5].reshape(L, R, 5))

@@ -193,6 +193,14 @@ def test_device_lbfgsb_limits_and_open_bounds(gpu):
             assert (info[:, 2] == 1).all() and (info[:, 0] == 2).all() and (info[:, 4] == 504).all()
     with pytest.raises(RuntimeError, match="lower bounds"):
         ops.lbfgsb_minimize(desc, th, dev(X0), [1, 0, 0, 0], [0, 1, 1, 1])
+    # the four results come home in one copy (views of one allocation) -- or one each when they are not
+    for L in (1, 3):
+        thL, X0L = th.repeat(L, 1), dev(np.repeat(X0, L, axis=0))
+        res = ops.lbfgsb_minimize(desc, thL, X0L, lo, hi, "sigmoid", True)
+        for got, want in zip(ops.lbfgsb_results_to_host(*res), res):
+            assert got.dtype == want.cpu().numpy().dtype and np.array_equal(got, want.cpu().numpy())
+        for got, want in zip(ops.lbfgsb_results_to_host(*(t.clone() for t in res)), res):
+            assert np.array_equal(got, want.cpu().numpy())
 
 
 @pytest.mark.parametrize("seed", [0, 42, 8888])
