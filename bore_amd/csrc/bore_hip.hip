@@ -284,6 +284,8 @@ __device__ __forceinline__ void dw_adam_static(const FitArgs &a, float *smem, fl
   // vector compares that narrow the execution mask -- the way from the mid-step barrier to the
   // wave's task was ~380 cycles of an Adam step, profiles/r3/fit_marks_dispatch.txt)
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  // (tasks go round the workgroup's waves: four, or eight in fit_kernel_w8 -- a power of two)
+  const int wmask = __builtin_amdgcn_readfirstlane((int)(blockDim.x >> 6)) - 1;
   int t = 0;
 #pragma unroll
   for (int l = 1; l <= L.n_layers; ++l) {
@@ -294,7 +296,7 @@ __device__ __forceinline__ void dw_adam_static(const FitArgs &a, float *smem, fl
       for (int cb = 0; cb < ncb; ++cb) {
         const bool transposed = L.w[l] == 1;
         const bool two = !transposed && split && L.w[l - 1] - kb * 16 > 2;
-        if ((t & 3) == wv)
+        if ((t & wmask) == wv)
           // (registers past the layer's inputs hold padding: a 2-input layer updates two, not four; a tile
           // split into two tasks: the bias rides with the SECOND half -- the first half's wave was the
           // heavier one: fit 392.7 -> 385.8 us per loop-iteration.  Tried beyond that and dropped: the bias
@@ -306,7 +308,7 @@ __device__ __forceinline__ void dw_adam_static(const FitArgs &a, float *smem, fl
                   KCH, alpha, omb1, omb2, a.eps);
         ++t;
         if (two) {
-          if ((t & 3) == wv)
+          if ((t & wmask) == wv)
             dw_task(L, smem, a.o_tile, a.o_m, a.o_v, l, kb, cb, 2, 4, kb == 0, false, KCH, alpha,
                     omb1, omb2, a.eps);
           ++t;
@@ -1102,7 +1104,7 @@ __device__ __forceinline__ void fit_body(const FitArgs &a, const long long slot,
       }
       // (wide shapes: every wave runs, rows past the batch are dead -- x = 0, delta = 0 -- so
       // that the weight-gradient tiles can always sum over all 64 rows)
-      if (wv * 16 < nr || bore_shape_is_wide(SHAPE > 0 ? SHAPE : 0)) {
+      if (wv * 16 < nr || (bore_shape_is_wide(SHAPE > 0 ? SHAPE : 0) && wv < BORE_THREADS / 64)) {
         const int rb = wv;
         if constexpr (SHAPE > 0) {
           // static shape: the row-block's activations and deltas stay in registers
@@ -1439,7 +1441,7 @@ __device__ __forceinline__ void fit_body(const FitArgs &a, const long long slot,
     }
     if (a.epoch_loss) {
       eloss = wave_sum(eloss);
-      if (lane == 0) misc[1 + wv] = eloss;
+      if (lane == 0 && wv < 4) misc[1 + wv] = eloss;  // (waves past the fourth own no rows: fit_kernel_w8)
       __syncthreads();
       if (tid == 0)
         a.epoch_loss[model * a.epochs + e] = (misc[1] + misc[2] + misc[3] + misc[4]) / (float)N;
@@ -1472,6 +1474,15 @@ __device__ __forceinline__ void fit_body(const FitArgs &a, const long long slot,
 
 template <int SHAPE>
 __global__ __launch_bounds__(BORE_THREADS) void fit_kernel(const FitArgs a) {
+  fit_body<SHAPE>(a, blockIdx.x);
+}
+// Eight waves for the same workgroup (static shapes with two weight-gradient tiles per wave: 6->32-32-1): rows
+// and row-blocks are still the first four waves'; the other four wait at the mid-step barrier and then take half
+// of the weight-gradient tasks -- one tile per wave instead of two in a row (a task is a chain of LDS requests,
+// dependent matrix instructions and sqrt / reciprocal chains that one wave walks alone).  For launches with no
+// more models than compute units: with more, two four-wave workgroups per CU do better.
+template <int SHAPE>
+__global__ __launch_bounds__(2 * BORE_THREADS) void fit_kernel_w8(const FitArgs a) {
   fit_body<SHAPE>(a, blockIdx.x);
 }
 
@@ -2434,6 +2445,18 @@ extern "C" int bore_mlp_fit(const bore_mlp_desc *desc, int n_models, float *thet
   int rc = fit_build(desc, n_models, theta, adam_m, adam_v, adam_t, X, z, N, epochs, batch_size, perm,
                      seed, model_index0, epoch0, adam, epoch_loss, a, off, shape);
   if (rc) return rc < 0 ? rc : 0;
+#if BORE_ON_2
+  {  // BORE_FIT_W8 = 0 / 1 forces the choice (A/B, tests)
+    const int forced = getenv("BORE_FIT_W8") ? atoi(getenv("BORE_FIT_W8")) : -1;
+    if (shape == 2 && !g_batch && (forced < 0 ? n_models <= device_cus() : forced != 0)) {
+      rc = allow_lds(fit_kernel_w8<2>, off * 4);
+      if (rc) return rc;
+      hipLaunchKernelGGL(fit_kernel_w8<2>, dim3(n_models), dim3(2 * BORE_THREADS), off * 4, (hipStream_t)stream, a);
+      HIP_TRY(hipGetLastError());
+      return 0;
+    }
+  }
+#endif
 #define BORE_LAUNCH_FIT(S)                                                              \
   case S:                                                                               \
     rc = allow_lds(fit_kernel<S>, off * 4);                                             \

@@ -230,6 +230,27 @@ def test_shuffle_stream_is_bit_exact_and_drives_fit(gpu):
         assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1]), N
 
 
+def test_eight_wave_fit_of_32_32_1_gives_the_same_bits(gpu, monkeypatch):
+    """fit_kernel_w8<2> (launches with no more models than compute units: the second four waves take half of the
+    weight-gradient tiles) against the four-wave kernel: the same tiles, sums and updates, handed out differently."""
+    rs = np.random.RandomState(11)
+    D, units, acts = 6, [32, 32, 1], ["relu", "relu", "sigmoid"]
+    desc = _lib.make_desc(D, units, acts)
+    for N, L, E in ((256, 3, 6), (100, 2, 5), (30, 1, 9)):
+        th0 = np.stack([pack(rand_model(rs, D, units)) for _ in range(L)])
+        X = dev(rs.uniform(size=(L, N, D)), torch.float32)
+        z = dev((rs.uniform(size=(L, N)) < 0.25).astype(np.float32))
+        outs = []
+        for w8 in ("0", "1"):
+            monkeypatch.setenv("BORE_FIT_W8", w8)
+            th = dev(th0)
+            m, v = torch.zeros_like(th), torch.zeros_like(th)
+            t = torch.zeros(L, dtype=torch.int64, device="cuda")
+            loss = ops.mlp_fit(desc, th, m, v, t, X, z, E, 64, seed=5)
+            outs.append([a.cpu().numpy() for a in (th, m, v, t, loss)])
+        assert all(np.array_equal(a, b) for a, b in zip(*outs)), N
+
+
 def test_one_wave_bucket_ranking_draws_the_same_shuffles(gpu, monkeypatch):
     """Round 4: the pipelined fit's fourth wave ranks an epoch's keys by buckets (make_perm_wave_buckets,
     ~1 k cycles at 100 rows instead of ~6 k).  Through bore_shuffle_perm's test switch: the SAME
