@@ -263,3 +263,31 @@ def test_argmax_batch_device_mode(gpu):
     np.testing.assert_allclose(devp, host, rtol=0, atol=1e-9)
     full = model.argmax_batch(8, bounds, random_state=5)          # the reference's 1000 iterations
     assert full.shape == (8, 2) and ((full >= 0) & (full <= 1)).all()
+
+
+@pytest.mark.gpu
+def test_argmax_batch_of_a_mixed_bfloat16_model_runs_on_the_device(gpu):
+    """BatchMaximizableSequential with dtype_policy="mixed_bfloat16" (BASELINE config 5's network): the device mode
+    takes the request (no fall-back warning) and agrees with the host statement around the same bfloat16 f/g kernel."""
+    import warnings
+    from scipy.optimize import Bounds
+    from bore_amd.layers import Dense
+    from bore_amd.models import BatchMaximizableSequential
+    rs = np.random.RandomState(3)
+    D = 32
+    model = BatchMaximizableSequential("sigmoid", seed=2, dtype_policy="mixed_bfloat16")
+    model.add(Dense(128, activation="relu", input_dim=D))
+    model.add(Dense(128, activation="relu"))
+    model.add(Dense(1))
+    model.compile(optimizer="adam", loss=__import__("bore_amd").BinaryCrossentropy(from_logits=True))
+    X = rs.uniform(size=(256, D))
+    y = np.sum((X - 0.4) ** 2, 1)
+    model.fit(X, y < np.quantile(y, 0.25), epochs=30, batch_size=64)
+    bounds = Bounds(np.zeros(D), np.ones(D))
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")                      # a fall-back to the host would warn
+        devp = model.argmax_batch(12, bounds, n_iter=50, step_size=1e-2, random_state=5)
+    model.svgd_mode = "host"
+    host = model.argmax_batch(12, bounds, n_iter=50, step_size=1e-2, random_state=5)
+    assert devp.shape == (12, D) and ((devp >= 0) & (devp <= 1)).all()
+    np.testing.assert_allclose(devp, host, rtol=0, atol=1e-9)
