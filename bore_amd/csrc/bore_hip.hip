@@ -131,6 +131,7 @@ struct FitArgs {
   float lr, beta1, beta2, eps;
   int state_in_lds, data_in_lds;
   int perm_in_lds;  // 0: an explicit perm too long for LDS is read from memory per step (generic flavours)
+  int perm_ahead;   // 1: room for two shuffles: the eight-wave kernel's fifth wave draws an epoch ahead (fit_body)
   // LDS carve (float offsets)
   int o_tile, o_zt, o_misc, o_stage, o_m, o_v, o_perm, o_keys, o_X, o_z, o_g, o_layout, total;
   // batch mode (bore_set_batch): slot -> loop ids[slot] at iteration its[slot]; N above is the
@@ -911,7 +912,7 @@ __device__ __forceinline__ void wide_rounds_f32(const Net &net, const float (&xi
 }
 
 // (the body is a device function so that the fused iteration kernel of bore_iter.hip can run it)
-template <int SHAPE>
+template <int SHAPE, int NW = 4>
 __device__ __forceinline__ void fit_body(const FitArgs &a, const long long slot,
                                          const int it_now = -1) {
   extern __shared__ float smem[];
@@ -996,6 +997,11 @@ __device__ __forceinline__ void fit_body(const FitArgs &a, const long long slot,
   // odd epoch instead -- 2.2 k cycles per epoch on the step chain).  (Tried in round 3: the pipelined form
   // also for last steps of 49..64 rows, drawn by the workgroup -- 623 against 593 us per fit at N 48..67,
   // profiles/r3/ab_headline.txt: those keep the four-epoch groups and the gather in the step.)
+  // Eight-wave kernel, more than 128 rows (one shuffle per epoch, 4 k cycles of the whole workgroup on the step
+  // chain): the fifth wave, which owns no rows, draws the NEXT epoch's shuffle alone, a third of it in each of the
+  // epoch's first three steps while the first four run the forward / backward pass (make_perm_buckets<true>) -- off
+  // the chain.
+  const bool ahead = NW == 8 && a.perm_ahead && !a.perm && PG == 1 && blockDim.x == 2 * BORE_THREADS;
   constexpr int PRE_KC = RegNet<(SHAPE > 0 ? SHAPE : 1), 1>::KC0;
   static_assert(WIDE || SHAPE <= 0 || (PRE_KC + 1) * BORE_THREADS <= BORE_FIT_STAGE_FLOATS, "stage region");
   float *stage = smem + a.o_stage + tid;  // [PRE_KC + 1][BORE_THREADS]: inputs 4 kc + q4, then the label
@@ -1055,6 +1061,9 @@ __device__ __forceinline__ void fit_body(const FitArgs &a, const long long slot,
         make_perm_group(a.seed, a.model0 + model, epoch0 + e, min(PG, a.epochs - e), N, keys,
                         perm_all);
       perm_s = perm_all + eg * N;
+    } else if (ahead) {  // two buffers; every epoch but the first was drawn during the one before it (below)
+      perm_s = perm_all + (e & 1) * N;
+      if (e == 0) make_perm(shuffle_base(a.seed, a.model0 + model, epoch0), N, keys, perm_s);
     } else {
       make_perm(shuffle_base(a.seed, a.model0 + model, epoch0 + e), N, keys, perm_s);
     }
@@ -1267,6 +1276,13 @@ __device__ __forceinline__ void fit_body(const FitArgs &a, const long long slot,
           else
             make_perm_wave_buckets(shuffle_base(a.seed, a.model0 + model, draw_epoch), N,
                                    reinterpret_cast<unsigned long long *>(keys), perm_all + (e & 1) * N);
+        }
+      } else {
+        if (ahead && wv == BORE_THREADS / 64 && s < 3 && e + 1 < a.epochs) {  // (more than 128 rows: >= 3 steps)
+          long long draw_epoch = epoch0 + e + 1;  // (opaque: the hash stays in this wave's branch, as above)
+          asm volatile("" : "+v"(draw_epoch));
+          make_perm_buckets<true>(shuffle_base(a.seed, a.model0 + model, draw_epoch), N, keys,
+                                  perm_all + ((e + 1) & 1) * N, s, s);
         }
       }
       __syncthreads();
@@ -1483,7 +1499,7 @@ __global__ __launch_bounds__(BORE_THREADS) void fit_kernel(const FitArgs a) {
 // more models than compute units: with more, two four-wave workgroups per CU do better.
 template <int SHAPE>
 __global__ __launch_bounds__(2 * BORE_THREADS) void fit_kernel_w8(const FitArgs a) {
-  fit_body<SHAPE>(a, blockIdx.x);
+  fit_body<SHAPE, 8>(a, blockIdx.x);
 }
 
 // ---------------------------------------------------------------------------
@@ -2372,6 +2388,10 @@ static int fit_build(const bore_mlp_desc *desc, int n_models, float *theta, floa
   if (!perm && stage_f && N <= 128 && perm_f < 4 * (size_t)N) perm_f = 4 * (size_t)N;
   // (... and its drawing wave ranks by buckets: make_perm_wave_buckets' scratch)
   if (!perm && stage_f && keys_f < BORE_PERM_WAVE_FLOATS) keys_f = BORE_PERM_WAVE_FLOATS;
+  // (6->32-32-1 with 129..512 rows, where the eight-wave kernel may run: a second shuffle buffer, fit_body `ahead`)
+  a.perm_ahead = !perm && !g_batch && a.perm_in_lds && PG == 1 && N <= 512 && batch_size == BORE_BATCH_MAX &&
+                 bore_match_shape(desc) == 2;
+  if (a.perm_ahead) perm_f = 2 * (size_t)N;
   if (g_batch)  // a slot's own N (<= this N) may shuffle more epochs together: room for each case
     for (long long nn : {(long long)(N < 64 ? N : 64), (long long)(N < 128 ? N : 128)}) {
       const int pg = perm_group(nn, BORE_THREADS);

@@ -378,8 +378,19 @@ __host__ __device__ __forceinline__ long long perm_scratch_floats(long long N) {
 // all-pairs count: the same permutation.  Scratch: the same perm_scratch_floats(N) -- N 64-bit words, then NB <= N
 // counters, then 8 ints.  Ends with a barrier.
 __device__ __forceinline__ int wave_inclusive_scan(int v);
-__device__ __forceinline__ void make_perm_buckets(unsigned long long base, int N, unsigned *keys, int *perm_out) {
-  const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wv = tid >> 6;
+// ONE_WAVE: the calling wave does it alone (wave-level LDS hand-overs instead of barriers), in three STAGES that
+// keep their state in the scratch -- the eight-wave fit's fifth wave draws the next epoch's shuffle this way, one
+// stage in each of the epoch's first three steps, while the first four waves run the forward / backward pass.
+// Stages: 0 count the rows per bucket, 1 scan the counts and scatter the words, 2 rank inside the buckets.
+template <bool ONE_WAVE = false>
+__device__ __forceinline__ void make_perm_buckets(unsigned long long base, int N, unsigned *keys, int *perm_out,
+                                                  int stage_lo = 0, int stage_hi = 2) {
+  const int lane = threadIdx.x & 63, wv = ONE_WAVE ? 0 : (int)(threadIdx.x >> 6);
+  const int tid = ONE_WAVE ? lane : (int)threadIdx.x, nthr = ONE_WAVE ? 64 : (int)blockDim.x;
+  auto sync = [] {
+    if constexpr (ONE_WAVE) wave_lds_sync();
+    else __syncthreads();
+  };
   const int N16 = (N + 15) & ~15;
   unsigned long long *mem = reinterpret_cast<unsigned long long *>(keys);  // [N] words, bucket by bucket
   int *cur = reinterpret_cast<int *>(mem + N16);                           // [NB] count -> first -> end
@@ -387,40 +398,48 @@ __device__ __forceinline__ void make_perm_buckets(unsigned long long base, int N
   int lg = 0;
   while ((2 << lg) <= N) ++lg;
   const int NB = 1 << lg, sh = 32 - lg;  // (N > 128: lg >= 7)
-  for (int b = tid; b < NB; b += nthr) cur[b] = 0;
-  __syncthreads();
-  for (int i = tid; i < N; i += nthr) atomicAdd(&cur[shuffle_key(base, i) >> sh], 1);
-  __syncthreads();
-  // exclusive scan of the NB counts in place: thread t owns the `per` consecutive buckets from t * per
-  const int per = (NB + nthr - 1) / nthr, b0 = tid * per;
-  int sum = 0;
-  for (int b = b0; b < min(b0 + per, NB); ++b) sum += cur[b];
-  const int incl = wave_inclusive_scan(sum);
-  if (lane == 63) tot[wv] = incl;
-  __syncthreads();
-  int run = incl - sum;
-  for (int w = 0; w < wv; ++w) run += tot[w];
-  for (int b = b0; b < min(b0 + per, NB); ++b) {
-    const int c = cur[b];
-    cur[b] = run;
-    run += c;
+  if (stage_lo <= 0 && 0 <= stage_hi) {
+    for (int b = tid; b < NB; b += nthr) cur[b] = 0;
+    sync();
+    for (int i = tid; i < N; i += nthr) atomicAdd(&cur[shuffle_key(base, i) >> sh], 1);
+    sync();
   }
-  __syncthreads();
-  // (a row's key is drawn again rather than kept: held in registers across the scan it was slower)
-  for (int i = tid; i < N; i += nthr) {
-    const unsigned key = shuffle_key(base, i);
-    mem[atomicAdd(&cur[key >> sh], 1)] = ((unsigned long long)key << 32) | (unsigned)i;
+  if (stage_lo <= 1 && 1 <= stage_hi) {
+    // exclusive scan of the NB counts in place: thread t owns the `per` consecutive buckets from t * per
+    const int per = (NB + nthr - 1) / nthr, b0 = tid * per;
+    int sum = 0;
+    for (int b = b0; b < min(b0 + per, NB); ++b) sum += cur[b];
+    const int incl = wave_inclusive_scan(sum);
+    int run = incl - sum;
+    if constexpr (!ONE_WAVE) {
+      if (lane == 63) tot[wv] = incl;
+      __syncthreads();
+      for (int w = 0; w < wv; ++w) run += tot[w];
+    }
+    for (int b = b0; b < min(b0 + per, NB); ++b) {
+      const int c = cur[b];
+      cur[b] = run;
+      run += c;
+    }
+    sync();
+    // (a row's key is drawn again rather than kept: held in registers across the scan it was slower)
+    for (int i = tid; i < N; i += nthr) {
+      const unsigned key = shuffle_key(base, i);
+      mem[atomicAdd(&cur[key >> sh], 1)] = ((unsigned long long)key << 32) | (unsigned)i;
+    }
+    sync();  // (cur[b] is now the END of bucket b = the first position of bucket b + 1)
   }
-  __syncthreads();  // (cur[b] is now the END of bucket b = the first position of bucket b + 1)
-  for (int p = tid; p < N; p += nthr) {
-    const unsigned long long w = mem[p];
-    const int b = (int)((unsigned)(w >> 32) >> sh);
-    const int lo = b ? cur[b - 1] : 0, hi = cur[b];
-    int r = lo;
-    for (int q = lo; q < hi; ++q) r += mem[q] < w;
-    perm_out[r] = (int)(unsigned)w;
+  if (stage_lo <= 2 && 2 <= stage_hi) {
+    for (int p = tid; p < N; p += nthr) {
+      const unsigned long long w = mem[p];
+      const int b = (int)((unsigned)(w >> 32) >> sh);
+      const int lo = b ? cur[b - 1] : 0, hi = cur[b];
+      int r = lo;
+      for (int q = lo; q < hi; ++q) r += mem[q] < w;
+      perm_out[r] = (int)(unsigned)w;
+    }
+    sync();
   }
-  __syncthreads();
 }
 
 // keys: LDS scratch of perm_scratch_floats(N) floats, 16-byte aligned; perm_out: [N] (LDS or

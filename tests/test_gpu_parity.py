@@ -232,11 +232,13 @@ def test_shuffle_stream_is_bit_exact_and_drives_fit(gpu):
 
 def test_eight_wave_fit_of_32_32_1_gives_the_same_bits(gpu, monkeypatch):
     """fit_kernel_w8<2> (launches with no more models than compute units: the second four waves take half of the
-    weight-gradient tiles) against the four-wave kernel: the same tiles, sums and updates, handed out differently."""
+    weight-gradient tiles, the fifth draws the shuffles ahead) against the four-wave kernel: the same tiles, sums,
+    updates and permutations, handed out differently."""
     rs = np.random.RandomState(11)
     D, units, acts = 6, [32, 32, 1], ["relu", "relu", "sigmoid"]
     desc = _lib.make_desc(D, units, acts)
-    for N, L, E in ((256, 3, 6), (100, 2, 5), (30, 1, 9)):
+    # (129..512 rows: the fifth wave draws every epoch's shuffle but the first one epoch ahead, a stage per step)
+    for N, L, E in ((256, 3, 6), (100, 2, 5), (30, 1, 9), (150, 1, 4), (512, 1, 3), (600, 1, 3)):
         th0 = np.stack([pack(rand_model(rs, D, units)) for _ in range(L)])
         X = dev(rs.uniform(size=(L, N, D)), torch.float32)
         z = dev((rs.uniform(size=(L, N)) < 0.25).astype(np.float32))
