@@ -1278,7 +1278,7 @@ __device__ __forceinline__ void fit_body(const FitArgs &a, const long long slot,
                                    reinterpret_cast<unsigned long long *>(keys), perm_all + (e & 1) * N);
         }
       } else {
-        if (ahead && wv == BORE_THREADS / 64 && s < 3 && e + 1 < a.epochs) {  // (more than 128 rows: >= 3 steps)
+        if (ahead && wv == BORE_THREADS / 64 && s < 3 && first_sub && e + 1 < a.epochs) {  // (> 128 rows: >= 3 steps)
           long long draw_epoch = epoch0 + e + 1;  // (opaque: the hash stays in this wave's branch, as above)
           asm volatile("" : "+v"(draw_epoch));
           make_perm_buckets<true>(shuffle_base(a.seed, a.model0 + model, draw_epoch), N, keys,
@@ -1295,6 +1295,7 @@ __device__ __forceinline__ void fit_body(const FitArgs &a, const long long slot,
 
       // ---- weight gradients (sums over all rows) + Adam, one 16x16 tile per wave at a time ----
       const int kch = (nr + 3) >> 2;
+      const int wmask_g = (int)(blockDim.x >> 6) - 1;
       int t = 0;
       if constexpr (ROUNDS) {
         // (gradients and update ran inside the row-block scope above: wide_rounds_f32)
@@ -1323,7 +1324,7 @@ __device__ __forceinline__ void fit_body(const FitArgs &a, const long long slot,
         for (int kb = 0; kb < nkb; ++kb)
 #pragma unroll
           for (int cb = 0; cb < ncb; ++cb, ++t) {
-            if ((t & 3) != wv) continue;
+            if ((t & wmask_g) != wv) continue;  // (round-robin over the workgroup's four or eight waves)
             // dW[k][j] = sum_rows A_{l-1}[row][k] * D_l[row][j]
             const float *ap = tile + L.aoff[l - 1] + q4 * lda_p + kb * 16 + m16;
             const float *bp = tile + L.doff[l] + q4 * ldd + cb * 16 + m16;
@@ -2388,9 +2389,12 @@ static int fit_build(const bore_mlp_desc *desc, int n_models, float *theta, floa
   if (!perm && stage_f && N <= 128 && perm_f < 4 * (size_t)N) perm_f = 4 * (size_t)N;
   // (... and its drawing wave ranks by buckets: make_perm_wave_buckets' scratch)
   if (!perm && stage_f && keys_f < BORE_PERM_WAVE_FLOATS) keys_f = BORE_PERM_WAVE_FLOATS;
-  // (6->32-32-1 with 129..512 rows, where the eight-wave kernel may run: a second shuffle buffer, fit_body `ahead`)
-  a.perm_ahead = !perm && !g_batch && a.perm_in_lds && PG == 1 && N <= 512 && batch_size == BORE_BATCH_MAX &&
-                 bore_match_shape(desc) == 2;
+  // (129..512 rows and a flavour with an eight-wave kernel: a second shuffle buffer, fit_body `ahead`)
+  {
+    const int fl = bore_kernel_flavour(desc, batch_size == BORE_BATCH_MAX);
+    a.perm_ahead = !perm && !g_batch && a.perm_in_lds && PG == 1 && N <= 512 && batch_size <= BORE_BATCH_MAX &&
+                   (fl == 2 || (fl < 0 && fl >= -4));
+  }
   if (a.perm_ahead) perm_f = 2 * (size_t)N;
   if (g_batch)  // a slot's own N (<= this N) may shuffle more epochs together: room for each case
     for (long long nn : {(long long)(N < 64 ? N : 64), (long long)(N < 128 ? N : 128)}) {
@@ -2465,18 +2469,42 @@ extern "C" int bore_mlp_fit(const bore_mlp_desc *desc, int n_models, float *thet
   int rc = fit_build(desc, n_models, theta, adam_m, adam_v, adam_t, X, z, N, epochs, batch_size, perm,
                      seed, model_index0, epoch0, adam, epoch_loss, a, off, shape);
   if (rc) return rc < 0 ? rc : 0;
-#if BORE_ON_2
-  {  // BORE_FIT_W8 = 0 / 1 forces the choice (A/B, tests)
+  {  // Eight waves (fit_kernel_w8): 6->32-32-1, and any net of up to four layers with more than four weight-gradient
+     // tiles whose Adam slots are in LDS -- launches with no more models than CUs.  BORE_FIT_W8 = 0 / 1 forces the
+     // choice (A/B, tests).
     const int forced = getenv("BORE_FIT_W8") ? atoi(getenv("BORE_FIT_W8")) : -1;
-    if (shape == 2 && !g_batch && (forced < 0 ? n_models <= device_cus() : forced != 0)) {
-      rc = allow_lds(fit_kernel_w8<2>, off * 4);
-      if (rc) return rc;
-      hipLaunchKernelGGL(fit_kernel_w8<2>, dim3(n_models), dim3(2 * BORE_THREADS), off * 4, (hipStream_t)stream, a);
-      HIP_TRY(hipGetLastError());
-      return 0;
+    int tiles = 0;
+    for (int l = 1; l <= a.L.n_layers; ++l) tiles += (a.L.Np[l - 1] >> 4) * (a.L.Np[l] >> 4);
+    const bool can = !g_batch && (shape == 2 || (shape < 0 && shape >= -4 && a.state_in_lds && tiles > 4));
+    if (can && (forced < 0 ? n_models <= device_cus() : forced != 0)) {
+#define BORE_LAUNCH_FIT_W8(S)                                                                               \
+  case S:                                                                                                   \
+    rc = allow_lds(fit_kernel_w8<S>, off * 4);                                                              \
+    if (rc) return rc;                                                                                      \
+    hipLaunchKernelGGL(fit_kernel_w8<S>, dim3(n_models), dim3(2 * BORE_THREADS), off * 4, (hipStream_t)stream, a); \
+    HIP_TRY(hipGetLastError());                                                                             \
+    return 0;
+      switch (shape) {
+#if BORE_ON_2
+        BORE_LAUNCH_FIT_W8(2)
+#endif
+#if BORE_ON_N1
+        BORE_LAUNCH_FIT_W8(-1)
+#endif
+#if BORE_ON_N2
+        BORE_LAUNCH_FIT_W8(-2)
+#endif
+#if BORE_ON_N3
+        BORE_LAUNCH_FIT_W8(-3)
+#endif
+#if BORE_ON_N4
+        BORE_LAUNCH_FIT_W8(-4)
+#endif
+        default: break;
+      }
+#undef BORE_LAUNCH_FIT_W8
     }
   }
-#endif
 #define BORE_LAUNCH_FIT(S)                                                              \
   case S:                                                                               \
     rc = allow_lds(fit_kernel<S>, off * 4);                                             \

@@ -230,12 +230,16 @@ def test_shuffle_stream_is_bit_exact_and_drives_fit(gpu):
         assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1]), N
 
 
-def test_eight_wave_fit_of_32_32_1_gives_the_same_bits(gpu, monkeypatch):
-    """fit_kernel_w8<2> (launches with no more models than compute units: the second four waves take half of the
-    weight-gradient tiles, the fifth draws the shuffles ahead) against the four-wave kernel: the same tiles, sums,
-    updates and permutations, handed out differently."""
+@pytest.mark.parametrize("D,units,acts", [(6, [32, 32, 1], ["relu", "relu", "sigmoid"]),          # static shape 2
+                                          (10, [32, 32, 1], ["elu", "relu", "sigmoid"]),          # generic, 3 layers
+                                          (12, [48, 1], ["tanh", "linear"]),                      # generic, 2 layers
+                                          (3, [16, 24, 16, 1], ["relu", "relu", "tanh", "sigmoid"])])  # 4 layers
+def test_eight_wave_fit_gives_the_same_bits(gpu, monkeypatch, D, units, acts):
+    """fit_kernel_w8 (launches with no more models than compute units; 6->32-32-1 and the generic flavours with
+    their Adam slots in LDS: the second four waves take half of the weight-gradient tiles, the fifth draws the
+    shuffles ahead) against the four-wave kernel: the same tiles, sums, updates and permutations, handed out
+    differently."""
     rs = np.random.RandomState(11)
-    D, units, acts = 6, [32, 32, 1], ["relu", "relu", "sigmoid"]
     desc = _lib.make_desc(D, units, acts)
     # (129..512 rows: the fifth wave draws every epoch's shuffle but the first one epoch ahead, a stage per step)
     for N, L, E in ((256, 3, 6), (100, 2, 5), (30, 1, 9), (150, 1, 4), (512, 1, 3), (600, 1, 3)):
