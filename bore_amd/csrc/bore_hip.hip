@@ -133,7 +133,7 @@ struct FitArgs {
   int perm_in_lds;  // 0: an explicit perm too long for LDS is read from memory per step (generic flavours)
   int perm_ahead;   // 1: room for two shuffles: the eight-wave kernel's fifth wave draws an epoch ahead (fit_body)
   // LDS carve (float offsets)
-  int o_tile, o_zt, o_misc, o_stage, o_m, o_v, o_perm, o_keys, o_X, o_z, o_g, o_layout, total;
+  int o_tile, o_zt, o_misc, o_stage, o_m, o_v, o_perm, o_perm2, o_keys, o_X, o_z, o_g, o_layout, total;
   // batch mode (bore_set_batch): slot -> loop ids[slot] at iteration its[slot]; N above is the
   // largest of the batch and the data buffers are `cap`-strided per loop
   const int *ids, *its;
@@ -941,6 +941,7 @@ __device__ __forceinline__ void fit_body(const FitArgs &a, const long long slot,
   float *misc = smem + a.o_misc;  // [0] l2 penalty of the current weights, [1..4] per-wave loss
   int *perm_all = reinterpret_cast<int *>(smem + a.o_perm);
   int *perm_s = perm_all;  // the current epoch's permutation
+  int *perm_two = reinterpret_cast<int *>(smem + a.o_perm2);  // (perm_ahead: the other epoch's)
   unsigned *keys = reinterpret_cast<unsigned *>(smem + a.o_keys);
   const int PG = a.perm ? 1 : perm_group(N, BORE_THREADS);
 
@@ -1062,7 +1063,7 @@ __device__ __forceinline__ void fit_body(const FitArgs &a, const long long slot,
                         perm_all);
       perm_s = perm_all + eg * N;
     } else if (ahead) {  // two buffers; every epoch but the first was drawn during the one before it (below)
-      perm_s = perm_all + (e & 1) * N;
+      perm_s = (e & 1) ? perm_two : perm_all;
       if (e == 0) make_perm(shuffle_base(a.seed, a.model0 + model, epoch0), N, keys, perm_s);
     } else {
       make_perm(shuffle_base(a.seed, a.model0 + model, epoch0 + e), N, keys, perm_s);
@@ -1282,7 +1283,7 @@ __device__ __forceinline__ void fit_body(const FitArgs &a, const long long slot,
           long long draw_epoch = epoch0 + e + 1;  // (opaque: the hash stays in this wave's branch, as above)
           asm volatile("" : "+v"(draw_epoch));
           make_perm_buckets<true>(shuffle_base(a.seed, a.model0 + model, draw_epoch), N, keys,
-                                  perm_all + ((e + 1) & 1) * N, s, s);
+                                  ((e + 1) & 1) ? perm_two : perm_all, s, s);
         }
       }
       __syncthreads();
@@ -2389,13 +2390,8 @@ static int fit_build(const bore_mlp_desc *desc, int n_models, float *theta, floa
   if (!perm && stage_f && N <= 128 && perm_f < 4 * (size_t)N) perm_f = 4 * (size_t)N;
   // (... and its drawing wave ranks by buckets: make_perm_wave_buckets' scratch)
   if (!perm && stage_f && keys_f < BORE_PERM_WAVE_FLOATS) keys_f = BORE_PERM_WAVE_FLOATS;
-  // (129..512 rows and a flavour with an eight-wave kernel: a second shuffle buffer, fit_body `ahead`)
-  {
-    const int fl = bore_kernel_flavour(desc, batch_size == BORE_BATCH_MAX);
-    a.perm_ahead = !perm && !g_batch && a.perm_in_lds && PG == 1 && N <= 512 && batch_size <= BORE_BATCH_MAX &&
-                   (fl == 2 || (fl < 0 && fl >= -4));
-  }
-  if (a.perm_ahead) perm_f = 2 * (size_t)N;
+  a.perm_ahead = 0;  // (decided below, once everything else has its place)
+  a.o_perm2 = 0;
   if (g_batch)  // a slot's own N (<= this N) may shuffle more epochs together: room for each case
     for (long long nn : {(long long)(N < 64 ? N : 64), (long long)(N < 128 ? N : 128)}) {
       const int pg = perm_group(nn, BORE_THREADS);
@@ -2429,6 +2425,15 @@ static int fit_build(const bore_mlp_desc *desc, int n_models, float *theta, floa
     a.o_X = (int)off; off += (size_t)N * L.w[0];
     a.o_z = (int)off; off += N;
   }
+  {  // 129..512 rows and a flavour with an eight-wave kernel: a second shuffle buffer (fit_body `ahead`) -- behind
+     // everything else and only when it still fits, so that it moves nothing and decides nothing
+    const int fl = bore_kernel_flavour(desc, batch_size == BORE_BATCH_MAX);
+    if (!perm && !g_batch && a.perm_in_lds && PG == 1 && N <= 512 && batch_size <= BORE_BATCH_MAX &&
+        (fl == 2 || (fl < 0 && fl >= -4)) && (off + (size_t)N + tail) * 4 <= BORE_LDS_BYTES) {
+      a.perm_ahead = 1;
+      a.o_perm2 = (int)off; off += (size_t)N;
+    }
+  }
   a.total = (int)off;
   off = (off + 3) & ~(size_t)3;
   a.o_layout = (int)off; off += BORE_LAYOUT_FLOATS;
@@ -2453,11 +2458,95 @@ static int fit_build(const bore_mlp_desc *desc, int n_models, float *theta, floa
   return 0;
 }
 
+// A float32 net with the widths and activations of a static shape (mlp_shapes.h) but FEWER inputs -- the plugin's
+// default 32-32-1 on a four-dimensional search space -- would run the generic flavour (layout tables read at run
+// time: 2.7x the static fit's time, tools/fit_generic_time.py).  Zero-padding is exact: padded inputs are 0, so the
+// padded rows of the first layer see zero gradients and Adam leaves them (and their slots) at 0, and every sum
+// gains terms that are exactly 0.  Which static shape the descriptor pads to, 0 if none:
+static int bore_pads_to_shape(const bore_mlp_desc *d) {
+  if (d->compute != BORE_COMPUTE_F32) return 0;
+  // (2->16-16-1 and 6->32-32-1: their static fits give the generic flavour's bits.  The wide 16->64-64-64-1 fit
+  // does not -- same tolerance against the oracle, other low bits -- so a net padded onto it would change with the
+  // path it takes: left on the generic flavour.)
+  for (int s = 1; s <= 2; ++s) {
+    if (!bore_flavour_built(s) || d->input_dim >= kShapes[s].D || d->n_layers != kShapes[s].n_layers) continue;
+    bool ok = true;
+    for (int i = 0; i < d->n_layers; ++i)
+      ok = ok && d->units[i] == kShapes[s].units[i] && (kShapes[s].act[0] < 0 || d->act[i] == kShapes[s].act[i]) &&
+           d->l2_kernel[i] == 0.f && d->l2_bias[i] == 0.f;
+    if (ok) return s;
+  }
+  return 0;
+}
+
+// The fit of such a net on the static kernels: theta / m / v and X repacked into the padded shape's layout in a
+// stream-ordered scratch (W_1 is the packed vector's first block, row-major [in][out]: the padded vector is the
+// same prefix, a gap of zeros, the same suffix), the static fit, the way back.  rc < 0 with nothing launched when
+// the padded shape's fit cannot take the request (the caller then runs the generic flavour).
+static int fit_padded(const bore_mlp_desc *desc, int S, int n_models, float *theta, float *adam_m, float *adam_v,
+                      int64_t *adam_t, const float *X, const float *z, int64_t N, int epochs, int batch_size,
+                      const int32_t *perm, uint64_t seed, int64_t model_index0, int64_t epoch0,
+                      const bore_adam_cfg *adam, float *epoch_loss, void *stream) {
+  bore_mlp_desc dp = *desc;
+  dp.input_dim = kShapes[S].D;
+  const size_t D = desc->input_dim, DS = dp.input_dim, H = desc->units[0];
+  const int64_t P = bore_param_count(desc), PS = bore_param_count(&dp);
+  {  // (would the static fit take it?  the same checks, nothing launched)
+    FitArgs probe;
+    size_t off = 0;
+    int shape = 0;
+    const int rc = fit_build(&dp, n_models, theta, adam_m, adam_v, adam_t, X, z, N, epochs, batch_size, perm, seed,
+                             model_index0, epoch0, adam, epoch_loss, probe, off, shape);
+    if (rc != 0 || shape != S) return BORE_E_UNSUPPORTED;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const size_t n_par = (size_t)n_models * PS, n_x = (size_t)n_models * N * DS;
+  float *buf = nullptr;
+  HIP_TRY(hipMallocAsync((void **)&buf, (3 * n_par + n_x) * sizeof(float), st));
+  float *th_p = buf, *m_p = buf + n_par, *v_p = buf + 2 * n_par, *X_p = buf + 3 * n_par;
+  const size_t head = D * H * 4, tail = ((size_t)P - D * H) * 4;  // bytes of W_1, and of everything behind it
+  auto copy_rows = [&](float *dst, size_t dpitch, size_t doff, const float *src, size_t spitch, size_t soff,
+                       size_t width, size_t rows) {
+    return hipMemcpy2DAsync((char *)dst + doff, dpitch, (const char *)src + soff, spitch, width, rows,
+                            hipMemcpyDeviceToDevice, st);
+  };
+  hipError_t e = hipMemsetAsync(buf, 0, (3 * n_par + n_x) * sizeof(float), st);
+  const float *user[3] = {theta, adam_m, adam_v};
+  float *padded[3] = {th_p, m_p, v_p};
+  for (int k = 0; k < 3 && e == hipSuccess; ++k) {
+    e = copy_rows(padded[k], PS * 4, 0, user[k], P * 4, 0, head, n_models);
+    if (e == hipSuccess) e = copy_rows(padded[k], PS * 4, DS * H * 4, user[k], P * 4, head, tail, n_models);
+  }
+  if (e == hipSuccess) e = copy_rows(X_p, DS * 4, 0, X, D * 4, 0, D * 4, (size_t)n_models * N);
+  int rc = e == hipSuccess ? 0 : fail(BORE_E_HIP, "fit (padded to a static shape): %s", hipGetErrorString(e));
+  if (rc == 0)
+    rc = bore_mlp_fit(&dp, n_models, th_p, m_p, v_p, adam_t, X_p, z, N, epochs, batch_size, perm, seed, model_index0,
+                      epoch0, adam, epoch_loss, stream);
+  float *back[3] = {theta, adam_m, adam_v};
+  for (int k = 0; k < 3 && rc == 0; ++k) {
+    e = copy_rows(back[k], P * 4, 0, padded[k], PS * 4, 0, head, n_models);
+    if (e == hipSuccess) e = copy_rows(back[k], P * 4, head, padded[k], PS * 4, DS * H * 4, tail, n_models);
+    if (e != hipSuccess) rc = fail(BORE_E_HIP, "fit (padded to a static shape): %s", hipGetErrorString(e));
+  }
+  (void)hipFreeAsync(buf, st);
+  return rc;
+}
+
 extern "C" int bore_mlp_fit(const bore_mlp_desc *desc, int n_models, float *theta, float *adam_m,
                             float *adam_v, int64_t *adam_t, const float *X, const float *z,
                             int64_t N, int epochs, int batch_size, const int32_t *perm,
                             uint64_t seed, int64_t model_index0, int64_t epoch0,
                             const bore_adam_cfg *adam, float *epoch_loss, void *stream) {
+  // (BORE_FIT_PAD = 0: such nets on the generic flavour, as before round 4 -- A/B, tests)
+  if (desc && !g_batch && theta && adam_m && adam_v && adam_t && X && z && adam && epochs > 0 && n_models >= 1 &&
+      N >= 1 && batch_size == BORE_BATCH_MAX && !(getenv("BORE_FIT_PAD") && !atoi(getenv("BORE_FIT_PAD")))) {
+    const int S = bore_pads_to_shape(desc);
+    if (S) {
+      const int rc = fit_padded(desc, S, n_models, theta, adam_m, adam_v, adam_t, X, z, N, epochs, batch_size, perm,
+                                seed, model_index0, epoch0, adam, epoch_loss, stream);
+      if (rc != BORE_E_UNSUPPORTED) return rc;
+    }
+  }
   if (desc && desc->compute == BORE_COMPUTE_BF16) {
     if (g_batch) return fail(BORE_E_UNSUPPORTED, "fit: batch mode is float32 only");
     return fit_bf16_impl(desc, n_models, theta, adam_m, adam_v, adam_t, X, z, N, epochs, batch_size,

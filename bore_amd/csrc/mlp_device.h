@@ -366,7 +366,7 @@ __host__ __device__ __forceinline__ unsigned shuffle_key(unsigned long long base
 
 // floats of LDS scratch make_perm needs: round_up(N, 16) 64-bit words + N rank counters
 __host__ __device__ __forceinline__ long long perm_scratch_floats(long long N) {
-  return 2 * ((N + 15) & ~15LL) + ((N + 3) & ~3LL) + 8;  // (+ 8: the wave totals of make_perm_buckets' scan)
+  return 2 * ((N + 15) & ~15LL) + ((N + 3) & ~3LL) + (N > 128 ? 8 : 0);  // (+ 8: make_perm_buckets' wave totals)
 }
 
 // More than 128 rows: rank by BUCKETS instead of all pairs (N^2 / threads compares: 8.4 k cycles per shuffle at

@@ -257,6 +257,35 @@ def test_eight_wave_fit_gives_the_same_bits(gpu, monkeypatch, D, units, acts):
         assert all(np.array_equal(a, b) for a, b in zip(*outs)), N
 
 
+@pytest.mark.parametrize("D,units,acts", [(4, [32, 32, 1], ["relu", "elu", "sigmoid"]),       # -> 6->32-32-1
+                                          (1, [16, 16, 1], ["relu", "relu", "sigmoid"]),      # -> 2->16-16-1
+                                          (10, [64, 64, 64, 1], ["tanh", "relu", "relu", "linear"])])  # (not padded)
+def test_fit_zero_padded_to_a_static_shape_gives_the_generic_flavours_bits(gpu, monkeypatch, D, units, acts):
+    """A float32 net with a static shape's widths and activations but fewer inputs is fitted on the static kernels,
+    zero-padded (bore_mlp_fit: fit_padded): padded inputs are 0, padded first-layer rows see zero gradients and
+    stay 0, every sum gains exact zeros -- the same bits as the generic flavour it replaces (BORE_FIT_PAD = 0),
+    cold and warm-started, with drawn and with explicit shuffles."""
+    rs = np.random.RandomState(7)
+    desc = _lib.make_desc(D, units, acts)
+    for N, L, E, explicit in ((100, 2, 5, False), (256, 3, 3, False), (13, 1, 6, False), (70, 2, 4, True)):
+        th0 = np.stack([pack(rand_model(rs, D, units)) for _ in range(L)])
+        X = dev(rs.uniform(size=(L, N, D)), torch.float32)
+        z = dev((rs.uniform(size=(L, N)) < 0.25).astype(np.float32))
+        perm = ops.shuffle_perm(9, L, 2 * E, N) if explicit else None
+        outs = []
+        for pad in ("0", "1"):
+            monkeypatch.setenv("BORE_FIT_PAD", pad)
+            th = dev(th0)
+            m, v = torch.zeros_like(th), torch.zeros_like(th)
+            t = torch.zeros(L, dtype=torch.int64, device="cuda")
+            l1 = ops.mlp_fit(desc, th, m, v, t, X, z, E, 64, seed=5, perm=None if perm is None else perm[:, :E].contiguous())
+            l2 = ops.mlp_fit(desc, th, m, v, t, X, z, E, 64, seed=5, epoch0=E,       # warm start
+                             perm=None if perm is None else perm[:, E:].contiguous())
+            outs.append([a.cpu().numpy() for a in (th, m, v, t, l1, l2)])
+        assert all(np.array_equal(a, b) for a, b in zip(*outs)), (N, explicit)
+        assert np.isfinite(outs[1][0]).all() and (outs[1][3] == 2 * E * ((N + 63) // 64)).all()
+
+
 def test_one_wave_bucket_ranking_draws_the_same_shuffles(gpu, monkeypatch):
     """Round 4: the pipelined fit's fourth wave ranks an epoch's keys by buckets (make_perm_wave_buckets,
     ~1 k cycles at 100 rows instead of ~6 k).  Through bore_shuffle_perm's test switch: the SAME
