@@ -1004,7 +1004,7 @@ __device__ __forceinline__ void fit_body(const FitArgs &a, const long long slot,
   // the chain.
   const bool ahead = NW == 8 && a.perm_ahead && !a.perm && PG == 1 && blockDim.x == 2 * BORE_THREADS;
   constexpr int PRE_KC = RegNet<(SHAPE > 0 ? SHAPE : 1), 1>::KC0;
-  static_assert(WIDE || SHAPE <= 0 || (PRE_KC + 1) * BORE_THREADS <= BORE_FIT_STAGE_FLOATS, "stage region");
+  static_assert(WIDE || SHAPE <= 0 || (PRE_KC + 1) * BORE_THREADS <= BORE_FIT_STAGE_FLOATS_OF(SHAPE), "stage region");
   float *stage = smem + a.o_stage + tid;  // [PRE_KC + 1][BORE_THREADS]: inputs 4 kc + q4, then the label
   // (pipe_perm) request this lane's share of row `srow`: every address valid, dead shares zeroed at the store
   auto request_row = [&](float (&gx)[PRE_KC], float &gz, const int srow) {  // (pipe_perm: the data is in LDS)
@@ -2313,8 +2313,12 @@ static int fit_build(const bore_mlp_desc *desc, int n_models, float *theta, floa
   // (+ keys) and the batch targets ride along
   const int tile_rows = batch_size < BORE_BATCH_MAX ? batch_size : BORE_BATCH_MAX;
   // (the parked-row slots of fit_body: the narrow static shapes only -- a wide one has no LDS to spare)
-  const int flavour_early = desc ? bore_kernel_flavour(desc, batch_size == BORE_BATCH_MAX) : 0;
-  const size_t stage_f = flavour_early > 0 && !bore_shape_is_wide(flavour_early) ? BORE_FIT_STAGE_FLOATS : 0;
+  // (the fit-only static shape: not in batch mode -- the fused iteration kernels have no case for it)
+  auto fit_flavour = [&](const bore_mlp_desc *d) {
+    return g_batch ? bore_kernel_flavour(d, batch_size == BORE_BATCH_MAX) : bore_fit_flavour(d, batch_size == BORE_BATCH_MAX);
+  };
+  const int flavour_early = desc ? fit_flavour(desc) : 0;
+  const size_t stage_f = flavour_early > 0 && !bore_shape_is_wide(flavour_early) ? BORE_FIT_STAGE_FLOATS_OF(flavour_early) : 0;
   const size_t fixed_extra = BORE_BATCH_MAX + 8 + stage_f + BORE_LAYOUT_FLOATS + 12;
   // 32->128-128-1 in float32 with 64-row batches: theta and the 64-row images do not share the LDS;
   // the weight gradients are formed in four rounds over 16-row images instead (wide_rounds_f32)
@@ -2427,9 +2431,10 @@ static int fit_build(const bore_mlp_desc *desc, int n_models, float *theta, floa
   }
   {  // 129..512 rows and a flavour with an eight-wave kernel: a second shuffle buffer (fit_body `ahead`) -- behind
      // everything else and only when it still fits, so that it moves nothing and decides nothing
-    const int fl = bore_kernel_flavour(desc, batch_size == BORE_BATCH_MAX);
+    const int fl = fit_flavour(desc);
     if (!perm && !g_batch && a.perm_in_lds && PG == 1 && N <= 512 && batch_size <= BORE_BATCH_MAX &&
-        (fl == 2 || (fl < 0 && fl >= -4)) && (off + (size_t)N + tail) * 4 <= BORE_LDS_BYTES) {
+        (fl == 2 || fl == BORE_FIT_SHAPE_16_32 || (fl < 0 && fl >= -4)) &&
+        (off + (size_t)N + tail) * 4 <= BORE_LDS_BYTES) {
       a.perm_ahead = 1;
       a.o_perm2 = (int)off; off += (size_t)N;
     }
@@ -2439,7 +2444,7 @@ static int fit_build(const bore_mlp_desc *desc, int n_models, float *theta, floa
   a.o_layout = (int)off; off += BORE_LAYOUT_FLOATS;
   // the constexpr-layout instantiation needs the layout it was compiled for (64-row tile)
   // (and keeps the Adam slots in LDS unconditionally)
-  int shape = bore_kernel_flavour(desc, batch_size == BORE_BATCH_MAX);
+  int shape = fit_flavour(desc);
   if (!a.perm_in_lds && shape > 0) {  // (only the generic flavours read the permutation from memory)
     if (bore_shape_is_wide(shape))
       return fail(BORE_E_UNSUPPORTED, "fit: N=%lld rows with this wide network: the shuffle must fit in LDS", (long long)N);
@@ -2464,11 +2469,11 @@ static int fit_build(const bore_mlp_desc *desc, int n_models, float *theta, floa
 // padded rows of the first layer see zero gradients and Adam leaves them (and their slots) at 0, and every sum
 // gains terms that are exactly 0.  Which static shape the descriptor pads to, 0 if none:
 static int bore_pads_to_shape(const bore_mlp_desc *d) {
-  if (d->compute != BORE_COMPUTE_F32) return 0;
+  if (d->compute != BORE_COMPUTE_F32 || bore_match_shape(d)) return 0;  // (a static shape itself: nothing to pad)
   // (2->16-16-1 and 6->32-32-1: their static fits give the generic flavour's bits.  The wide 16->64-64-64-1 fit
   // does not -- same tolerance against the oracle, other low bits -- so a net padded onto it would change with the
   // path it takes: left on the generic flavour.)
-  for (int s = 1; s <= 2; ++s) {
+  for (int s : {1, 2, BORE_FIT_SHAPE_16_32}) {  // (32-32-1: six inputs first -- fewer zero columns)
     if (!bore_flavour_built(s) || d->input_dim >= kShapes[s].D || d->n_layers != kShapes[s].n_layers) continue;
     bool ok = true;
     for (int i = 0; i < d->n_layers; ++i)
@@ -2564,7 +2569,8 @@ extern "C" int bore_mlp_fit(const bore_mlp_desc *desc, int n_models, float *thet
     const int forced = getenv("BORE_FIT_W8") ? atoi(getenv("BORE_FIT_W8")) : -1;
     int tiles = 0;
     for (int l = 1; l <= a.L.n_layers; ++l) tiles += (a.L.Np[l - 1] >> 4) * (a.L.Np[l] >> 4);
-    const bool can = !g_batch && (shape == 2 || (shape < 0 && shape >= -4 && a.state_in_lds && tiles > 4));
+    const bool can = !g_batch && (shape == 2 || shape == BORE_FIT_SHAPE_16_32 ||
+                                  (shape < 0 && shape >= -4 && a.state_in_lds && tiles > 4));
     if (can && (forced < 0 ? n_models <= device_cus() : forced != 0)) {
 #define BORE_LAUNCH_FIT_W8(S)                                                                               \
   case S:                                                                                                   \
@@ -2576,6 +2582,9 @@ extern "C" int bore_mlp_fit(const bore_mlp_desc *desc, int n_models, float *thet
       switch (shape) {
 #if BORE_ON_2
         BORE_LAUNCH_FIT_W8(2)
+#endif
+#if BORE_ON_5
+        BORE_LAUNCH_FIT_W8(BORE_FIT_SHAPE_16_32)
 #endif
 #if BORE_ON_N1
         BORE_LAUNCH_FIT_W8(-1)
@@ -2614,6 +2623,9 @@ extern "C" int bore_mlp_fit(const bore_mlp_desc *desc, int n_models, float *thet
 #endif
 #if BORE_ON_4
     BORE_LAUNCH_FIT(4)
+#endif
+#if BORE_ON_5
+    BORE_LAUNCH_FIT(BORE_FIT_SHAPE_16_32)
 #endif
 #if BORE_ON_N1
     BORE_LAUNCH_FIT(-1)
