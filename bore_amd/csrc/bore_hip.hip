@@ -2470,10 +2470,10 @@ static int fit_build(const bore_mlp_desc *desc, int n_models, float *theta, floa
 // gains terms that are exactly 0.  Which static shape the descriptor pads to, 0 if none:
 static int bore_pads_to_shape(const bore_mlp_desc *d) {
   if (d->compute != BORE_COMPUTE_F32 || bore_match_shape(d)) return 0;  // (a static shape itself: nothing to pad)
-  // (2->16-16-1 and 6->32-32-1: their static fits give the generic flavour's bits.  The wide 16->64-64-64-1 fit
-  // does not -- same tolerance against the oracle, other low bits -- so a net padded onto it would change with the
+  // (2->16-16-1, 6->32-32-1 and the two fit-only shapes: their static fits give the generic flavour's bits.  The
+  // wide 16->64-64-64-1 fit does not -- same tolerance against the oracle, other low bits -- so a net padded onto it would change with the
   // path it takes: left on the generic flavour.)
-  for (int s : {1, 2, BORE_FIT_SHAPE_16_32}) {  // (32-32-1: six inputs first -- fewer zero columns)
+  for (int s : {1, 2, BORE_FIT_SHAPE_16_32, BORE_FIT_SHAPE_16_16}) {  // (the fewest zero columns first)
     if (!bore_flavour_built(s) || d->input_dim >= kShapes[s].D || d->n_layers != kShapes[s].n_layers) continue;
     bool ok = true;
     for (int i = 0; i < d->n_layers; ++i)
@@ -2626,6 +2626,9 @@ extern "C" int bore_mlp_fit(const bore_mlp_desc *desc, int n_models, float *thet
 #endif
 #if BORE_ON_5
     BORE_LAUNCH_FIT(BORE_FIT_SHAPE_16_32)
+#endif
+#if BORE_ON_6
+    BORE_LAUNCH_FIT(BORE_FIT_SHAPE_16_16)
 #endif
 #if BORE_ON_N1
     BORE_LAUNCH_FIT(-1)

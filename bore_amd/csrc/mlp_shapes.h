@@ -16,14 +16,17 @@
 // fit_padded in bore_hip.hip) -- the generic flavour takes 2.5x as long.  The acquisition kernels of such nets stay
 // generic (a fifth of the fit's time).
 #define BORE_FIT_SHAPE_16_32 5
+// ... and 16->16-16-1 with any activations (README.rst:60-63's widths on more than two inputs).
+#define BORE_FIT_SHAPE_16_16 6
+#define BORE_N_FIT_SHAPES 2  // ids BORE_N_SHAPES + 1 .. BORE_N_SHAPES + BORE_N_FIT_SHAPES
 
 // Which kernel flavours a build instantiates (experiment builds only: tools/build_variant.sh fast1
 // -DBORE_SHAPE_MASK=0x2 compiles the 2->16-16-1 kernels alone in a fifth of the time; a request for
 // a flavour that was left out is refused with BORE_E_UNSUPPORTED).  Bit 0: the generic flavour 0,
-// bits 1..4: static shapes 1..4, bits 5..8: flavours -1..-4, bit 9: the fit-only shape 5.  The shipped library has
+// bits 1..4: static shapes 1..4, bits 5..8: flavours -1..-4, bits 9, 10: the fit-only shapes 5, 6.  The shipped library has
 // them all.
 #ifndef BORE_SHAPE_MASK
-#define BORE_SHAPE_MASK 0x3ff
+#define BORE_SHAPE_MASK 0x7ff
 #endif
 #define BORE_ON_0 ((BORE_SHAPE_MASK) & 0x001)
 #define BORE_ON_1 ((BORE_SHAPE_MASK) & 0x002)
@@ -35,6 +38,7 @@
 #define BORE_ON_N3 ((BORE_SHAPE_MASK) & 0x080)
 #define BORE_ON_N4 ((BORE_SHAPE_MASK) & 0x100)
 #define BORE_ON_5 ((BORE_SHAPE_MASK) & 0x200)
+#define BORE_ON_6 ((BORE_SHAPE_MASK) & 0x400)
 #define BORE_FLAVOUR_LEFT_OUT "this build of the library leaves the kernel flavour out (BORE_SHAPE_MASK)"
 
 struct ShapeSpec {
@@ -47,18 +51,19 @@ struct ShapeSpec {
 // 2: BASELINE config 2 (Hartmann-6D, 32-32-1)
 // 3: BASELINE config 3 (16-D, 64-64-64-1)
 // 4: BASELINE config 5 (32-D, 128-128-1; fp32 forward / input gradient / L-BFGS-B only)
-// 5: fit kernels only (BORE_FIT_SHAPE_16_32)
-static constexpr ShapeSpec kShapes[BORE_N_SHAPES + 2] = {
+// 5, 6: fit kernels only (BORE_FIT_SHAPE_16_32, BORE_FIT_SHAPE_16_16)
+static constexpr ShapeSpec kShapes[BORE_N_SHAPES + 1 + BORE_N_FIT_SHAPES] = {
     {0, 0, {0, 0, 0, 0}, {0, 0, 0, 0}},
     {2, 3, {16, 16, 1, 0}, {BORE_ACT_RELU, BORE_ACT_RELU, BORE_ACT_SIGMOID, 0}},
     {6, 3, {32, 32, 1, 0}, {-1, 0, 0, 0}},
     {16, 4, {64, 64, 64, 1}, {-1, 0, 0, 0}},
     {32, 3, {128, 128, 1, 0}, {-1, 0, 0, 0}},
     {16, 3, {32, 32, 1, 0}, {-1, 0, 0, 0}},
+    {16, 3, {16, 16, 1, 0}, {-1, 0, 0, 0}},
 };
 // shapes with a register-row-block fit (4 does not fit fp32 theta + a 64-row tile in LDS)
 static constexpr bool bore_shape_has_static_fit(int shape) {
-  return (shape >= 1 && shape <= 3) || shape == BORE_FIT_SHAPE_16_32;
+  return (shape >= 1 && shape <= 3) || (shape > BORE_N_SHAPES && shape <= BORE_N_SHAPES + BORE_N_FIT_SHAPES);
 }
 // wide shapes: the fit walks its weight-gradient tiles in a run-time loop, Adam slots in HBM
 static constexpr bool bore_shape_is_wide(int shape) { return shape == 3 || shape == 4; }
@@ -113,15 +118,18 @@ static inline int bore_kernel_flavour(const bore_mlp_desc *d, bool full_tile) {
 static inline int bore_fit_flavour(const bore_mlp_desc *d, bool full_tile) {
   const int f = bore_kernel_flavour(d, full_tile);
   if (f > 0 || !full_tile) return f;
-  constexpr int s = BORE_FIT_SHAPE_16_32;
-  if (d->input_dim != kShapes[s].D || d->n_layers != kShapes[s].n_layers) return f;
-  for (int i = 0; i < d->n_layers; ++i)
-    if (d->units[i] != kShapes[s].units[i] || d->l2_kernel[i] != 0.f || d->l2_bias[i] != 0.f) return f;
-  return s;
+  for (int s = BORE_N_SHAPES + 1; s <= BORE_N_SHAPES + BORE_N_FIT_SHAPES; ++s) {
+    if (d->input_dim != kShapes[s].D || d->n_layers != kShapes[s].n_layers) continue;
+    bool ok = true;
+    for (int i = 0; i < d->n_layers; ++i)
+      ok = ok && d->units[i] == kShapes[s].units[i] && d->l2_kernel[i] == 0.f && d->l2_bias[i] == 0.f;
+    if (ok) return s;
+  }
+  return f;
 }
 
 // (experiment builds: was this flavour compiled in?)
 static inline bool bore_flavour_built(int flavour) {
-  const int bit = flavour == BORE_FIT_SHAPE_16_32 ? 9 : (flavour >= 0 ? flavour : 4 - flavour);
+  const int bit = flavour > BORE_N_SHAPES ? 4 + flavour : (flavour >= 0 ? flavour : 4 - flavour);  // (5, 6 -> 9, 10)
   return ((BORE_SHAPE_MASK) >> bit) & 1;
 }

@@ -260,6 +260,8 @@ def test_eight_wave_fit_gives_the_same_bits(gpu, monkeypatch, D, units, acts):
 @pytest.mark.parametrize("D,units,acts", [(4, [32, 32, 1], ["relu", "elu", "sigmoid"]),       # -> 6->32-32-1
                                           (10, [32, 32, 1], ["tanh", "relu", "linear"]),      # -> 16->32-32-1 (fit only)
                                           (1, [16, 16, 1], ["relu", "relu", "sigmoid"]),      # -> 2->16-16-1
+                                          (6, [16, 16, 1], ["relu", "tanh", "sigmoid"]),      # -> 16->16-16-1 (fit only)
+                                          (1, [16, 16, 1], ["elu", "relu", "linear"]),        # -> 16->16-16-1 (activations)
                                           (10, [64, 64, 64, 1], ["tanh", "relu", "relu", "linear"])])  # (not padded)
 def test_fit_zero_padded_to_a_static_shape_gives_the_generic_flavours_bits(gpu, monkeypatch, D, units, acts):
     """A float32 net with a static shape's widths and activations but fewer inputs is fitted on the static kernels,
