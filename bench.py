@@ -624,7 +624,10 @@ def run_rank(args):
         raise SystemExit(f"bench.py: rank {rank} told to fail (BORE_BENCH_FAIL_RANK)")
     if os.environ.get("BORE_BENCH_ONE_DEVICE") == "1":     # rehearsal: every rank on cuda:0
         local = 0
-    cores = pin_rank_cores(rank, world)     # (before the engine starts its threads: they inherit the mask)
+    # (the affinity mask and the cgroup quota are the NODE's: slice them by this node's ranks -- torchrun and
+    # spawn_ranks export LOCAL_RANK / LOCAL_WORLD_SIZE -- not by the job's)
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+    cores = pin_rank_cores(int(os.environ.get("LOCAL_RANK", rank)), local_world)     # (before the engine starts its threads: they inherit the mask)
     if not dry:
         torch.cuda.set_device(local)
     if world > 1:
@@ -755,10 +758,12 @@ def run_rank(args):
         if st["fit_ms"] == 0.0:        # asynchronous schedule: fit + argmax are ONE kernel per launch
             kernels = [roof("iteration_kernel", st["argmax_ms"], st["fit_bytes"] + st["argmax_bytes"],
                             st["argmax_launches"])]
-            # (only while every loop of the launch is RESIDENT -- a handful of launches per region: with more
-            # loops than the device holds at once workgroups queue behind each other, busy time per launch
-            # is no longer the sum / loops and the figures would overstate the rate)
-            if st.get("phase_iterations") and st["argmax_launches"] <= 4:
+            # (only while every loop of the launch is RESIDENT -- as many workgroups side by side as loops, the
+            # engine says: with more loops than the device holds at once -- the work-queue schedule, which is ONE
+            # launch per run as well -- workgroups serve several loops each, busy time per launch is no longer
+            # the sum / loops and the figures would overstate the rate)
+            side = int(st.get("side_by_side_workgroups") or 0)
+            if st.get("phase_iterations") and st["argmax_launches"] <= 4 and side >= loops:
                 # A resident launch spans the host's turn-around as well: its workgroups wait on their
                 # CUs for the objective values.  `achieved` / `frac` above are per the contract (a
                 # launch's algorithmic bytes / its HIP-event duration, = the rocprofv3 duration); the

@@ -86,7 +86,9 @@ class EngineStats(C.Structure):
                 ("ready_to_launch_s", C.c_double), ("launch_to_result_s", C.c_double),
                 ("result_to_ready_s", C.c_double), ("phase_iterations", C.c_int64),
                 ("batches", C.c_int64), ("worker_streams", C.c_int64),
-                ("stream_concurrency", C.c_int64), ("n_fg_requests", C.c_int64)]
+                ("stream_concurrency", C.c_int64), ("n_fg_requests", C.c_int64),
+                ("loops_per_cu", C.c_int64), ("side_by_side_workgroups", C.c_int64),
+                ("host_threads", C.c_int64)]
 
 
 OBJECTIVE_FN = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_double), C.c_int64, C.c_int32,

@@ -612,7 +612,14 @@ extern "C" int bore_debug_lpp(unsigned long long *out) {  // [LB_PP_MAX][64]
 // ALWAYS_COOP: the caller's launches never give a wave more than one problem at a time (the fused
 // iteration kernel): the lane-per-problem loop is not compiled.
 // MAYQ: the caller's launches may set a.queue (the fused iteration kernel's never do).
-template <int SHAPE, bool BF16 = false, bool LEAN = false, bool ALWAYS_COOP = false, bool MAYQ = true>
+// PUBLISH (batch mode: how a loop's pick reaches the host).  0: behind a system-scope release -- on gfx950 a
+// write-back of the XCD's whole L2 (buffer_wbl2 sc0 sc1), after which ANY later reader of the loop's state, on
+// any XCD or the host, is served.  1: the caller guarantees that the loop's next iteration runs on this XCD (the
+// resident kernel: the same workgroup; the work-queue kernel: one queue per XCD) -- the pick and the flag go to the
+// pinned block as write-through stores, the flag after the others have been acknowledged, and the L2 keeps its
+// dirty lines: that write-back, one per loop-iteration and serialised per XCD, was what held every schedule of
+// round 4 at ~0.71 M loop-iterations per second (profiles/r5/ab_log.txt).
+template <int SHAPE, bool BF16 = false, bool LEAN = false, bool ALWAYS_COOP = false, bool MAYQ = true, int PUBLISH = 0>
 __device__ __forceinline__ void lbfgsb_body(const LbfgsbArgs &a, const long long model,
                                             const int block_y, const int it_now = -1) {
   extern __shared__ float smem[];
@@ -622,7 +629,9 @@ __device__ __forceinline__ void lbfgsb_body(const LbfgsbArgs &a, const long long
   const long long c_begun = BORE_LCLOCK();
   int tid = threadIdx.x;
   BORE_OPAQUE_TID(tid);
-  const int wv = tid >> 6, lane = tid & 63;
+  // (the wave number is wave-uniform: said so, the optimiser's two dozen workspace addresses -- all of the form
+  // base(wave) + offset -- are scalar values instead of a vector register each)
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   // `model` is the slot: it indexes x0 / x / fun / jac / info
   const long long lid = a.ids ? uniform_i64(a.ids[model]) : model;  // whose weights (and record, and result)
   const int n_lay = layer_count<SHAPE>(L), D = L.w[0];
@@ -1057,23 +1066,35 @@ __device__ __forceinline__ void lbfgsb_body(const LbfgsbArgs &a, const long long
   }
   if (lane == 0) {
     double *out = a.result + lid * (D + 8);
-    for (int d = 0; d < D; ++d) out[d] = best >= 0 ? res[best * (D + 3) + 3 + d] : 0.0;
-    out[D] = (double)best;
-    out[D + 1] = nfev_sum;
-    out[D + 2] = nfev_max;
+    auto put = [&](int i, double v) {
+      if constexpr (PUBLISH == 1)
+        __hip_atomic_store(reinterpret_cast<long long *>(out) + i, __double_as_longlong(v), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
+      else
+        out[i] = v;
+    };
+    for (int d = 0; d < D; ++d) put(d, best >= 0 ? res[best * (D + 3) + 3 + d] : 0.0);
+    put(D, (double)best);
+    put(D + 1, nfev_sum);
+    put(D + 2, nfev_max);
     if (a.stamps) {  // device-clock ticks per phase of this loop-iteration (fused kernel)
       const long long *s = a.stamps + lid * 4;
       const long long now = wall_clock64();
-      out[D + 3] = (double)(s[1] - s[0]);
-      out[D + 4] = (double)(s[2] - s[1]);
-      out[D + 5] = (double)(s[3] - s[2]);
-      out[D + 6] = (double)(now - s[3]);
+      put(D + 3, (double)(s[1] - s[0]));
+      put(D + 4, (double)(s[2] - s[1]));
+      put(D + 5, (double)(s[3] - s[2]));
+      put(D + 6, (double)(now - s[3]));
     } else {
-      out[D + 3] = out[D + 4] = out[D + 5] = out[D + 6] = 0.0;
+      for (int i = 3; i < 7; ++i) put(D + i, 0.0);
     }
-    out[D + 7] = exec_sum;  // evaluations that ran the network (<= nfev_sum: the image shortcut serves the rest)
-    __threadfence_system();
-    __hip_atomic_store(a.flag + lid, it_done + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    put(D + 7, exec_sum);  // evaluations that ran the network (<= nfev_sum: the image shortcut serves the rest)
+    if constexpr (PUBLISH == 1) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (this lane's stores -- the pick above among them -- are acknowledged)
+      __hip_atomic_store(a.flag + lid, it_done + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    } else {
+      __threadfence_system();
+      __hip_atomic_store(a.flag + lid, it_done + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
   }
   }  // passes
   if (use_big) {  // the workgroup's last wave to get here frees the pool slot
@@ -1095,6 +1116,13 @@ template <int SHAPE, bool BF16 = false>
 __global__ __launch_bounds__(BORE_THREADS, 2) void lbfgsb_kernel_occ2(const LbfgsbArgs a) {
   lbfgsb_body<SHAPE, BF16, true, true>(a, blockIdx.x, blockIdx.y);
 }
+#ifdef BORE_RU_PROBE  // (register-pressure probe of the fused kernel's restart phase on its own; never launched)
+template <int SHAPE>
+__global__ __launch_bounds__(BORE_THREADS, BORE_RU_PROBE) void lbfgsb_kernel_probe(const LbfgsbArgs a) {
+  lbfgsb_body<SHAPE, false, true, true, false>(a, blockIdx.x, 0, 0);
+}
+template __global__ void lbfgsb_kernel_probe<1>(const LbfgsbArgs a);
+#endif
 // The same for the wide shapes, whose weights take too much LDS for two workgroups: ONE workgroup of
 // up to eight waves (two per SIMD), one problem per wave, the weights staged once for all of them.
 template <int SHAPE, bool BF16 = false>

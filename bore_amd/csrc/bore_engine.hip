@@ -19,8 +19,13 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
+#include <mutex>
 #include <new>
+#include <thread>
 #include <vector>
+
+#include <sched.h>
 
 #include "../../include/bore_hip.h"
 #include "host_common.h"
@@ -124,9 +129,13 @@ struct Async {
   // workgroups: ring of entries (pinned), ticket counter (device), entries written so far, identity index
   bool queue = false;
   QueueEntry *q_ring = nullptr;
-  unsigned long long *q_head = nullptr, q_tail = 0;
+  unsigned long long *q_head = nullptr, q_tail = 0;  // q_head: device, 2 words: ticket counter | copy of the tail
+  unsigned long long *q_tail_host = nullptr;         // pinned: entries published so far (all ones: exit)
   int q_mask = 0, q_wgs = 0;
+  int per_cu = 0;  // loops of this model one CU holds (async_decide_schedule)
+  int host_threads = 1;  // of the last work-queue run
   int32_t *d_ident = nullptr;
+  std::vector<int> q_owner;  // per ring slot: (loop, iteration) of the entry written there last
   long long n_resident = 0, n_parked = 0;
   int stream_concurrency = 0;  // worker streams the device ran at once in the creation probe
   // diagnostics (BORE_ASYNC_DEBUG): waits between a loop's states
@@ -351,6 +360,69 @@ int async_alloc(bore_engine *e, int64_t cap) {
   return 0;
 }
 
+// How many loops of this engine's model one CU holds (the fused kernels' registers and the LDS their phases need at
+// the current record capacity: iteration_launch asked without launching), and from that the schedule: all loops
+// resident, or -- more loops than resident workgroups -- the work queue.  BORE_ASYNC_QUEUE = 0 / 1 forces the
+// launch-per-batch schedule of round 3 / the queue (tests, A/B).  Called when the engine is created and whenever
+// the records have grown (a longer data set in LDS may cost a loop per CU).
+static int async_decide_schedule(bore_engine *e) {
+  Async &A = *e->as;
+  const bore_engine_cfg &c = e->cfg;
+  const int L = c.n_loops, D = e->D, R = c.num_starts;
+  A.queue = false;
+  A.q_wgs = 0;
+  if (!A.fused) return 0;
+  Worker &w = A.workers[0];
+  int per_cu = 0;
+  {
+    bore_batch bt;
+    std::memset(&bt, 0, sizeof(bt));
+    bt.ids = w.d_int; bt.its = w.d_int; bt.n_init = c.n_init; bt.deduplicate = c.deduplicate;
+    bt.cap = A.cap; bt.X_seen = A.X_seen; bt.result = A.result; bt.flag = A.flag; bt.stamps = A.stamps;
+    bore_set_batch(&bt);
+    IterArgs probe;
+    const int rc = iteration_launch(&e->desc, L, e->theta, e->adam_m, e->adam_v, e->adam_t, A.X_seen, A.y_seen, A.X32,
+                                    A.z, w.d_dbl, w.d_dbl + (size_t)L * D, c.gamma, c.epochs, c.batch_size, c.seed,
+                                    c.loop_id0, &c.adam, c.num_samples, e->low.data(), e->high.data(), R, c.transform,
+                                    &c.lbfgsb, w.x0, w.idx, w.x, w.fun, w.jac, w.info, &probe, w.d_args, w.stage_bytes,
+                                    w.stream, 0, nullptr, nullptr, 0, &per_cu);
+    bore_set_batch(nullptr);
+    if (rc) return rc;
+  }
+  if (getenv("BORE_ASYNC_PER_CU") && atoi(getenv("BORE_ASYNC_PER_CU")) > 0 && atoi(getenv("BORE_ASYNC_PER_CU")) < per_cu)
+    per_cu = atoi(getenv("BORE_ASYNC_PER_CU"));  // (A/B: fewer loops per CU than the device would hold)
+  A.per_cu = per_cu;
+  const int forced = getenv("BORE_ASYNC_QUEUE") ? atoi(getenv("BORE_ASYNC_QUEUE")) : -1;
+  const int resident_cap = per_cu * device_cus();
+  A.queue = forced < 0 ? L > resident_cap : forced != 0;
+  if (A.queue) {
+    A.q_wgs = L < resident_cap ? L : resident_cap;
+    int capq = 1;
+    while (capq < 2 * (L + A.q_wgs) + 64) capq <<= 1;   // (outstanding entries <= loops + exit tokens)
+    if (capq - 1 > A.q_mask || !A.q_ring) {
+      if (A.q_ring) (void)hipHostFree(A.q_ring);
+      A.q_ring = nullptr;
+      int rc;
+      if ((rc = pin_alloc(&A.q_ring, (size_t)capq))) return rc;
+      A.q_mask = capq - 1;
+    }
+    std::memset(A.q_ring, 0, ((size_t)A.q_mask + 1) * sizeof(QueueEntry));
+    if (!A.q_head) {
+      int rc;
+      if ((rc = dev_alloc(&A.q_head, 2)) || (rc = pin_alloc(&A.q_tail_host, 1)) || (rc = dev_alloc(&A.d_ident, (size_t)L)))
+        return rc;
+      *A.q_tail_host = 0;
+      std::vector<int32_t> ident((size_t)L);
+      for (int l = 0; l < L; ++l) ident[(size_t)l] = (int32_t)l;
+      HIP_TRY(hipMemcpy(A.d_ident, ident.data(), (size_t)L * 4, hipMemcpyHostToDevice));
+    }
+  }
+  if (getenv("BORE_ASYNC_DEBUG"))
+    fprintf(stderr, "[bore] engine: %d loops, records of %lld rows: %d loops per CU -> %s\n", L, (long long)A.cap, per_cu,
+            A.queue ? "work queue" : "all resident");
+  return 0;
+}
+
 int async_create(bore_engine *e, const double *X0, const double *y0) {
   const size_t L = e->cfg.n_loops, D = e->D, R = e->cfg.num_starts, n0 = e->cfg.n_init;
   if (R > 16) return fail(BORE_E_UNSUPPORTED, "engine_create: async_loops needs num_starts <= 16");
@@ -358,7 +430,9 @@ int async_create(bore_engine *e, const double *X0, const double *y0) {
   if (!e->as) return fail(BORE_E_HIP, "engine_create: out of memory");
   Async &A = *e->as;
   int rc;
-  if ((rc = async_alloc(e, n0 * 2 > 256 ? n0 * 2 : 256))) return rc;
+  // (records grow by doubling, async_run; the fit keeps a loop's data set in LDS, sized by this capacity: with 128
+  // rows three loops of the 2->16-16-1 model share a CU, with 256 two)
+  if ((rc = async_alloc(e, n0 * 2 > 128 ? n0 * 2 : 128))) return rc;
   std::vector<float> x32(L * n0 * D);
   for (size_t i = 0; i < x32.size(); ++i) x32[i] = (float)X0[i];
   HIP_TRY(hipMemcpy2D(A.X_seen, A.cap * D * 8, X0, n0 * D * 8, n0 * D * 8, L, hipMemcpyHostToDevice));
@@ -394,25 +468,6 @@ int async_create(bore_engine *e, const double *X0, const double *y0) {
   A.launched_at.assign(L, 0.0);
   A.done_ids.assign(L, 0);
   A.fused = iteration_supported(&e->desc);
-  // More loops than resident workgroups (two per CU for this kernel): the work-queue schedule.
-  // BORE_ASYNC_QUEUE = 0 / 1 forces the launch-per-batch schedule of round 3 / the queue (tests, A/B).
-  {
-    const int forced = getenv("BORE_ASYNC_QUEUE") ? atoi(getenv("BORE_ASYNC_QUEUE")) : -1;
-    const int resident_cap = 2 * device_cus();
-    A.queue = A.fused && (forced < 0 ? (int)L > resident_cap : forced != 0);
-    if (A.queue) {
-      A.q_wgs = (int)L < resident_cap ? (int)L : resident_cap;
-      int capq = 1;
-      while (capq < 2 * ((int)L + A.q_wgs) + 64) capq <<= 1;   // (outstanding entries <= loops + exit tokens)
-      A.q_mask = capq - 1;
-      if ((rc = pin_alloc(&A.q_ring, (size_t)capq)) || (rc = dev_alloc(&A.q_head, 1)) || (rc = dev_alloc(&A.d_ident, L)))
-        return rc;
-      std::memset(A.q_ring, 0, (size_t)capq * sizeof(QueueEntry));
-      std::vector<int32_t> ident(L);
-      for (size_t l = 0; l < L; ++l) ident[l] = (int32_t)l;
-      HIP_TRY(hipMemcpy(A.d_ident, ident.data(), L * 4, hipMemcpyHostToDevice));
-    }
-  }
   // Residency: a loop's workgroup stays on its CU between iterations and waits this long for the
   // objective value before it gives its slot up (BORE_ASYNC_RESIDENT_US; 0 = one iteration per
   // launch).  Dropped by the launcher when the device cannot hold all loops at once.
@@ -489,7 +544,7 @@ int async_create(bore_engine *e, const double *X0, const double *y0) {
                 1e3 * one, A.workers.size(), 1e3 * dt, conc, queues, A.workers.size());
     }
   }
-  return 0;
+  return async_decide_schedule(e);
 }
 
 void async_destroy(bore_engine *e) {
@@ -512,6 +567,7 @@ void async_destroy(bore_engine *e) {
   if (A.flag) (void)hipHostFree(A.flag);
   if (A.ynew) (void)hipHostFree(A.ynew);
   if (A.q_ring) (void)hipHostFree(A.q_ring);
+  if (A.q_tail_host) (void)hipHostFree(A.q_tail_host);
   if (A.q_head) (void)hipFree(A.q_head);
   if (A.d_ident) (void)hipFree(A.d_ident);
   delete e->as;
@@ -625,28 +681,31 @@ int async_drain(bore_engine *e) {
 
 // The host has seen loop l's result (flag[l] == it[l] + 1): statistics, the suggestion (or the reference's
 // random fall-back) into the objective's input block.  Returns the new number of results waiting there.
-static int take_async_result(bore_engine *e, int l, double t0, int n_done) {
+// (st / sum_flight: where the statistics go -- the engine's own, or a host thread's share of them; xbuf / ids: the
+// objective's input block and the list of loops in it -- the engine's, or a host thread's slice of them)
+static int take_async_result(bore_engine *e, int l, double t0, int n_done, bore_engine_stats &st, double &sum_flight,
+                             double *xbuf, int *ids) {
   Async &A = *e->as;
   const bore_engine_cfg &c = e->cfg;
   const int L = c.n_loops, D = e->D;
   A.state[l] = 3;  // result taken, objective pending
   const double *r = A.result + (size_t)l * (D + 8);
-  double *xn = &A.cb_x[(size_t)n_done * D];
-  A.sum_flight += t0 - A.launched_at[l];
+  double *xn = xbuf + (size_t)n_done * D;
+  sum_flight += t0 - A.launched_at[l];
   A.seen_at[l] = t0;
-  e->st.launch_to_result_s += t0 - A.launched_at[l];
-  e->st.phase_ns_labels += r[D + 3] * A.ns_per_tick;
-  e->st.phase_ns_fit += r[D + 4] * A.ns_per_tick;
-  e->st.phase_ns_screen += r[D + 5] * A.ns_per_tick;
-  e->st.phase_ns_lbfgsb += r[D + 6] * A.ns_per_tick;
-  ++e->st.phase_iterations;
+  st.launch_to_result_s += t0 - A.launched_at[l];
+  st.phase_ns_labels += r[D + 3] * A.ns_per_tick;
+  st.phase_ns_fit += r[D + 4] * A.ns_per_tick;
+  st.phase_ns_screen += r[D + 5] * A.ns_per_tick;
+  st.phase_ns_lbfgsb += r[D + 6] * A.ns_per_tick;
+  ++st.phase_iterations;
   if (A.loop_acc.size() == (size_t)L * 6) {
     double *la = &A.loop_acc[(size_t)l * 6];
     la[0] += r[D + 4] * A.ns_per_tick; la[1] += r[D + 6] * A.ns_per_tick;
     la[2] += r[D + 1]; la[3] += r[D + 2]; la[4] += t0 - A.launched_at[l]; la[5] += 1.0;
   }
   if (r[D] < 0.0) {  // reference: fall back to a random point of this loop's stream
-    ++e->st.none_results;
+    ++st.none_results;
     Mt19937 &rs = e->rs[l];
     for (int d = 0; d < D; ++d) xn[d] = e->low[d] + (e->high[d] - e->low[d]) * rs.next_double();
   } else {
@@ -654,36 +713,87 @@ static int take_async_result(bore_engine *e, int l, double t0, int n_done) {
   }
   // (r[D + 7]: evaluations that ran the network; r[D + 1] = nfev also counts the trial points the
   // image shortcut served -- the algorithmic bytes are those of the evaluations that ran)
-  e->st.n_fg_rows += (int64_t)r[D + 7];
-  e->st.n_fg_requests += (int64_t)r[D + 1];
-  e->st.n_rounds += (int64_t)r[D + 2];
-  e->st.argmax_bytes += r[D + 7] * 4.0 * (2 * D + 1) + r[D + 2] * 4.0 * e->P;
+  st.n_fg_rows += (int64_t)r[D + 7];
+  st.n_fg_requests += (int64_t)r[D + 1];
+  st.n_rounds += (int64_t)r[D + 2];
+  st.argmax_bytes += r[D + 7] * 4.0 * (2 * D + 1) + r[D + 2] * 4.0 * e->P;
   const double N = c.n_init + A.it[l], steps = std::ceil(N / c.batch_size);
-  e->st.fit_bytes += c.epochs * (4.0 * N * (D + 1) + steps * 24.0 * e->P);
-  A.done_ids[n_done++] = l;
+  st.fit_bytes += c.epochs * (4.0 * N * (D + 1) + steps * 24.0 * e->P);
+  ids[n_done++] = l;
   return n_done;
+}
+static int take_async_result(bore_engine *e, int l, double t0, int n_done) {
+  Async &A = *e->as;
+  return take_async_result(e, l, t0, n_done, e->st, A.sum_flight, A.cb_x.data(), A.done_ids.data());
 }
 
 // The work-queue schedule (bore_iter.hip: queue_kernel): ONE launch of q_wgs workgroups per run; the
 // host appends a (loop, iteration) entry whenever a loop becomes ready -- all of them at the start, then
 // each again as soon as its objective value is known -- and ends the workgroups with exit entries.
+//
+// Host threads (round 5).  One thread serving every loop -- poll the flags, take a result (two lines of pinned
+// memory the device has just written: cache misses), the objective, the row and the queue entry -- needs ~1.3 us
+// per loop-iteration: ~0.7 M per second, which is what 512 resident workgroups deliver and less than 768 do.  The
+// loops are therefore dealt to `T` threads in contiguous shares; a thread owns its loops' host state outright
+// (it[], state[], ynew, x_new / y_new, the objective's input block of its share), keeps its own statistics, merged
+// at the end, and shares only the queue's tail -- tickets drawn with an atomic add, an entry published by the
+// release store of its sequence number, exactly what a waiting workgroup looks for.  A user's objective is called
+// by one thread at a time (the library's own Branin is re-entrant).  BORE_ASYNC_HOST_THREADS overrides T.
+static int async_host_threads(const bore_engine *e, int L) {
+  if (getenv("BORE_ASYNC_HOST_THREADS")) {
+    const int t = atoi(getenv("BORE_ASYNC_HOST_THREADS"));
+    return t < 1 ? 1 : (t > 16 ? 16 : t);
+  }
+  int cores = (int)std::thread::hardware_concurrency();
+  cpu_set_t set;
+  if (sched_getaffinity(0, sizeof(set), &set) == 0) cores = CPU_COUNT(&set);
+  // (measured, 4 096 loops on 768 workgroups: 1, 2, 4 and 6 threads give the same 0.70 - 0.74 M it/s -- one thread
+  // is not what bounds the schedule; more than one from 8 192 loops on, where a scan of every flag takes long)
+  int t = L / 8192 + 1;
+  if (t > 4) t = 4;
+  if (t > cores - 1) t = cores - 1;  // (the caller's thread is one of them; leave a core to the interpreter's others)
+  (void)e;
+  return t < 1 ? 1 : t;
+}
+
 static int async_run_queue(bore_engine *e, int n_steps) {
   Async &A = *e->as;
   const bore_engine_cfg &c = e->cfg;
   const int L = c.n_loops, D = e->D, R = c.num_starts;
   Worker &w = A.workers[0];
-  std::memset(A.q_ring, 0, ((size_t)A.q_mask + 1) * sizeof(QueueEntry));
+  const size_t ring_n = (size_t)A.q_mask + 1;
+  std::memset(A.q_ring, 0, ring_n * sizeof(QueueEntry));
   A.q_tail = 0;
-  HIP_TRY(hipMemsetAsync(A.q_head, 0, sizeof(unsigned long long), w.stream));
+  // (which loop-iteration a slot of the ring held last: a slot is written again only when that entry's result
+  // has been seen -- its workgroup read the entry long ago.  With 2 x (loops + workgroups) slots the wait never
+  // happens unless a workgroup holding a ticket is descheduled for whole iterations of everybody else; then it
+  // keeps that workgroup's entry from being overwritten under it, which would leave it polling for ever.)
+  A.q_owner.assign(ring_n * 2, -1);
+  HIP_TRY(hipMemsetAsync(A.q_head, 0, 2 * sizeof(unsigned long long), w.stream));
+  __atomic_store_n(A.q_tail_host, 0ull, __ATOMIC_RELEASE);
+  std::atomic<int> stop{0};  // != 0: a thread has failed (1: callback, 2: no progress for 30 s)
+  // An entry is written at the ticket its producer drew and PUBLISHED by the tail counter, which moves over the
+  // tickets in order: a producer waits until the tail has reached its ticket (only other host threads' entries,
+  // a store each, can be ahead of it) and then moves it one on.
   auto push = [&](int lid, int it) {
-    QueueEntry *en = A.q_ring + (A.q_tail & (unsigned long long)A.q_mask);
-    en->lid = lid;
-    en->it = it;
-    __atomic_store_n(&en->seq, (long long)(A.q_tail + 1), __ATOMIC_RELEASE);
-    ++A.q_tail;
+    const unsigned long long t = __atomic_fetch_add(&A.q_tail, 1ull, __ATOMIC_RELAXED);
+    const size_t slot = (size_t)(t & (unsigned long long)A.q_mask);
+    int *own = &A.q_owner[slot * 2];
+    const int old_lid = __atomic_load_n(&own[0], __ATOMIC_ACQUIRE), old_it = own[1];
+    if (old_lid >= 0) {
+      const double t0 = now_s();
+      while (__atomic_load_n(&A.flag[old_lid], __ATOMIC_ACQUIRE) < old_it + 1 && !stop.load(std::memory_order_relaxed))
+        if (now_s() - t0 > 30.0) { stop.store(2); break; }
+    }
+    own[1] = it;
+    __atomic_store_n(&own[0], lid, __ATOMIC_RELEASE);
+    const unsigned long long word = (unsigned long long)(unsigned)lid | ((unsigned long long)(unsigned)it << 32);
+    __atomic_store_n(reinterpret_cast<unsigned long long *>(A.q_ring + slot), word, __ATOMIC_RELAXED);
+    while (__atomic_load_n(A.q_tail_host, __ATOMIC_RELAXED) != t)
+      if (stop.load(std::memory_order_relaxed)) return;
+    __atomic_store_n(A.q_tail_host, t + 1, __ATOMIC_RELEASE);
   };
   const double start = now_s();
-  int remaining = L;
   for (int l = 0; l < L; ++l) {
     A.target[l] = A.it[l] + n_steps;
     A.state[l] = 1;
@@ -708,7 +818,7 @@ static int async_run_queue(bore_engine *e, int n_steps) {
                           A.z, w.d_dbl, w.d_dbl + (size_t)L * D, c.gamma, c.epochs, c.batch_size, c.seed,
                           c.loop_id0, &c.adam, c.num_samples, e->low.data(), e->high.data(), R, c.transform,
                           &c.lbfgsb, w.x0, w.idx, w.x, w.fun, w.jac, w.info, w.h_args, w.d_args, w.stage_bytes,
-                          w.stream, A.q_wgs, A.q_ring, A.q_head, A.q_mask);
+                          w.stream, A.q_wgs, A.q_ring, A.q_head, A.q_mask, nullptr, A.q_tail_host);
   if (!rc && hipEventRecord(w.ev[3], w.stream) != hipSuccess) rc = fail(BORE_E_HIP, "hipEventRecord");
   bore_set_batch(nullptr);
   if (rc) {
@@ -718,51 +828,103 @@ static int async_run_queue(bore_engine *e, int n_steps) {
   ++A.n_batches;
   ++e->st.batches;
   A.n_slots += L;
-  double last_progress = start;
-  int n_done = 0;
-  while (remaining) {
-    const double t0 = now_s();
-    for (int l = 0; l < L; ++l) {
-      if (A.state[l] != 1) continue;
-      if (__atomic_load_n(&A.flag[l], __ATOMIC_ACQUIRE) != A.it[l] + 1) continue;
-      n_done = take_async_result(e, l, t0, n_done);
-    }
-    if (n_done) {
-      if (e->objective(A.cb_x.data(), n_done, D, A.cb_y.data(), e->user)) {
-        async_drain(e);
-        for (int l = 0; l < L; ++l) A.state[l] = 2;
-        return fail(BORE_E_CALLBACK, "engine_run: the objective callback failed");
+
+  const int T = async_host_threads(e, L);
+  A.host_threads = T;
+  const bool own_objective = e->objective == bore_objective_branin01;
+  std::mutex objective_mutex;
+  struct Share {
+    bore_engine_stats st;
+    double sum_flight = 0;
+    long long n_resident = 0;
+  };
+  std::vector<Share> shares((size_t)T);
+  for (Share &sh : shares) std::memset(&sh.st, 0, sizeof(sh.st));
+  auto serve = [&](int ti) {
+    const int l0 = (int)((long long)L * ti / T), l1 = (int)((long long)L * (ti + 1) / T);
+    Share &sh = shares[(size_t)ti];
+    double *xbuf = A.cb_x.data() + (size_t)l0 * D, *ybuf = A.cb_y.data() + l0;
+    int *ids = A.done_ids.data() + l0;
+    int remaining = l1 - l0, n_done = 0;
+    double last_progress = now_s();
+    while (remaining && !stop.load(std::memory_order_relaxed)) {
+      const double t0 = now_s();
+      for (int l = l0; l < l1; ++l) {
+        if (A.state[l] != 1) continue;
+        if (__atomic_load_n(&A.flag[l], __ATOMIC_ACQUIRE) != A.it[l] + 1) continue;
+        n_done = take_async_result(e, l, t0, n_done, sh.st, sh.sum_flight, xbuf, ids);
       }
-      const double now = now_s();
-      for (int k = 0; k < n_done; ++k) {
-        const int l = A.done_ids[k];
-        std::memcpy(&A.x_new[(size_t)l * D], &A.cb_x[(size_t)k * D], (size_t)D * 8);
-        A.y_new[l] = A.cb_y[k];
-        e->st.result_to_ready_s += now - A.seen_at[l];
-        ++A.it[l];
-        if (A.it[l] >= A.target[l]) {
-          A.state[l] = 2;
-          --remaining;
+      if (n_done) {
+        int cb;
+        if (own_objective) {
+          cb = e->objective(xbuf, n_done, D, ybuf, e->user);
         } else {
-          double *yn = A.ynew + (size_t)l * (D + 1);
-          std::memcpy(yn, &A.cb_x[(size_t)k * D], (size_t)D * 8);
-          yn[D] = A.cb_y[k];
-          push(l, A.it[l]);   // (the entry's release store orders the row before it)
-          A.state[l] = 1;
-          A.launched_at[l] = now;
-          ++A.n_resident;
+          std::lock_guard<std::mutex> lock(objective_mutex);
+          cb = e->objective(xbuf, n_done, D, ybuf, e->user);
         }
+        if (cb) {
+          stop.store(1);
+          break;
+        }
+        const double now = now_s();
+        for (int k = 0; k < n_done; ++k) {
+          const int l = ids[k];
+          std::memcpy(&A.x_new[(size_t)l * D], &xbuf[(size_t)k * D], (size_t)D * 8);
+          A.y_new[l] = ybuf[k];
+          sh.st.result_to_ready_s += now - A.seen_at[l];
+          ++A.it[l];
+          if (A.it[l] >= A.target[l]) {
+            A.state[l] = 2;
+            --remaining;
+          } else {
+            double *yn = A.ynew + (size_t)l * (D + 1);
+            std::memcpy(yn, &xbuf[(size_t)k * D], (size_t)D * 8);
+            yn[D] = ybuf[k];
+            push(l, A.it[l]);   // (the entry's release store orders the row before it)
+            A.state[l] = 1;
+            A.launched_at[l] = now;
+            ++sh.n_resident;
+          }
+        }
+        last_progress = now;
+        sh.st.host_finalize_s += now - t0;
+        n_done = 0;
+      } else if (t0 - last_progress > 30.0) {
+        stop.store(2);
       }
-      last_progress = now;
-      e->st.host_finalize_s += now - t0;
-      n_done = 0;
     }
-    if (now_s() - last_progress > 30.0) {
-      async_drain(e);
-      return fail(BORE_E_HIP, "engine_run: no loop finished for 30 s");
-    }
+  };
+  {
+    std::vector<std::thread> helpers;
+    for (int ti = 1; ti < T; ++ti) helpers.emplace_back(serve, ti);
+    serve(0);
+    for (std::thread &th : helpers) th.join();
   }
-  for (int i = 0; i < A.q_wgs; ++i) push(-1, 0);  // every workgroup draws one exit entry
+  for (const Share &sh : shares) {  // (sums; host_finalize_s: the busiest thread's, the bound on the host side)
+    const bore_engine_stats &p = sh.st;
+    bore_engine_stats &q = e->st;
+    q.launch_to_result_s += p.launch_to_result_s; q.result_to_ready_s += p.result_to_ready_s;
+    q.phase_ns_labels += p.phase_ns_labels; q.phase_ns_fit += p.phase_ns_fit; q.phase_ns_screen += p.phase_ns_screen;
+    q.phase_ns_lbfgsb += p.phase_ns_lbfgsb; q.phase_iterations += p.phase_iterations; q.none_results += p.none_results;
+    q.n_fg_rows += p.n_fg_rows; q.n_fg_requests += p.n_fg_requests; q.n_rounds += p.n_rounds;
+    q.argmax_bytes += p.argmax_bytes; q.fit_bytes += p.fit_bytes;
+    A.sum_flight += sh.sum_flight;
+    A.n_resident += sh.n_resident;
+  }
+  {
+    double busiest = 0;
+    for (const Share &sh : shares) busiest = sh.st.host_finalize_s > busiest ? sh.st.host_finalize_s : busiest;
+    e->st.host_finalize_s += busiest;
+  }
+  if (stop.load()) {
+    const int why = stop.load();
+    __atomic_store_n(A.q_tail_host, ~0ull, __ATOMIC_RELEASE);
+    async_drain(e);
+    for (int l = 0; l < L; ++l) A.state[l] = 2;
+    return why == 1 ? fail(BORE_E_CALLBACK, "engine_run: the objective callback failed")
+                    : fail(BORE_E_HIP, "engine_run: no loop finished for 30 s");
+  }
+  __atomic_store_n(A.q_tail_host, ~0ull, __ATOMIC_RELEASE);  // (no more work: every workgroup sees it through the copy)
   HIP_TRY(hipStreamSynchronize(w.stream));
   float ms = 0.f;
   HIP_TRY(hipEventElapsedTime(&ms, w.ev[2], w.ev[3]));
@@ -783,7 +945,7 @@ int async_run(bore_engine *e, int n_steps) {
   if (c.n_init + max_it + n_steps > A.cap) {
     int64_t cap = A.cap;
     while (cap < c.n_init + max_it + n_steps) cap *= 2;
-    if ((rc = async_alloc(e, cap))) return rc;
+    if ((rc = async_alloc(e, cap)) || (rc = async_decide_schedule(e))) return rc;
   }
   if (A.queue) return async_run_queue(e, n_steps);
   const double start = now_s();
@@ -1170,6 +1332,9 @@ extern "C" int bore_engine_get_stats(bore_engine *e, bore_engine_stats *out, int
   *out = e->st;
   out->worker_streams = e->as ? (int64_t)e->as->workers.size() : (int64_t)e->groups.size();
   out->stream_concurrency = e->as ? e->as->stream_concurrency : 0;
+  out->loops_per_cu = e->as ? e->as->per_cu : 0;
+  out->side_by_side_workgroups = e->as && e->as->fused ? (e->as->queue ? e->as->q_wgs : e->cfg.n_loops) : 0;
+  out->host_threads = e->as ? e->as->host_threads : 1;
   if (reset) std::memset(&e->st, 0, sizeof(e->st));
   return 0;
 }

@@ -2441,7 +2441,8 @@ static int fit_build(const bore_mlp_desc *desc, int n_models, float *theta, floa
   }
   a.total = (int)off;
   off = (off + 3) & ~(size_t)3;
-  a.o_layout = (int)off; off += BORE_LAYOUT_FLOATS;
+  a.o_layout = (int)off;
+  const size_t off_layout = off;
   // the constexpr-layout instantiation needs the layout it was compiled for (64-row tile)
   // (and keeps the Adam slots in LDS unconditionally)
   int shape = fit_flavour(desc);
@@ -2458,7 +2459,9 @@ static int fit_build(const bore_mlp_desc *desc, int n_models, float *theta, floa
                   "the transposed images must fit the tile region");
     if (a.state_in_lds) return fail(BORE_E_UNSUPPORTED, "fit: internal: wide shape with Adam slots in LDS");
   }
-  lds_floats = off;
+  // (the LDS copy of the layout tables is the generic flavour's alone, begin_kernel: the others read a constant
+  // expression or the kernel arguments -- 496 B that decide whether three loops of the fused kernel share a CU)
+  lds_floats = off_layout + (shape == 0 ? BORE_LAYOUT_FLOATS : 0);
   shape_out = shape;
   return 0;
 }

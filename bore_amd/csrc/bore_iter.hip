@@ -13,11 +13,10 @@
 // Static shape 1 (2 -> 16-16-1, the BASELINE config) only; anything else keeps the launch chain.
 // Included by bore_all.hip after bore_hip.hip and bore_argmax.hip.
 
-// One entry of the work queue of queue_kernel (pinned host memory, written by the host in ticket order:
-// lid and it first, then seq = ticket + 1 with release semantics; lid < 0 = "no more work, exit").
+// One entry of the work queue of queue_kernel (pinned host memory, written by the host in ticket order and
+// published by the queue's tail counter, IterArgs::q_tail_host): the loop and its iteration, one 64-bit word.
 struct QueueEntry {
   int lid, it;
-  long long seq;
 };
 
 struct IterArgs {
@@ -48,6 +47,9 @@ struct IterArgs {
   const QueueEntry *q_ring;
   unsigned long long *q_head;
   int q_mask;
+  // ... how many entries the host has published (pinned; all ones = no more work, exit) and the device's copy of
+  // that number (device memory, zeroed by the host before the launch: the 64-bit word after q_head)
+  const unsigned long long *q_tail_host;
   // Resident launches: loop-iterations finished by the whole grid since the launch (zeroed by the
   // upload of this block; device copy only, touched with agent-scope atomics and never through the
   // constant-address-space view of the block).  A loop behind the grid's mean raises its waves'
@@ -79,14 +81,30 @@ __device__ __forceinline__ double load_host_f64(const double *p) {
 #ifndef BORE_LAG_YIELD_Q
 #define BORE_LAG_YIELD_Q 3  // a leader yields while it is more than Q / 4 iterations ahead of the mean
 #endif
-template <int SHAPE>
+// One phase hands its results to the next through global memory (labels z, the fitted theta, the screened x0),
+// written and read by waves of the SAME workgroup: the writers' stores are acknowledged (the vector L1 writes
+// through to the XCD's L2), barrier, and the CU's L1 drops what it fetched before (buffer_inv sc0: this CU's
+// lines alone).  Rounds 2 - 4 put an agent-scope fence here -- on gfx950, whose eight XCDs have an L2 each, that
+// is a write-back of the XCD's L2 plus an invalidate of it, four times per loop-iteration from every workgroup.
+__device__ __forceinline__ void phase_handoff() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  asm volatile("buffer_inv sc0\n\ts_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// LOCAL: everything this loop's state has been through stayed on this XCD (see lbfgsb_body's PUBLISH).
+template <int SHAPE, bool LOCAL = false>
 __device__ __forceinline__ void iteration_once(const IterArgs *__restrict__ pa,
                                                          const long long slot, const int it,
-                                                         const bool staged) {
+                                                         const bool staged, const long long t_begin = 0) {
   const IterArgs &a = *pa;
   const long long lid = uniform_i64(a.f.ids[slot]), cap = a.f.cap;
   long long *stp = a.stamps ? a.stamps + lid * 4 : nullptr;  // read back by the restart phase's epilogue
-  if (stp && threadIdx.x == 0) stp[0] = wall_clock64();
+  // (t_begin != 0, -DBORE_QUEUE_STAMP_DRAW: the first phase is charged from the moment the workgroup drew its
+  // ticket -- the wait for the queue entry shows up in `labels`)
+  if (stp && threadIdx.x == 0) stp[0] = t_begin ? t_begin : wall_clock64();
   if (it > 0) {  // append (append_kernel's batch branch)
     const long long row = a.f.n_init + it - 1;
     // (the launch brought the row of its first iteration; later ones come from the host)
@@ -98,28 +116,44 @@ __device__ __forceinline__ void iteration_once(const IterArgs *__restrict__ pa,
     if (threadIdx.x == 0)
       a.y_seen[lid * cap + row] = staged ? a.y_new[slot] : load_host_f64(a.ynew + lid * (a.D + 1) + a.D);
   }
-  __threadfence();
-  __syncthreads();
+  if constexpr (LOCAL) phase_handoff();
+  else {
+    __threadfence();
+    __syncthreads();
+  }
   labels_body(a.y_seen, 0, 0.0, a.z, nullptr, a.f.ids, a.f.its, a.f.n_init, cap, a.gamma, slot, it);
   if (stp && threadIdx.x == 0) stp[1] = wall_clock64();
-  __threadfence();
-  __syncthreads();
+  if constexpr (LOCAL) phase_handoff();
+  else {
+    __threadfence();
+    __syncthreads();
+  }
   fit_body<SHAPE>(a.f, slot, it);
   if (stp && threadIdx.x == 0) stp[2] = wall_clock64();
-  __threadfence();
-  __syncthreads();
+  if constexpr (LOCAL) phase_handoff();
+  else {
+    __threadfence();
+    __syncthreads();
+  }
   screen_body<SHAPE, false>(a.s, slot, it);
   if (stp && threadIdx.x == 0) stp[3] = wall_clock64();
-  __threadfence();
-  __syncthreads();
-  lbfgsb_body<SHAPE, false, true, true, false>(a.b, slot, 0, it);  // (publishes flag[lid] = it + 1)
+  if constexpr (LOCAL) phase_handoff();
+  else {
+    __threadfence();
+    __syncthreads();
+  }
+  lbfgsb_body<SHAPE, false, true, true, false, LOCAL ? 1 : 0>(a.b, slot, 0, it);  // (publishes flag[lid] = it + 1)
 }
 
 // RESIDENT: the workgroup may go on to later iterations of its loop.  Otherwise ONE iteration -- the
 // launch for loops that do not wait on their CU (more loops than the device holds at once,
 // wait_ticks = 0): no loop, no scratch at all.
-template <int SHAPE, bool RESIDENT>
-__global__ __launch_bounds__(BORE_THREADS, 2) void iteration_kernel(const IterArgs *__restrict__ pa) {
+// OCC: loops (workgroups) per CU the kernel is compiled for.  2: the whole register file of two waves per SIMD (256
+// registers, no scratch) -- the kernel for up to 2 x CUs loops.  3: 168 registers, the restart phase pays with spills
+// to scratch (its per-loop time +7 %), and a CU runs three loops: the kernel for more loops than that (round 5;
+// 768 loops 549 -> 606 k it/s).
+template <int SHAPE, bool RESIDENT, int OCC = 2>
+__global__ __launch_bounds__(BORE_THREADS, OCC) void iteration_kernel(const IterArgs *__restrict__ pa) {
   const long long slot = blockIdx.x;
   const int it_first = uniform_i32(pa->f.its[slot]);
   if constexpr (!RESIDENT) {
@@ -193,7 +227,7 @@ __global__ __launch_bounds__(BORE_THREADS, 2) void iteration_kernel(const IterAr
     unsigned long long pa_bits = reinterpret_cast<unsigned long long>(pa);
     asm volatile("" : "+s"(pa_bits));
     typedef const __attribute__((address_space(4))) IterArgs *IterArgsConst;
-    iteration_once<SHAPE>((const IterArgs *)(IterArgsConst)pa_bits, slot, it, it == it_first);
+    iteration_once<SHAPE, true>((const IterArgs *)(IterArgsConst)pa_bits, slot, it, it == it_first);
     __syncthreads();  // the waves leave the restart phase one by one: LDS is reused below
     ++it;
 #if BORE_LAG_PRIO
@@ -209,7 +243,9 @@ __global__ __launch_bounds__(BORE_THREADS, 2) void iteration_kernel(const IterAr
       for (;;) {
         // (relaxed polls, one acquire once the row is there: see queue_kernel)
         if (__hip_atomic_load(yseq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) >= it) {
-          __atomic_thread_fence(__ATOMIC_ACQUIRE);
+          // (the row is read with system-scope loads that bypass the caches, load_host_f64: no invalidate --
+          // a system-scope acquire here is an invalidate of the XCD's L2 under every other workgroup)
+          asm volatile("" ::: "memory");
           go = 1;
           break;
         }
@@ -252,34 +288,81 @@ __global__ __launch_bounds__(BORE_THREADS, 2) void iteration_kernel(const IterAr
 // resident kernel does, and draws again.  No launch, no upload and no batch per loop-iteration (round 3:
 // one launch per batch of ready loops, ~13 % below the device's rate at 4 096 loops), and the workgroups
 // balance themselves over the loops.  An entry with lid < 0 ends a workgroup.
-template <int SHAPE>
-__global__ __launch_bounds__(BORE_THREADS, 2) void queue_kernel(const IterArgs *__restrict__ pa) {
+#ifdef BORE_QUEUE_STAMP_DRAW
+// (diagnostics: when each workgroup of the last queue launch started, and where -- HW_ID, XCC_ID)
+__device__ long long g_wg_start[4096][2];
+extern "C" int bore_debug_wg_starts(long long *out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wg_start), sizeof(long long) * 4096 * 2);
+}
+#endif
+template <int SHAPE, int OCC = 2>
+__global__ __launch_bounds__(BORE_THREADS, OCC) void queue_kernel(const IterArgs *__restrict__ pa) {
   __shared__ __attribute__((aligned(16))) int s_q4[4];  // (16 B: the dynamic LDS keeps its alignment)
+#ifdef BORE_QUEUE_STAMP_DRAW
+  if (threadIdx.x == 0 && blockIdx.x < 4096) {
+    g_wg_start[blockIdx.x][0] = wall_clock64();
+    const unsigned hw = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));    // HW_REG_HW_ID, 32 bits
+    const unsigned xcc = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11));  // HW_REG_XCC_ID
+    g_wg_start[blockIdx.x][1] = ((long long)xcc << 32) | hw;
+  }
+#endif
   for (;;) {
     if (threadIdx.x == 0) {
-      const QueueEntry *ring = pa->q_ring;
-      const int *abort_flag = pa->abort_flag;
+#ifdef BORE_QUEUE_STAMP_DRAW
+      const long long t_draw = wall_clock64();
+      s_q4[2] = (int)(t_draw & 0xffffffffll);
+      s_q4[3] = (int)(t_draw >> 32);
+#endif
       const unsigned long long t =
           __hip_atomic_fetch_add(pa->q_head, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const QueueEntry *e = ring + (t & (unsigned long long)pa->q_mask);
+      // Waiting for entry t.  Round 4: every waiting workgroup polled the entry's sequence number in pinned memory --
+      // a read over the bus every ~2 us from each of them.  With hundreds of workgroups idle (fewer ready loops than
+      // workgroups; the end of every run) those reads saturate the link, and everything else that crosses it -- the
+      // rows the busy workgroups fetch, their results, their flags -- queues behind them: 1 024 loops on 768
+      // workgroups ran at 0.17 M it/s, and every run() ended with ~20 ms of it (profiles/r5/ab_log.txt).  Now the
+      // host publishes a tail counter, the device keeps a copy of it, and only the workgroup at the HEAD of the line
+      // (ticket == copy: tickets are unique, so there is one) asks the host; it moves the copy on for everybody.  The
+      // others watch the copy, and the further back they stand the longer they sleep between looks.
+      unsigned long long *tail_dev = pa->q_head + 1;
+      const unsigned long long *tail_host = pa->q_tail_host;
       int lid = -1, it = 0;
       for (;;) {
-        // (relaxed polls, ONE acquire when the entry is there: an acquire per poll is a cache invalidate per
-        // poll, from every waiting workgroup)
-        if (__hip_atomic_load(&e->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == (long long)(t + 1)) {
-          __atomic_thread_fence(__ATOMIC_ACQUIRE);
-          lid = __hip_atomic_load(&e->lid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-          it = __hip_atomic_load(&e->it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        unsigned long long tail = __hip_atomic_load(tail_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tail == t) {
+          const unsigned long long th = __hip_atomic_load(tail_host, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          if (th > t) {
+            __hip_atomic_fetch_max(tail_dev, th, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            tail = th;
+          }
+        }
+        if (tail == ~0ull) break;  // (the run is over, or aborted: lid stays -1)
+        if (tail > t) {
+          // (the entry was written before the tail that covers it, both by the host; read past the caches)
+          const long long w = __hip_atomic_load(reinterpret_cast<const long long *>(pa->q_ring + (t & (unsigned long long)pa->q_mask)),
+                                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          lid = (int)(w & 0xffffffffll);
+          it = (int)(w >> 32);
+          // (the loop's previous iteration may have run on another XCD: its state went through the system-scope
+          // release of lbfgsb_body's PUBLISH = 0; what this XCD's L2 and this CU's L1 hold of it from an earlier
+          // visit is dropped here, by one wave, ahead of the barrier that lets the others go)
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
           break;
         }
-        if (__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) break;  // (lid stays -1)
-        __builtin_amdgcn_s_sleep(16);
+        // (entries arrive at ~0.8 per us when the device is full: a workgroup d places back is d us or more away)
+        const int back = (int)(t - tail < 64ull ? t - tail : 64ull);
+        __builtin_amdgcn_s_sleep(8);
+        for (int z = 0; z < back; ++z) __builtin_amdgcn_s_sleep(20);
       }
       s_q4[0] = lid;
       s_q4[1] = it;
     }
     __syncthreads();
     const int lid = uniform_i32(s_q4[0]), it = uniform_i32(s_q4[1]);
+#ifdef BORE_QUEUE_STAMP_DRAW
+    const long long t_begin = ((long long)s_q4[3] << 32) | (unsigned)s_q4[2];
+#else
+    const long long t_begin = 0;
+#endif
     __syncthreads();
     if (lid < 0) break;
     // (the argument block through the constant address space, its address opaque per iteration: see the
@@ -288,7 +371,7 @@ __global__ __launch_bounds__(BORE_THREADS, 2) void queue_kernel(const IterArgs *
     unsigned long long pa_bits = reinterpret_cast<unsigned long long>(pa);
     asm volatile("" : "+s"(pa_bits));
     typedef const __attribute__((address_space(4))) IterArgs *IterArgsConst;
-    iteration_once<SHAPE>((const IterArgs *)(IterArgsConst)pa_bits, (long long)lid, it, false);
+    iteration_once<SHAPE>((const IterArgs *)(IterArgsConst)pa_bits, (long long)lid, it, false, t_begin);
     __syncthreads();  // the waves leave the restart phase one by one: LDS is reused by the next iteration
   }
 }
@@ -302,6 +385,31 @@ static int iteration_supported(const bore_mlp_desc *desc) {
   return desc->compute == BORE_COMPUTE_F32 && bore_kernel_flavour(desc, true) == 1;
 }
 
+// Loops (workgroups) of the fused kernels one CU holds at a time with `lds_bytes` of dynamic LDS each: what the
+// runtime's occupancy query says (registers, waves), and no more than the LDS allows at its allocation granularity
+// -- 1 280 B on gfx950, which the query does not apply: at 54 240 B it answers 3 where the hardware places 2, and
+// a resident grid sized by that answer waits for workgroups that never start (331 k it/s instead of 560 k).
+static int iteration_loops_per_cu(size_t lds_bytes, int *per_cu_out) {
+  static thread_local size_t seen_bytes = ~(size_t)0;
+  static thread_local int seen_per_cu = 0, seen_dev = -1;
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  if (seen_bytes != lds_bytes || seen_dev != dev) {  // (per device: a thread may drive several)
+    int per_cu = 0, q_per_cu = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, iteration_kernel<1, true, 3>, BORE_THREADS, lds_bytes));
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&q_per_cu, queue_kernel<1, 3>, BORE_THREADS, lds_bytes));
+    if (q_per_cu < per_cu) per_cu = q_per_cu;
+    const size_t granule = 1280, static_bytes = 16;  // (s_go4 / s_q4)
+    const size_t each = (lds_bytes + static_bytes + granule - 1) / granule * granule;
+    const int by_lds = (int)(BORE_LDS_BYTES / each);
+    if (by_lds < per_cu) per_cu = by_lds;
+    if (per_cu > 3) per_cu = 3;  // (what the kernels are compiled for)
+    seen_bytes = lds_bytes; seen_dev = dev; seen_per_cu = per_cu;
+  }
+  *per_cu_out = seen_per_cu;
+  return 0;
+}
+
 static int iteration_launch(const bore_mlp_desc *desc, int n_slots, float *theta, float *adam_m,
                             float *adam_v, int64_t *adam_t, double *X_seen, double *y_seen,
                             float *X32, float *z, const double *x_new, const double *y_new,
@@ -312,7 +420,8 @@ static int iteration_launch(const bore_mlp_desc *desc, int n_slots, float *theta
                             double *fun, double *jac, int32_t *info, IterArgs *h,
                             const IterArgs *d_args, size_t upload_bytes, void *stream,
                             int queue_wgs = 0, const QueueEntry *q_ring = nullptr,
-                            unsigned long long *q_head = nullptr, int q_mask = 0) {
+                            unsigned long long *q_head = nullptr, int q_mask = 0, int *per_cu_out = nullptr,
+                            const unsigned long long *q_tail_host = nullptr) {
   if (!g_batch) return fail(BORE_E_INVALID, "iteration_launch: no batch set");
   const int64_t cap = g_batch->cap;
   size_t lf = 0, ls = 0, lb = 0;
@@ -343,50 +452,52 @@ static int iteration_launch(const bore_mlp_desc *desc, int n_slots, float *theta
   h->gamma = gamma;
   h->D = desc->input_dim;
   h->progress = 0;
-  h->q_ring = q_ring; h->q_head = q_head; h->q_mask = q_mask;
+  h->q_ring = q_ring; h->q_head = q_head; h->q_mask = q_mask; h->q_tail_host = q_tail_host;
   size_t floats = lf > ls ? lf : ls;
   floats = floats > lb ? floats : lb;
   const size_t labels_floats = 2 * ((size_t)cap + 2);
   floats = floats > labels_floats ? floats : labels_floats;
-  if ((rc = allow_lds(iteration_kernel<1, true>, floats * 4)) ||
-      (rc = allow_lds(iteration_kernel<1, false>, floats * 4)) || (rc = allow_lds(queue_kernel<1>, floats * 4)))
+  if ((rc = allow_lds(iteration_kernel<1, true, 2>, floats * 4)) || (rc = allow_lds(iteration_kernel<1, true, 3>, floats * 4)) ||
+      (rc = allow_lds(iteration_kernel<1, false, 2>, floats * 4)) || (rc = allow_lds(queue_kernel<1, 2>, floats * 4)) ||
+      (rc = allow_lds(queue_kernel<1, 3>, floats * 4)))
     return rc;
+  if (per_cu_out) {  // (a question, not a launch: how many loops of this model one CU holds)
+    *per_cu_out = 0;
+    return iteration_loops_per_cu(floats * 4, per_cu_out);
+  }
   if (queue_wgs > 0) {  // the work-queue form: a fixed grid, fed by the host through q_ring
-    if (!q_ring || !q_head || !g_batch->ynew || !g_batch->abort_flag)
+    if (!q_ring || !q_head || !q_tail_host || !g_batch->ynew || !g_batch->abort_flag)
       return fail(BORE_E_INVALID, "iteration_launch: incomplete work queue");
     h->targets = nullptr;
     h->wait_ticks = 0;
     HIP_TRY(hipMemcpyAsync(const_cast<IterArgs *>(d_args), h, sizeof(IterArgs), hipMemcpyHostToDevice,
                            (hipStream_t)stream));
-    hipLaunchKernelGGL((queue_kernel<1>), dim3(queue_wgs), dim3(BORE_THREADS), floats * 4, (hipStream_t)stream,
-                       d_args);
+    // (no more workgroups than two per CU: the kernel with the whole register file)
+    if (queue_wgs <= 2 * device_cus())
+      hipLaunchKernelGGL((queue_kernel<1, 2>), dim3(queue_wgs), dim3(BORE_THREADS), floats * 4, (hipStream_t)stream, d_args);
+    else
+      hipLaunchKernelGGL((queue_kernel<1, 3>), dim3(queue_wgs), dim3(BORE_THREADS), floats * 4, (hipStream_t)stream, d_args);
     HIP_TRY(hipGetLastError());
     return 0;
   }
   if (h->wait_ticks > 0) {  // waiting workgroups hold their slots: only when all of them fit at once
-    static thread_local size_t cap_bytes = ~(size_t)0;
-    static thread_local int cap_wgs = 0, cap_dev = -1;
-    int dev = 0;
-    HIP_TRY(hipGetDevice(&dev));
-    if (cap_bytes != floats * 4 || cap_dev != dev) {  // (per device: a thread may drive several)
-      int per_cu = 0, cus = 0;
-      HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, iteration_kernel<1, true>, BORE_THREADS,
-                                                           floats * 4));
-      HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-      cap_bytes = floats * 4;
-      cap_dev = dev;
-      cap_wgs = per_cu * cus;
-    }
-    if (g_batch->resident_loops > cap_wgs) h->wait_ticks = 0;
+    int per_cu = 0;
+    if ((rc = iteration_loops_per_cu(floats * 4, &per_cu))) return rc;
+    if (getenv("BORE_ASYNC_DEBUG"))
+      fprintf(stderr, "[bore] fused kernel: %zu B of LDS per loop (fit %zu, screen %zu, restarts %zu, labels %zu), %d loops per CU\n", floats * 4, lf * 4, ls * 4, lb * 4, labels_floats * 4, per_cu);
+    if (g_batch->resident_loops > per_cu * device_cus()) h->wait_ticks = 0;
   }
   // h heads the caller's staging block (arguments | per-slot inputs | index lists): one upload
   HIP_TRY(hipMemcpyAsync(const_cast<IterArgs *>(d_args), h, upload_bytes, hipMemcpyHostToDevice,
                          (hipStream_t)stream));
-  if (h->wait_ticks > 0)
-    hipLaunchKernelGGL((iteration_kernel<1, true>), dim3(n_slots), dim3(BORE_THREADS), floats * 4,
+  if (h->wait_ticks > 0 && g_batch->resident_loops > 2 * device_cus())  // (three loops per CU: see iteration_kernel)
+    hipLaunchKernelGGL((iteration_kernel<1, true, 3>), dim3(n_slots), dim3(BORE_THREADS), floats * 4,
+                       (hipStream_t)stream, d_args);
+  else if (h->wait_ticks > 0)
+    hipLaunchKernelGGL((iteration_kernel<1, true, 2>), dim3(n_slots), dim3(BORE_THREADS), floats * 4,
                        (hipStream_t)stream, d_args);
   else
-    hipLaunchKernelGGL((iteration_kernel<1, false>), dim3(n_slots), dim3(BORE_THREADS), floats * 4,
+    hipLaunchKernelGGL((iteration_kernel<1, false, 2>), dim3(n_slots), dim3(BORE_THREADS), floats * 4,
                        (hipStream_t)stream, d_args);
   HIP_TRY(hipGetLastError());
   return 0;

@@ -1798,6 +1798,15 @@ LB_HD int lbfgsb_advance(State &s, const Work &w, const double *l, const double 
       resume_ls = false;
       first_ls = false;
     } else {
+      // (a new iteration: the line search's saved locals are dead -- dcsrch sets every one of them when the next
+      // search starts -- and saying so here keeps the compiler from carrying 13 fp64 values through the
+      // once-per-iteration routines below)
+      s.brackt = 0; s.ls_stage = 0;
+      s.ginit = s.gtest = s.gx = s.gy = s.finit = s.fx = s.fy = s.stx = s.sty = s.stmin = s.stmax = 0.0;
+      s.width = s.width1 = 0.0;
+      // (... and so are the scalars lnsrlb sets when a search starts)
+      s.xstep = s.gd = s.gdold = s.stp = s.dtd = s.dnorm = s.stpmx = s.fold = 0.0;
+      s.ifun = s.iback = 0;
       s.iword = -1;
       if (!s.cnstnd && s.col > 0) {
         for (int i = coop.lane; i < n; i += coop.nl) w.z[i] = w.x[i];

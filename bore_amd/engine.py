@@ -203,6 +203,10 @@ class NativeEngine:
         return X[np.arange(self.L), i], y[np.arange(self.L), i]
 
 
+import threading as _threading
+_ENV_LOCK = _threading.Lock()
+
+
 class ShardedEngine:
     """(Round 4's first answer to more loops than the device holds at once; the engine's work-queue
     schedule -- one persistent launch fed by the host, bore_iter.hip: queue_kernel -- has since become the
@@ -221,6 +225,9 @@ class ShardedEngine:
         import os
         ids = np.asarray(loop_ids, dtype=np.int64)
         shards = int(max(1, min(shards, len(ids))))
+        # (bore_engine_create reads these three from the environment: the swap is process-wide, so engines are
+        # created under a lock and what the user had set comes back afterwards)
+        _ENV_LOCK.acquire()
         saved = {k: os.environ.get(k) for k in ("BORE_ASYNC_RESIDENT_US", "BORE_ASYNC_WORKERS", "BORE_ASYNC_QUEUE")}
         try:
             if shards > 1:      # (read by bore_engine_create)
@@ -235,6 +242,7 @@ class ShardedEngine:
                     os.environ.pop(k, None)
                 else:
                     os.environ[k] = v
+            _ENV_LOCK.release()
         e0 = self.engines[0]
         self.loop_ids, self.L, self.D, self.P = ids, len(ids), e0.D, e0.P
         self.n_groups = e0.n_groups
@@ -289,6 +297,7 @@ class ShardedEngine:
         stats = [e.take_stats(reset) for e in self.engines]
         out = {k: sum(s[k] for s in stats) for k in stats[0]}
         out["stream_concurrency"] = min(s["stream_concurrency"] for s in stats)
+        out["loops_per_cu"] = min(s["loops_per_cu"] for s in stats)
         return out
 
     def best(self):

@@ -122,6 +122,14 @@ def resolve(t):
     # applied as the callable it is, not silently replaced by the kernel transform of that name.
     if t in _KNOWN_OBJECTS():
         return TRANSFORMS[t.__name__ if t.__name__ != "expit" else "sigmoid"]
+    # The reference's own idiom: transform=tf.identity (bore/mixins.py:16, 94), and the plugin's table of
+    # tf.identity / tf.sigmoid / tf.exp (bore/plugins/hpbandster/base.py:128-131).  Functions that COME FROM
+    # tensorflow / jax / numpy under one of the three names are those functions (code ported from the reference
+    # keeps working); a user's own function of that name stays the callable it is.
+    mod = getattr(t, "__module__", None) or ""
+    name = getattr(t, "__name__", None)
+    if name in TRANSFORMS and mod.split(".")[0] in ("tensorflow", "jax", "numpy", "keras"):
+        return TRANSFORMS[name]
     if callable(t):                 # any other elementwise, torch-differentiable callable
         return CallableTransform(t)
     raise TypeError(f"transform {t!r}: pass 'identity', 'sigmoid', 'exp', a bore_amd.transforms "

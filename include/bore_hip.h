@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define BORE_ABI_VERSION 10
+#define BORE_ABI_VERSION 11
 #define BORE_MAX_LAYERS 8
 #define BORE_BATCH_MAX 64 /* rows per tile == wavefront width */
 #define BORE_DIM_MAX 64   /* largest input dimension for the by-value bound arrays */
@@ -433,6 +433,11 @@ typedef struct bore_engine_stats {
    * from the image shortcut of the fused kernel (SciPy's nfev counts them too).  Launch-chain
    * schedules only see nfev: there the two are equal. */
   int64_t n_fg_requests;
+  /* ABI 11 (asynchronous schedule, fused kernel; not reset): loops of this model one CU holds at the records'
+   * current capacity, and the workgroups that serve the loops side by side -- n_loops when every loop is resident,
+   * the size of the work-queue kernel's grid otherwise (0: launch chains).  Also: host threads of the last
+   * work-queue run. */
+  int64_t loops_per_cu, side_by_side_workgroups, host_threads;
 } bore_engine_stats;
 
 typedef struct bore_engine bore_engine;

@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol(built):
     raw = ctypes.CDLL(_lib.LIB_PATH)
     for name in header_functions():
         assert hasattr(raw, name), name
-    assert built.bore_abi_version() == 10
+    assert built.bore_abi_version() == 11
 
 
 def test_param_count_and_descriptor_validation(built):

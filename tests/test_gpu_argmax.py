@@ -813,6 +813,8 @@ def test_lbfgsb_problem_queue_gives_the_same_bits(gpu, monkeypatch, D, units, co
                      ("0", {"BORE_LBFGSB_W8": "1", "BORE_LBFGSB_BIG": "1"}),
                      ("7", {"BORE_LBFGSB_W8": "1", "BORE_LBFGSB_BIG": "0"})):
         monkeypatch.setenv("BORE_LBFGSB_QUEUE", q)
+        for k in ("BORE_LBFGSB_W8", "BORE_LBFGSB_OCC2", "BORE_LBFGSB_BIG"):   # (each combination is what its label says)
+            monkeypatch.delenv(k, raising=False)
         for k, v in extra.items():
             monkeypatch.setenv(k, v)
         outs.append([t.cpu().numpy() for t in ops.lbfgsb_minimize(desc, th, X0, lo, hi, "identity", True, **opts)])

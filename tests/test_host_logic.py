@@ -198,6 +198,21 @@ def test_callable_transforms_are_applied_on_the_host():
         return u * u
     mine = resolve(exp)
     assert isinstance(mine, CallableTransform) and mine.name is None
+
+    # the reference's own idiom, transform=tf.identity / tf.sigmoid / tf.exp (bore/mixins.py:16,94;
+    # plugins/hpbandster/base.py:128-131): a function that comes from tensorflow under one of the three names is
+    # that transform (TensorFlow is not installed here: an object with its module and name stands in)
+    def identity(u):
+        raise AssertionError("never called: resolved by origin and name")
+    identity.__module__ = "tensorflow.python.ops.array_ops"
+    assert resolve(identity) is transforms.identity
+
+    def sigmoid(u):
+        raise AssertionError("never called")
+    sigmoid.__module__ = "tensorflow.python.ops.math_ops"
+    assert resolve(sigmoid).name == "sigmoid"
+    sigmoid.__module__ = "my_project.activations"              # a user's own function of that name: the callable
+    assert isinstance(resolve(sigmoid), CallableTransform)
     np.testing.assert_allclose(mine.value_and_derivative(f)[0], f * f, rtol=1e-6)
     with pytest.raises(TypeError, match="torch tensor"):
         resolve(np.tanh).value_and_derivative(f)
