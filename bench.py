@@ -440,6 +440,19 @@ WIDE_CONFIGS = {
 }
 
 
+# The network the reference's only in-repo caller builds (bore/plugins/hpbandster/base.py:23-33 -> DenseSequential's
+# fall-through, bore/models.py:16-19): D -> 32-32-32-1, elu x3 + a linear output under from_logits BCE,
+# transform="sigmoid", num_starts=5, num_samples=1024, gamma = 1/3, epochs = num_steps_per_iter // steps per epoch
+# = 1000 // ceil(N / 64) (base.py:176-184).  Static shape 5: at 16 inputs as compiled, at 6 zero-padded (fit) /
+# with the input dimension as a run-time argument (acquisition).
+PLUGIN_CONFIGS = {
+    "plugin_default_D6": dict(D=6, units=[32, 32, 32, 1], acts=["elu", "elu", "elu", "linear"], transform="sigmoid",
+                              R=5, Ns=1024, N=100, gamma=1.0 / 3.0, epochs=1000 // 2, compute="float32"),
+    "plugin_default_D16": dict(D=16, units=[32, 32, 32, 1], acts=["elu", "elu", "elu", "linear"], transform="sigmoid",
+                               R=5, Ns=1024, N=100, gamma=1.0 / 3.0, epochs=1000 // 2, compute="float32"),
+}
+
+
 def _synthetic(rs, L, N, D):
     """Seeded smooth synthetic objective on [0,1]^D (value distribution irrelevant to cost)."""
     X = rs.uniform(size=(L, N, D))
@@ -460,7 +473,8 @@ def config_gpu(name, c, loops, epochs=200, batch=64, reps=3):
     import torch
     from bore_amd import _lib, ops
     D, units, R, Ns, N = c["D"], c["units"], c["R"], c["Ns"], c["N"]
-    acts = ["relu"] * (len(units) - 1) + ["sigmoid"]
+    acts = c.get("acts") or ["relu"] * (len(units) - 1) + ["sigmoid"]
+    transform, gamma, epochs = c.get("transform", "identity"), c.get("gamma", 0.25), c.get("epochs", epochs)
     desc = _lib.make_desc(D, units, acts, compute=c["compute"])
     M, P = _counts(D, units)
     rs = np.random.RandomState(0)
@@ -473,7 +487,7 @@ def config_gpu(name, c, loops, epochs=200, batch=64, reps=3):
             off += fan * u + u
             fan = u
     X, y = _synthetic(rs, loops, N, D)
-    z = (y < np.quantile(y, 0.25, axis=1)[:, None]).astype(np.float32)
+    z = (y < np.quantile(y, gamma, axis=1)[:, None]).astype(np.float32)
     dev = torch.device("cuda", torch.cuda.current_device())
     theta = torch.from_numpy(th).to(dev)
     m, v = torch.zeros_like(theta), torch.zeros_like(theta)
@@ -490,7 +504,7 @@ def config_gpu(name, c, loops, epochs=200, batch=64, reps=3):
         e[1].record()
         x0, _ = ops.sample_screen_topk(desc, theta, 0, Ns, lo, hi, R, draw_index=k)
         e[2].record()
-        x, fun, jac, info = ops.lbfgsb_minimize(desc, theta, x0, lo, hi, "identity", True,
+        x, fun, jac, info = ops.lbfgsb_minimize(desc, theta, x0, lo, hi, transform, True,
                                                 maxiter=1000, ftol=1e-9)
         e[3].record()
         ops.select_best(x, fun, info)
@@ -514,7 +528,7 @@ def config_gpu(name, c, loops, epochs=200, batch=64, reps=3):
     peak_tf = BF16_PEAK_TF if c["compute"] == "bfloat16" else FP32_PEAK_TF
     kern = {"fit": ph[0], "screen": ph[1], "fg": ph[2]}
     return {
-        "loops": loops, "it_per_s": loops / (total_ms * 1e-3),
+        "loops": loops, "it_per_s": loops / (total_ms * 1e-3), "epochs": int(epochs), "adam_steps": int(S),
         "ms": {"fit": float(ph[0]), "screen": float(ph[1]), "lbfgsb": float(ph[2]),
                "pick": float(ph[3]), "iteration": total_ms},
         # (the driver's box and the builder's differ by up to 20 % on these launches: every phase is
@@ -553,13 +567,15 @@ def config_cpu(c, epochs_sample=4, restarts_sample=6, batch=64, epochs=200):
         import contextlib
         ctx = contextlib.nullcontext()
     D, units, R, Ns, N = c["D"], c["units"], c["R"], c["Ns"], c["N"]
-    acts = ["relu"] * (len(units) - 1) + ["sigmoid"]
+    acts = c.get("acts") or ["relu"] * (len(units) - 1) + ["sigmoid"]
+    transform, gamma, epochs = c.get("transform", "identity"), c.get("gamma", 0.25), c.get("epochs", epochs)
+    restarts_sample = min(restarts_sample, R)
     rs = np.random.RandomState(0)
     with ctx:
         p = O.glorot_uniform_params(D, units, rs)
         st = O.AdamState(p)
         X, y = _synthetic(rs, 1, N, D)
-        z, _ = O.labels(y[0], 0.25)
+        z, _ = O.labels(y[0], gamma)
         perms = np.stack([rs.permutation(N) for _ in range(epochs_sample)])
         bf16 = c["compute"] == "bfloat16"
         t0 = time.perf_counter()
@@ -567,7 +583,7 @@ def config_cpu(c, epochs_sample=4, restarts_sample=6, batch=64, epochs=200):
         t_fit = (time.perf_counter() - t0) * epochs / epochs_sample
         t0 = time.perf_counter()
         res = O.maxima(p, acts, Bounds(np.zeros(D), np.ones(D)), num_starts=restarts_sample,
-                       num_samples=Ns, random_state=rs)
+                       num_samples=Ns, random_state=rs, transform=transform)
         t_arg = time.perf_counter() - t0
         t0 = time.perf_counter()
         O.predict(p, acts, rs.uniform(size=(Ns, D)))
@@ -576,6 +592,10 @@ def config_cpu(c, epochs_sample=4, restarts_sample=6, batch=64, epochs=200):
     total = t_fit + t_scr + t_restart * R
     return dict(value=1.0 / total, unit="BO-iterations/s", cores=1, kind="port",
                 ms=dict(fit=1e3 * t_fit, screen=1e3 * t_scr, lbfgsb=1e3 * t_restart * R),
+                # (context only: the restarts run on a net that has seen `epochs_sample` epochs, not `epochs` --
+                # another objective surface, other evaluation counts than the device's, whose restarts follow
+                # the full fit; the fit and screening legs are like for like)
+                same_work_as_device=False,
                 sample=f"{epochs_sample} of {epochs} epochs of the fit and {restarts_sample} of {R} "
                        f"sequential scipy restarts (fp32 numpy arithmetic"
                        f"{'; the fit in the bf16 statement' if bf16 else ''}), scaled; mean nit "
@@ -593,7 +613,7 @@ def all_configs(args, barrier, cpu):
     if hasattr(r["eng"], "close"):
         r["eng"].close()
     del r
-    for name, c in WIDE_CONFIGS.items():
+    for name, c in list(WIDE_CONFIGS.items()) + list(PLUGIN_CONFIGS.items()):
         try:
             one = config_gpu(name, c, loops=1)
             many = config_gpu(name, c, loops=256, reps=5)

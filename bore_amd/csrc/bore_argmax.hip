@@ -171,6 +171,7 @@ struct ScreenArgs {
   long long model0, draw;
   const int *ids, *its;  // batch mode: theta and the stream of loop ids[slot], draw its[slot]
   BoxArgs box;
+  int d_in;  // the net's input dimension (<= the static shape's: stage_theta_in)
 };
 
 // float -> unsigned that sorts like the float
@@ -204,13 +205,14 @@ __device__ __forceinline__ void screen_body(const ScreenArgs &a, const long long
   const int nthr = blockDim.x;
   // `model` is the output slot
   const long long lid = a.ids ? uniform_i64(a.ids[model]) : model;        // whose weights and stream
-  const int n = layer_count<SHAPE>(L), D = L.w[0];
+  const int n = layer_count<SHAPE>(L), D = (bore_shape_takes_fewer_inputs(SHAPE) && !BF16) ? a.d_in : L.w[0];
   const int Ns = (int)a.n_samples;
   float *th = smem, *tile = smem + a.o_tile;
   unsigned long long *keys = reinterpret_cast<unsigned long long *>(smem + a.o_keys);
   const int wv = tid >> 6, lane = tid & 63, m16 = lane & 15, q4 = lane >> 4;
   if constexpr (MODE != 2) {
     if constexpr (BF16) arg_bf16_stage<SHAPE>(a.theta + lid * L.P, smem);  // (arg_bf16_mfma.h)
+    else if constexpr (bore_shape_takes_fewer_inputs(SHAPE)) stage_theta_in<false>(L, n, a.theta, lid, D, smem);
     else stage_theta<false>(L, n, a.theta + lid * L.P, smem);
   }
   const double *X = a.sampled ? nullptr : a.X + (a.x_shared ? 0 : model * a.n_samples * D);
@@ -389,7 +391,8 @@ static int screen_build(const bore_mlp_desc *desc, int n_models, const float *th
     }
   }
   size_t off = a.L.P_lds;
-  const int flav = bore_kernel_flavour(desc, true);
+  a.d_in = desc->input_dim;
+  const int flav = bore_acq_flavour(desc, true);
   const bool bf_img = desc->compute == BORE_COMPUTE_BF16 && bore_shape_is_wide(flav);
   // (a bfloat16 model: the fragment-order images of arg_bf16_mfma.h, activations in registers)
   if (bf_img) off = flav == 3 ? ArgBf16Plan<3>::floats : ArgBf16Plan<4>::floats;
@@ -402,7 +405,7 @@ static int screen_build(const bore_mlp_desc *desc, int n_models, const float *th
   off = (off + 3) & ~(size_t)3;
   a.o_layout = (int)off; off += BORE_LAYOUT_FLOATS;
   lds_floats = off;
-  shape_out = bore_kernel_flavour(desc, true);  // (static flavours do not use the tile)
+  shape_out = flav;  // (static flavours do not use the tile)
   return 0;
 }
 
@@ -494,6 +497,9 @@ static int screen_launch(const bore_mlp_desc *desc, int n_models, const float *t
 #if BORE_ON_4
     BORE_LAUNCH_SCREEN(4)
 #endif
+#if BORE_ON_5
+    BORE_LAUNCH_SCREEN(5)
+#endif
 #if BORE_ON_N1
     BORE_LAUNCH_SCREEN(-1)
 #endif
@@ -577,6 +583,7 @@ struct LbfgsbArgs {
   double *result;
   int *flag;
   const long long *stamps;  // [n_loops][4] clock stamps of the fused kernel's earlier phases, or NULL
+  int d_in;  // the net's input dimension = the optimiser's problem size (<= the static shape's: stage_theta_in)
 };
 
 // -DBORE_STAMPS: cycles spent in the optimiser / in f-g evaluation by wave 0 of workgroup 0
@@ -634,7 +641,7 @@ __device__ __forceinline__ void lbfgsb_body(const LbfgsbArgs &a, const long long
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   // `model` is the slot: it indexes x0 / x / fun / jac / info
   const long long lid = a.ids ? uniform_i64(a.ids[model]) : model;  // whose weights (and record, and result)
-  const int n_lay = layer_count<SHAPE>(L), D = L.w[0];
+  const int n_lay = layer_count<SHAPE>(L), D = (bore_shape_takes_fewer_inputs(SHAPE) && !BF16) ? a.d_in : L.w[0];
   const int p0 = block_y * a.PB;                  // first problem of this workgroup
   const int np = min(a.PB, a.R - p0);             // problems here (>= 1 by grid construction)
   float *th = smem, *tile = smem + a.o_tile, *vals = smem + a.o_vals;
@@ -647,6 +654,7 @@ __device__ __forceinline__ void lbfgsb_body(const LbfgsbArgs &a, const long long
     bnbd[tid] = a.nbd[tid];
   }
   if constexpr (BF16) arg_bf16_stage<SHAPE>(a.theta + lid * L.P, smem);  // (arg_bf16_mfma.h)
+  else if constexpr (bore_shape_takes_fewer_inputs(SHAPE)) stage_theta_in<false>(L, n_lay, a.theta, lid, D, smem);
   else stage_theta<false>(L, n_lay, a.theta + lid * L.P, smem);
   __syncthreads();
 
@@ -1187,7 +1195,8 @@ static int lbfgsb_build(const bore_mlp_desc *desc, int n_models, const float *th
   const long long coop_grid_max =
       getenv("BORE_LBFGSB_COOP_GRID") ? atoll(getenv("BORE_LBFGSB_COOP_GRID")) : (1LL << 22);
   if (PB > 4 && !g_batch && (long long)n_models * ((num_starts + 3) / 4) <= coop_grid_max) PB = 4;
-  const int flavour = bore_kernel_flavour(desc, true);
+  const int flavour = bore_acq_flavour(desc, true);
+  a.d_in = D;
   // More workgroups than CUs, wide static shape: up to eight problems = eight waves per workgroup
   // (as many as fit beside the weights; lbfgsb_kernel_w8).  BORE_LBFGSB_W8 = 0 / 1 forces either.
   bool w8 = false;
@@ -1373,19 +1382,24 @@ extern "C" int bore_lbfgsb_minimize(const bore_mlp_desc *desc, int n_models, con
     // problem sooner.  BORE_LBFGSB_OCC2 = 0 / 1 forces either (tests, measurements).
     const int forced = getenv("BORE_LBFGSB_OCC2") ? atoi(getenv("BORE_LBFGSB_OCC2")) : -1;
     const bool many = (long long)n_models * blocks > device_cus();
-#if BORE_ON_2
-    // (one problem per wave only: the kernel does not carry the lane-per-problem loop)
-    if (flavour == 2 && (a.PB <= 4 || a.queue) && off * 4 <= BORE_LDS_BYTES / 2 && (forced < 0 ? many : forced != 0)) {
-      rc = allow_lds(lbfgsb_kernel_occ2<2>, off * 4);
-      if (rc) return rc;
-      hipLaunchKernelGGL(lbfgsb_kernel_occ2<2>, dim3(n_models, blocks), dim3(BORE_THREADS), off * 4,
-                         (hipStream_t)stream, a);
-      HIP_TRY(hipGetLastError());
-      return 0;
-    }
-#else
     (void)forced; (void)many;
+    // (one problem per wave only: the kernel does not carry the lane-per-problem loop)
+#define BORE_LAUNCH_OCC2(S)                                                                                                 \
+    if (flavour == (S) && (a.PB <= 4 || a.queue) && off * 4 <= BORE_LDS_BYTES / 2 && (forced < 0 ? many : forced != 0)) { \
+      rc = allow_lds(lbfgsb_kernel_occ2<S>, off * 4);                                                                       \
+      if (rc) return rc;                                                                                                    \
+      hipLaunchKernelGGL(lbfgsb_kernel_occ2<S>, dim3(n_models, blocks), dim3(BORE_THREADS), off * 4,                       \
+                         (hipStream_t)stream, a);                                                                           \
+      HIP_TRY(hipGetLastError());                                                                                           \
+      return 0;                                                                                                             \
+    }
+#if BORE_ON_2
+    BORE_LAUNCH_OCC2(2)
 #endif
+#if BORE_ON_5
+    BORE_LAUNCH_OCC2(5)  // (the plugin's default network: 5 restarts per loop, many loops)
+#endif
+#undef BORE_LAUNCH_OCC2
   }
   if (!bore_flavour_built(flavour)) return fail(BORE_E_UNSUPPORTED, BORE_FLAVOUR_LEFT_OUT);
 #define BORE_LAUNCH_LBFGSB(S)                                                                  \
@@ -1407,6 +1421,9 @@ extern "C" int bore_lbfgsb_minimize(const bore_mlp_desc *desc, int n_models, con
 #endif
 #if BORE_ON_4
     BORE_LAUNCH_LBFGSB(4)
+#endif
+#if BORE_ON_5
+    BORE_LAUNCH_LBFGSB(5)
 #endif
 #if BORE_ON_N1
     BORE_LAUNCH_LBFGSB(-1)

@@ -2086,6 +2086,7 @@ struct RowArgs {
   int x_shared, transform;
   float sign;  // -1: T(-f) (minimisation form), +1: T(f)
   int o_tile, o_vals, o_layout, total, shape, bf16;
+  int d_in;  // the net's input dimension (<= the static shape's: stage_theta_in)
 };
 
 template <bool WITH_GRAD, int SHAPE, bool BF16 = false>
@@ -2096,9 +2097,10 @@ __global__ __launch_bounds__(BORE_THREADS) void rows_kernel(const RowArgs a) {
   const int tid = threadIdx.x;
   const int wv = tid >> 6, lane = tid & 63, m16 = lane & 15, q4 = lane >> 4;
   const long long model = blockIdx.x;
-  const int n = layer_count<SHAPE>(L), D = L.w[0];
+  const int n = layer_count<SHAPE>(L), D = (bore_shape_takes_fewer_inputs(SHAPE) && !BF16) ? a.d_in : L.w[0];
   float *th = smem, *tile = smem + a.o_tile, *vals = smem + a.o_vals;
   if constexpr (BF16) arg_bf16_stage<SHAPE>(a.theta + model * L.P, smem);
+  else if constexpr (bore_shape_takes_fewer_inputs(SHAPE)) stage_theta_in<false>(L, n, a.theta, model, D, smem);
   else stage_theta<false>(L, n, a.theta + model * L.P, smem);
   __syncthreads();
   // waves that own a 16-row slice of the tile buffers (the bf16-MFMA form has no tile: all four)
@@ -2433,7 +2435,7 @@ static int fit_build(const bore_mlp_desc *desc, int n_models, float *theta, floa
      // everything else and only when it still fits, so that it moves nothing and decides nothing
     const int fl = fit_flavour(desc);
     if (!perm && !g_batch && a.perm_in_lds && PG == 1 && N <= 512 && batch_size <= BORE_BATCH_MAX &&
-        (fl == 2 || fl == BORE_FIT_SHAPE_16_32 || (fl < 0 && fl >= -4)) &&
+        (fl == 2 || fl == 5 || fl == BORE_FIT_SHAPE_16_32 || (fl < 0 && fl >= -4)) &&
         (off + (size_t)N + tail) * 4 <= BORE_LDS_BYTES) {
       a.perm_ahead = 1;
       a.o_perm2 = (int)off; off += (size_t)N;
@@ -2476,7 +2478,7 @@ static int bore_pads_to_shape(const bore_mlp_desc *d) {
   // (2->16-16-1, 6->32-32-1 and the two fit-only shapes: their static fits give the generic flavour's bits.  The
   // wide 16->64-64-64-1 fit does not -- same tolerance against the oracle, other low bits -- so a net padded onto it would change with the
   // path it takes: left on the generic flavour.)
-  for (int s : {1, 2, BORE_FIT_SHAPE_16_32, BORE_FIT_SHAPE_16_16}) {  // (the fewest zero columns first)
+  for (int s : {1, 2, 5, BORE_FIT_SHAPE_16_32, BORE_FIT_SHAPE_16_16}) {  // (the fewest zero columns first)
     if (!bore_flavour_built(s) || d->input_dim >= kShapes[s].D || d->n_layers != kShapes[s].n_layers) continue;
     bool ok = true;
     for (int i = 0; i < d->n_layers; ++i)
@@ -2572,7 +2574,7 @@ extern "C" int bore_mlp_fit(const bore_mlp_desc *desc, int n_models, float *thet
     const int forced = getenv("BORE_FIT_W8") ? atoi(getenv("BORE_FIT_W8")) : -1;
     int tiles = 0;
     for (int l = 1; l <= a.L.n_layers; ++l) tiles += (a.L.Np[l - 1] >> 4) * (a.L.Np[l] >> 4);
-    const bool can = !g_batch && (shape == 2 || shape == BORE_FIT_SHAPE_16_32 ||
+    const bool can = !g_batch && (shape == 2 || shape == 5 || shape == BORE_FIT_SHAPE_16_32 ||
                                   (shape < 0 && shape >= -4 && a.state_in_lds && tiles > 4));
     if (can && (forced < 0 ? n_models <= device_cus() : forced != 0)) {
 #define BORE_LAUNCH_FIT_W8(S)                                                                               \
@@ -2587,6 +2589,9 @@ extern "C" int bore_mlp_fit(const bore_mlp_desc *desc, int n_models, float *thet
         BORE_LAUNCH_FIT_W8(2)
 #endif
 #if BORE_ON_5
+        BORE_LAUNCH_FIT_W8(5)
+#endif
+#if BORE_ON_6
         BORE_LAUNCH_FIT_W8(BORE_FIT_SHAPE_16_32)
 #endif
 #if BORE_ON_N1
@@ -2628,9 +2633,12 @@ extern "C" int bore_mlp_fit(const bore_mlp_desc *desc, int n_models, float *thet
     BORE_LAUNCH_FIT(4)
 #endif
 #if BORE_ON_5
-    BORE_LAUNCH_FIT(BORE_FIT_SHAPE_16_32)
+    BORE_LAUNCH_FIT(5)
 #endif
 #if BORE_ON_6
+    BORE_LAUNCH_FIT(BORE_FIT_SHAPE_16_32)
+#endif
+#if BORE_ON_7
     BORE_LAUNCH_FIT(BORE_FIT_SHAPE_16_16)
 #endif
 #if BORE_ON_N1
@@ -2803,6 +2811,9 @@ static int row_launch(bool with_grad, int n_models, RowArgs &a, void *stream) {
 #if BORE_ON_4
     BORE_ROWS_BOTH(4)
 #endif
+#if BORE_ON_5
+    BORE_ROWS_BOTH(5)
+#endif
 #if BORE_ON_N1
     BORE_ROWS_BOTH(-1)
 #endif
@@ -2840,7 +2851,8 @@ extern "C" int bore_mlp_forward(const bore_mlp_desc *desc, int n_models, const f
   if (n_rows == 0) return 0;
   a.theta = theta; a.Xf = X; a.Xd = nullptr; a.out = out; a.grad = nullptr;
   a.n_rows = n_rows; a.x_shared = x_shared; a.transform = 0; a.sign = 1.f;
-  a.shape = bore_kernel_flavour(desc, true);
+  a.shape = bore_acq_flavour(desc, true);
+  a.d_in = desc->input_dim;
   a.bf16 = desc->compute == BORE_COMPUTE_BF16;
   if (a.bf16 && !bore_shape_is_wide(a.shape)) return fail(BORE_E_UNSUPPORTED, kBf16Shapes);
   return row_launch(false, n_models, a, stream);
@@ -2863,7 +2875,8 @@ extern "C" int bore_mlp_value_and_input_grad(const bore_mlp_desc *desc, int n_mo
   if (n_rows == 0) return 0;
   a.theta = theta; a.Xf = nullptr; a.Xd = X; a.out = val; a.grad = grad;
   a.n_rows = n_rows; a.x_shared = 0; a.transform = transform; a.sign = negate ? -1.f : 1.f;
-  a.shape = bore_kernel_flavour(desc, true);
+  a.shape = bore_acq_flavour(desc, true);
+  a.d_in = desc->input_dim;
   a.bf16 = desc->compute == BORE_COMPUTE_BF16;
   if (a.bf16 && !bore_shape_is_wide(a.shape)) return fail(BORE_E_UNSUPPORTED, kBf16Shapes);
   return row_launch(true, n_models, a, stream);

@@ -188,9 +188,9 @@ __device__ __forceinline__ long long uniform_i64(long long v) {
 // fit_body's `stage`: one slot per work-item and k-chunk of the first layer (static shapes 1, 2: at most two)
 // plus one for the label -- each lane's share of its next-step row (bore_hip.hip, pipe_perm)
 #define BORE_FIT_STAGE_FLOATS (3 * BORE_THREADS)
-// (the fit-only shapes -- 16 inputs -- have four k-chunks in their first layer)
+// (16->32-32-32-1 and the fit-only shapes -- 16 inputs -- have four k-chunks in their first layer)
 // (2->16-16-1 has one: two slots, which is part of what lets three loops of the fused kernel share a CU's LDS)
-#define BORE_FIT_STAGE_FLOATS_OF(shape) ((shape) > BORE_N_SHAPES ? 5 * BORE_THREADS : (shape) == 1 ? 2 * BORE_THREADS : BORE_FIT_STAGE_FLOATS)
+#define BORE_FIT_STAGE_FLOATS_OF(shape) ((shape) >= 5 ? 5 * BORE_THREADS : (shape) == 1 ? 2 * BORE_THREADS : BORE_FIT_STAGE_FLOATS)
 
 // Start of every kernel: zero the LDS, then hand out the layout.  Three kernel flavours:
 //   SHAPE > 0   a shape of mlp_shapes.h: the caller holds a constexpr layout (everything folds)

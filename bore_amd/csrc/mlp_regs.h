@@ -463,4 +463,21 @@ __device__ __forceinline__ void stage_theta(const MlpLayout &L, int n, const flo
   }
 }
 
+// The same for a static shape's kernel serving a net of FEWER inputs (d_in <= L.w[0]; mlp_shapes.h:
+// bore_acq_flavour): the packed vector holds d_in rows of W_1 (its first block, row-major [in][out]) where the
+// static layout counts L.w[0] -- same prefix, then everything behind W_1 shifted by the missing rows; the rows
+// d_in .. of the LDS image keep the zeros begin_kernel put there.  `g_all`: the first model's vector.
+template <bool BF16>
+__device__ __forceinline__ void stage_theta_in(const MlpLayout &L, int n, const float *__restrict__ g_all,
+                                               long long model, int d_in, float *smem) {
+  const int gap = (L.w[0] - d_in) * L.w[1], head = d_in * L.w[1], P_in = L.P - gap;
+  const float *g = g_all + model * P_in;
+  if (gap == 0) {
+    stage_theta<BF16>(L, n, g, smem);
+    return;
+  }
+  static_assert(!BF16, "float32 nets");
+  for (int p = threadIdx.x; p < P_in; p += blockDim.x) smem[param_ref(L, p < head ? p : p + gap, n).lds] = g[p];
+}
+
 }  // namespace bore

@@ -146,11 +146,13 @@ int bore_mlp_value_and_input_grad(const bore_mlp_desc *desc, int n_models,
  *   epoch_loss  device fp32 [n_models][epochs] or NULL: Keras' logged loss
  *   batch_size  >= 1 (more than BORE_BATCH_MAX rows: 64-row sub-tiles of one Adam step)
  * Kernel flavours: the networks BASELINE.json quotes have kernels with a compile-time layout (2->16-16-1,
- * 6->32-32-1, 16->64-64-64-1; bfloat16: the last and 32->128-128-1), the fit also for 16->32-32-1 (the HpBandSter
- * plugin's default widths) and 16->16-16-1; a float32 network with the widths and activations of 16-16-1 or 32-32-1 but FEWER
- * inputs is fitted on those kernels zero-padded (exact: the same bits as the generic flavour, 2.5x sooner; the
- * repack lives in a stream-ordered scratch, hipMallocAsync); anything else on the generic flavour (any widths, up
- * to 8 layers).
+ * 6->32-32-1, 16->64-64-64-1; bfloat16: the last and 32->128-128-1), and so has 16->32-32-32-1 -- what the
+ * reference's HpBandSter plugin builds by default (num_layers=2, num_units=32 go through DenseSequential's
+ * num_layers + 1 hidden layers, bore/models.py:16-19; fit AND acquisition kernels).  The fit also for 16->32-32-1
+ * (num_layers=1) and 16->16-16-1.  A float32 network with the widths and activations of one of these (2->16-16-1
+ * and the three 16-input layouts) but FEWER inputs is fitted on those kernels zero-padded (exact: the same bits as
+ * the generic flavour, 2.5x sooner; the repack lives in a stream-ordered scratch, hipMallocAsync); anything else on
+ * the generic flavour (any widths, up to 8 layers).
  */
 int bore_mlp_fit(const bore_mlp_desc *desc, int n_models, float *theta,
                  float *adam_m, float *adam_v, int64_t *adam_t, const float *X,

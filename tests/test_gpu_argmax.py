@@ -73,7 +73,8 @@ def test_screen_topk_selects_the_best_rows(gpu, Ns, R):
 
 
 @pytest.mark.parametrize("D,units,Ns,R", [(2, [16, 16, 1], 1024, 3), (6, [32, 32, 1], 1000, 40),
-                                          (16, [64, 64, 64, 1], 1024, 1024), (3, [8, 24, 1], 77, 5)])
+                                          (16, [64, 64, 64, 1], 1024, 1024), (3, [8, 24, 1], 77, 5),
+                                          (16, [32, 32, 32, 1], 1024, 5), (7, [32, 32, 32, 1], 1024, 5)])
 def test_sample_screen_topk_equals_the_two_launches(gpu, D, units, Ns, R):
     """bore_sample_screen_topk never writes the candidates: same picks and rows, bit for bit, as
     bore_uniform_candidates followed by bore_screen_topk."""
@@ -92,7 +93,8 @@ def test_sample_screen_topk_equals_the_two_launches(gpu, D, units, Ns, R):
 
 CASES = [(2, [16, 16, 1], ["relu", "relu", "sigmoid"], "identity", 3),
          (6, [32, 32, 1], ["relu", "relu", "linear"], "sigmoid", 40),
-         (3, [32, 32, 32, 1], ["elu"] * 3 + ["linear"], "exp", 9),
+         (3, [32, 32, 32, 1], ["elu"] * 3 + ["linear"], "exp", 9),          # static shape 5, three inputs
+         (10, [32, 32, 32, 1], ["elu"] * 3 + ["linear"], "sigmoid", 13),    # ... ten (the plugin's transform)
          (16, [64, 64, 64, 1], ["relu"] * 3 + ["linear"], "sigmoid", 70),
          (32, [128, 128, 1], ["relu", "relu", "linear"], "sigmoid", 10)]
 
@@ -100,7 +102,7 @@ CASES = [(2, [16, 16, 1], ["relu", "relu", "sigmoid"], "identity", 3),
 # lower bounds on the share of restarts whose whole record (nit, nfev, status, x) is scipy's, by input
 # dimension of the case -- set just below what this test measures (printed)
 # (measured r2: D=2 6/6, D=6 79/80, D=3 18/18, D=16 116/140, D=32 15/20)
-MIN_SAME = {2: 1.0, 6: 0.95, 3: 0.95, 16: 0.78, 32: 0.65}
+MIN_SAME = {2: 1.0, 6: 0.95, 3: 0.95, 10: 0.75, 16: 0.78, 32: 0.65}
 
 
 @pytest.mark.parametrize("D,units,acts,tr,R", CASES)

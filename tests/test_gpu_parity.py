@@ -50,7 +50,9 @@ CONFIGS = [  # BASELINE.json configs 1-3 and 5 (fp32), plus ragged shapes
     (6, [32, 32, 1], ["relu", "relu", "linear"]),
     (16, [64, 64, 64, 1], ["relu", "relu", "relu", "linear"]),
     (32, [128, 128, 1], ["relu", "relu", "linear"]),
-    (3, [32, 32, 32, 1], ["elu", "elu", "elu", "linear"]),
+    (3, [32, 32, 32, 1], ["elu", "elu", "elu", "linear"]),      # the plugin's default network: static shape 5's
+    (16, [32, 32, 32, 1], ["elu", "elu", "elu", "linear"]),     # acquisition kernels on 3, 16 and 11 inputs
+    (11, [32, 32, 32, 1], ["tanh", "relu", "elu", "sigmoid"]),
     (1, [1], ["sigmoid"]),
     (5, [7, 3, 1], ["tanh", "sigmoid", "linear"]),
 ]
@@ -233,7 +235,8 @@ def test_shuffle_stream_is_bit_exact_and_drives_fit(gpu):
 @pytest.mark.parametrize("D,units,acts", [(6, [32, 32, 1], ["relu", "relu", "sigmoid"]),          # static shape 2
                                           (10, [32, 32, 1], ["elu", "relu", "sigmoid"]),          # generic, 3 layers
                                           (12, [48, 1], ["tanh", "linear"]),                      # generic, 2 layers
-                                          (3, [16, 24, 16, 1], ["relu", "relu", "tanh", "sigmoid"])])  # 4 layers
+                                          (3, [16, 24, 16, 1], ["relu", "relu", "tanh", "sigmoid"]),  # 4 layers
+                                          (16, [32, 32, 32, 1], ["elu", "elu", "elu", "linear"])])    # static shape 5
 def test_eight_wave_fit_gives_the_same_bits(gpu, monkeypatch, D, units, acts):
     """fit_kernel_w8 (launches with no more models than compute units; 6->32-32-1 and the generic flavours with
     their Adam slots in LDS: the second four waves take half of the weight-gradient tiles, the fifth draws the
@@ -262,6 +265,8 @@ def test_eight_wave_fit_gives_the_same_bits(gpu, monkeypatch, D, units, acts):
                                           (1, [16, 16, 1], ["relu", "relu", "sigmoid"]),      # -> 2->16-16-1
                                           (6, [16, 16, 1], ["relu", "tanh", "sigmoid"]),      # -> 16->16-16-1 (fit only)
                                           (1, [16, 16, 1], ["elu", "relu", "linear"]),        # -> 16->16-16-1 (activations)
+                                          (10, [32, 32, 32, 1], ["elu", "elu", "elu", "linear"]),    # -> 16->32-32-32-1
+                                          (3, [32, 32, 32, 1], ["relu", "tanh", "elu", "sigmoid"]),   # -> 16->32-32-32-1
                                           (10, [64, 64, 64, 1], ["tanh", "relu", "relu", "linear"])])  # (not padded)
 def test_fit_zero_padded_to_a_static_shape_gives_the_generic_flavours_bits(gpu, monkeypatch, D, units, acts):
     """A float32 net with a static shape's widths and activations but fewer inputs is fitted on the static kernels,
@@ -610,6 +615,41 @@ def test_fit_with_more_than_64_rows_per_batch_against_oracle(gpu, N, B):
         np.testing.assert_allclose(h.cpu().numpy()[0], hist, rtol=5e-5)
         np.testing.assert_allclose(theta.cpu().numpy()[0], pack(p64), rtol=2e-4, atol=1e-5)
         np.testing.assert_allclose(m.cpu().numpy()[0], pack(st.m), rtol=2e-3, atol=1e-7)
+
+
+@pytest.mark.parametrize("units,acts", [([32, 32, 32, 1], ["elu", "elu", "elu", "linear"]),      # static shape 5
+                                        ([32, 32, 1], ["tanh", "relu", "sigmoid"]),                # fit-only shape 6
+                                        ([16, 16, 1], ["relu", "elu", "linear"])])                 # fit-only shape 7
+@pytest.mark.parametrize("N", [40, 64, 100, 200])
+def test_sixteen_input_static_fits_against_the_float64_trajectory(gpu, units, acts, N):
+    """The static fits on SIXTEEN inputs -- the plugin's real default network 16->32-32-32-1 and the two fit-only
+    layouts -- at their exact input dimension (no padding involved), straight against the oracle's float64
+    trajectory (rounds 3 - 4 held them to the generic flavour only): theta, m, v, the Adam
+    counter and the epoch losses, cold and warm-started, for data sets of one batch, one full batch, two and four."""
+    D, E, B = 16, 4, 64
+    rs = np.random.RandomState(N + len(units))
+    p = rand_model(rs, D, units)
+    X = rs.uniform(size=(N, D))
+    z = rs.uniform(size=N) < 1.0 / 3.0
+    perms = np.stack([rs.permutation(N) for _ in range(2 * E)])
+    p64 = [a.astype(np.float64) for a in p]
+    st = O.AdamState(p64)
+    desc = _lib.make_desc(D, units, acts)
+    theta = dev(pack(p)).reshape(1, -1)
+    m, v = torch.zeros_like(theta), torch.zeros_like(theta)
+    t = torch.zeros(1, dtype=torch.int64, device="cuda")
+    for half in range(2):           # (the second call warm-starts from the first one's state)
+        pe = perms[half * E:(half + 1) * E]
+        hist = O.fit(p64, acts, st, X.astype(np.float32), z, pe, batch_size=B, dtype=np.float64)
+        h = ops.mlp_fit(desc, theta, m, v, t, dev(X, torch.float32).reshape(1, N, D),
+                        dev(z.astype(np.float32)).reshape(1, N), E, B, perm=dev(pe.astype(np.int32)).reshape(1, E, N))
+        assert int(t[0]) == st.t == (half + 1) * E * O.steps_per_epoch(N, B)
+        np.testing.assert_allclose(h.cpu().numpy()[0], hist, rtol=2e-5)
+        ref = pack(p64)
+        err = np.abs(theta.cpu().numpy()[0] - ref) / (5e-6 + 1e-4 * np.abs(ref))   # (DESIGN 2: theta after a few steps)
+        assert err.max() <= 1.0, (half, float(err.max()))
+        np.testing.assert_allclose(m.cpu().numpy()[0], pack(st.m), rtol=1e-3, atol=1e-7)
+        np.testing.assert_allclose(v.cpu().numpy()[0], pack(st.v), rtol=1e-3, atol=1e-9)
 
 
 @pytest.mark.parametrize("D,units,compute", [(16, [64, 64, 64, 1], "float32"), (16, [64, 64, 64, 1], "bfloat16"),
