@@ -59,10 +59,10 @@ BF16_PEAK_TF = 2500.0    # dense bf16 MFMA peak
 TOTAL_LOOPS = 512        # BASELINE.json config 4
 def _latest(name):
     """profiles/rN/<name> of the newest round that has it."""
-    for rnd in ("r4", "r3"):
+    for rnd in ("r5", "r4", "r3"):
         if os.path.exists(os.path.join(ROOT, "profiles", rnd, name)):
             return os.path.join("profiles", rnd, name)
-    return os.path.join("profiles", "r4", name)
+    return os.path.join("profiles", "r5", name)
 
 
 TRAFFIC_FILE = _latest("pmc_traffic.json")
@@ -70,19 +70,11 @@ SWEEP_FILE = _latest("loops_sweep.json")   # T(1, L) measured on one GPU
 
 
 def csrc_digest():
-    """sha256 over the kernel sources (bore_amd/csrc/*.hip, *.h and include/bore_hip.h, names and
-    contents in sorted order): what a committed PMC pass was collected on (tools/collect_r4.py stores
-    it in pmc_traffic.json) against what this run times -- `traffic_stale` in the line."""
-    import hashlib
-    h = hashlib.sha256()
-    csrc = os.path.join(ROOT, "bore_amd", "csrc")
-    files = sorted(os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".h")))
-    files.append(os.path.join(ROOT, "include", "bore_hip.h"))
-    for f in files:
-        h.update(os.path.basename(f).encode() + b"\0")
-        with open(f, "rb") as fh:
-            h.update(fh.read())
-    return h.hexdigest()
+    """sha256 over the kernel sources: what a committed PMC pass was collected on (tools/collect_r5.py stores it in
+    pmc_traffic.json) against what this run times -- `traffic_stale` in the line.  (bore_amd._lib.source_digest: the
+    same digest the library carries.)"""
+    from bore_amd import _lib
+    return _lib.source_digest()
 
 
 def predicted_efficiency(world, total):
@@ -527,6 +519,21 @@ def config_gpu(name, c, loops, epochs=200, batch=64, reps=3):
     total_ms = float(ph.sum())
     peak_tf = BF16_PEAK_TF if c["compute"] == "bfloat16" else FP32_PEAK_TF
     kern = {"fit": ph[0], "screen": ph[1], "fg": ph[2]}
+    # HBM traffic by the counters, per phase: the committed PMC pass of the 256-loop launches of this config
+    # (tools/collect_r5.py: per kernel AND grid size).  Not collected in this run; stale when the sources moved.
+    traffic = {}
+    try:
+        with open(os.path.join(ROOT, TRAFFIC_FILE)) as f:
+            pmc = json.load(f)
+        if loops == 256:
+            for k, e in pmc.get("configs", {}).get(name, {}).items():
+                if isinstance(e, dict) and "hbm_bytes_per_launch" in e:
+                    traffic[k] = dict(kernel=e.get("kernel"), bytes=e["hbm_bytes_per_launch"],
+                                      frac_by_counters=e["hbm_bytes_per_launch"] / (kern[k] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                      issue_slot_utilisation=e.get("issue_slot_utilisation"),
+                                      stale=pmc.get("csrc_sha256") != csrc_digest())
+    except Exception:
+        pass
     return {
         "loops": loops, "it_per_s": loops / (total_ms * 1e-3), "epochs": int(epochs), "adam_steps": int(S),
         "ms": {"fit": float(ph[0]), "screen": float(ph[1]), "lbfgsb": float(ph[2]),
@@ -541,8 +548,11 @@ def config_gpu(name, c, loops, epochs=200, batch=64, reps=3):
         "fg_rows_per_iteration": rows, "restarts_ok_frac": float(np.mean(status <= 1)),
         "algorithmic_bytes": {k: float(x) for k, x in by.items()},
         "algorithmic_flops": {k: float(x) for k, x in fl.items()},
+        # ("frac": the streaming MODEL's bytes over measured time -- may exceed 1, see the note; "traffic" /
+        # "frac_by_counters": what the counters saw move, the fraction to quote)
         "roofline_hbm": {k: {"achieved_GBs": by[k] / (kern[k] * 1e-3) / 1e9,
-                             "frac": by[k] / (kern[k] * 1e-3) / 1e9 / HBM_PEAK_GBS} for k in by},
+                             "frac": by[k] / (kern[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, "frac_is": "model bytes / time",
+                             "traffic": traffic.get(k)} for k in by},
         "roofline_fma": {k: {"achieved_TFs": fl[k] / (kern[k] * 1e-3) / 1e12,
                              "frac": fl[k] / (kern[k] * 1e-3) / 1e12 / peak_tf,
                              "peak_TFs": peak_tf} for k in fl},
@@ -765,6 +775,11 @@ def run_rank(args):
                     "passes, committed; NOT collected in this run)",
                     # the committed pass belongs to THESE kernel sources (hash stored at collection)?
                     "traffic_stale": None if per_model is None else pmc.get("csrc_sha256") != digest,
+                    # the bound that means something for a chain of dependent small steps: wave-cycles in which a
+                    # wave issued an instruction / all wave-cycles (SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES of the same
+                    # committed pass; its complement is mostly SQ_WAIT_ANY)
+                    "issue_slot_utilisation": pmc.get(name, {}).get("issue_slot_utilisation"),
+                    "waiting_share_of_wave_cycles": pmc.get(name, {}).get("waiting_share_of_wave_cycles"),
                     "avg_launch_ms": float(ms_sum / launches),
                     "algorithmic_bytes_per_launch": float(bytes_sum / launches),
                     "launches": int(launches),

@@ -34,7 +34,7 @@ TRANSFORM = dict(identity=0, sigmoid=1, exp=2)
 
 # every symbol include/bore_hip.h declares (tests check the .so exports them all)
 EXPORTS = [
-    "bore_abi_version", "bore_last_error", "bore_param_count", "bore_mlp_forward",
+    "bore_abi_version", "bore_source_digest", "bore_last_error", "bore_param_count", "bore_mlp_forward",
     "bore_mlp_value_and_input_grad", "bore_mlp_fit", "bore_mlp_evaluate",
     "bore_shuffle_perm", "bore_labels", "bore_uniform_candidates", "bore_screen_topk", "bore_sample_screen_topk",
     "bore_lbfgsb_minimize", "bore_append_observations", "bore_select_best",
@@ -102,14 +102,45 @@ def hipcc_path():
     return None
 
 
+def source_digest():
+    """sha256 over the kernel sources (bore_amd/csrc/*.hip, *.h and include/bore_hip.h, names and contents in sorted
+    order): compiled into the library (bore_source_digest), stored with every committed PMC pass."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h")))
+    files.append(HEADER)
+    for f in files:
+        h.update(os.path.basename(f).encode() + b"\0")
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+def built_digest(path=None):
+    """The source digest compiled into the library at `path` (None: no library, or one from before ABI 11)."""
+    path = path or DEFAULT_LIB_PATH
+    if not os.path.exists(path):
+        return None
+    try:
+        L = C.CDLL(path)
+        L.bore_source_digest.restype = C.c_char_p
+        return L.bore_source_digest().decode()
+    except (OSError, AttributeError):
+        return None
+
+
 def build_native(force=False, verbose=False):
     """Compile libbore_hip.so for gfx950.  Cross-compiles without a GPU.  Always the default
-    in-tree path: an experimental build named by BORE_LIB_PATH is never overwritten."""
+    in-tree path: an experimental build named by BORE_LIB_PATH is never overwritten.
+    Up to date = the digest compiled into the library is the digest of the sources in the tree (file times say
+    nothing once a tree has travelled); BORE_FORCE_BUILD=1 or force=True compiles regardless."""
     out = DEFAULT_LIB_PATH
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hip"))] + [HEADER]
-    if (not force and os.path.exists(out)
-            and os.path.getmtime(out) >= max(os.path.getmtime(d) for d in deps)):
+    digest = source_digest()
+    force = force or os.environ.get("BORE_FORCE_BUILD", "0") not in ("", "0")
+    if not force and built_digest(out) == digest:
+        if verbose:
+            print(f"{out}: built from these sources ({digest[:16]}...), nothing to do")
         return out
     hipcc = hipcc_path()
     if hipcc is None:
@@ -118,7 +149,7 @@ def build_native(force=False, verbose=False):
     # out (fmaf); the fp64 L-BFGS-B then rounds exactly like its host build (tests compare
     # the two bit for bit) and like the unfused numpy/scipy arithmetic of the oracle.
     cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC",
-           "-ffp-contract=off", "-Wall", "-Wextra", *srcs, "-o", out]
+           "-ffp-contract=off", "-Wno-pass-failed", f'-DBORE_SRC_DIGEST="{digest}"', *srcs, "-o", out]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True, cwd=CSRC)

@@ -1124,6 +1124,19 @@ template <int SHAPE, bool BF16 = false>
 __global__ __launch_bounds__(BORE_THREADS, 2) void lbfgsb_kernel_occ2(const LbfgsbArgs a) {
   lbfgsb_body<SHAPE, BF16, true, true>(a, blockIdx.x, blockIdx.y);
 }
+#ifdef BORE_RU_PROBE_WIDE  // (register-pressure probes: the wide restart kernels at three waves per SIMD; never launched)
+template <int SHAPE, bool BF16>
+__global__ __launch_bounds__(BORE_THREADS, 3) void lbfgsb_kernel_occ3_probe(const LbfgsbArgs a) {
+  lbfgsb_body<SHAPE, BF16, true, true>(a, blockIdx.x, blockIdx.y);
+}
+template <int SHAPE, bool BF16>
+__global__ __launch_bounds__(3 * BORE_THREADS) void lbfgsb_kernel_w12_probe(const LbfgsbArgs a) {
+  lbfgsb_body<SHAPE, BF16, true, true>(a, blockIdx.x, blockIdx.y);
+}
+template __global__ void lbfgsb_kernel_occ3_probe<2, false>(const LbfgsbArgs a);
+template __global__ void lbfgsb_kernel_w12_probe<3, false>(const LbfgsbArgs a);
+template __global__ void lbfgsb_kernel_w12_probe<4, true>(const LbfgsbArgs a);
+#endif
 #ifdef BORE_RU_PROBE  // (register-pressure probe of the fused kernel's restart phase on its own; never launched)
 template <int SHAPE>
 __global__ __launch_bounds__(BORE_THREADS, BORE_RU_PROBE) void lbfgsb_kernel_probe(const LbfgsbArgs a) {
@@ -1283,7 +1296,7 @@ static int lbfgsb_build(const bore_mlp_desc *desc, int n_models, const float *th
   if (!g_batch && PB <= (w8 ? 8 : 4) && num_starts > PB && q_env != 0) {
     // (the 32-32-1 flavour stages 6 KB of weights and runs two workgroups per CU: finer shares -- 32 per CU
     // over the launch -- measured best there, profiles/r4/ab_log.txt; the wide flavours stage 40 - 50 KB)
-    const long long want = q_env > 0 ? q_env : (flavour == 2 ? 32LL : 4LL) * device_cus();
+    const long long want = q_env > 0 ? q_env : (flavour == 2 || flavour == 5 ? 32LL : 4LL) * device_cus();
     long long per_model = (want + n_models - 1) / n_models;
     const long long most = (num_starts + slots - 1) / slots;
     if (per_model > most) per_model = most;
@@ -1384,6 +1397,9 @@ extern "C" int bore_lbfgsb_minimize(const bore_mlp_desc *desc, int n_models, con
     const bool many = (long long)n_models * blocks > device_cus();
     (void)forced; (void)many;
     // (one problem per wave only: the kernel does not carry the lane-per-problem loop)
+    // (three per CU -- 168 registers, 12 spilled after round 5's register work -- measured the same 19.0 ms on
+    // BASELINE config 2 x 256 loops: the kernel is bound by vector-ALU issue of the optimiser's float64 arithmetic,
+    // which all 64 lanes carry out alike, not by latency another wave could hide; profiles/r5/ab_log.txt)
 #define BORE_LAUNCH_OCC2(S)                                                                                                 \
     if (flavour == (S) && (a.PB <= 4 || a.queue) && off * 4 <= BORE_LDS_BYTES / 2 && (forced < 0 ? many : forced != 0)) { \
       rc = allow_lds(lbfgsb_kernel_occ2<S>, off * 4);                                                                       \

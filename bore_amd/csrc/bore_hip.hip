@@ -98,6 +98,10 @@ extern "C" int bore_debug_wide_stamps(long long *out, int reset) {
 #endif
 
 extern "C" int bore_abi_version(void) { return BORE_ABI_VERSION; }
+#ifndef BORE_SRC_DIGEST
+#define BORE_SRC_DIGEST "unknown"
+#endif
+extern "C" const char *bore_source_digest(void) { return BORE_SRC_DIGEST; }
 
 extern "C" void bore_set_batch(const bore_batch *batch) {
   if (batch) {

@@ -16,11 +16,26 @@ from .mixins import BatchMaximizableMixin, MaximizableMixin
 
 
 class History:
-    """What Keras ``fit`` returns: ``.history['loss']`` is the per-epoch logged loss."""
+    """What Keras ``fit`` returns: ``.history['loss']`` is the per-epoch logged loss.
+
+    The losses are computed by the fit kernel either way; they are DOWNLOADED when first looked at.  ``fit`` itself
+    no longer waits for its kernel (round 5): the caller's next lines -- README.rst:93-95 goes straight on to
+    ``argmax`` -- run while the device fits, and a loop that never reads the history never pays for the copy."""
 
     def __init__(self, loss):
-        self.history = {"loss": [float(v) for v in loss]}
-        self.epoch = list(range(len(self.history["loss"])))
+        self._loss, self._history = loss, None
+
+    @property
+    def history(self):
+        if self._history is None:
+            loss = self._loss() if callable(self._loss) else self._loss
+            self._history = {"loss": [float(v) for v in loss]}
+            self._loss = None
+        return self._history
+
+    @property
+    def epoch(self):
+        return list(range(len(self.history["loss"])))
 
 
 class Sequential:
@@ -166,10 +181,19 @@ class Sequential:
             # host arrays (the reference's callers): features and labels cross PCIe in ONE copy
             xh = np.asarray(x, dtype=np.float32).reshape(-1, self._input_dim)
             N = xh.shape[0]
-            both = np.empty(N * (self._input_dim + 1), dtype=np.float32)
+            # (through a pinned staging buffer the model keeps: the copy is asynchronous and half the cost of one
+            # from pageable memory, tools/xfer_probe.py; the buffer is reused once its last copy has been seen done)
+            n_both = N * (self._input_dim + 1)
+            st = getattr(self, "_stage", None)
+            if st is None or st[0].numel() < n_both:
+                st = self._stage = (torch.empty(max(2 * n_both, 1024), dtype=torch.float32).pin_memory(), torch.cuda.Event())
+            else:
+                st[1].synchronize()
+            both = st[0].numpy()[:n_both]
             both[:N * self._input_dim] = xh.ravel()
             both[N * self._input_dim:] = np.asarray(y).reshape(-1)     # (raises on a length mismatch)
-            both = torch.from_numpy(both).to(self.theta.device)
+            both = st[0][:n_both].to(self.theta.device, non_blocking=True)
+            st[1].record()
             X = both[:N * self._input_dim].reshape(1, N, self._input_dim)
             z = both[N * self._input_dim:].reshape(1, N)
         else:
@@ -212,11 +236,15 @@ class Sequential:
                                              X, z, ne, batch_size, perm=pc, **kw))
                 loss = torch.cat(parts, dim=1)
             self._epochs_seen += n_epochs
-            return loss[0].cpu().numpy()
+            return loss
 
         callbacks = list(callbacks or [])
         if not callbacks:
-            return History(launch(0, epochs))
+            loss = launch(0, epochs)                 # (enqueued: nothing waits for the kernel here)
+            if verbose:
+                for e, v in enumerate(loss[0].cpu().numpy()):
+                    print(f"Epoch {e + 1}/{epochs} - loss: {float(v):.4f}")
+            return History(lambda: loss[0].cpu().numpy())
 
         def call(name, *args):
             for cb in callbacks:
@@ -230,7 +258,7 @@ class Sequential:
         losses = []
         for e in range(epochs):
             call("on_epoch_begin", e, {})
-            losses.append(float(launch(e, 1)[0]))
+            losses.append(float(launch(e, 1)[0].cpu().numpy()[0]))
             call("on_epoch_end", e, {"loss": losses[-1]})
             if self.stop_training:
                 break

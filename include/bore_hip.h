@@ -96,6 +96,10 @@ typedef struct bore_adam_cfg {
 } bore_adam_cfg;
 
 int bore_abi_version(void);
+/* ABI 11: sha256 (hex) of the kernel sources this library was compiled from -- the .hip and .h files of bore_amd/csrc and this
+ * header, names and contents in sorted order (bore_amd._lib.source_digest) -- or "unknown" for a build that was not
+ * given one.  bore_amd._lib.build_native() rebuilds when it differs from the tree's. */
+const char *bore_source_digest(void);
 const char *bore_last_error(void);
 
 /* Number of fp32 parameters P of the packed vector; <0 on a bad descriptor. */

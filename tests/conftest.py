@@ -59,10 +59,21 @@ def record_measurement(name, values):
         path = os.path.join(out_dir, "parity_measured.json")
         data = {}
         if os.path.exists(path):
-            with open(path) as f:
-                data = json.load(f)
+            try:
+                with open(path) as f:
+                    data = json.load(f)
+            except ValueError:      # (a file an interrupted run left half written: start over)
+                data = {}
         data[name] = values
-        with open(path, "w") as f:
-            json.dump(data, f, indent=1, sort_keys=True)
+
+        def plain(o):               # numpy scalars in a measurement are numbers, not a reason to fail
+            import numpy as np
+            if isinstance(o, np.generic):
+                return o.item()
+            raise TypeError(f"{type(o).__name__} in a recorded measurement")
+        text = json.dumps(data, indent=1, sort_keys=True, default=plain)
+        with open(path + ".tmp", "w") as f:
+            f.write(text)
+        os.replace(path + ".tmp", path)
     except OSError:          # a read-only tree must not fail a parity test
         pass

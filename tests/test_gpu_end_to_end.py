@@ -81,6 +81,10 @@ def test_fused_iteration_kernel_against_the_oracle_teacher_forced(gpu):
     n_iter = n_same_starts = n_pick_same = n_clean = n_clean_same = n_none_both = n_none_one = 0
     n_rest = n_rest_accept_agree = n_rest_both = n_rest_both_same = 0
     regret64 = []
+    # iterations where the two sides part visibly -- None on one side only, or a pick more than 1e-3 apart under
+    # the float64 network -- and what SciPy's own L-BFGS-B makes of the DEVICE's f / g from the device's starts
+    odd = dict(none_one_side=0, regret_above_1e3=0, explained_by_float32_objective=0, unexplained=[])
+    from bore_amd.optimizers import lockstep
     for it in range(T):
         th_prev, m_prev, v_prev, t_prev = eng.state()
         X_prev, y_prev = eng.observations()
@@ -136,11 +140,36 @@ def test_fused_iteration_kernel_against_the_oracle_teacher_forced(gpu):
             pick_same = (best is not None and bestd[l] >= 0
                          and np.allclose(x_eng, best.x, rtol=0, atol=1e-5))
             n_pick_same += pick_same
+            is_odd = bool((best is None) != (bestd[l] < 0))
+            odd["none_one_side"] += int(is_odd)
             if best is not None and bestd[l] >= 0:
                 # the suggestion valued by the FLOAT64 network against the oracle's own suggestion
                 v64 = lambda xx: float(O.value_and_input_grad(pe, ACTS, np.asarray(xx)[None, :], "identity",
                                                               dtype=np.float64)[0][0])
                 regret64.append(v64(x_eng) - v64(best.x))
+                if abs(regret64[-1]) > 1e-3:
+                    is_odd = True
+                    odd["regret_above_1e3"] += 1
+            if is_odd:
+                # Cause: the device's restarts ARE SciPy's restarts on the device's own
+                # float32 f / g -- same acceptance, accepted points within 1e-5 -- so what parts the two sides
+                # is the objective's arithmetic (float32 kernel against float32 numpy: other summation orders,
+                # other last bits, a line search at the noise floor ending one evaluation apart), not the
+                # optimiser's logic.
+                def fg_dev(Xb, l=l):
+                    Xb = np.atleast_2d(Xb)
+                    vv, gg = ops.mlp_value_and_input_grad(desc, thd[l:l + 1], torch.from_numpy(Xb[None]).cuda(),
+                                                          "identity", True)
+                    return vv.cpu().numpy()[0], gg.cpu().numpy()[0]
+                ref = lockstep.minimize_lockstep(fg_dev, x0d[l], bounds=BOUNDS, maxiter=1000, ftol=1e-9)
+                same = True
+                for r in range(R):
+                    acc_s, acc_d = bool(ref[r].success or ref[r].status == 1), infod[l, r, 2] in (0, 1)
+                    same = same and acc_s == acc_d and (not acc_s or np.allclose(ref[r].x, xd[l, r], rtol=0, atol=1e-5))
+                if same:
+                    odd["explained_by_float32_objective"] += 1
+                else:
+                    odd["unexplained"].append([int(it), int(l)])
             if not same_starts:
                 continue
             clean = True
@@ -169,13 +198,16 @@ def test_fused_iteration_kernel_against_the_oracle_teacher_forced(gpu):
         same_starts=[int(n_same_starts), n_iter], acceptance_agrees=[int(n_rest_accept_agree), n_rest],
         accepted_within_1e5=[int(n_rest_both_same), n_rest_both],
         pick_same_overall=[int(n_pick_same), n_iter], pick_same_clean=[int(n_clean_same), n_clean],
-        none_both=int(n_none_both), none_one_side=int(n_none_one),
+        none_both=int(n_none_both), none_one_side=int(n_none_one), visible_differences_by_cause=odd,
         pick_regret_under_float64_objective_quantiles_0_50_90_100=[
             float(q) for q in np.quantile(np.abs(regret64), [0.0, 0.5, 0.9, 1.0])]))
     # the stated float32 tolerance for suggested candidates: valued by the float64 network, the engine's
     # suggestion is within 1e-3 of the oracle's in at least 95 % of the iterations where both suggest one
     # (a restart that ends on another float32 plateau of the sigmoid accounts for the rest)
     assert np.mean(np.abs(regret64) <= 1e-3) >= 0.95, np.sort(np.abs(regret64))[-5:]
+    # ... and every visible difference has the cause named above: SciPy on the device's f / g does what the device did
+    print("[end-to-end, teacher-forced] visible differences:", odd)
+    assert not odd["unexplained"], odd
     # measured (r2, 16 loops x 5 iterations): same starts 77/80 (0.96); acceptance agrees 192/231
     # (0.83); accepted restarts within 1e-5: 166/172 (0.97); suggestion 48/50 (0.96) where all
     # acceptances agree, 64/80 (0.80) overall.  Floors = measured - 5 points.
@@ -422,6 +454,7 @@ def _wide_chain_teacher_forced(name, D2, U2, A2, compute, L, T, R, NS, E, N0, se
     n_iter = n_same_starts = n_pick_same = n_none_dev = n_none_ora = 0
     n_rest = n_acc_agree = n_both = n_both_same = 0
     start_overlap, dfun, regret, regret64, theta_within, fit_loss_rel = [], [], [], [], [], []
+    bf16_logit_ulps, bf16_causes = [], dict(gate=0, step=0, other=0, weights=0)
     # why an accepted-by-one restart is not accepted by the other: (oracle status, device status)
     status_pairs = {}
     for it in range(T):
@@ -463,10 +496,44 @@ def _wide_chain_teacher_forced(name, D2, U2, A2, compute, L, T, R, NS, E, N0, se
                 theta_within.append(float(np.mean(err <= 1.0)))
                 a_dev = O.forward_bf16(pe, A2[:-1] + ["linear"], X[l])
                 a_ref = O.forward_bf16(p, A2[:-1] + ["linear"], X[l])
+                # -- the FUNCTION, row by row: the two classifiers' logits on the training set,
+                # in bfloat16 steps at the logit's magnitude (2^-7 relative: the output is rounded to bfloat16)
+                ulp = 2.0 ** (np.floor(np.log2(np.maximum(np.maximum(np.abs(a_dev), np.abs(a_ref)), 2.0 ** -6))) - 7)
+                bf16_logit_ulps.append(float(np.max(np.abs(a_dev - a_ref) / ulp)))
+                # -- the out-of-tolerance weights by cause: (gate) the weight feeds or leaves a hidden unit that is
+                # ON for some training row under one net and OFF under the other -- a ReLU gate flipped by a
+                # rounding --, (step) it differs by no more than a handful of Adam steps (a near-zero gradient
+                # whose sign a rounding flips moves the weight by lr the other way: 2 lr per such step), (other)
+                hs_d = O.forward_bf16(pe, A2[:-1] + ["linear"], X[l], return_all=True)
+                hs_r = O.forward_bf16(p, A2[:-1] + ["linear"], X[l], return_all=True)
+                flipped = [np.zeros(D2, bool)] + [np.any((hd > 0) != (hr > 0), axis=0) for hd, hr in zip(hs_d[1:], hs_r[1:])]
+                off, fan = 0, D2
+                cause = np.zeros(len(ref), np.int8)            # 1 gate, 2 step, 3 other (0: within tolerance)
+                diff = np.abs(th[l] - ref)
+                for li, u in enumerate(U2):
+                    gate_w = (flipped[li][:, None] | flipped[li + 1][None, :]).ravel()
+                    gate = np.concatenate([gate_w, flipped[li + 1]])
+                    seg = slice(off, off + fan * u + u)
+                    bad = err[seg] > 1.0
+                    cause[seg] = np.where(bad, np.where(gate, 1, np.where(diff[seg] <= 8e-3, 2, 3)), 0)
+                    off += fan * u + u
+                    fan = u
+                for k, nm in ((1, "gate"), (2, "step"), (3, "other")):
+                    bf16_causes[nm] += int(np.sum(cause == k))
+                bf16_causes["weights"] += len(ref)
                 l_dev = float(O.bce_with_logits(a_dev, z[l].reshape(-1, 1)).mean())
                 l_ref = float(O.bce_with_logits(a_ref, z[l].reshape(-1, 1)).mean())
                 fit_loss_rel.append(abs(l_dev - l_ref) / l_ref)
-                assert theta_within[-1] >= 0.97 and fit_loss_rel[-1] <= 0.02, (name, it, l, theta_within[-1], fit_loss_rel[-1])
+                # What is asserted (round 5): the FUNCTION -- every training row's logit within 8 bfloat16 steps of
+                # the oracle's (measured: <= 4), the losses within 2 % -- and that the weights outside the tolerance
+                # are the ones a flipped ReLU gate or a flipped near-zero gradient explains (measured: 656 of 659).
+                # The share of weights inside the tolerance (measured 0.975 - 1.0) is recorded, with a floor far
+                # enough below it that a rounding flipped on another box does not turn the suite red.
+                n_bad = int(np.sum(err > 1.0))
+                n_other = int(np.sum(cause == 3))
+                assert bf16_logit_ulps[-1] <= 8.0 and fit_loss_rel[-1] <= 0.02, (name, it, l, bf16_logit_ulps[-1], fit_loss_rel[-1])
+                assert n_other <= max(3, 0.1 * n_bad), (name, it, l, n_bad, n_other)
+                assert theta_within[-1] >= 0.93, (name, it, l, theta_within[-1])
             else:
                 assert err.max() <= 1.0, (name, it, l, float(err.max()))
             Xc = sampling.uniform_candidates(5, 1, NS, lo, hi, model_index0=100 + l, draw_index=it)[0]
@@ -518,6 +585,8 @@ def _wide_chain_teacher_forced(name, D2, U2, A2, compute, L, T, R, NS, E, N0, se
         acceptance_agrees=[int(n_acc_agree), n_rest], accepted_within_1e5=[int(n_both_same), n_both],
         status_pairs_oracle_device=status_pairs,
         bf16_fit_theta_share_within_tolerance=theta_within or None, bf16_fit_loss_relative_difference=fit_loss_rel or None,
+        bf16_fit_worst_logit_difference_in_bf16_ulps=bf16_logit_ulps or None,
+        bf16_fit_out_of_tolerance_weights_by_cause=bf16_causes if bf else None,
         pick_same_or_equally_good=[int(n_pick_same), n_iter], none_device=int(n_none_dev), none_oracle=int(n_none_ora),
         abs_dfun_q50_q90_q99_max=[float(q) for q in np.quantile(dfun, [0.5, 0.9, 0.99, 1.0])] if len(dfun) else None,
         pick_regret_under_oracle_objective=[float(q) for q in np.sort(regret)],

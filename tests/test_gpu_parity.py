@@ -756,3 +756,35 @@ def test_fit_of_a_data_set_whose_shuffle_does_not_fit_in_lds(gpu):
     hm = model.fit(X, z, epochs=E, batch_size=B)
     np.testing.assert_array_equal(np.asarray(hm.history["loss"], dtype=np.float32), h.cpu().numpy()[0])
     np.testing.assert_array_equal(model.theta.cpu().numpy()[0], theta.cpu().numpy()[0])
+
+
+@pytest.mark.parametrize("D,units,acts,compute,N,E", [
+    (16, [64, 64, 64, 1], ["relu", "elu", "tanh", "sigmoid"], "float32", 64, 1),     # fit_kernel<3>: one cold step
+    (16, [64, 64, 64, 1], ["relu", "elu", "tanh", "sigmoid"], "float32", 256, 3),
+    (16, [64, 64, 64, 1], ["relu", "elu", "tanh", "sigmoid"], "bfloat16", 64, 1),    # fit_bf16_mfma_kernel<3>
+    (32, [128, 128, 1], ["relu", "relu", "sigmoid"], "bfloat16", 64, 1),             # fit_bf16_mfma_kernel<4>
+    (32, [128, 128, 1], ["relu", "relu", "sigmoid"], "bfloat16", 256, 2),
+    (16, [32, 32, 32, 1], ["elu", "elu", "elu", "linear"], "float32", 100, 2)])      # fit_kernel_w8<5>
+def test_wide_fits_reproduce_bit_for_bit_over_200_runs(gpu, D, units, acts, compute, N, E):
+    """The wide fits stream m / v from HBM tile by tile with requests several tiles ahead of their use.  Round 4's
+    eight-wave variant of the float32 one stored a slot's value from BEFORE its update in 13 - 68 % of cold
+    single-step runs (profiles/r4/ab_log.txt; cause not found, variant dropped).  The kernels that ship use the
+    same request scheme: until that cause is understood every one of them is held to run-to-run reproducibility
+    here -- the same launch 200 times from the same state, cold single steps included (the failing case), theta,
+    m and v compared bit for bit."""
+    rs = np.random.RandomState(11)
+    desc = _lib.make_desc(D, units, acts, compute=compute)
+    th0 = np.stack([pack(rand_model(rs, D, units)) for _ in range(2)])
+    X = dev(rs.uniform(size=(2, N, D)), torch.float32)
+    z = dev((rs.uniform(size=(2, N)) < 0.25).astype(np.float32))
+
+    def run():
+        th = dev(th0)
+        m, v = torch.zeros_like(th), torch.zeros_like(th)
+        t = torch.zeros(2, dtype=torch.int64, device="cuda")
+        ops.mlp_fit(desc, th, m, v, t, X, z, E, 64, seed=5, want_loss=False)
+        return torch.cat([th.view(-1), m.view(-1), v.view(-1)])
+
+    ref = run()
+    bad = sum(int(not torch.equal(run(), ref)) for _ in range(200))
+    assert bad == 0, f"{bad} of 200 runs differ"
