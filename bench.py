@@ -719,6 +719,20 @@ def run_rank(args):
     st = r["st"]
 
     t_repeats_done = time.perf_counter()
+    # N > 1, config 4 as written (512 loops over the node): the same line also carries the WEAK point -- 512 loops on
+    # EVERY GPU, what a single GPU runs for the headline -- so that one invocation per N gives the scaling curve that
+    # means something for this path (eff_w: same per-GPU load) beside the as-written one (64 loops per GPU at N = 8:
+    # a loop is a serial chain that an emptier GPU runs no faster).  All ranks take part; max over ranks.
+    weak = None
+    if world > 1 and not args.no_efficiency and args.loops is None and args.total_loops is None:
+        rw = timed_run(args, shard_loop_ids(rank, world, TOTAL_LOOPS), barrier)
+        if hasattr(rw["eng"], "close"):
+            rw["eng"].close()
+        tw = torch.tensor([rw["dt"]], dtype=torch.float64, device="cuda" if args.backend == "nccl" and not dry else "cpu")
+        dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+        weak = {"loops_per_gpu": TOTAL_LOOPS, "total_loops": TOTAL_LOOPS * world, "scaling": "weak",
+                "value": TOTAL_LOOPS * world * args.steps / float(tw[0]), "ms_per_step": 1e3 * float(tw[0]) / args.steps}
+        del rw
     # N > 1: the single-GPU reference points of the two efficiencies, timed by rank 0 ALONE
     eff = None
     if world > 1 and not args.no_efficiency:
@@ -739,6 +753,9 @@ def run_rank(args):
             v_share = ref_point(loops)
             v_all = ref_point(total)
             v = med["value"]
+            if weak is not None:          # (T(1, 512) is v_all when the job is config 4 as written)
+                weak["T_1"] = v_all if total == TOTAL_LOOPS else ref_point(TOTAL_LOOPS)
+                weak["eff_w"] = weak["value"] / (world * weak["T_1"])
             eff = {"T_N_total": v, "T_1_share": v_share, "T_1_total": v_all,
                    "share_loops": loops, "total_loops": total,
                    "eff_w": v / (world * v_share), "eff_s": v / (world * v_all),
@@ -919,6 +936,8 @@ def run_rank(args):
             out["loops_sweep_committed"] = None
         if eff is not None:
             out["efficiency"] = eff
+        if weak is not None:
+            out["weak_point_512_loops_per_gpu"] = weak
         if world > 1:
             # said before it is measured: config 4 AS WRITTEN (512 loops in total) leaves each GPU
             # total/N loops, and a loop is a sequential chain that runs no faster on an emptier GPU

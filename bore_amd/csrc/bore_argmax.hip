@@ -1098,7 +1098,11 @@ __device__ __forceinline__ void lbfgsb_body(const LbfgsbArgs &a, const long long
     put(D + 7, exec_sum);  // evaluations that ran the network (<= nfev_sum: the image shortcut serves the rest)
     if constexpr (PUBLISH == 1) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (this lane's stores -- the pick above among them -- are acknowledged)
-      __hip_atomic_store(a.flag + lid, it_done + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      // (an exchange, not a store: the wave waits for it to have happened.  As a plain write-through store the flag
+      // reached the host late and in bursts -- the host's result -> row turn-around went from 1.5 to 17 us per
+      // loop-iteration, all of what the cheaper hand-overs had saved; a buffer_wbl2 after the store changed nothing,
+      // profiles/r5/ab_log.txt)
+      (void)__hip_atomic_exchange(a.flag + lid, it_done + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     } else {
       __threadfence_system();
       __hip_atomic_store(a.flag + lid, it_done + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);

@@ -227,7 +227,10 @@ __global__ __launch_bounds__(BORE_THREADS, OCC) void iteration_kernel(const Iter
     unsigned long long pa_bits = reinterpret_cast<unsigned long long>(pa);
     asm volatile("" : "+s"(pa_bits));
     typedef const __attribute__((address_space(4))) IterArgs *IterArgsConst;
-    iteration_once<SHAPE, true>((const IterArgs *)(IterArgsConst)pa_bits, slot, it, it == it_first);
+#ifndef BORE_ITER_LOCAL
+#define BORE_ITER_LOCAL true  // -DBORE_ITER_LOCAL=false: rounds 2 - 4's agent / system-scope fences (A/B, profiles/r5/ab_log.txt)
+#endif
+    iteration_once<SHAPE, BORE_ITER_LOCAL>((const IterArgs *)(IterArgsConst)pa_bits, slot, it, it == it_first);
     __syncthreads();  // the waves leave the restart phase one by one: LDS is reused below
     ++it;
 #if BORE_LAG_PRIO

@@ -36,6 +36,11 @@ def test_spawns_its_own_ranks_config4_as_written():
     eff = d["efficiency"]
     assert eff["share_loops"] == 256 and eff["total_loops"] == 512
     assert set(("eff_w", "eff_s", "T_1_share", "T_1_total", "T_N_total")) <= set(eff)
+    # ... and, in the same line, the weak point: 512 loops on EVERY GPU (what one GPU runs for the headline), with
+    # its own eff_w against T(1, 512) -- the curve that means something for a path of independent serial chains
+    weak = d["weak_point_512_loops_per_gpu"]
+    assert weak["loops_per_gpu"] == 512 and weak["total_loops"] == 1024 and weak["scaling"] == "weak"
+    assert weak["T_1"] == eff["T_1_total"] and abs(weak["eff_w"] - weak["value"] / (2 * weak["T_1"])) < 1e-12
 
 
 def test_eight_ranks_the_drivers_widest_launch():

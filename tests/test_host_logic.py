@@ -230,14 +230,21 @@ def test_tools_and_committed_measurements_are_readable():
     for path in scripts:
         py_compile.compile(path, doraise=True)
     import bench
-    assert bench.TRAFFIC_FILE.startswith(os.path.join("profiles", "r4")) and bench.SWEEP_FILE.startswith(os.path.join("profiles", "r4"))
+    assert bench.TRAFFIC_FILE.startswith(os.path.join("profiles", "r5")) and bench.SWEEP_FILE.startswith(os.path.join("profiles", "r5"))
     traffic = json.load(open(os.path.join(root, bench.TRAFFIC_FILE)))
     assert traffic["iteration_kernel"]["hbm_bytes_per_model"] > 0
     # the PMC pass names the kernel sources it was collected on; bench.py compares with the tree it times
     assert len(traffic["csrc_sha256"]) == 64 and len(bench.csrc_digest()) == 64
     sweep = json.load(open(os.path.join(root, bench.SWEEP_FILE)))
-    assert set(sweep["it_per_s"]) >= {"64", "512", "1024", "4096"}
-    line = json.loads(open(os.path.join(root, "profiles", "r4", "bench_driver_form.json")).read().strip().splitlines()[-1])
+    assert set(sweep["it_per_s"]) >= {"64", "512", "768", "1024", "4096"}
+    # (round 5: per (kernel, grid) counter passes; per config and phase the 256-loop launch's bytes and its kernel)
+    assert 0.0 < traffic["iteration_kernel"]["issue_slot_utilisation"] < 1.0
+    for cfg in ("cfg2_hartmann6_32-32-1_R256", "cfg3_hpo16_64-64-64-1_R1024", "cfg5_nas32_128-128-1_bf16_R4096", "plugin_default_D16"):
+        for phase in ("fit", "screen", "fg"):
+            e = traffic["configs"][cfg][phase]
+            assert e["hbm_bytes_per_launch"] > 0 and e["kernel"] and e["avg_ns_kernel_trace"] > 0
+    line = json.loads(open(os.path.join(root, "profiles", "r5", "bench_driver_form.json")).read().strip().splitlines()[-1])
+    assert line["configs"]["plugin_default_D16"]["many_loops"]["loops"] == 256
     for cfg in ("cfg2_hartmann6_32-32-1_R256", "cfg3_hpo16_64-64-64-1_R1024", "cfg5_nas32_128-128-1_bf16_R4096"):
         reps = line["configs"][cfg]["many_loops"]["ms_reps"]
         assert reps["n"] >= 5 and reps["min"]["lbfgsb"] <= line["configs"][cfg]["many_loops"]["ms"]["lbfgsb"] <= reps["max"]["lbfgsb"]

@@ -1,6 +1,6 @@
 """Phase cycles of the restart kernels of the wide BASELINE configs, summed over the problems of ONE loop
 (diagnostic build libbore_hip_stamps.so = -DBORE_STAMPS [-DBORE_SHAPE_MASK=...]; GPU box).
-usage: python tools/wide_phases.py <cfg2|cfg3|cfg5> [loops]"""
+usage: python tools/wide_phases.py <cfg2|cfg3|cfg5> [loops] [restarts per loop]"""
 import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -13,6 +13,8 @@ key = {"cfg2": "cfg2_hartmann6_32-32-1_R256", "cfg3": "cfg3_hpo16_64-64-64-1_R10
 loops = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 c = bench.WIDE_CONFIGS[key]
 D, units, R, Ns, N = c["D"], c["units"], c["R"], c["Ns"], c["N"]
+if len(sys.argv) > 3:          # (restarts per loop: 4 = one workgroup of four waves, ONE wave per SIMD)
+    R = int(sys.argv[3])
 acts = ["relu"] * (len(units) - 1) + ["sigmoid"]
 desc = _lib.make_desc(D, units, acts, compute=c["compute"])
 P = ops.param_count(desc)
