@@ -1155,6 +1155,15 @@ __global__ __launch_bounds__(2 * BORE_THREADS) void lbfgsb_kernel_w8(const Lbfgs
   lbfgsb_body<SHAPE, BF16, true, true>(a, blockIdx.x, blockIdx.y);
 }
 
+// Twelve waves (three per SIMD, 168 registers) for the narrow shapes, whose problems are small enough for twelve
+// workspaces beside the weights in ONE workgroup's LDS: the restart kernels run chains of dependent LDS round trips
+// and float64 operations -- a call of cauchy takes the same 13 - 15 k cycles alone on the device and at two waves
+// per SIMD on a full one (profiles/r5/ab_log.txt) -- so a third wave per SIMD is throughput for free.
+template <int SHAPE, bool BF16 = false>
+__global__ __launch_bounds__(3 * BORE_THREADS) void lbfgsb_kernel_w12(const LbfgsbArgs a) {
+  lbfgsb_body<SHAPE, BF16, true, true>(a, blockIdx.x, blockIdx.y);
+}
+
 static int lbfgsb_build(const bore_mlp_desc *desc, int n_models, const float *theta,
                         int transform, int negate, const double *x0, int num_starts,
                         const double *lb, const double *ub, const bore_lbfgsb_opts *opts, double *x,
@@ -1223,6 +1232,14 @@ static int lbfgsb_build(const bore_mlp_desc *desc, int n_models, const float *th
     w8 = forced < 0 ? (long long)n_models * ((num_starts + 3) / 4) > device_cus() : forced != 0;
     if (w8) PB = 8;
   }
+  // ... and up to twelve for the narrow static shapes (lbfgsb_kernel_w12; BORE_LBFGSB_W12 = 0 / 1 forces either)
+  bool w12 = false;
+  if (waves_out && !g_batch && PB == 4 && num_starts >= 12 && (flavour == 2 || flavour == 5)) {
+    const int forced = getenv("BORE_LBFGSB_W12") ? atoi(getenv("BORE_LBFGSB_W12")) : -1;
+    w12 = forced < 0 ? (long long)n_models * ((num_starts + 3) / 4) > device_cus() : forced != 0;
+    if (w12) PB = 12;
+  }
+  const int wmax = w12 ? 12 : (w8 ? 8 : 4);  // waves (= problems at a time) per workgroup of this launch's kernel
   const int shape = flavour > 0 ? flavour : 0;  // constexpr-layout kernels assume a 64-row tile
   size_t off = 0;
   for (;; --PB) {
@@ -1243,7 +1260,7 @@ static int lbfgsb_build(const bore_mlp_desc *desc, int n_models, const float *th
     a.o_tile = (int)off;
     // (one problem per wave -- up to 4 problems, 8 in the eight-wave kernel, 16 in batch mode -- reads
     // its point straight from the optimiser's vector: no staging region at all)
-    const bool per_wave = PB <= (w8 ? 8 : 4) || (g_batch && PB <= 16);
+    const bool per_wave = PB <= wmax || (g_batch && PB <= 16);
     off += shape ? (per_wave ? 0 : 2 * (size_t)BORE_BATCH_MAX * a.L.lda[0]) : (size_t)a.L.tile_floats;
     a.o_vals = (int)off; off += BORE_BATCH_MAX;
     off = (off + 3) & ~(size_t)3;  // 16-byte boundary for the fp64 regions
@@ -1297,10 +1314,10 @@ static int lbfgsb_build(const bore_mlp_desc *desc, int n_models, const float *th
   const int slots = PB;  // workspaces = waves with a problem
   a.queue = 0;
   const long long q_env = getenv("BORE_LBFGSB_QUEUE") ? atoll(getenv("BORE_LBFGSB_QUEUE")) : -1;
-  if (!g_batch && PB <= (w8 ? 8 : 4) && num_starts > PB && q_env != 0) {
+  if (!g_batch && PB <= wmax && num_starts > PB && q_env != 0) {
     // (the 32-32-1 flavour stages 6 KB of weights and runs two workgroups per CU: finer shares -- 32 per CU
     // over the launch -- measured best there, profiles/r4/ab_log.txt; the wide flavours stage 40 - 50 KB)
-    const long long want = q_env > 0 ? q_env : (flavour == 2 || flavour == 5 ? 32LL : 4LL) * device_cus();
+    const long long want = q_env > 0 ? q_env : ((flavour == 2 || flavour == 5) && !w12 ? 32LL : 4LL) * device_cus();
     long long per_model = (want + n_models - 1) / n_models;
     const long long most = (num_starts + slots - 1) / slots;
     if (per_model > most) per_model = most;
@@ -1309,7 +1326,7 @@ static int lbfgsb_build(const bore_mlp_desc *desc, int n_models, const float *th
     a.queue = PB > slots;
   }
   a.PB = PB;
-  if (waves_out) *waves_out = w8 && slots > 4 ? slots : 4;
+  if (waves_out) *waves_out = (w8 || w12) && slots > 4 ? slots : 4;
   if (a.L.w[a.L.n_layers] != 1)
     return fail(BORE_E_INVALID, "lbfgsb_minimize: the last Dense layer must have 1 unit");
   a.theta = theta; a.x0 = x0; a.x = x; a.fun = fun; a.jac = jac; a.info = info;
@@ -1356,8 +1373,14 @@ extern "C" int bore_lbfgsb_minimize(const bore_mlp_desc *desc, int n_models, con
     hipLaunchKernelGGL((K), dim3(n_models, blocks), dim3(64 * waves), off * 4, (hipStream_t)stream, a); \
   }
     if (!bore_flavour_built(flavour)) return fail(BORE_E_UNSUPPORTED, BORE_FLAVOUR_LEFT_OUT);
-    if (!(flavour == 3 || (flavour == 4 && bf)))
-      return fail(BORE_E_UNSUPPORTED, "lbfgsb_minimize: no eight-wave kernel for this flavour");
+    if (!(flavour == 3 || (flavour == 4 && bf) || ((flavour == 2 || flavour == 5) && !bf)))
+      return fail(BORE_E_UNSUPPORTED, "lbfgsb_minimize: no many-wave kernel for this flavour");
+#if BORE_ON_2
+    if (flavour == 2) BORE_LAUNCH_W8((lbfgsb_kernel_w12<2, false>))
+#endif
+#if BORE_ON_5
+    if (flavour == 5) BORE_LAUNCH_W8((lbfgsb_kernel_w12<5, false>))
+#endif
 #if BORE_ON_3
     if (flavour == 3 && !bf) BORE_LAUNCH_W8((lbfgsb_kernel_w8<3, false>))
     if (flavour == 3 && bf) BORE_LAUNCH_W8((lbfgsb_kernel_w8<3, true>))
@@ -1401,9 +1424,7 @@ extern "C" int bore_lbfgsb_minimize(const bore_mlp_desc *desc, int n_models, con
     const bool many = (long long)n_models * blocks > device_cus();
     (void)forced; (void)many;
     // (one problem per wave only: the kernel does not carry the lane-per-problem loop)
-    // (three per CU -- 168 registers, 12 spilled after round 5's register work -- measured the same 19.0 ms on
-    // BASELINE config 2 x 256 loops: the kernel is bound by vector-ALU issue of the optimiser's float64 arithmetic,
-    // which all 64 lanes carry out alike, not by latency another wave could hide; profiles/r5/ab_log.txt)
+    // (launches with many workgroups of a narrow shape take the twelve-wave kernel above first: lbfgsb_build)
 #define BORE_LAUNCH_OCC2(S)                                                                                                 \
     if (flavour == (S) && (a.PB <= 4 || a.queue) && off * 4 <= BORE_LDS_BYTES / 2 && (forced < 0 ? many : forced != 0)) { \
       rc = allow_lds(lbfgsb_kernel_occ2<S>, off * 4);                                                                       \

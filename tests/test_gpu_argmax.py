@@ -793,6 +793,7 @@ def test_lbfgsb_eight_waves_per_workgroup_give_the_same_bits(gpu, monkeypatch, D
 @pytest.mark.parametrize("D,units,compute,R,opts", [
     (2, [16, 16, 1], "float32", 37, dict(maxiter=1000, ftol=1e-9)),
     (6, [32, 32, 1], "float32", 70, dict(maxiter=1000, ftol=1e-9)),
+    (9, [32, 32, 32, 1], "float32", 50, dict(maxiter=1000, ftol=1e-9)),          # static shape 5 on nine inputs
     (16, [64, 64, 64, 1], "float32", 45, dict(maxiter=200, ftol=1e-9)),
     (16, [64, 64, 64, 1], "bfloat16", 21, dict(maxiter=200, ftol=1e-9)),
     (32, [128, 128, 1], "bfloat16", 29, dict(maxiter=200, ftol=1e-9, maxcor=4))])
@@ -813,9 +814,11 @@ def test_lbfgsb_problem_queue_gives_the_same_bits(gpu, monkeypatch, D, units, co
     for q, extra in (("0", {}), ("3", {}), ("7", {}), ("7", {"BORE_LBFGSB_W8": "1", "BORE_LBFGSB_OCC2": "1"}),
                      ("7", {"BORE_LBFGSB_W8": "1", "BORE_LBFGSB_BIG": "1"}),
                      ("0", {"BORE_LBFGSB_W8": "1", "BORE_LBFGSB_BIG": "1"}),
-                     ("7", {"BORE_LBFGSB_W8": "1", "BORE_LBFGSB_BIG": "0"})):
+                     ("7", {"BORE_LBFGSB_W8": "1", "BORE_LBFGSB_BIG": "0"}),
+                     ("7", {"BORE_LBFGSB_W12": "1"}), ("0", {"BORE_LBFGSB_W12": "1"}),       # (twelve waves: narrow shapes)
+                     ("5", {"BORE_LBFGSB_W12": "0", "BORE_LBFGSB_OCC2": "1"})):
         monkeypatch.setenv("BORE_LBFGSB_QUEUE", q)
-        for k in ("BORE_LBFGSB_W8", "BORE_LBFGSB_OCC2", "BORE_LBFGSB_BIG"):   # (each combination is what its label says)
+        for k in ("BORE_LBFGSB_W8", "BORE_LBFGSB_OCC2", "BORE_LBFGSB_BIG", "BORE_LBFGSB_W12"):   # (each combination is what its label says)
             monkeypatch.delenv(k, raising=False)
         for k, v in extra.items():
             monkeypatch.setenv(k, v)
