@@ -221,14 +221,21 @@ __shared__ unsigned g_lb_lds[8][64];
       __hip_atomic_fetch_add(&g_lb_lds[(threadIdx.x >> 6) & 7][32 + (i)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
     }                                                                                     \
   } while (0)
-#ifdef BORE_STAMPS_FORMK
+#if defined(BORE_STAMPS_FORMK) || defined(BORE_STAMPS_CAUCHY)
 // (-DBORE_STAMPS_FORMK: the gaps are lumped into bucket 15 and their buckets 19..27 take the stages of
 // formk instead: new rows, old parts, assembly, first factorisation, triangular solves, (2,2) block,
-// second factorisation; tools/engine_phases.py formk)
+// second factorisation; tools/engine_phases.py formk.  -DBORE_STAMPS_CAUCHY: the stages of cauchy -- 19 variables
+// classified + sums over the moving ones, 20 first product with the middle matrix, per breakpoint 21 the heap, 22 the
+// workspace updates, 23 the middle-matrix part (col > 0), 24 the tail; tools/wide_phases.py)
 #define LB_PHASE_BEGIN(g) LB_MARK(s, 15)
 struct LbLocalClock { long long lb_last; };
+#ifdef BORE_STAMPS_CAUCHY
+#define CK_MARK_DECL LbLocalClock ck_clock{clock64()}
+#define CK_MARK(i) LB_MARK(ck_clock, i)
+#else
 #define FK_MARK_DECL LbLocalClock fk_clock{clock64()}
 #define FK_MARK(i) LB_MARK(fk_clock, i)
+#endif
 #else
 #define LB_PHASE_BEGIN(g) LB_MARK(s, g)
 #endif
@@ -242,6 +249,10 @@ struct LbLocalClock { long long lb_last; };
 #ifndef FK_MARK
 #define FK_MARK_DECL ((void)0)
 #define FK_MARK(i) ((void)0)
+#endif
+#ifndef CK_MARK
+#define CK_MARK_DECL ((void)0)
+#define CK_MARK(i) ((void)0)
 #endif
 
 // The value `v` holds in lane `src` (wave-uniform), in every lane of the wave.
@@ -280,6 +291,40 @@ LB_HD double lanes_sum_ordered(double term, int n) {
   for (int i = 0; i < n; ++i) s += lane_bcast(term, i);
   return s;
 }
+
+#if defined(__HIP_DEVICE_COMPILE__)
+// a float64 as an unsigned that sorts like it (-0.0 first made +0.0: the sequential code's `<` does not tell them apart)
+LB_HD unsigned long long orderable_f64(double v) {
+  const unsigned long long u = (unsigned long long)__double_as_longlong(v + 0.0);
+  return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+}
+// the smallest of the 64 lanes' keys, in every lane: four DPP shifts inside each row of 16 lanes (a lane without a
+// source keeps its own), the four rows' results by v_readlane -- no LDS round trips (__shfl_xor: six of them)
+LB_HD unsigned long long wave_min_key(unsigned long long v) {
+  unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
+#define LB_MIN_STEP(ctrl)                                                                        \
+  {                                                                                              \
+    const unsigned plo = (unsigned)__builtin_amdgcn_update_dpp((int)lo, (int)lo, ctrl, 0xf, 0xf, false); \
+    const unsigned phi = (unsigned)__builtin_amdgcn_update_dpp((int)hi, (int)hi, ctrl, 0xf, 0xf, false); \
+    const bool less = phi < hi || (phi == hi && plo < lo);                                       \
+    lo = less ? plo : lo;                                                                        \
+    hi = less ? phi : hi;                                                                        \
+  }
+  LB_MIN_STEP(0x111)  // row_shr:1
+  LB_MIN_STEP(0x112)  // row_shr:2
+  LB_MIN_STEP(0x114)  // row_shr:4
+  LB_MIN_STEP(0x118)  // row_shr:8
+#undef LB_MIN_STEP
+  unsigned long long best = ~0ull;
+#pragma unroll
+  for (int r = 15; r < 64; r += 16) {
+    const unsigned long long k = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)hi, r) << 32) |
+                                 (unsigned)__builtin_amdgcn_readlane((int)lo, r);
+    best = k < best ? k : best;
+  }
+  return best;
+}
+#endif
 
 // ---- small dense kernels ------------------------------------------------------
 // Sums strictly left to right (results do not depend on the unrolling); operands are fetched
@@ -669,6 +714,7 @@ LB_HDN int cauchy(const IterArgs s, const Work w, const double *l, const double 
   int nfree = n + 1, nbreak = 0, ibkmin = 0;
   double bkmin = 0.0, f1 = 0.0;
   const Coop cp = s.c;
+  CK_MARK_DECL;
   for (int i = cp.lane; i < col2; i += cp.nl) p[i] = 0.0;  // lane j owns p[j] throughout
 
   if (VL && cp.nl > 1 && n <= cp.nl && m <= cp.nl) {
@@ -725,6 +771,35 @@ LB_HDN int cauchy(const IterArgs s, const Work w, const double *l, const double 
     // f1, p: sequential sums over the moving variables; lane j keeps p[j], p[col + j] in registers
     double pa = 0.0, pb = 0.0;
     const int jrow = cp.lane < col ? wrap(s.head + cp.lane, m) * n : 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+    // (round 5: the sums alone in the loop over the variables -- col == 0, the first iteration of every restart,
+    // needs f1 only -- and the first smallest breakpoint by a wave minimum: this loop was 10 k of cauchy's 35 k
+    // cycles per call at n = 32)
+    if (col > 0) {
+      for (int i = 0; i < n; ++i) {
+        if (!((mmove >> i) & 1ull)) continue;  // (wave-uniform)
+        const double ng = lane_bcast(neggi, i);
+        f1 -= ng * ng;
+        if (cp.lane < col) {
+          pa += w.wy[jrow + i] * ng;
+          pb += w.ws[jrow + i] * ng;
+        }
+      }
+    } else {
+      for (int i = 0; i < n; ++i) {
+        if (!((mmove >> i) & 1ull)) continue;
+        const double ng = lane_bcast(neggi, i);
+        f1 -= ng * ng;
+      }
+    }
+    if (mbrk) {  // the first smallest breakpoint, in list order = the lowest lane among the smallest
+      const unsigned long long key = kind == 1 ? orderable_f64(tbrk) : ~0ull;
+      const unsigned long long kmin = wave_min_key(key);
+      const int lp = __builtin_ctzll(lanes_ballot(kind == 1 && key == kmin));
+      bkmin = lane_bcast(tbrk, lp);
+      ibkmin = bits_below(mbrk, lp) + 1;
+    }
+#else
     int k = 0;
     for (int i = 0; i < n; ++i) {
       if (!((mmove >> i) & 1ull)) continue;  // (wave-uniform)
@@ -743,6 +818,7 @@ LB_HDN int cauchy(const IterArgs s, const Work w, const double *l, const double 
         }
       }
     }
+#endif
     if (cp.lane < col) {
       p[cp.lane] = pa;
       p[col + cp.lane] = pb;
@@ -817,6 +893,7 @@ LB_HDN int cauchy(const IterArgs s, const Work w, const double *l, const double 
   } else {
     for (int i = 0; i < n; ++i) xcp[i] = x[i];
   }
+  CK_MARK(19);
   if (nbreak == 0 && nfree == n + 1) return LB_CAUCHY_RET(0);  // d is zero: GCP = x
   for (int j = cp.lane; j < col2; j += cp.nl) c[j] = 0.0;
   LB_LANES_SYNC();
@@ -832,12 +909,46 @@ LB_HDN int cauchy(const IterArgs s, const Work w, const double *l, const double 
   double tsum = 0.0;
   nseg = 1;
   bool skip_to_999 = false;
+  CK_MARK(20);
 
   if (nbreak > 0) {
     int nleft = nbreak, iter = 1, ibp = 0;
     double tj = 0.0;
+#if defined(__HIP_DEVICE_COMPILE__)
+    // One variable per lane above: breakpoint k of the list sits in lane k's registers and the next one is the
+    // smallest still there -- a wave minimum (ties: the lowest list position) instead of the heap in the workspace,
+    // whose every step is a dependent LDS round trip made by all 64 lanes together (building it for the second
+    // breakpoint and sifting: 4.2 k cycles per breakpoint at n = 32, 21 k of cauchy's 35 k per call).  The heap hands
+    // out the breakpoints in ascending order too; where two are EQUAL its order is an accident of its shape, so the
+    // host build may then differ in the last bits (exactly equal breakpoints: not seen in any test or run).
+    const bool in_lanes = VL && cp.nl > 1 && n <= cp.nl && m <= cp.nl;
+    double t_l = 0.0;
+    int o_l = 0;
+    bool alive = false;
+    if (in_lanes && cp.lane < nbreak) {
+      t_l = t[cp.lane];
+      o_l = iorder[cp.lane];
+      alive = true;
+    }
+    const unsigned long long key_l = orderable_f64(t_l);
+#endif
     for (;;) {
       const double tj0 = tj;
+#if defined(__HIP_DEVICE_COMPILE__)
+      if (in_lanes) {
+        int lp;
+        if (iter == 1) {
+          tj = bkmin;
+          lp = ibkmin - 1;
+        } else {
+          const unsigned long long kmin = wave_min_key(alive ? key_l : ~0ull);
+          lp = __builtin_ctzll(lanes_ballot(alive && key_l == kmin));
+          tj = lane_bcast(t_l, lp);
+        }
+        ibp = __builtin_amdgcn_readlane(o_l, lp);
+        alive = alive && cp.lane != lp;
+      } else
+#endif
       if (iter == 1) {
         tj = bkmin;
         ibp = iorder[ibkmin - 1];
@@ -852,6 +963,7 @@ LB_HDN int cauchy(const IterArgs s, const Work w, const double *l, const double 
         tj = t[nleft - 1];
         ibp = iorder[nleft - 1];
       }
+      CK_MARK(21);
       const double dt = tj - tj0;
       if (dtm < dt) break;  // the minimiser lies in this segment
       tsum += dt;
@@ -878,6 +990,7 @@ LB_HDN int cauchy(const IterArgs s, const Work w, const double *l, const double 
       const double dibp2 = dibp * dibp;
       f1 = f1 + dt * f2 + dibp2 - theta * dibp * zibp;
       f2 = f2 - theta * dibp2;
+      CK_MARK(22);
       if (col > 0) {
         for (int j = cp.lane; j < col2; j += cp.nl) c[j] += dt * p[j];
         for (int j = cp.lane; j < col; j += cp.nl) {
@@ -896,6 +1009,7 @@ LB_HDN int cauchy(const IterArgs s, const Work w, const double *l, const double 
         f2 += 2.0 * dibp * wmp - dibp2 * wmw;
       }
       f2 = fmax(LB_EPSMCH * f2_org, f2);
+      CK_MARK(23);
       if (nleft > 0) {
         dtm = -f1 / f2;
         continue;
@@ -921,6 +1035,7 @@ LB_HDN int cauchy(const IterArgs s, const Work w, const double *l, const double 
   if (col > 0)
     for (int j = cp.lane; j < col2; j += cp.nl) c[j] += dtm * p[j];
   LB_LANES_SYNC();
+  CK_MARK(24);
   return LB_CAUCHY_RET(0);
 #undef LB_CAUCHY_RET
 }

@@ -46,3 +46,19 @@ for i, nm in enumerate(names):
     cyc, calls = pp[:, i].sum(), pp[:, 32 + i].sum()
     if calls:
         print(f"  {nm:8s}: {100 * cyc / (tot_adv + tot_fg):5.1f} %  {cyc / calls:8.0f} cycles per call, {calls / rounds:5.2f} calls per evaluation")
+if os.environ.get("BORE_PHASES_CAUCHY"):      # a -DBORE_STAMPS -DBORE_STAMPS_CAUCHY build: the stages of cauchy
+    cnames = {19: "classify + sums over the moving variables", 20: "first middle-matrix product", 21: "per breakpoint: heap",
+              22: "per breakpoint: workspace updates", 23: "per breakpoint: middle-matrix part (col > 0)", 24: "tail"}
+    calls_c = pp[:, 32 + 0].sum()
+    for i, nm in cnames.items():
+        cyc, calls = pp[:, i].sum(), pp[:, 32 + i].sum()
+        if calls:
+            print(f"  cauchy / {nm:48s}: {cyc / max(calls_c, 1):8.0f} cycles per call of cauchy ({calls / max(calls_c, 1):5.2f} marks per call, {cyc / calls:7.0f} cycles each)")
+if os.environ.get("BORE_PHASES_FORMK"):       # a -DBORE_STAMPS -DBORE_STAMPS_FORMK build: the stages of formk (and dcsrch)
+    fnames = {19: "new rows / column (after an update)", 20: "old parts (entered / left variables)", 21: "assembly of WN",
+              22: "Cholesky of block (1,1)", 23: "diagonal check + triangular solves", 24: "block (2,2)", 25: "Cholesky of block (2,2)"}
+    calls_f = pp[:, 32 + 1].sum()
+    for i, nm in fnames.items():
+        cyc, calls = pp[:, i].sum(), pp[:, 32 + i].sum()
+        if calls:
+            print(f"  formk / {nm:44s}: {cyc / max(calls_f, 1):8.0f} cycles per call of formk ({calls / max(calls_f, 1):5.2f} marks per call)")
