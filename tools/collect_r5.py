@@ -113,7 +113,7 @@ out["configs"] = {}
 for name, (shape, bf) in named.items():
     e = {}
     for phase, prefixes in (("fit", ("fit_bf16_mfma_kernel", "fit_kernel_w8", "fit_kernel") if bf else ("fit_kernel_w8", "fit_kernel")),
-                            ("screen", ("screen_topk_kernel",)), ("fg", ("lbfgsb_kernel_w8", "lbfgsb_kernel_occ2", "lbfgsb_kernel"))):
+                            ("screen", ("screen_topk_kernel",)), ("fg", ("lbfgsb_kernel_w12", "lbfgsb_kernel_w8", "lbfgsb_kernel_occ2", "lbfgsb_kernel"))):
         kern = None
         for pre in prefixes:               # (the many-loops launch is the one with the larger grid: prefer its kernel)
             cand = [c for c in cfgs if c.startswith(pre + "<") and re.search(rf"<(?:true,|false,)?{shape}[,>]", c)]

@@ -12,7 +12,7 @@ all of them is a figure nobody can reproduce.  Written:
 import csv, glob, os, re, sys, collections
 d, outp = sys.argv[1], sys.argv[2]
 KNOWN = ("iteration_kernel", "queue_kernel", "fit_bf16_mfma_kernel", "fit_bf16_kernel", "fit_kernel_w8", "fit_kernel",
-         "lbfgsb_kernel_occ2", "lbfgsb_kernel_w8", "lbfgsb_kernel", "screen_topk_kernel", "rows_kernel",
+         "lbfgsb_kernel_occ2", "lbfgsb_kernel_w12", "lbfgsb_kernel_w8", "lbfgsb_kernel", "screen_topk_kernel", "rows_kernel",
          "candidates_kernel", "labels_kernel", "evaluate_kernel", "shuffle_kernel", "svgd_big_kernel", "svgd_kernel",
          "append_kernel", "select_kernel", "bore_spin_kernel")
 
