@@ -145,11 +145,13 @@ def build_native(force=False, verbose=False):
     hipcc = hipcc_path()
     if hipcc is None:
         raise RuntimeError("hipcc not found: cannot build libbore_hip.so")
+    # (-Wall -Wextra is clean; -Wno-pass-failed: the 161 "loop not unrolled" notes of round 4's build log are the
+    # optimiser declining `#pragma unroll` hints on loops with run-time trip counts, not defects)
     # -ffp-contract=off: no implicit FMA formation.  The fp32 network code spells its FMAs
     # out (fmaf); the fp64 L-BFGS-B then rounds exactly like its host build (tests compare
     # the two bit for bit) and like the unfused numpy/scipy arithmetic of the oracle.
     cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC",
-           "-ffp-contract=off", "-Wno-pass-failed", f'-DBORE_SRC_DIGEST="{digest}"', *srcs, "-o", out]
+           "-ffp-contract=off", "-Wall", "-Wextra", "-Wno-pass-failed", f'-DBORE_SRC_DIGEST="{digest}"', *srcs, "-o", out]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True, cwd=CSRC)
