@@ -66,6 +66,10 @@ def _check_counts(num_starts, num_samples):
 class MaximizableMixin:
 
     restart_mode = "device"
+    #: "device" (default): the screening kernel picks the starts and the restarts follow it on the stream, the results
+    #: handed out in the reference's (np.argpartition's) order -- same list as "host", one wait per call instead of
+    #: two (_maxima_on_device).  "host": predict, argpartition on the host, then the restarts: the literal form.
+    screen_mode = "device"
 
     def __init__(self, transform=identity, *args, **kwargs):
         # first positional argument is `transform`, as in the reference (bore/mixins.py:16)
@@ -97,11 +101,55 @@ class MaximizableMixin:
         x, fun, jac, info = ops.lbfgsb_minimize(self._desc, self.theta, x0, low, high, tr.name,
                                                 tr.negate, **options)
         x, fun, jac, info = (t[0] for t in ops.lbfgsb_results_to_host(x, fun, jac, info))
+        return self._results(x, fun, jac, info, range(len(X0)))
+
+    def _results(self, x, fun, jac, info, rows):
         return [OptimizeResult(x=x[r], fun=float(fun[r]), jac=jac[r], nit=int(info[r, 0]),
                                nfev=int(info[r, 1]), njev=int(info[r, 1]),
                                status=int(info[r, 2]), success=bool(info[r, 2] == 0),
                                message=_message(int(info[r, 3]), int(info[r, 4])))
-                for r in range(len(X0))]
+                for r in rows]
+
+    def _maxima_on_device(self, X_init, bounds, num_starts, options):
+        """``maxima`` without the stop in the middle (round 5).  The reference predicts on the candidates, picks the
+        starts on the host and runs the restarts (bore/mixins.py:45-60); done literally that is two waits for the
+        device per call -- the predictions, then the restarts -- with the host's argpartition and an upload between
+        them.  Here the screening kernel picks the starts on the device and the restarts follow it on the stream;
+        the predictions come back meanwhile and the host computes THE REFERENCE'S order of the starts
+        (np.argpartition's) from them while the restarts run, then hands the results out in that order.  The same
+        list as the literal form, bit for bit (tested); if the device's set of starts ever differs from
+        argpartition's -- a tie across the cut -- the literal form runs (returns None here)."""
+        import torch
+        from . import ops
+        (low, high), dim = from_bounds(bounds)
+        num_samples = len(X_init)
+        lo = [-np.inf if v is None else v for v in low]
+        hi = [np.inf if v is None else v for v in high]
+        unknown = set(options) - {"maxcor", "ftol", "gtol", "maxfun", "maxiter", "maxls"}
+        if unknown:
+            raise TypeError(f"unknown L-BFGS-B options: {sorted(unknown)}")
+        self._ensure_built(X_init)
+        dev = self.theta.device
+        Xd = torch.from_numpy(np.ascontiguousarray(X_init, dtype=np.float64)).to(dev)
+        x0, idx, pred = ops.screen_topk(self._desc, self.theta, Xd, num_starts, want_pred=True)
+        st = getattr(self, "_screen_stage", None)
+        if st is None or st[0].numel() < num_samples or st[1].numel() < num_starts:
+            st = self._screen_stage = (torch.empty(num_samples, dtype=torch.float32).pin_memory(),
+                                       torch.empty(num_starts, dtype=torch.int32).pin_memory(), torch.cuda.Event())
+        st[0][:num_samples].copy_(pred[0], non_blocking=True)
+        st[1][:num_starts].copy_(idx[0], non_blocking=True)
+        st[2].record()
+        tr = self._func_min.transform
+        x, fun, jac, info = ops.lbfgsb_minimize(self._desc, self.theta, x0, lo, hi, tr.name, tr.negate, **options)
+        st[2].synchronize()                       # (fit + screening are done; the restarts are running)
+        f_init = -st[0][:num_samples].numpy()
+        picks = st[1][:num_starts].numpy()
+        order = np.argpartition(f_init, kth=num_starts - 1, axis=None)[:num_starts]
+        where = {int(r): k for k, r in enumerate(picks)}
+        if len(where) != num_starts or any(int(r) not in where for r in order):
+            return f_init, None                   # (a tie across the cut: the literal form decides)
+        x, fun, jac, info = (t[0] for t in ops.lbfgsb_results_to_host(x, fun, jac, info))
+        return f_init, self._results(x, fun, jac, info, [where[int(r)] for r in order])
 
     def _minimize_from(self, X0, bounds, method, options):
         assert self.restart_mode in RESTART_MODES, self.restart_mode
@@ -130,15 +178,27 @@ class MaximizableMixin:
         samples, as a list of ``OptimizeResult`` (bore/mixins.py:22-72)."""
         random_state = check_random_state(random_state)   # mutated, shared with the caller
         _check_counts(num_starts, num_samples)
-        X_init, f_init = self._screen(bounds, num_samples, random_state)
+        (low, high), dim = from_bounds(bounds)
+        X_init = random_state.uniform(low=low, high=high, size=(num_samples, dim))    # (ONE draw, bore/mixins.py:45-47)
+        f_init = results = None
+        if (self.screen_mode == "device" and self.restart_mode == "device" and method == "L-BFGS-B" and num_starts > 0
+                and self._func_min.transform.name is not None):
+            from ._lib import UnsupportedError
+            try:
+                f_init, results = self._maxima_on_device(X_init, bounds, num_starts, dict(options or {}))
+            except UnsupportedError:
+                f_init = None                          # (the literal form below says why, or takes another route)
+        if f_init is None:
+            f_init = -self.predict(X_init).squeeze(axis=-1)
 
         if num_starts == 0:
             # legal: the best random sample, wrapped (bore/mixins.py:67-70)
             best = np.argmin(f_init, axis=None)
             return [OptimizeResult(x=X_init[best], fun=f_init[best], success=True)]
 
-        order = np.argpartition(f_init, kth=num_starts - 1, axis=None)[:num_starts]
-        results = self._minimize_from(X_init[order], bounds, method, options)
+        if results is None:
+            order = np.argpartition(f_init, kth=num_starts - 1, axis=None)[:num_starts]
+            results = self._minimize_from(X_init[order], bounds, method, options)
         for k, res in enumerate(results, start=1):
             print_fn(f"[Maximum {k:02d}: value={res.fun:.3f}] "
                      f"success: {res.success}, "

@@ -296,3 +296,36 @@ def test_callable_transform_drives_the_host_restart_modes(gpu):
     res2 = model.argmax(b, num_starts=4, num_samples=128, print_fn=lambda s: None,
                         random_state=np.random.RandomState(2))
     assert np.array_equal(res.x, res2.x) and res.fun == res2.fun
+
+
+@pytest.mark.parametrize("seed", [0, 3, 11])
+@pytest.mark.parametrize("D,units,acts,tr,R", [(2, [16, 16, 1], ["relu", "relu", "sigmoid"], "identity", 3),
+                                               (6, [32, 32, 32, 1], ["elu", "elu", "elu", "linear"], "sigmoid", 5),
+                                               (5, [24, 7, 1], ["tanh", "relu", "sigmoid"], "exp", 8)])
+def test_maxima_with_device_screening_hands_out_the_literal_forms_list(gpu, seed, D, units, acts, tr, R):
+    """``maxima`` picks its starts with the screening kernel and lets the restarts follow on the stream
+    (screen_mode "device", round 5: one wait per call instead of two); the results come back in the reference's
+    order -- np.argpartition's over the predictions (bore/mixins.py:53-57) -- so the list is the literal form's
+    (screen_mode "host": predict, argpartition on the host, restarts) bit for bit, and so is the caller's random
+    state afterwards."""
+    from scipy.optimize import Bounds
+    from bore_amd.layers import Dense
+    from bore_amd.models import MaximizableSequential
+    bounds = Bounds(np.zeros(D), np.ones(D))
+    outs = []
+    for mode in ("host", "device"):
+        model = MaximizableSequential(tr, seed=seed)
+        for u, a in zip(units, acts):
+            model.add(Dense(u, activation=a))
+        model.compile(optimizer="adam", loss="binary_crossentropy" if acts[-1] == "sigmoid" else None)
+        model.build(D)
+        model.screen_mode = mode
+        rs = np.random.RandomState(100 + seed)
+        lines = []
+        res = model.maxima(bounds, num_starts=R, num_samples=256, print_fn=lines.append, random_state=rs)
+        outs.append((res, lines, rs.uniform()))
+    (a, la, ua), (b, lb, ub) = outs
+    assert ua == ub and la == lb and len(a) == len(b) == R
+    for ra, rb in zip(a, b):
+        assert np.array_equal(ra.x, rb.x) and ra.fun == rb.fun and np.array_equal(ra.jac, rb.jac)
+        assert (ra.nit, ra.nfev, ra.status, ra.success, ra.message) == (rb.nit, rb.nfev, rb.status, rb.success, rb.message)

@@ -12,7 +12,7 @@ L = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 warm = int(sys.argv[3]) if len(sys.argv) > 3 else 5
 lib.bore_debug_engine_loop_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
-eng = NativeEngine(np.arange(L), async_loops=True)
+eng = NativeEngine(np.arange(L), async_loops=True, objective="branin01")
 eng.run(warm)
 eng.take_stats()
 lib.bore_debug_engine_loop_stats(eng._h, None, 1)
