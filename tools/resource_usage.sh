@@ -3,7 +3,7 @@
 # usage: tools/resource_usage.sh [out_file]
 out=$(realpath -m "${1:-/tmp/bore_resource_usage.txt}")
 cd "$(dirname "$0")/../bore_amd/csrc" || exit 1
-/opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -std=c++17 -c -fPIC -ffp-contract=off \
+/opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -std=c++17 -c -fPIC -ffp-contract=off -Wno-pass-failed \
   -Rpass-analysis=kernel-resource-usage bore_all.hip -o /tmp/bore_all.o 2> /tmp/bore_ru_raw.txt
 python3 - "$out" <<'PY'
 import re, sys
