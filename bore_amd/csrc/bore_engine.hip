@@ -391,6 +391,7 @@ static int async_decide_schedule(bore_engine *e) {
   }
   if (getenv("BORE_ASYNC_PER_CU") && atoi(getenv("BORE_ASYNC_PER_CU")) > 0 && atoi(getenv("BORE_ASYNC_PER_CU")) < per_cu)
     per_cu = atoi(getenv("BORE_ASYNC_PER_CU"));  // (A/B: fewer loops per CU than the device would hold)
+  if (per_cu < 1) return fail(BORE_E_UNSUPPORTED, "engine: the fused kernel does not fit a compute unit with records of %lld rows", (long long)A.cap);
   A.per_cu = per_cu;
   const int forced = getenv("BORE_ASYNC_QUEUE") ? atoi(getenv("BORE_ASYNC_QUEUE")) : -1;
   const int resident_cap = per_cu * device_cus();
