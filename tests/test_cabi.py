@@ -37,6 +37,19 @@ def test_library_exports_every_declared_symbol(built):
     assert built.bore_abi_version() == 11
 
 
+def test_library_carries_the_digest_of_its_sources(built):
+    """ABI 11: the sha256 of the kernel sources is compiled into the library; `build_native` compares it with the
+    tree's instead of file times (which say nothing once a tree has travelled) -- a library built from THESE sources
+    is what the suite runs, and an up-to-date one is not rebuilt."""
+    if _lib.LIB_PATH != _lib.DEFAULT_LIB_PATH:
+        pytest.skip("an experiment build named by BORE_LIB_PATH")
+    digest = _lib.source_digest()
+    assert len(digest) == 64 and _lib.built_digest() == digest
+    built.bore_source_digest.restype = ctypes.c_char_p
+    assert built.bore_source_digest().decode() == digest
+    assert _lib.build_native() == _lib.DEFAULT_LIB_PATH      # (nothing to do: returns at once)
+
+
 def test_param_count_and_descriptor_validation(built):
     d = _lib.make_desc(2, [16, 16, 1], ["relu", "relu", "sigmoid"])
     assert built.bore_param_count(ctypes.byref(d)) == 337          # SURVEY.md §8 table

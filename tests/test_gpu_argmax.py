@@ -660,6 +660,30 @@ def test_work_queue_engine_beyond_the_resident_capacity(gpu):
     assert st["phase_iterations"] == 3300 and st["argmax_launches"] == 1
 
 
+def test_three_loops_per_cu_resident_and_back_to_two_when_the_records_grow(gpu):
+    """Round 5: a new engine's records hold 128 rows, with which three loops of the fused kernel share a CU's LDS
+    (53 728 B each: bore_engine_stats.loops_per_cu); 2 x CUs < loops <= 3 x CUs stay resident on the 168-register
+    build.  Past 128 rows the records double, the data set in LDS with them, the engine goes back to two per CU and
+    serves the same loops from the work queue -- one trajectory throughout, the lock-step engine's."""
+    import torch
+    from bore_amd.engine import NativeEngine
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    L = 2 * cus + 40
+    kw = dict(epochs=4, num_samples=64, n_init=60)
+    a = NativeEngine(np.arange(L), async_loops=True, objective="branin01", **kw)
+    b = NativeEngine(np.arange(L), groups=3, objective="branin01", **kw)
+    a.run(6)
+    st = a.take_stats(reset=False)
+    assert st["loops_per_cu"] == 3 and st["side_by_side_workgroups"] == L          # all resident
+    a.run(66)                                                                       # 132 rows: the records grow
+    st = a.take_stats(reset=False)
+    assert st["loops_per_cu"] == 2 and st["side_by_side_workgroups"] == 2 * cus    # the work queue
+    b.run(72)
+    assert np.array_equal(a.X, b.X) and np.array_equal(a.y, b.y)
+    for u, v in zip(a.state(), b.state()):
+        assert np.array_equal(u, v)
+
+
 def test_sharded_engine_equals_one_engine(gpu):
     """ShardedEngine: the loops of one GPU split over several engines, each with its own host thread (what
     bench.py uses beyond 512 loops).  A loop's trajectory does not depend on its shard: the same
