@@ -740,13 +740,11 @@ __device__ __forceinline__ void lbfgsb_body(const LbfgsbArgs &a, const long long
       for (int i = lane; i < a.prob_floats / 4; i += 64) b4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
       wave_lds_sync();
     }
-    if (my_big) {  // every problem finds the two matrices zeroed, as in the zeroed LDS
-      double2 *b2 = reinterpret_cast<double2 *>(my_big);
-      for (int i = lane; i < a.big_wave / 2; i += 64) b2[i] = make_double2(0.0, 0.0);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
     wk = lbfgsb::make_work(reinterpret_cast<double *>(base + a.o_dw),
                            reinterpret_cast<int *>(base + a.o_iw), D, a.opt.m, my_big);
+    // (the pool slot holds the last problem's matrices: the optimiser zeroes them if and when this problem's first
+    // subspace minimisation comes -- as the zeroed LDS would have been found -- not 6.4 KB of writes per problem)
+    if (my_big) wk.vm = lbfgsb::LB_BIG_LAZY;
     const double *x0 = a.x0 + (model * a.R + p0 + myp) * (long long)D;
     lbfgsb::lbfgsb_init(st, wk, D, a.opt.m, x0, blo, bhi, bnbd);
 #ifdef BORE_STAMPS

@@ -113,7 +113,10 @@ struct Work {
   double *rwn;              // 2m: 1 / diag of the two Cholesky factors in wn
   double *rsy, *rsq;        // m each: 1 / sy_ii and 1 / sqrt(sy_ii)
   int *index, *iwhere, *indx2;
-  int vm;                   // wn / snd are outside the caller's dw (global memory on the device)
+  // wn / snd are outside the caller's dw (make_work's `big`: global memory on the device).  0: inside dw, zeroed
+  // with it by the caller; 1: outside, zeroed by the caller; 2: outside and NOT zeroed -- lbfgsb_advance zeroes them
+  // itself, before formk first touches them (LB_BIG_LAZY)
+  int vm;
 };
 
 LB_HD Work make_work(double *dw, int *iw, int n, int m, double *big = nullptr) {
@@ -192,6 +195,19 @@ struct Coop {
 #define LB_LANES_SYNC_VM(vm) ((void)(vm))
 #define LB_OPAQUE_LANE(x) ((void)0)
 #endif
+
+// Work::vm == LB_BIG_LAZY: the two 2m x 2m matrices (8 m^2 doubles from w.wn on: make_work) start as whatever the
+// buffer held.  formk builds them up incrementally and counts on zeros (SciPy hands setulb a zeroed work array), but
+// only a problem that reaches a subspace minimisation ever looks at them -- one in twenty of BASELINE config 5's,
+// whose launches spent 6.4 GB of writes per million restarts on zeroing pool slots nobody read.
+enum { LB_BIG_INSIDE = 0, LB_BIG_ZEROED = 1, LB_BIG_LAZY = 2 };
+LB_HD void zero_big(const Work &w, int m, const Coop c) {
+  for (int i = 2 * c.lane; i < 8 * m * m; i += 2 * c.nl) {  // (pairs: 16-byte stores; 8 m^2 is even)
+    w.wn[i] = 0.0;
+    w.wn[i + 1] = 0.0;
+  }
+  LB_LANES_SYNC_VM(1);
+}
 
 // -DBORE_STAMPS: per-phase cycle accumulators, diagnostics only.  g_lb_phase: workgroup 0,
 // thread 0.  g_lb_pp[q][i]: every problem q = 4*blockIdx.x + wave of a one-problem-per-wave launch
@@ -1809,6 +1825,10 @@ LB_HD int lbfgsb_advance(State &s, const Work &w, const double *l, const double 
   bool resume_ls = (s.stage == S_FG_LNSRCH);
 
   if (s.stage == S_FINISHED) return LB_DONE;
+  // (LB_BIG_LAZY: this call sees the whole problem in the DIRECT form and zeroes the outside matrices in front of
+  // the first formk; the reverse-communication form returns in between and zeroes them on its first call)
+  bool big_stale = w.vm == LB_BIG_LAZY;
+  if (!DIRECT && big_stale && s.stage == S_INIT) zero_big(w, m, coop_in);
   LB_MARK(s, 15);  // (everything since the previous return: the evaluation)
 
   // fresh f, g at w.x have arrived: remember the point (SciPy's ScalarFunction cache)
@@ -1953,6 +1973,10 @@ LB_HD int lbfgsb_advance(State &s, const Work &w, const double *l, const double 
                           LB_UNI(s.iupdat, coop), s.theta, s.sbgnrm, coop};
         if (s.wrk) {
           LB_PHASE_BEGIN(23);
+          if (DIRECT && big_stale) {
+            zero_big(w, m, coop);
+            big_stale = false;
+          }
           const int fk = formk(ia, w);
           LB_PHASE_END(1);
           if (fk) { refresh_memory(s); continue; }
