@@ -820,7 +820,10 @@ def test_lbfgsb_eight_waves_per_workgroup_give_the_same_bits(gpu, monkeypatch, D
     (9, [32, 32, 32, 1], "float32", 50, dict(maxiter=1000, ftol=1e-9)),          # static shape 5 on nine inputs
     (16, [64, 64, 64, 1], "float32", 45, dict(maxiter=200, ftol=1e-9)),
     (16, [64, 64, 64, 1], "bfloat16", 21, dict(maxiter=200, ftol=1e-9)),
-    (32, [128, 128, 1], "bfloat16", 29, dict(maxiter=200, ftol=1e-9, maxcor=4))])
+    (32, [128, 128, 1], "bfloat16", 29, dict(maxiter=200, ftol=1e-9, maxcor=4)),
+    # (ten corrections: the pooled matrices at their full size, slots reused by problem after problem and zeroed by
+    # the optimiser only in front of a problem's first subspace minimisation -- lbfgsb.h, LB_BIG_LAZY)
+    (32, [128, 128, 1], "bfloat16", 41, dict(maxiter=200, ftol=1e-9))])
 def test_lbfgsb_problem_queue_gives_the_same_bits(gpu, monkeypatch, D, units, compute, R, opts):
     """Many restarts per model: a workgroup's waves draw problem after problem from a queue in LDS
     (weights staged once, workspace slots reused) instead of one workgroup per four (eight)
