@@ -66,6 +66,28 @@ def _latest(name):
 
 
 TRAFFIC_FILE = _latest("pmc_traffic.json")
+# the optimiser's own float64 operations per evaluation request, counted in a host build of lbfgsb.h on device-trained
+# networks (tools/lbfgsb_flops.py, tests/native/lbfgsb_flops.cpp)
+OPT_FLOPS_FILE = _latest("optimiser_flops.json")
+FP64_PEAK_TF = FP32_PEAK_TF / 2   # float64 vector rate: half the float32 vector rate of the same guide
+
+
+def optimiser_fp64(name, requests, seconds):
+    """Restart-phase roofline of the L-BFGS-B bookkeeping itself: counted float64 operations per evaluation request
+    (a committed count, not taken in this run) x the run's requests over the phase's time, against the float64
+    vector peak.  None when the count is missing."""
+    try:
+        with open(os.path.join(ROOT, OPT_FLOPS_FILE)) as f:
+            e = json.load(f)["configs"][name]
+    except Exception:
+        return None
+    per = e["addsubmul_per_evaluation"] + e["divsqrt_per_evaluation"]
+    ach = per * requests / max(seconds, 1e-12) / 1e12
+    return {"float64_ops_per_evaluation_request": per, "of_which_divisions_and_square_roots": e["divsqrt_per_evaluation"],
+            "achieved_TFs": ach, "peak_TFs": FP64_PEAK_TF, "frac": ach / FP64_PEAK_TF,
+            "network_flops_per_evaluation": e["network_flops_per_evaluation_fwd_bwd"],
+            "source": f"{OPT_FLOPS_FILE}: lbfgsb.h's float64 operations counted in a host build, {e['restarts_counted']} "
+                      "restarts of a device-trained loop; says the phase is a serial latency chain, not arithmetic"}
 SWEEP_FILE = _latest("loops_sweep.json")   # T(1, L) measured on one GPU
 
 
@@ -556,6 +578,8 @@ def config_gpu(name, c, loops, epochs=200, batch=64, reps=3):
         "roofline_fma": {k: {"achieved_TFs": fl[k] / (kern[k] * 1e-3) / 1e12,
                              "frac": fl[k] / (kern[k] * 1e-3) / 1e12 / peak_tf,
                              "peak_TFs": peak_tf} for k in fl},
+        # (the restart phase's OTHER arithmetic: the optimiser's float64 bookkeeping around the evaluations)
+        "roofline_fp64_optimiser": optimiser_fp64(name, float(nfev.sum() / reps), kern["fg"] * 1e-3),
         # (SURVEY 8d's streaming model charges every Adam step a read and a write of theta, m and v: 24 P bytes.
         # The kernels keep theta in LDS or registers for the whole launch -- the bfloat16 fit its float32 masters
         # in registers, m and v in HBM: 16 P bytes per step -- so the fit's "achieved" is the model's bytes over
@@ -853,6 +877,10 @@ def run_rank(args):
                      "achieved": flops / dt / 1e12, "peak": FP32_PEAK_TF, "unit": "TFLOP/s",
                      "frac": flops / dt / 1e12 / FP32_PEAK_TF,
                      "algorithmic_flops_per_iteration": flops / (loops * args.steps)}
+        # (beside the network's FLOPs: the float64 bookkeeping of the restarts' optimiser, counted -- what the restart
+        # phase, half of a loop-iteration, actually computes with)
+        flop_roof["optimiser_fp64"] = optimiser_fp64("cfg1_branin2_16-16-1_R3",
+                                                     float(st.get("n_fg_requests", st["n_fg_rows"])), dt)
         phases = {"fg_rows_per_step": st["n_fg_rows"] / args.steps,          # evaluations that ran the network
                   # (the optimisers' nfev: also counts trial points the image shortcut served)
                   "fg_requests_per_step": st.get("n_fg_requests", st["n_fg_rows"]) / args.steps,

@@ -186,3 +186,46 @@ def test_the_three_forms_of_the_routine_give_the_same_bits():
             n_cases += 1
             n_abnormal += r0.status == 2
     assert n_cases >= 70 and n_abnormal >= 3      # (the abnormal endings are exercised)
+
+
+def test_counting_build_runs_the_same_optimisation(tmp_path):
+    """tests/native/lbfgsb_flops.cpp -- lbfgsb.h with `double` replaced by an operation-counting wrapper, the build
+    behind bench.py's `roofline_fp64_optimiser` (tools/lbfgsb_flops.py) -- walks the same path as the plain host build:
+    same point bit for bit, same counts of iterations and evaluations; and it does count."""
+    import ctypes as C
+    import os
+    import subprocess
+    here = os.path.dirname(os.path.abspath(__file__))
+    so = str(tmp_path / "liblbfgsb_flops.so")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-ffp-contract=off",
+                    os.path.join(here, "native", "lbfgsb_flops.cpp"), "-o", so], check=True)
+    lib = C.CDLL(so)
+    CB = C.CFUNCTYPE(None, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double))
+    n = 6
+    rs = np.random.RandomState(4)
+    lb, ub = np.full(n, -1.5), np.full(n, 0.9)
+
+    def fun(x):
+        return rosen(x), rosen_der(x)
+
+    def cb(n_, xp, fp, gp):
+        x = np.ctypeslib.as_array(xp, shape=(n_,)).copy()
+        f, g = fun(x)
+        fp[0] = float(f)
+        for i in range(n_):
+            gp[i] = g[i]
+
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    for _ in range(3):
+        x0 = rs.uniform(-1.4, 0.8, size=n)
+        ref = H.minimize(fun, x0, (lb, ub), **OPTS)
+        xo, fo = np.empty(n), C.c_double()
+        oi, oc = np.zeros(3, dtype=np.int32), np.zeros(2, dtype=np.uint64)
+        nbd = np.full(n, 2, dtype=np.int32)
+        lib.lbfgsb_flops_minimize(n, 10, dp(np.ascontiguousarray(x0)), dp(lb), dp(ub), nbd.ctypes.data_as(C.POINTER(C.c_int)),
+                                  C.c_double(OPTS["ftol"] / np.finfo(float).eps), C.c_double(1e-5), OPTS["maxiter"], 15000, 20,
+                                  CB(cb), dp(xo), C.byref(fo), oi.ctypes.data_as(C.POINTER(C.c_int)),
+                                  oc.ctypes.data_as(C.POINTER(C.c_ulonglong)))
+        assert (int(oi[0]), int(oi[1]), int(oi[2])) == (ref.nit, ref.nfev, ref.status)
+        assert np.array_equal(xo, ref.x) and fo.value == ref.fun
+        assert oc[0] > 100 * ref.nit and 0 < oc[1] < oc[0]

@@ -13,6 +13,7 @@ for leg in ("headline", "configs"):
     pairs[f"{tag}_{leg}_kernel_by_grid.csv"] = f"{leg}_kernel_by_grid.csv"
     for pmc, nm in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write"), ("sq", "sq"), ("sq2", "sq2")):
         pairs[f"{tag}_{leg}_{pmc}_pmc_by_grid.csv"] = f"{leg}_pmc_{nm}_by_grid.csv"
+pairs[os.path.join("r5", "optimiser_flops.json")] = "optimiser_flops.json"   # (tools/lbfgsb_flops.py, its own GPU call)
 for src, dst in pairs.items():
     if os.path.exists(os.path.join(G, src)):
         shutil.copyfile(os.path.join(G, src), os.path.join(P, dst))
