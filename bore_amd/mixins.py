@@ -130,12 +130,22 @@ class MaximizableMixin:
             raise TypeError(f"unknown L-BFGS-B options: {sorted(unknown)}")
         self._ensure_built(X_init)
         dev = self.theta.device
-        Xd = torch.from_numpy(np.ascontiguousarray(X_init, dtype=np.float64)).to(dev)
-        x0, idx, pred = ops.screen_topk(self._desc, self.theta, Xd, num_starts, want_pred=True)
         st = getattr(self, "_screen_stage", None)
-        if st is None or st[0].numel() < num_samples or st[1].numel() < num_starts:
+        if st is None or st[0].numel() < num_samples or st[1].numel() < num_starts or st[3].numel() < num_samples * dim:
             st = self._screen_stage = (torch.empty(num_samples, dtype=torch.float32).pin_memory(),
-                                       torch.empty(num_starts, dtype=torch.int32).pin_memory(), torch.cuda.Event())
+                                       torch.empty(num_starts, dtype=torch.int32).pin_memory(), torch.cuda.Event(),
+                                       torch.empty(num_samples * dim, dtype=torch.float64).pin_memory(), torch.cuda.Event())
+            st[4].record()
+        # (the candidates go up through pinned memory: a pageable upload is stream-ordered on the HOST as well -- the
+        # caller would stand here until the fit in front of it on the stream is done, and the screening, the copies and
+        # the restarts below would be enqueued one by one onto an idle device instead of behind a running fit)
+        st[4].synchronize()                        # (the last call's upload has left the buffer)
+        xs = st[3][:num_samples * dim].view(num_samples, dim)
+        xs.copy_(torch.from_numpy(np.ascontiguousarray(X_init, dtype=np.float64)))
+        Xd = torch.empty((num_samples, dim), dtype=torch.float64, device=dev)
+        Xd.copy_(xs, non_blocking=True)
+        st[4].record()
+        x0, idx, pred = ops.screen_topk(self._desc, self.theta, Xd, num_starts, want_pred=True)
         st[0][:num_samples].copy_(pred[0], non_blocking=True)
         st[1][:num_starts].copy_(idx[0], non_blocking=True)
         st[2].record()
