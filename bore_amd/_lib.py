@@ -117,16 +117,21 @@ def source_digest():
 
 
 def built_digest(path=None):
-    """The source digest compiled into the library at `path` (None: no library, or one from before ABI 11)."""
+    """The source digest compiled into the library at `path` (None: no library, or one from before ABI 11).
+    Read from the FILE (the 64-hex-digit string `bore_source_digest()` returns sits in its read-only data), not by
+    loading it: this runs before anything else of the package -- `build()` -- and a library opened ahead of torch
+    binds to the system's HIP runtime instead of the one torch brings, after which no call of it sees a device
+    (`lib()` imports torch first for that reason)."""
     path = path or DEFAULT_LIB_PATH
     if not os.path.exists(path):
         return None
-    try:
-        L = C.CDLL(path)
-        L.bore_source_digest.restype = C.c_char_p
-        return L.bore_source_digest().decode()
-    except (OSError, AttributeError):
-        return None
+    import re
+    with open(path, "rb") as f:
+        found = set(re.findall(rb"(?<![0-9a-f])([0-9a-f]{64})\x00", f.read()))
+    want = source_digest().encode()
+    if want in found:
+        return want.decode()
+    return sorted(found)[0].decode() if found else None
 
 
 def build_native(force=False, verbose=False):

@@ -71,3 +71,16 @@ def test_param_count_and_descriptor_validation(built):
 def test_struct_layout_matches_header():
     assert ctypes.sizeof(_lib.MlpDesc) == 4 * (2 + 4 * _lib.MAX_LAYERS + 1)      # + compute
     assert ctypes.sizeof(_lib.AdamCfg) == 16
+
+
+def test_reading_the_built_digest_does_not_load_the_library():
+    """`build()` asks for the digest before anything else of the package has run.  Opened ahead of torch, the library
+    binds to the system's HIP runtime and every later call of it in that process fails with "no ROCm-capable device"
+    (found on the GPU box: build() followed by smoke() in one interpreter) -- so the digest is read from the file."""
+    import subprocess
+    import sys
+    code = ("from bore_amd import _lib; d = _lib.built_digest(); import sys; "
+            "assert d is None or len(d) == 64; assert 'torch' not in sys.modules; "
+            "assert 'libbore_hip' not in open('/proc/self/maps').read()")
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-1500:]

@@ -329,3 +329,17 @@ def test_maxima_with_device_screening_hands_out_the_literal_forms_list(gpu, seed
     for ra, rb in zip(a, b):
         assert np.array_equal(ra.x, rb.x) and ra.fun == rb.fun and np.array_equal(ra.jac, rb.jac)
         assert (ra.nit, ra.nfev, ra.status, ra.success, ra.message) == (rb.nit, rb.nfev, rb.status, rb.success, rb.message)
+
+
+@pytest.mark.gpu
+def test_build_then_smoke_in_one_interpreter(gpu):
+    """The driver's two hooks back to back in ONE process: build() must leave the process able to compute (it once
+    opened the library ahead of torch -- two HIP runtimes, no device in the second: tests/test_cabi.py)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.build(); g.smoke()"], cwd=root,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-500:], r.stderr[-1500:])
+    assert "smoke ok" in r.stdout
