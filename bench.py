@@ -25,15 +25,15 @@ Schedules: `--schedule async` (default): every loop advances on its own, one fus
 loops are ready; `--schedule groups`: four groups of loops in lock-step, five launches per
 group-iteration.  Same trajectories.
 
-Prints ONE JSON line on rank 0 (driver contract) with the `roofline` of the dominant kernel
-(algorithmic bytes per SURVEY.md 8d divided by the HIP-event duration measured on the launching
-stream), `roofline_flops` (secondary), `runs` (N = 1: the timed region is repeated on fresh
-engines while it is shorter than a second; `value` is the median run), `configs` (N = 1: one
-driver-visible figure per BASELINE config -- single-loop config 1, configs 2, 3 and 5 -- with
-per-phase times, algorithmic bytes / FLOPs, both roofline fractions and a bounded CPU-oracle
-timing) and `cpu_baseline` (the numpy/scipy oracle, which mirrors the reference's per-step
-structure, on this host's cores -- one single-threaded process per core -- for a bounded sample;
-`cpu_baseline_1core` is the one-core figure).
+The LAST line of rank 0's stdout is the driver's record: one compact JSON line, never above 4 KB (`compact_line`),
+with BASELINE.json's metric, the `roofline` of the dominant kernel (algorithmic bytes per SURVEY.md 8d divided by the
+HIP-event duration measured on the launching stream), `roofline_flops` (secondary), `cpu_baseline` (the numpy/scipy
+oracle, which mirrors the reference's per-step structure, on this host's cores -- one single-threaded process per core
+-- for a bounded sample), the efficiencies for N > 1 and one figure per BASELINE config.  Everything else -- `runs`
+(N = 1: the timed region is repeated on fresh engines while it is shorter than a second; `value` is the median run),
+`configs` (per-phase times, algorithmic bytes / FLOPs, both roofline fractions, per-repetition evaluation counts and a
+bounded CPU-oracle timing per BASELINE config), `kernels`, `phases`, `ranks` -- goes to the side file the record names
+(`detail`: bench_detail_n{N}.json beside this script and under gpurun_out/).
 """
 import argparse
 import json
@@ -999,9 +999,116 @@ def run_rank(args):
                 out["cpu_baseline"] = allc
                 if one is not None:
                     out["cpu_baseline_1core"] = one
-        print(json.dumps(out))
+        emit(out, args)
     if world > 1:
         dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------------------------------
+# the line: compact record last on stdout (<= LINE_LIMIT bytes), everything else in a side file
+# ------------------------------------------------------------------------------------------
+LINE_LIMIT = 4096        # the driver keeps an 8 KB tail of stdout: the record must fit it with room to spare
+
+
+def _sig(x, n=6):
+    """Floats to n significant digits (the line is read by people and a parser, not re-computed from)."""
+    if isinstance(x, float):
+        return float(f"{x:.{n}g}") if np.isfinite(x) else None
+    if isinstance(x, dict):
+        return {k: _sig(v, n) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_sig(v, n) for v in x]
+    if isinstance(x, np.generic):
+        return _sig(x.item(), n)
+    return x
+
+
+def _pick(d, keys):
+    return None if d is None else {k: d[k] for k in keys if k in d and d[k] is not None}
+
+
+def compact_line(out, detail_file):
+    """The driver's record: BASELINE.json's metric with `roofline` and `cpu_baseline`, the efficiencies for N > 1
+    and one figure per BASELINE config; `detail` names the file with everything else.  Never above LINE_LIMIT bytes:
+    optional blocks are dropped, least important first, until it fits."""
+    c = out.get("config") or {}
+    line = {k: out.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
+                                    "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+    line["config"] = _pick(c, ("workload", "loops_per_gpu", "total_loops", "schedule", "host_loop", "N_start",
+                               "N_end", "parallelism"))
+    line["roofline"] = _pick(out.get("roofline"), (
+        "bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_stale", "issue_slot_utilisation",
+        "avg_launch_ms", "algorithmic_bytes_per_launch", "launches", "frac_busy"))
+    line["roofline_flops"] = _pick(out.get("roofline_flops"), ("bound", "achieved", "peak", "unit", "frac"))
+    cb = out.get("cpu_baseline")
+    line["cpu_baseline"] = None if cb is None else dict(
+        _pick(cb, ("value", "unit", "cores", "kind")), sample=str(cb.get("sample", ""))[:160])
+    if out.get("cpu_baseline_1core"):
+        line["cpu_baseline_1core"] = _pick(out["cpu_baseline_1core"], ("value", "cores", "kind"))
+    if out.get("dry_run"):
+        line["dry_run"] = True
+    optional = []            # (key, value) in order of importance; dropped from the END when the line is too long
+    if out.get("efficiency"):
+        optional.append(("efficiency", _pick(out["efficiency"], (
+            "eff_w", "eff_s", "T_N_total", "T_1_share", "T_1_total", "share_loops", "total_loops"))))
+    if out.get("weak_point_512_loops_per_gpu"):
+        optional.append(("weak_point_512_loops_per_gpu", _pick(out["weak_point_512_loops_per_gpu"], (
+            "value", "ms_per_step", "loops_per_gpu", "total_loops", "scaling", "T_1", "eff_w"))))
+    if out.get("efficiency_predicted"):
+        optional.append(("efficiency_predicted", _pick(out["efficiency_predicted"], ("eff_w", "eff_s", "gain_over_one_gpu"))))
+    if out.get("runs"):
+        optional.append(("runs", _pick(out["runs"], ("n", "min", "p25", "p75", "max", "value_is"))))
+    if out.get("ranks"):
+        optional.append(("ranks", _pick(out["ranks"], ("backend", "backend_world_size"))))
+    if out.get("configs"):
+        cf = {}
+        for name, e in out["configs"].items():
+            if "error" in e:
+                cf[name] = {"error": e["error"][:80]}
+                continue
+            m = e.get("many_loops", e)
+            cf[name] = {"loops": m.get("loops"), "it_per_s": m.get("it_per_s"),
+                        "ms": _pick(m.get("ms"), ("fit", "screen", "lbfgsb", "iteration"))}
+        optional.append(("configs", cf))
+    if out.get("survey_form"):
+        optional.append(("survey_form", _pick(out["survey_form"], ("value", "steps", "N_start", "N_end"))))
+    if out.get("phases"):
+        ph = out["phases"]
+        optional.append(("phases", {"none_results": ph.get("none_results"),
+                                    "per_loop_iteration_us": _pick(ph.get("per_loop_iteration_us"),
+                                                                   ("labels", "fit", "screen", "lbfgsb"))}))
+    line["tf_keras"] = out.get("tf_keras")
+    line["detail"] = detail_file
+    for k, v in optional:
+        line[k] = v
+    line = _sig(line)
+    while optional and len(json.dumps(line, separators=(",", ":"))) > LINE_LIMIT - 64:
+        line.pop(optional.pop()[0])
+    text = json.dumps(line, separators=(",", ":"))
+    if len(text) > LINE_LIMIT:          # (cannot happen with the fixed key sets above; refuse rather than print it)
+        raise SystemExit(f"bench.py: compact record is {len(text)} bytes (> {LINE_LIMIT})")
+    return text
+
+
+def emit(out, args):
+    """Side file first (everything: `configs`, `kernels`, `phases`, `runs`, `ranks`, ...), then the compact record as
+    the LAST line of stdout.  The side file goes beside the script (bench_detail_n{N}.json) and, when that directory
+    exists, under gpurun_out/ as well so that a gpurun call brings it back."""
+    name = f"bench_detail_n{out.get('n_gpus', 1)}.json"
+    written = None
+    for d in ([args.detail_dir] if args.detail_dir else [ROOT, os.path.join(ROOT, "gpurun_out")]):
+        try:
+            if os.path.isdir(d):
+                with open(os.path.join(d, name), "w") as f:
+                    json.dump(out, f)
+                written = written or os.path.relpath(os.path.join(d, name), ROOT)
+        except OSError:
+            pass
+    if args.print_detail:
+        print(json.dumps(out))
+    sys.stdout.flush()
+    print(compact_line(out, written))
+    sys.stdout.flush()
 
 
 def parse_args(argv=None):
@@ -1032,6 +1139,10 @@ def parse_args(argv=None):
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU: run the multi-rank flow (spawn, rendezvous over gloo, barriers, "
                          "gather) around an engine stand-in; the line carries \"dry_run\" and no value")
+    ap.add_argument("--detail-dir", default=None,
+                    help="directory of the side file bench_detail_n{N}.json (default: beside this script and gpurun_out/)")
+    ap.add_argument("--print-detail", action="store_true",
+                    help="also print the full record as a line BEFORE the compact one (the compact record stays last)")
     ap.add_argument("--no-efficiency", action="store_true",
                     help="N > 1: skip rank 0's single-GPU reference runs (eff_w / eff_s)")
     ap.add_argument("--groups", type=int, default=4,
