@@ -459,7 +459,13 @@ WIDE_CONFIGS = {
 # transform="sigmoid", num_starts=5, num_samples=1024, gamma = 1/3, epochs = num_steps_per_iter // steps per epoch
 # = 1000 // ceil(N / 64) (base.py:176-184).  Static shape 5: at 16 inputs as compiled, at 6 zero-padded (fit) /
 # with the input dimension as a run-time argument (acquisition).
+# (the third leg: the same network and fit with transform="identity" -- one of the plugin's own choices,
+# plugins/hpbandster/base.py:18 -- whose acquisition surface is the logit itself: sigmoid(-f) of a 500-epoch classifier
+# is flat at the screened starts, L-BFGS-B returns at iteration 0 and the default legs time no restart that iterates)
 PLUGIN_CONFIGS = {
+    "plugin_D16_transform_identity": dict(D=16, units=[32, 32, 32, 1], acts=["elu", "elu", "elu", "linear"],
+                                          transform="identity", R=5, Ns=1024, N=100, gamma=1.0 / 3.0, epochs=1000 // 2,
+                                          compute="float32"),
     "plugin_default_D6": dict(D=6, units=[32, 32, 32, 1], acts=["elu", "elu", "elu", "linear"], transform="sigmoid",
                               R=5, Ns=1024, N=100, gamma=1.0 / 3.0, epochs=1000 // 2, compute="float32"),
     "plugin_default_D16": dict(D=16, units=[32, 32, 32, 1], acts=["elu", "elu", "elu", "linear"], transform="sigmoid",
@@ -529,6 +535,7 @@ def config_gpu(name, c, loops, epochs=200, batch=64, reps=3):
                         for k in range(1, reps + 1)])                     # [rep][phase] ms
     ph = np.median(per_rep, axis=0)                                       # ms per phase: the median rep
     nfev = np.stack([i.cpu().numpy()[:, :, 1] for i in infos[1:]]).astype(np.float64)
+    nit = np.stack([i.cpu().numpy()[:, :, 0] for i in infos[1:]]).astype(np.float64)
     rows = float(nfev.sum() / reps)                                      # f/g rows per iteration
     rounds = float(nfev.max(axis=2).sum() / reps)                        # rounds, summed over loops
     status = np.stack([i.cpu().numpy()[:, :, 2] for i in infos[1:]])
@@ -566,6 +573,13 @@ def config_gpu(name, c, loops, epochs=200, batch=64, reps=3):
         "ms_reps": {"n": int(reps), "value_is": "median",
                     "min": {k: float(per_rep[:, i].min()) for i, k in enumerate(("fit", "screen", "lbfgsb", "pick"))},
                     "max": {k: float(per_rep[:, i].max()) for i, k in enumerate(("fit", "screen", "lbfgsb", "pick"))}},
+        # every repetition by itself: its restart launch's time beside the evaluation requests it served (a repetition
+        # is a further fit and new starts: other surfaces, other counts) -- ms per million requests is the comparable figure
+        "lbfgsb_reps": [{"ms": float(per_rep[k, 2]), "nfev": float(nfev[k].sum()), "nit": float(nit[k].sum()),
+                         "nfev_max": float(nfev[k].max()),
+                         "ms_per_million_requests": float(per_rep[k, 2] / max(nfev[k].sum(), 1.0) * 1e6)}
+                        for k in range(reps)],
+        "nit_per_restart": float(nit.mean()), "nfev_per_restart": float(nfev.mean()),
         "us_per_adam_step": 1e3 * float(ph[0]) / S,
         "fg_rows_per_iteration": rows, "restarts_ok_frac": float(np.mean(status <= 1)),
         "algorithmic_bytes": {k: float(x) for k, x in by.items()},

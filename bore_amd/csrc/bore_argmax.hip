@@ -584,6 +584,10 @@ struct LbfgsbArgs {
   int *flag;
   const long long *stamps;  // [n_loops][4] clock stamps of the fused kernel's earlier phases, or NULL
   int d_in;  // the net's input dimension = the optimiser's problem size (<= the static shape's: stage_theta_in)
+  // PUBLISH = 1 launches: 0 = the flag goes out by a system-scope atomic exchange on the pinned block (the link to
+  // the host does native atomics: host_common.h, device_host_atomics), 1 = by a release store behind a system-scope
+  // fence (on a link without them the exchange may never land and the host would wait for a flag forever)
+  int flag_by_store;
 };
 
 // -DBORE_STAMPS: cycles spent in the optimiser / in f-g evaluation by wave 0 of workgroup 0
@@ -667,7 +671,7 @@ __device__ __forceinline__ void lbfgsb_body(const LbfgsbArgs &a, const long long
   // (launches with more workgroups than CUs may run 5..8 waves per workgroup, one problem each:
   // lbfgsb_kernel_w8; batch mode always has four)
 #ifdef BORE_STAMPS
-  lbfgsb::g_lb_lds[wv & 7][lane] = 0;
+  lbfgsb::g_lb_lds[wv & 15][lane] = 0;
 #endif
   const int NW = (int)(blockDim.x >> 6);
   const bool multi = a.result && np > 4 && np <= 16;
@@ -990,8 +994,8 @@ __device__ __forceinline__ void lbfgsb_body(const LbfgsbArgs &a, const long long
   if (coop && lane == 0 && 4 * blockIdx.x + wv < LB_PP_MAX) {  // (one writer per row: plain adds)
     unsigned long long *pp = lbfgsb::g_lb_pp[4 * blockIdx.x + wv];
     for (int i = 0; i < 64; ++i) {
-      pp[i] += lbfgsb::g_lb_lds[wv & 7][i];
-      lbfgsb::g_lb_lds[wv & 7][i] = 0;
+      pp[i] += lbfgsb::g_lb_lds[wv & 15][i];
+      lbfgsb::g_lb_lds[wv & 15][i] = 0;
     }
     pp[13] += (unsigned long long)t_adv;
     pp[14] += (unsigned long long)t_fg;
@@ -1100,7 +1104,16 @@ __device__ __forceinline__ void lbfgsb_body(const LbfgsbArgs &a, const long long
       // reached the host late and in bursts -- the host's result -> row turn-around went from 1.5 to 17 us per
       // loop-iteration, all of what the cheaper hand-overs had saved; a buffer_wbl2 after the store changed nothing,
       // profiles/r5/ab_log.txt)
-      (void)__hip_atomic_exchange(a.flag + lid, it_done + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      // Ordering: the pick's stores are write-through and ACKNOWLEDGED (vmcnt(0) above) before the flag's operation is
+      // issued -- what gfx942 / gfx950 guarantee for system-scope (sc0 sc1) stores to fine-grained host memory, not
+      // a formal release.  Where the link has no native atomics (a.flag_by_store) the flag is a release store behind a
+      // system-scope fence instead: slower (the XCD's L2 is written back), correct everywhere.
+      if (a.flag_by_store) {
+        __threadfence_system();
+        __hip_atomic_store(a.flag + lid, it_done + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      } else {
+        (void)__hip_atomic_exchange(a.flag + lid, it_done + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
     } else {
       __threadfence_system();
       __hip_atomic_store(a.flag + lid, it_done + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1162,6 +1175,10 @@ __global__ __launch_bounds__(3 * BORE_THREADS) void lbfgsb_kernel_w12(const Lbfg
   lbfgsb_body<SHAPE, BF16, true, true>(a, blockIdx.x, blockIdx.y);
 }
 
+// (Sixteen waves -- four per SIMD, 128 registers -- fit since round 6 stores the optimiser's two 2m x 2m matrices as the
+// two triangles of one block, lbfgsb.h: 90 registers spilled, 8.45 ms per million evaluation requests of config 2
+// against 7.93 for twelve waves on the same inputs, profiles/r6/ab_log.txt.  Not kept.)
+
 static int lbfgsb_build(const bore_mlp_desc *desc, int n_models, const float *theta,
                         int transform, int negate, const double *x0, int num_starts,
                         const double *lb, const double *ub, const bore_lbfgsb_opts *opts, double *x,
@@ -1221,23 +1238,27 @@ static int lbfgsb_build(const bore_mlp_desc *desc, int n_models, const float *th
   if (PB > 4 && !g_batch && (long long)n_models * ((num_starts + 3) / 4) <= coop_grid_max) PB = 4;
   const int flavour = bore_acq_flavour(desc, true);
   a.d_in = D;
-  // More workgroups than CUs, wide static shape: up to eight problems = eight waves per workgroup
-  // (as many as fit beside the weights; lbfgsb_kernel_w8).  BORE_LBFGSB_W8 = 0 / 1 forces either.
-  bool w8 = false;
-  if (waves_out && !g_batch && PB == 4 && num_starts >= 8 &&
-      (flavour == 3 || (flavour == 4 && desc->compute == BORE_COMPUTE_BF16))) {
-    const int forced = getenv("BORE_LBFGSB_W8") ? atoi(getenv("BORE_LBFGSB_W8")) : -1;
-    w8 = forced < 0 ? (long long)n_models * ((num_starts + 3) / 4) > device_cus() : forced != 0;
-    if (w8) PB = 8;
+  // More workgroups than CUs, static shape: ONE workgroup per CU with a problem per wave and as many waves as
+  // workspaces fit beside the weights, up to the kernel's launch bound -- 8 for the wide shapes (lbfgsb_kernel_w8),
+  // 12 for the narrow ones (lbfgsb_kernel_w12, the same body at 168 registers).  The restart kernels are chains of
+  // dependent LDS round trips and float64 operations: waves in flight are throughput -- while the registers last: ten
+  // waves of 16->64-64-64-1 at 168 registers (154 spilled) measured no faster than eight at 256, sixteen of 6->32-32-1
+  // at 128 (90 spilled) slower than twelve (profiles/r6/ab_log.txt).  BORE_LBFGSB_WAVES = 4 keeps the four-wave
+  // kernels, = 8 / 12 forces the many-wave kernel with at most that many waves (tests, A/B).
+  const int waves_env = getenv("BORE_LBFGSB_WAVES") ? atoi(getenv("BORE_LBFGSB_WAVES")) : -1;
+  const bool bf16_model = desc->compute == BORE_COMPUTE_BF16;
+  int wmax = 4;  // waves (= problems at a time) per workgroup of this launch's kernel
+  if (waves_out && !g_batch && PB == 4) {
+    int bound = 4;
+    if ((flavour == 3 || (flavour == 4 && bf16_model)) && num_starts >= 8) bound = 8;
+    if ((flavour == 2 || flavour == 5) && !bf16_model && num_starts >= 12) bound = 12;
+    if (waves_env >= 4) wmax = bound < waves_env ? bound : waves_env;
+    else if ((long long)n_models * ((num_starts + 3) / 4) > device_cus()) wmax = bound;
+    if (wmax > num_starts) wmax = num_starts;
+    if (wmax < 8) wmax = 4;
+    PB = wmax;
   }
-  // ... and up to twelve for the narrow static shapes (lbfgsb_kernel_w12; BORE_LBFGSB_W12 = 0 / 1 forces either)
-  bool w12 = false;
-  if (waves_out && !g_batch && PB == 4 && num_starts >= 12 && (flavour == 2 || flavour == 5)) {
-    const int forced = getenv("BORE_LBFGSB_W12") ? atoi(getenv("BORE_LBFGSB_W12")) : -1;
-    w12 = forced < 0 ? (long long)n_models * ((num_starts + 3) / 4) > device_cus() : forced != 0;
-    if (w12) PB = 12;
-  }
-  const int wmax = w12 ? 12 : (w8 ? 8 : 4);  // waves (= problems at a time) per workgroup of this launch's kernel
+  const bool w8 = wmax > 4 && (flavour == 3 || flavour == 4);
   const int shape = flavour > 0 ? flavour : 0;  // constexpr-layout kernels assume a 64-row tile
   size_t off = 0;
   for (;; --PB) {
@@ -1315,7 +1336,7 @@ static int lbfgsb_build(const bore_mlp_desc *desc, int n_models, const float *th
   if (!g_batch && PB <= wmax && num_starts > PB && q_env != 0) {
     // (the 32-32-1 flavour stages 6 KB of weights and runs two workgroups per CU: finer shares -- 32 per CU
     // over the launch -- measured best there, profiles/r4/ab_log.txt; the wide flavours stage 40 - 50 KB)
-    const long long want = q_env > 0 ? q_env : ((flavour == 2 || flavour == 5) && !w12 ? 32LL : 4LL) * device_cus();
+    const long long want = q_env > 0 ? q_env : ((flavour == 2 || flavour == 5) && wmax == 4 ? 32LL : 4LL) * device_cus();
     long long per_model = (want + n_models - 1) / n_models;
     const long long most = (num_starts + slots - 1) / slots;
     if (per_model > most) per_model = most;
@@ -1324,13 +1345,14 @@ static int lbfgsb_build(const bore_mlp_desc *desc, int n_models, const float *th
     a.queue = PB > slots;
   }
   a.PB = PB;
-  if (waves_out) *waves_out = (w8 || w12) && slots > 4 ? slots : 4;
+  if (waves_out) *waves_out = wmax > 4 && slots > 4 ? slots : 4;
   if (a.L.w[a.L.n_layers] != 1)
     return fail(BORE_E_INVALID, "lbfgsb_minimize: the last Dense layer must have 1 unit");
   a.theta = theta; a.x0 = x0; a.x = x; a.fun = fun; a.jac = jac; a.info = info;
   a.R = num_starts; a.transform = transform; a.sign = negate ? -1.f : 1.f;
   a.ids = a.its = nullptr; a.n_init = a.dedup = 0; a.cap = 0;
   a.X_seen = nullptr; a.result = nullptr; a.flag = nullptr; a.stamps = nullptr;
+  a.flag_by_store = device_host_atomics() ? 0 : 1;
   if (g_batch) {
     if (num_starts > 16 || PB < num_starts)
       return fail(BORE_E_UNSUPPORTED, "lbfgsb_minimize: batch mode needs num_starts <= 16 in one workgroup");
@@ -1373,6 +1395,7 @@ extern "C" int bore_lbfgsb_minimize(const bore_mlp_desc *desc, int n_models, con
     if (!bore_flavour_built(flavour)) return fail(BORE_E_UNSUPPORTED, BORE_FLAVOUR_LEFT_OUT);
     if (!(flavour == 3 || (flavour == 4 && bf) || ((flavour == 2 || flavour == 5) && !bf)))
       return fail(BORE_E_UNSUPPORTED, "lbfgsb_minimize: no many-wave kernel for this flavour");
+    // (the kernel whose launch bound covers the waves: a launch of fewer waves than the bound is fine)
 #if BORE_ON_2
     if (flavour == 2) BORE_LAUNCH_W8((lbfgsb_kernel_w12<2, false>))
 #endif

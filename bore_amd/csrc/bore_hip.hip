@@ -152,18 +152,7 @@ struct FitArgs {
 // (ocml expf, IEEE division and sqrt: ~30 dependent instructions per updated register) were 0.8 - 1.2 k
 // cycles of a 3.3 - 3.7 k-cycle Adam step (profiles/r3/fit_marks_final.txt).  The L-BFGS-B (fp64,
 // lbfgsb.h) and the objective evaluation keep their IEEE forms.
-__device__ __forceinline__ float fit_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
-__device__ __forceinline__ float fit_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
-// exp(x) for x <= 0: 2^(x log2 e) with the product's rounding error fed back (the argument's error
-// would otherwise be |x| 2^-24 in the exponent); flushes to zero below 2^-126 like the result's use
-// (1 + e) does not notice
-__device__ __forceinline__ float fit_exp_neg(float x) {
-  const float L2E = 1.442695040888963f, L2E_LO = 1.925963033500e-8f;  // log2(e) = hi + lo
-  const float t = x * L2E;
-  const float r = fmaf(x, L2E_LO, fmaf(x, L2E, -t));                 // exact remainder of the product
-  const float e = __builtin_amdgcn_exp2f(t);
-  return fmaf(e, r * 0.6931471805599453f, e);                          // 2^(t + r) = 2^t (1 + r ln 2)
-}
+// (fit_rcp, fit_sqrt, fit_exp_neg, fit_elu: mlp_device.h -- the register network of mlp_regs.h uses them too)
 
 // Adam update of one parameter (ResourceApplyAdam, non-nesterov); returns the new weight.
 __device__ __forceinline__ float adam_update(float w, float g, float &m, float &v, float alpha,
@@ -1238,7 +1227,7 @@ __device__ __forceinline__ void fit_body(const FitArgs &a, const long long slot,
           }
         }
         wave_lds_sync();
-        fwd_all(L, n, th, tile, rb, /*keep_logits=*/true);
+        fwd_all<true>(L, n, th, tile, rb, /*keep_logits=*/true);
         if (lane < 16) {  // loss + d loss / d logit (the final layer has one unit)
           const int row = rb * 16 + lane;
           float delta = 0.f;

@@ -73,6 +73,27 @@ inline int device_cus() {
   return cus[dev];
 }
 
+// Does the link between the current device and the host do native atomics (PCIe AtomicOps or a coherent fabric)?
+// The fused kernels publish a loop's flag to pinned host memory with a system-scope atomic exchange when it does and
+// with a fenced release store when it does not (lbfgsb_body, PUBLISH = 1).  BORE_ASYNC_DEBUG=2 takes the
+// store path regardless (tests).  Per device, cached.
+inline bool device_host_atomics() {
+  static int seen[64];  // 0 unknown, 1 no, 2 yes
+  static std::mutex mu;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+  std::lock_guard<std::mutex> lock(mu);
+  if (!seen[dev]) {
+    int v = 0;
+    const bool ok = hipDeviceGetAttribute(&v, hipDeviceAttributeHostNativeAtomicSupported, dev) == hipSuccess && v != 0;
+    const char *dbg = getenv("BORE_ASYNC_DEBUG");
+    seen[dev] = ok && !(dbg && atoi(dbg) == 2) ? 2 : 1;
+    if (dbg) fprintf(stderr, "[bore] device %d: host-native atomics %s -> flags by %s\n", dev, ok ? "yes" : "no",
+                     seen[dev] == 2 ? "atomic exchange" : "fenced release store");
+  }
+  return seen[dev] == 2;
+}
+
 // Device scratch for the restart kernels whose optimiser keeps its two 2m x 2m matrices outside the
 // LDS (lbfgsb.h: make_work's `big`): BIG_SLOTS workgroup slots of `per_slot` doubles each plus one
 // lock word per slot (0 = free).  A workgroup takes a free slot when it starts and frees it when its

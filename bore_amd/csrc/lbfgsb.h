@@ -88,22 +88,29 @@ struct State {
 // caller must hand in a 16-byte aligned base: the device compiler merges adjacent fp64 LDS
 // loads into ds_read_b128, which returns WRONG data at 8-byte alignment on gfx950 (found as a
 // host/device mismatch for odd n; see tests/test_gpu_argmax.py).
-// big_outside: the two 2m x 2m matrices of the subspace minimisation (wn, snd: 8 m^2 doubles, 37 % of a
-// 32-variable problem's workspace) live in a buffer of the caller's (big_size doubles, 16-byte aligned,
+// The two 2m x 2m matrices of the subspace minimisation share ONE (2m) x (2m + 1) block (round 6): formk keeps
+// the LOWER triangle of `snd` (the "WN1" of the published code: blocks (1,1), (2,1), (2,2) by rows >= columns) and
+// builds / factors the UPPER triangle of `wn`; dpofa and the triangular solves touch the upper triangle only (the
+// wavefront forms read, and never use, entries below the diagonal).  With `wn` one column to the right of `snd`
+// -- wn(i, j) at block[(j + 1) * 2m + i], i <= j; snd(i, j) at block[j * 2m + i], i >= j -- the two triangles tile
+// the block exactly, every index expression keeps its leading dimension 2m and its 16-byte column alignment, and
+// a problem's workspace loses 4 m^2 - 2 m doubles (m = 10: 3 040 of 11.3 KB at 6 variables) -- which is what bounds
+// the problems, i.e. the latency chains, in flight per CU.  Same arithmetic, same bits.
+// big_outside: that block lives in a buffer of the caller's (big_size doubles, 16-byte aligned,
 // any address space -- the device kernels put it in global memory when that lets more problems share
 // the LDS) instead of inside dw.
+LB_HD int big_size(int m) { return 2 * m * (2 * m + 1); }
 LB_HD int dwork_size(int n, int m, bool big_outside = false) {
   const int ne = (n + 1) & ~1, mne = (m * n + 1) & ~1, mm = (m * m + 1) & ~1;
-  return 2 * mne + 3 * mm + (big_outside ? 0 : 8 * m * m) + 8 * m + 9 * ne + 6 * m;
+  return 2 * mne + 3 * mm + (big_outside ? 0 : big_size(m)) + 8 * m + 9 * ne + 6 * m;
 }
-LB_HD int big_size(int m) { return 8 * m * m; }
 LB_HD int iwork_size(int n) { return 3 * n; }
 
 // Views into the workspaces (all 0-based; matrices column-major like the original).
 struct Work {
   double *ws, *wy;          // [m][n]: correction j is ws[j*n .. j*n+n)
   double *sy, *ss, *wt;     // m x m, element (i,j) at [j*m + i]
-  double *wn, *snd;         // 2m x 2m, element (i,j) at [j*2m + i]
+  double *wn, *snd;         // 2m x 2m, element (i,j) at [j*2m + i]; wn == snd + 2m: two triangles of one block (above)
   double *z, *r, *d, *t, *xp, *x, *g;
   double *xlast, *glast;    // last point actually evaluated (SciPy's ScalarFunction cache)
   double *wa;               // 8m: p | c | wbp | v
@@ -129,12 +136,11 @@ LB_HD Work make_work(double *dw, int *iw, int n, int m, double *big = nullptr) {
   w.wt = dw; dw += mm;
   w.vm = big != nullptr;
   if (big) {  // (dwork_size(n, m, true) + big_size(m))
-    w.wn = big;
-    w.snd = big + 4 * m * m;
+    w.snd = big;
   } else {
-    w.wn = dw; dw += 4 * m * m;
-    w.snd = dw; dw += 4 * m * m;
+    w.snd = dw; dw += big_size(m);
   }
+  w.wn = w.snd + 2 * m;  // (one column to the right: the upper triangle beside snd's lower one)
   w.z = dw; dw += ne;
   w.r = dw; dw += ne;
   w.d = dw; dw += ne;
@@ -196,15 +202,15 @@ struct Coop {
 #define LB_OPAQUE_LANE(x) ((void)0)
 #endif
 
-// Work::vm == LB_BIG_LAZY: the two 2m x 2m matrices (8 m^2 doubles from w.wn on: make_work) start as whatever the
+// Work::vm == LB_BIG_LAZY: the two 2m x 2m matrices (big_size(m) doubles from w.snd on: make_work) start as whatever the
 // buffer held.  formk builds them up incrementally and counts on zeros (SciPy hands setulb a zeroed work array), but
 // only a problem that reaches a subspace minimisation ever looks at them -- one in twenty of BASELINE config 5's,
 // whose launches spent 6.4 GB of writes per million restarts on zeroing pool slots nobody read.
 enum { LB_BIG_INSIDE = 0, LB_BIG_ZEROED = 1, LB_BIG_LAZY = 2 };
 LB_HD void zero_big(const Work &w, int m, const Coop c) {
-  for (int i = 2 * c.lane; i < 8 * m * m; i += 2 * c.nl) {  // (pairs: 16-byte stores; 8 m^2 is even)
-    w.wn[i] = 0.0;
-    w.wn[i + 1] = 0.0;
+  for (int i = 2 * c.lane; i < big_size(m); i += 2 * c.nl) {  // (pairs: 16-byte stores; 2m (2m + 1) is even)
+    w.snd[i] = 0.0;
+    w.snd[i + 1] = 0.0;
   }
   LB_LANES_SYNC_VM(1);
 }
@@ -221,7 +227,7 @@ __device__ unsigned long long g_lb_pp[LB_PP_MAX][64];
 // Accumulated per wave in LDS (ds_add without return: no round trip in the optimiser's chain; the
 // r2 form added to global memory with returning atomics, ~2 k cycles per stamped phase); the kernel
 // flushes a wave's row to g_lb_pp when its problem ends.
-__shared__ unsigned g_lb_lds[8][64];
+__shared__ unsigned g_lb_lds[16][64];
 #endif
 #if defined(BORE_STAMPS) && defined(__HIP_DEVICE_COMPILE__)
 // Every cycle of lbfgsb_advance lands in exactly one bucket: LB_PHASE_BEGIN(g) charges the time
@@ -233,8 +239,8 @@ __shared__ unsigned g_lb_lds[8][64];
     const unsigned lb_dt_ = (unsigned)(lb_now_ - (s_).lb_last);                           \
     (s_).lb_last = lb_now_;                                                               \
     if ((threadIdx.x & 63) == 0) {                                                        \
-      __hip_atomic_fetch_add(&g_lb_lds[(threadIdx.x >> 6) & 7][i], lb_dt_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
-      __hip_atomic_fetch_add(&g_lb_lds[(threadIdx.x >> 6) & 7][32 + (i)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
+      __hip_atomic_fetch_add(&g_lb_lds[(threadIdx.x >> 6) & 15][i], lb_dt_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
+      __hip_atomic_fetch_add(&g_lb_lds[(threadIdx.x >> 6) & 15][32 + (i)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
     }                                                                                     \
   } while (0)
 #if defined(BORE_STAMPS_FORMK) || defined(BORE_STAMPS_CAUCHY)
@@ -1130,7 +1136,36 @@ LB_HDN int formk(const IterArgs s, const Work w) {
   int upcl;
   FK_MARK_DECL;
   if (s.updatd) {
-    if (s.iupdat > m) {  // shift the old part of WN1 (overlapping moves: kept sequential)
+    if (s.iupdat > m) {  // shift the old part of WN1: every entry moves one up and one to the left
+      if (c.nl > 1) {
+        // Round 6.  The sequential form below is 2 (m - 1) + (m - 1)^2 + ... = 171 moves at m = 10, each a load that its
+        // store waits for, done by all 64 lanes alike: ~15 k cycles per call once the memory is full (BASELINE config 2:
+        // formk 36 k cycles per call against 24 k for config 3, whose restarts end before it fills).  The moves of the
+        // three blocks touch disjoint entries, and within a block an entry's source lies one COLUMN to the right of
+        // it: taken in column order, a source is overwritten by a LATER move only.  So the (jy, i) grid is dealt to
+        // the lanes in that order, a pass loads its sources, waits, then stores -- and a source of this pass was the
+        // destination of no earlier one.  Same values moved to the same places.
+        const int m1 = m - 1;
+        for (int e0 = 0; e0 < m1 * m1; e0 += c.nl) {
+          const int e = e0 + c.lane;
+          const bool on = e < m1 * m1;
+          const int jy = on ? e / m1 : 0, i = on ? e - jy * m1 : 0, js = m + jy;
+          const bool tri = on && i < m1 - jy;
+          double a = 0.0, b = 0.0, cc = 0.0;
+          if (tri) {
+            a = WN1(jy + 1 + i, jy + 1);
+            b = WN1(js + 1 + i, js + 1);
+          }
+          if (on) cc = WN1(m + 1 + i, jy + 1);
+          LB_LANES_SYNC_VM(w.vm);
+          if (tri) {
+            WN1(jy + i, jy) = a;
+            WN1(js + i, js) = b;
+          }
+          if (on) WN1(m + i, jy) = cc;
+          LB_LANES_SYNC_VM(w.vm);
+        }
+      } else {
       for (int jy = 0; jy < m - 1; ++jy) {
         const int js = m + jy;
         for (int i = 0; i < m - 1 - jy; ++i) {
@@ -1138,6 +1173,7 @@ LB_HDN int formk(const IterArgs s, const Work w) {
           WN1(js + i, js) = WN1(js + 1 + i, js + 1);
         }
         for (int i = 0; i < m - 1; ++i) WN1(m + i, jy) = WN1(m + 1 + i, jy + 1);
+      }
       }
       LB_LANES_SYNC_VM(w.vm);
     }
@@ -1226,6 +1262,23 @@ LB_HDN int formk(const IterArgs s, const Work w) {
   // upper triangle of WN = [D+Y'ZZ'Y/theta   -L_a'+R_z'] [-L_a+R_z   S'AA'S*theta]
   // (each iy writes its own columns iy and col+iy)
   const double theta = s.theta, rtheta = 1.0 / s.theta;
+  if (c.nl > 1) {
+    // (round 6: one ENTRY per lane instead of one column -- a column was up to 3 col loads each followed by its
+    // store, one after the other; every entry is its own product of one stored value)
+    for (int e = c.lane; e < col * col; e += c.nl) {
+      const int iy = e / col, jy = e - iy * col;
+      const int is = col + iy, is1 = m + iy, js = col + jy, js1 = m + jy;
+      const double v21 = WN1(is1, jy);
+      if (jy <= iy) {
+        const double v11 = WN1(iy, jy), v22 = WN1(is1, js1);
+        double t11 = v11 * rtheta;
+        if (jy == iy) t11 += w.sy[iy * m + iy];
+        WN(jy, iy) = t11;
+        WN(js, is) = v22 * theta;
+      }
+      WN(jy, is) = jy < iy ? -v21 : v21;
+    }
+  } else {
   for (int iy = c.lane; iy < col; iy += c.nl) {
     const int is = col + iy, is1 = m + iy;
     for (int jy = 0; jy <= iy; ++jy) {
@@ -1236,6 +1289,7 @@ LB_HDN int formk(const IterArgs s, const Work w) {
     for (int jy = 0; jy < iy; ++jy) WN(jy, is) = -WN1(is1, jy);
     for (int jy = iy; jy < col; ++jy) WN(jy, is) = WN1(is1, jy);
     WN(iy, iy) += w.sy[iy * m + iy];
+  }
   }
   LB_LANES_SYNC_VM(w.vm);
   FK_MARK(21);
@@ -1711,7 +1765,27 @@ LB_HD void matupd(State &s, const Work &w, double rr, double dr, const Coop c = 
   }
   s.theta = rr / dr;
   const int col = s.col;
-  if (s.iupdat > m) {  // move old information
+  if (VL && c.nl > 1 && s.iupdat > m) {
+    // (round 6: the same moves dealt to the lanes -- see formk's shift: sources lie one column to the right of their
+    // destinations, the (j, i) grid goes out in column order, a pass loads, waits, stores.  108 dependent load /
+    // store pairs by every lane alike were ~5 k of matupd's 7 k cycles once the memory is full)
+    const int c1 = col - 1;
+    for (int e0 = 0; e0 < c1 * c1; e0 += c.nl) {
+      const int e = e0 + c.lane;
+      const bool on = e < c1 * c1;
+      const int j = on ? e / c1 : 0, i = on ? e - j * c1 : 0;
+      const bool up = on && i <= j, lo = on && i < c1 - j, first = on && i == 0;
+      double a = 0.0, b = 0.0, r1 = 0.0, r2 = 0.0;
+      if (up) a = w.ss[(j + 1) * m + (i + 1)];
+      if (lo) b = w.sy[(j + 1) * m + (j + 1 + i)];
+      if (first) { r1 = w.rsy[j + 1]; r2 = w.rsq[j + 1]; }
+      LB_LANES_SYNC();
+      if (up) w.ss[j * m + i] = a;
+      if (lo) w.sy[j * m + (j + i)] = b;
+      if (first) { w.rsy[j] = r1; w.rsq[j] = r2; }
+      LB_LANES_SYNC();
+    }
+  } else if (s.iupdat > m) {  // move old information
     for (int j = 0; j < col - 1; ++j) {
       w.rsy[j] = w.rsy[j + 1];
       w.rsq[j] = w.rsq[j + 1];

@@ -35,10 +35,43 @@ __device__ __forceinline__ float sigmoid_stable(float x) {
   return x >= 0.f ? 1.f / d : e / d;
 }
 
+// ---- the FIT's arithmetic: "<= 1 ulp per operation" (DESIGN.md 2), hardware rcp / sqrt / 2^t ----
+__device__ __forceinline__ float fit_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float fit_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+// exp(x) for x <= 0: 2^(x log2 e) with the product's rounding error fed back (the argument's error
+// would otherwise be |x| 2^-24 in the exponent); flushes to zero below 2^-126 like the result's use
+// (1 + e) does not notice
+__device__ __forceinline__ float fit_exp_neg(float x) {
+  const float L2E = 1.442695040888963f, L2E_LO = 1.925963033500e-8f;  // log2(e) = hi + lo
+  const float t = x * L2E;
+  const float r = fmaf(x, L2E_LO, fmaf(x, L2E, -t));                 // exact remainder of the product
+  const float e = __builtin_amdgcn_exp2f(t);
+  return fmaf(e, r * 0.6931471805599453f, e);                          // 2^(t + r) = 2^t (1 + r ln 2)
+}
+// elu(x) in the fit (round 6).  The reference's layers are Keras `activation="elu"` (plugins/hpbandster/base.py:
+// 152-155), whose TF kernel forms exp(x) - 1 for x < 0 (Eigen: features.exp() - 1).  ocml's expm1f is ~60
+// instructions with branches, 24 calls per lane in a forward pass of 16->32-32-32-1: 6.7 k of an 18 k-cycle Adam
+// step (profiles/r6/fit_marks_plugin.txt).  Here, for x < 0: the hardware's 2^(x log2 e) minus one -- the error of
+// the rounded exponent is e^x |x| 2^-24 <= 0.37 x 2^-24 in absolute terms, under the half-ulp the exponential itself
+// may be off near 1, so no feedback term; the subtraction is exact from x >= -0.69 on -- and the series
+// x + x^2/2 + x^3/6 + x^4/24 where that difference would cancel (|x| < 1/32: truncation x^5 / 120 < 2^-26 |x|).
+// Absolute error <= 2^-24 everywhere against the float64 oracle's expm1, relative <= 2e-6 (at the seam).
+__device__ __forceinline__ float fit_elu(float x) {
+  const float xn = fminf(x, 0.f);
+  const float big = __builtin_amdgcn_exp2f(xn * 1.442695040888963f) - 1.f;
+  const float ser = xn * fmaf(xn, fmaf(xn, fmaf(xn, 1.f / 24.f, 1.f / 6.f), 0.5f), 1.f);
+  const float neg = xn > -0.03125f ? ser : big;
+  return x > 0.f ? x : neg;
+}
+
+// FIT: the caller is a fit kernel (fit_elu instead of ocml's expm1f; everything else alike)
+template <bool FIT = false>
 __device__ __forceinline__ float act_fwd(int a, float x) {
   switch (a) {
     case BORE_ACT_RELU: return fmaxf(x, 0.f);
-    case BORE_ACT_ELU: return x > 0.f ? x : expm1f(x);
+    case BORE_ACT_ELU:
+      if constexpr (FIT) return fit_elu(x);
+      else return x > 0.f ? x : expm1f(x);
     case BORE_ACT_SIGMOID: return sigmoid_stable(x);
     case BORE_ACT_TANH: return tanhf(x);
     default: return x;
@@ -254,6 +287,7 @@ __device__ __forceinline__ f32x4 tile_mma(const float *ap, int sa, const float *
 }
 
 // Rows [16 rb, 16 rb + 16) of A_l = act_l(A_{l-1} W_l + b_l), by the calling wave.
+template <bool FIT = false>
 __device__ __forceinline__ void fwd_rowblock(const MlpLayout &L, const float *th, float *tile,
                                              int l, int rb, bool keep_logits) {
   const int lane = threadIdx.x & 63, m = lane & 15, q = lane >> 4;
@@ -272,7 +306,7 @@ __device__ __forceinline__ void fwd_rowblock(const MlpLayout &L, const float *th
     const bool valid = col < wl;
     const float b = valid ? bias[col] : 0.f;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) Aout[r * lda_out + col] = valid ? act_fwd(a, acc[r] + b) : 0.f;
+    for (int r = 0; r < 4; ++r) Aout[r * lda_out + col] = valid ? act_fwd<FIT>(a, acc[r] + b) : 0.f;
   }
 }
 
@@ -303,11 +337,12 @@ __device__ __forceinline__ void bwd_rowblock(const MlpLayout &L, const float *th
 }
 
 // Forward through every layer for one row-block (calling wave).
+template <bool FIT = false>
 __device__ __forceinline__ void fwd_all(const MlpLayout &L, int n, const float *th, float *tile,
                                         int rb, bool keep_logits) {
 #pragma unroll
   for (int l = 1; l <= n; ++l) {
-    fwd_rowblock(L, th, tile, l, rb, keep_logits && l == n);
+    fwd_rowblock<FIT>(L, th, tile, l, rb, keep_logits && l == n);
     wave_lds_sync();
   }
 }

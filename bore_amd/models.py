@@ -33,6 +33,10 @@ class History:
             self._loss = None
         return self._history
 
+    @history.setter
+    def history(self, value):        # (Keras' History.history is a plain attribute: callers may assign it)
+        self._history, self._loss = value, None
+
     @property
     def epoch(self):
         return list(range(len(self.history["loss"])))
@@ -170,7 +174,14 @@ class Sequential:
         ``on_train_end``.  Without callbacks the whole fit is ONE kernel; with them it is one
         launch per epoch, so that ``model.stop_training = True`` (early stopping) takes effect at
         the epoch boundary as in Keras -- same arithmetic either way (Adam state and the shuffle
-        stream carry over between launches)."""
+        stream carry over between launches).
+
+        ASYNCHRONOUS without callbacks: the call returns once the kernel is enqueued on the model's stream (launch
+        errors -- bad arguments, an unsupported shape -- are raised here; the library checks ``hipGetLastError`` after
+        every launch).  The returned ``History`` keeps the device tensor of the losses and downloads it when
+        ``.history`` is first read; an error the device reports while the kernel RUNS surfaces at the next call that
+        waits for the stream (``.history``, ``predict``, ``argmax``, ``get_weights``), as with any stream-ordered API.
+        ``verbose=True`` or callbacks make the call wait."""
         x = np.asarray(x) if not isinstance(x, torch.Tensor) else x
         self._ensure_built(x)
         self._check_loss()

@@ -126,9 +126,13 @@ def resolve(t):
     # tf.identity / tf.sigmoid / tf.exp (bore/plugins/hpbandster/base.py:128-131).  Functions that COME FROM
     # tensorflow / jax / numpy under one of the three names are those functions (code ported from the reference
     # keeps working); a user's own function of that name stays the callable it is.
-    mod = getattr(t, "__module__", None) or ""
+    # (by (package, name) PAIRS that are the elementwise function -- numpy.identity / jax.numpy.identity
+    # build identity MATRICES and stay the callables they are)
+    mod = (getattr(t, "__module__", None) or "").split(".")[0]
     name = getattr(t, "__name__", None)
-    if name in TRANSFORMS and mod.split(".")[0] in ("tensorflow", "jax", "numpy", "keras"):
+    elementwise = {"tensorflow": ("identity", "sigmoid", "exp"), "keras": ("identity", "sigmoid", "exp"),
+                   "numpy": ("exp",), "jax": ("sigmoid", "exp")}
+    if name in TRANSFORMS and name in elementwise.get(mod, ()):
         return TRANSFORMS[name]
     if callable(t):                 # any other elementwise, torch-differentiable callable
         return CallableTransform(t)

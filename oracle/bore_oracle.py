@@ -42,8 +42,9 @@ published TF 2.5 semantics:
 PARITY UNPINNED for the Keras numerics: the reference holds no golden vector,
 known-answer test or fixture for fit / predict / gradients; its
 only test of this path, tests/test_models.py:12-50, is a property test which
-``tests/test_reference_properties.py`` re-runs against both this oracle and the
-HIP path.  What IS pinned against the reference itself (imported in the build
+this repository re-runs against this oracle (tests/test_oracle_golden.py, the
+linear-net maximiser test) and against the HIP path (tests/test_gpu_models.py,
+tests/test_gpu_argmax.py::test_reference_property_test_with_device_restarts).  What IS pinned against the reference itself (imported in the build
 container, vectors committed under tests/golden/): the label step
 (bore.data.Record), steps_per_epoch (bore.math), from_bounds
 (bore.optimizers.utils).  The SciPy half is pinned by calling the real

@@ -796,9 +796,9 @@ def test_lbfgsb_two_workgroups_per_cu_gives_the_same_bits(gpu, monkeypatch):
 @pytest.mark.parametrize("D,units,compute", [(16, [64, 64, 64, 1], "float32"), (16, [64, 64, 64, 1], "bfloat16"),
                                              (32, [128, 128, 1], "bfloat16")])
 def test_lbfgsb_eight_waves_per_workgroup_give_the_same_bits(gpu, monkeypatch, D, units, compute):
-    """Wide shapes, launches with more workgroups than CUs: one workgroup of up to eight waves (as
-    many problems as fit in LDS beside the weights) instead of four; BORE_LBFGSB_W8 forces either
-    kernel: same results bit for bit (incl. a last workgroup with fewer problems than waves)."""
+    """Wide shapes, launches with more workgroups than CUs: one workgroup of up to eight waves (as many problems
+    as fit in LDS beside the weights) instead of four; BORE_LBFGSB_WAVES forces either kernel: same results bit
+    for bit (incl. a last workgroup with fewer problems than waves)."""
     rs = np.random.RandomState(10)
     acts = ["relu"] * (len(units) - 1) + ["sigmoid"]
     desc = _lib.make_desc(D, units, acts, compute=compute)
@@ -806,12 +806,13 @@ def test_lbfgsb_eight_waves_per_workgroup_give_the_same_bits(gpu, monkeypatch, D
     X0 = dev(rs.uniform(size=(2, 21, D)))
     lo, hi = np.zeros(D), np.ones(D)
     outs = []
-    for w8 in ("0", "1"):
-        monkeypatch.setenv("BORE_LBFGSB_W8", w8)
+    for w8 in ("4", "8"):
+        monkeypatch.setenv("BORE_LBFGSB_WAVES", w8)
         outs.append([t.cpu().numpy() for t in ops.lbfgsb_minimize(desc, th, X0, lo, hi, "identity", True,
                                                                   maxiter=200, ftol=1e-9)])
-    for a, b in zip(*outs):
-        assert np.array_equal(a, b)
+    for other in outs[1:]:
+        for a, b in zip(outs[0], other):
+            assert np.array_equal(a, b)
 
 
 @pytest.mark.parametrize("D,units,compute,R,opts", [
@@ -838,14 +839,14 @@ def test_lbfgsb_problem_queue_gives_the_same_bits(gpu, monkeypatch, D, units, co
     lo, hi = np.zeros(D), np.ones(D)
     outs = []
     # (BORE_LBFGSB_BIG: the eight-wave kernel with the optimiser's two 2m x 2m matrices in the device pool)
-    for q, extra in (("0", {}), ("3", {}), ("7", {}), ("7", {"BORE_LBFGSB_W8": "1", "BORE_LBFGSB_OCC2": "1"}),
-                     ("7", {"BORE_LBFGSB_W8": "1", "BORE_LBFGSB_BIG": "1"}),
-                     ("0", {"BORE_LBFGSB_W8": "1", "BORE_LBFGSB_BIG": "1"}),
-                     ("7", {"BORE_LBFGSB_W8": "1", "BORE_LBFGSB_BIG": "0"}),
-                     ("7", {"BORE_LBFGSB_W12": "1"}), ("0", {"BORE_LBFGSB_W12": "1"}),       # (twelve waves: narrow shapes)
-                     ("5", {"BORE_LBFGSB_W12": "0", "BORE_LBFGSB_OCC2": "1"})):
+    for q, extra in (("0", {}), ("3", {}), ("7", {}), ("7", {"BORE_LBFGSB_WAVES": "8", "BORE_LBFGSB_OCC2": "1"}),
+                     ("7", {"BORE_LBFGSB_WAVES": "8", "BORE_LBFGSB_BIG": "1"}),
+                     ("0", {"BORE_LBFGSB_WAVES": "8", "BORE_LBFGSB_BIG": "1"}),
+                     ("7", {"BORE_LBFGSB_WAVES": "8", "BORE_LBFGSB_BIG": "0"}),
+                     ("7", {"BORE_LBFGSB_WAVES": "12"}), ("0", {"BORE_LBFGSB_WAVES": "12"}),   # (twelve waves: 168 registers)
+                     ("5", {"BORE_LBFGSB_WAVES": "4", "BORE_LBFGSB_OCC2": "1"})):
         monkeypatch.setenv("BORE_LBFGSB_QUEUE", q)
-        for k in ("BORE_LBFGSB_W8", "BORE_LBFGSB_OCC2", "BORE_LBFGSB_BIG", "BORE_LBFGSB_W12"):   # (each combination is what its label says)
+        for k in ("BORE_LBFGSB_WAVES", "BORE_LBFGSB_OCC2", "BORE_LBFGSB_BIG"):   # (each combination is what its label says)
             monkeypatch.delenv(k, raising=False)
         for k, v in extra.items():
             monkeypatch.setenv(k, v)

@@ -211,6 +211,13 @@ def test_callable_transforms_are_applied_on_the_host():
         raise AssertionError("never called")
     sigmoid.__module__ = "tensorflow.python.ops.math_ops"
     assert resolve(sigmoid).name == "sigmoid"
+    #  by (package, name) pairs: numpy.identity builds identity MATRICES -- not the elementwise identity --
+    # and stays the callable it is; so does a function called identity that comes from jax
+    assert isinstance(resolve(np.identity), CallableTransform)
+    identity.__module__ = "jax._src.numpy.lax_numpy"
+    assert isinstance(resolve(identity), CallableTransform)
+    sigmoid.__module__ = "jax._src.nn.functions"
+    assert resolve(sigmoid).name == "sigmoid"
     sigmoid.__module__ = "my_project.activations"              # a user's own function of that name: the callable
     assert isinstance(resolve(sigmoid), CallableTransform)
     np.testing.assert_allclose(mine.value_and_derivative(f)[0], f * f, rtol=1e-6)
@@ -249,3 +256,19 @@ def test_tools_and_committed_measurements_are_readable():
         reps = line["configs"][cfg]["many_loops"]["ms_reps"]
         assert reps["n"] >= 5 and reps["min"]["lbfgsb"] <= line["configs"][cfg]["many_loops"]["ms"]["lbfgsb"] <= reps["max"]["lbfgsb"]
     assert line["unit"] == "BO-iterations/s" and line["roofline"]["frac"] > 0 and line["cpu_baseline"]["value"] > 0
+
+
+def test_history_is_lazy_and_assignable_like_keras():
+    """`fit` returns a History that downloads the losses when first read (and, as in Keras, `history` is
+    an attribute a caller may assign)."""
+    from bore_amd.models import History
+    calls = []
+    h = History(lambda: calls.append(1) or np.array([0.7, 0.6], dtype=np.float32))
+    assert calls == []                                   # nothing downloaded yet
+    assert h.history == {"loss": [pytest.approx(0.7), pytest.approx(0.6)]} and h.epoch == [0, 1] and calls == [1]
+    assert h.history["loss"] and calls == [1]            # once
+    h.history = {"loss": [1.0], "val_loss": [2.0]}
+    assert h.history["val_loss"] == [2.0] and h.epoch == [0]
+    h2 = History(lambda: (_ for _ in ()).throw(AssertionError("never downloaded")))
+    h2.history = {"loss": []}                           # assigned before it was ever read: no download
+    assert h2.epoch == []

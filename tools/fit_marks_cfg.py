@@ -1,6 +1,8 @@
 """Where an Adam step of the 6->32-32-1 fit (BASELINE config 2, N = 256) spends its cycles: the marks of
 tools/fit_marks.py around a stand-alone fit launch (diagnostic build libbore_hip_fitmarks.so =
--DBORE_FIT_MARKS; GPU box).  usage: python tools/fit_marks_cfg.py [N] [loops]"""
+-DBORE_FIT_MARKS; GPU box).  usage: python tools/fit_marks_cfg.py [N] [loops] [cfg2|plugin]
+(plugin: the plugin's default network 16->32-32-32-1, elu x3 + linear; BORE_FIT_W8=0 for the four-wave body the marks
+are kept per wave for)"""
 import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -9,9 +11,10 @@ import numpy as np, torch
 from bore_amd import _lib, ops
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 L = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-D, units, E = 6, [32, 32, 1], 40
+which = sys.argv[3] if len(sys.argv) > 3 else "cfg2"
+D, units, E = (6, [32, 32, 1], 40) if which == "cfg2" else (16, [32, 32, 32, 1], 40)
 rs = np.random.RandomState(7)
-desc = _lib.make_desc(D, units, ["relu", "relu", "sigmoid"])
+desc = _lib.make_desc(D, units, ["relu", "relu", "sigmoid"] if which == "cfg2" else ["elu", "elu", "elu", "linear"])
 P = ops.param_count(desc)
 th = torch.from_numpy(rs.normal(scale=0.2, size=(L, P)).astype(np.float32)).cuda()
 m, v = torch.zeros_like(th), torch.zeros_like(th)
@@ -33,7 +36,7 @@ names = ["gather+requests", "forward", "loss+delta", "backward+copies", "wait mi
          "step loop top -> step", "  task: requests", "  task: matrix chain", "  task: Adam+stores", "(a mark itself)", "(end barrier -> epoch top)",
          "(epoch top -> shuffle chosen)", "(-> step loop top)", "(mid barrier -> own task done)"]
 n_steps = a[:, 16 + 5].max()
-print(f"6->32-32-1, N {N}, {L} loops, {E} epochs: {1e3 * e0.elapsed_time(e1) / (E * ((N + 63) // 64)):.2f} us per Adam step (marks build); {n_steps:.0f} steps marked")
+print(f"{D}->{'-'.join(map(str, units))}, N {N}, {L} loops, {E} epochs: {1e3 * e0.elapsed_time(e1) / (E * ((N + 63) // 64)):.2f} us per Adam step (marks build); {n_steps:.0f} steps marked")
 for i, nm in enumerate(names):
     print(f"  {nm:30s} " + "  ".join(f"{a[w, i] / max(a[w, 16 + i], 1):7.0f} ({a[w, 16 + i] / max(n_steps, 1):4.2f})" for w in range(4)))
 print("  sum of 0..7 per step           " + "  ".join(f"{sum(a[w, i] for i in range(8)) / max(n_steps, 1):7.0f}       " for w in range(4)))
