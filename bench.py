@@ -59,10 +59,10 @@ BF16_PEAK_TF = 2500.0    # dense bf16 MFMA peak
 TOTAL_LOOPS = 512        # BASELINE.json config 4
 def _latest(name):
     """profiles/rN/<name> of the newest round that has it."""
-    for rnd in ("r5", "r4", "r3"):
+    for rnd in ("r6", "r5", "r4", "r3"):
         if os.path.exists(os.path.join(ROOT, "profiles", rnd, name)):
             return os.path.join("profiles", rnd, name)
-    return os.path.join("profiles", "r5", name)
+    return os.path.join("profiles", "r6", name)
 
 
 TRAFFIC_FILE = _latest("pmc_traffic.json")
@@ -92,7 +92,7 @@ SWEEP_FILE = _latest("loops_sweep.json")   # T(1, L) measured on one GPU
 
 
 def csrc_digest():
-    """sha256 over the kernel sources: what a committed PMC pass was collected on (tools/collect_r5.py stores it in
+    """sha256 over the kernel sources: what a committed PMC pass was collected on (tools/collect_r6.py stores it in
     pmc_traffic.json) against what this run times -- `traffic_stale` in the line.  (bore_amd._lib.source_digest: the
     same digest the library carries.)"""
     from bore_amd import _lib
@@ -549,7 +549,7 @@ def config_gpu(name, c, loops, epochs=200, batch=64, reps=3):
     peak_tf = BF16_PEAK_TF if c["compute"] == "bfloat16" else FP32_PEAK_TF
     kern = {"fit": ph[0], "screen": ph[1], "fg": ph[2]}
     # HBM traffic by the counters, per phase: the committed PMC pass of the 256-loop launches of this config
-    # (tools/collect_r5.py: per kernel AND grid size).  Not collected in this run; stale when the sources moved.
+    # (tools/collect_r6.py: per kernel AND grid size).  Not collected in this run; stale when the sources moved.
     traffic = {}
     try:
         with open(os.path.join(ROOT, TRAFFIC_FILE)) as f:
@@ -650,6 +650,41 @@ def config_cpu(c, epochs_sample=4, restarts_sample=6, batch=64, epochs=200):
                        f"{np.mean([r.nit for r in res]):.1f}, nfev {np.mean([r.nfev for r in res]):.1f}")
 
 
+def _synthetic_objective(X):
+    """The smooth synthetic objective of _synthetic (centre 0.4), as the engine's callback: [n, D] -> [n]."""
+    return np.sum((X - 0.4) ** 2, axis=-1) + 0.1 * np.sin(5.0 * X.sum(axis=-1))
+
+
+def plugin_engine(loops, steps=8, warmup=2):
+    """The network the reference's only in-repo caller builds (PLUGIN_CONFIGS: 16 -> 32-32-32-1, elu, transform sigmoid,
+    5 restarts from 1024 samples, gamma 1/3, 500 epochs at N ~ 100) as whole BO LOOPS on the replica engine: round 6
+    gives static shape 5 the fused loop kernel (label -> fit -> screen -> restarts -> pick, resident workgroups, two
+    loops per CU; beyond that the work queue), where round 5 ran four lock-step launches per batch.  One step = one BO
+    iteration of every loop; the objective is a numpy callback."""
+    import torch
+    from bore_amd.engine import NativeEngine
+    c = PLUGIN_CONFIGS["plugin_default_D16"]
+    eng = NativeEngine(np.arange(loops), input_dim=c["D"], units=tuple(c["units"]), acts=tuple(c["acts"]),
+                       transform=c["transform"], gamma=c["gamma"], epochs=c["epochs"], num_starts=c["R"],
+                       num_samples=c["Ns"], n_init=c["N"], objective=_synthetic_objective, async_loops=True)
+    eng.run(warmup)
+    eng.take_stats(reset=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    eng.run(steps)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    st = eng.take_stats()
+    n_it = max(st.get("phase_iterations", 0), 1)
+    out = {"loops": loops, "steps": steps, "it_per_s": loops * steps / dt, "ms": {"iteration": 1e3 * dt / steps},
+           "N_start": int(c["N"] + warmup), "N_end": int(eng.N), "schedule": "fused loop kernel" if st["fit_ms"] == 0.0 else "launch chain",
+           "loops_per_cu": st.get("loops_per_cu"), "side_by_side_workgroups": st.get("side_by_side_workgroups"),
+           "per_loop_iteration_us": {k: 1e-3 * st["phase_ns_" + k] / n_it for k in ("labels", "fit", "screen", "lbfgsb")},
+           "none_results": int(st["none_results"]), "fg_requests_per_iteration": st.get("n_fg_requests", 0) / n_it}
+    eng.close()
+    return out
+
+
 def all_configs(args, barrier, cpu):
     out = {}
     # config 1 as ONE loop (the literal "Branin-2D ... 3 restarts" configuration)
@@ -670,6 +705,11 @@ def all_configs(args, barrier, cpu):
                 out[name]["cpu_baseline"] = config_cpu(c)
         except Exception as e:                     # a config that cannot run says so in the line
             out[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
+    for loops in (256, 512):                       # (whole loops of the plugin's network on the replica engine)
+        try:
+            out[f"plugin_default_D16_engine_{loops}_loops"] = plugin_engine(loops)
+        except Exception as e:
+            out[f"plugin_default_D16_engine_{loops}_loops"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     return out
 
 

@@ -138,11 +138,10 @@ def build_native(force=False, verbose=False):
     """Compile libbore_hip.so for gfx950.  Cross-compiles without a GPU.  Always the default
     in-tree path: an experimental build named by BORE_LIB_PATH is never overwritten.
     Up to date = the digest compiled into the library is the digest of the sources in the tree (file times say
-    nothing once a tree has travelled); BORE_FORCE_BUILD=1 or force=True compiles regardless."""
+    nothing once a tree has travelled); force=True compiles regardless."""
     out = DEFAULT_LIB_PATH
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
     digest = source_digest()
-    force = force or os.environ.get("BORE_FORCE_BUILD", "0") not in ("", "0")
     if not force and built_digest(out) == digest:
         if verbose:
             print(f"{out}: built from these sources ({digest[:16]}...), nothing to do")

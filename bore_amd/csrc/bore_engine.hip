@@ -389,8 +389,6 @@ static int async_decide_schedule(bore_engine *e) {
     bore_set_batch(nullptr);
     if (rc) return rc;
   }
-  if (getenv("BORE_ASYNC_PER_CU") && atoi(getenv("BORE_ASYNC_PER_CU")) > 0 && atoi(getenv("BORE_ASYNC_PER_CU")) < per_cu)
-    per_cu = atoi(getenv("BORE_ASYNC_PER_CU"));  // (A/B: fewer loops per CU than the device would hold)
   if (per_cu < 1) return fail(BORE_E_UNSUPPORTED, "engine: the fused kernel does not fit a compute unit with records of %lld rows", (long long)A.cap);
   A.per_cu = per_cu;
   const int forced = getenv("BORE_ASYNC_QUEUE") ? atoi(getenv("BORE_ASYNC_QUEUE")) : -1;
@@ -399,7 +397,11 @@ static int async_decide_schedule(bore_engine *e) {
   if (A.queue) {
     A.q_wgs = L < resident_cap ? L : resident_cap;
     int capq = 1;
+#ifdef BORE_QUEUE_STALL_TEST
+    while (capq < L + 64) capq <<= 1;   // (test build: the smallest ring -- every slot comes round every ~L tickets)
+#else
     while (capq < 2 * (L + A.q_wgs) + 64) capq <<= 1;   // (outstanding entries <= loops + exit tokens)
+#endif
     if (capq - 1 > A.q_mask || !A.q_ring) {
       if (A.q_ring) (void)hipHostFree(A.q_ring);
       A.q_ring = nullptr;
@@ -739,12 +741,8 @@ static int take_async_result(bore_engine *e, int l, double t0, int n_done) {
 // (it[], state[], ynew, x_new / y_new, the objective's input block of its share), keeps its own statistics, merged
 // at the end, and shares only the queue's tail -- tickets drawn with an atomic add, an entry published by the
 // release store of its sequence number, exactly what a waiting workgroup looks for.  A user's objective is called
-// by one thread at a time (the library's own Branin is re-entrant).  BORE_ASYNC_HOST_THREADS overrides T.
+// by one thread at a time (the library's own Branin is re-entrant).
 static int async_host_threads(const bore_engine *e, int L) {
-  if (getenv("BORE_ASYNC_HOST_THREADS")) {
-    const int t = atoi(getenv("BORE_ASYNC_HOST_THREADS"));
-    return t < 1 ? 1 : (t > 16 ? 16 : t);
-  }
   int cores = (int)std::thread::hardware_concurrency();
   cpu_set_t set;
   if (sched_getaffinity(0, sizeof(set), &set) == 0) cores = CPU_COUNT(&set);

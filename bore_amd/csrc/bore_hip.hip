@@ -2688,8 +2688,7 @@ static int fit_bf16_impl(const bore_mlp_desc *desc, int n_models, float *theta, 
   const int PGn = perm ? 1 : perm_group(N, BORE_THREADS);
   const size_t perm_bytes = 4 * (size_t)PGn * N + (perm ? 0 : 4 * (size_t)perm_group_scratch_floats(N, PGn)) + 96;
   const size_t new_bytes = (shape == 3 ? Bf16Plan<3>::o_end : Bf16Plan<4>::o_end) + perm_bytes;
-  const bool old_form = (getenv("BORE_BF16_FP32MFMA") && atoi(getenv("BORE_BF16_FP32MFMA"))) ||
-                        new_bytes > BORE_LDS_BYTES;
+  const bool old_form = new_bytes > BORE_LDS_BYTES;
   // LDS carve (bytes).  bf16-MFMA form: weight images | biases | A^T / D^T images (= gradient
   // image) | misc | perm | keys;  fp32-MFMA form: theta bf16 | A/D copies bf16 | misc | perm | keys
   size_t off;

@@ -10,7 +10,9 @@
 // other through global memory (labels z, the fitted theta, the screened x0): a workgroup-wide
 // barrier plus an agent-scope fence separates them (the fit re-reads nothing it wrote, but the
 // screening phase loads theta lines the fit's prologue may have left in the vector L1).
-// Static shape 1 (2 -> 16-16-1, the BASELINE config) only; anything else keeps the launch chain.
+// Static shape 1 (2 -> 16-16-1, the BASELINE config) and, round 6, static shape 5 at its full 16 inputs (16 ->
+// 32-32-32-1: the network the reference's only in-repo caller builds, bore/plugins/hpbandster/base.py:23-33 ->
+// bore/models.py:16-19); anything else keeps the launch chain.
 // Included by bore_all.hip after bore_hip.hip and bore_argmax.hip.
 
 // One entry of the work queue of queue_kernel (pinned host memory, written by the host in ticket order and
@@ -75,12 +77,9 @@ __device__ __forceinline__ double load_host_f64(const double *p) {
 // constants of the register network (100 B of scratch, spilled once per BO iteration; same speed:
 // profiles/r3/resident_inline_vs_call.txt).
 // (the restart phase re-requests the network's operands per evaluation: lbfgsb_body's LEAN)
-#ifndef BORE_LAG_PRIO
-#define BORE_LAG_PRIO 1  // -DBORE_LAG_PRIO=0: no wave priority for lagging loops, no yielding leaders (profiles/r4/ab_log.txt)
-#endif
-#ifndef BORE_LAG_YIELD_Q
-#define BORE_LAG_YIELD_Q 3  // a leader yields while it is more than Q / 4 iterations ahead of the mean
-#endif
+// a leader yields while it is more than Q / 4 iterations ahead of the mean (iteration_kernel; the A/B of the wave
+// priorities and of the yielding: profiles/r4/ab_log.txt -- closed, the switch BORE_LAG_PRIO is gone)
+#define BORE_LAG_YIELD_Q 3
 // One phase hands its results to the next through global memory (labels z, the fitted theta, the screened x0),
 // written and read by waves of the SAME workgroup: the writers' stores are acknowledged (the vector L1 writes
 // through to the XCD's L2), barrier, and the CU's L1 drops what it fetched before (buffer_inv sc0: this CU's
@@ -195,7 +194,6 @@ __global__ __launch_bounds__(BORE_THREADS, OCC) void iteration_kernel(const Iter
   }
   __shared__ __attribute__((aligned(16))) int s_go4[4];  // (16 B: the dynamic LDS keeps its alignment)
   const int target = pa->targets ? uniform_i32(pa->targets[slot]) : it_first + 1;
-#if BORE_LAG_PRIO
   // Two loops share a CU (512 loops on 256 CUs) and their waves share the SIMDs' issue slots.  The
   // timed region of K iterations ends with the SLOWEST loop -- loops whose restarts need twice the
   // evaluations, 1.45x the mean loop's time (profiles/r3/loop_tail.txt) -- so a loop that is behind
@@ -207,9 +205,7 @@ __global__ __launch_bounds__(BORE_THREADS, OCC) void iteration_kernel(const Iter
     asm volatile("" : "+s"(pb));
     prog = reinterpret_cast<int *>(pb);
   }
-#endif
   for (int it = it_first;;) {
-#if BORE_LAG_PRIO
     {
       const int total = __hip_atomic_load(prog, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const int n_wg = (int)gridDim.x;
@@ -218,7 +214,6 @@ __global__ __launch_bounds__(BORE_THREADS, OCC) void iteration_kernel(const Iter
       else if (lead > (n_wg >> 1)) __builtin_amdgcn_s_setprio(0);
       else __builtin_amdgcn_s_setprio(1);
     }
-#endif
     // (the argument block's address is made opaque per iteration, so that nothing read through it
     // is hoisted out of the loop and kept live around it)
     // (the block is written by the host before the launch and never by a kernel: read through the
@@ -227,15 +222,11 @@ __global__ __launch_bounds__(BORE_THREADS, OCC) void iteration_kernel(const Iter
     unsigned long long pa_bits = reinterpret_cast<unsigned long long>(pa);
     asm volatile("" : "+s"(pa_bits));
     typedef const __attribute__((address_space(4))) IterArgs *IterArgsConst;
-#ifndef BORE_ITER_LOCAL
-#define BORE_ITER_LOCAL true  // -DBORE_ITER_LOCAL=false: rounds 2 - 4's agent / system-scope fences (A/B, profiles/r5/ab_log.txt)
-#endif
-    iteration_once<SHAPE, BORE_ITER_LOCAL>((const IterArgs *)(IterArgsConst)pa_bits, slot, it, it == it_first);
+    // (LOCAL: workgroup-scope hand-overs; rounds 2 - 4's agent / system-scope fences lost the A/B, profiles/r5/ab_log.txt)
+    iteration_once<SHAPE, true>((const IterArgs *)(IterArgsConst)pa_bits, slot, it, it == it_first);
     __syncthreads();  // the waves leave the restart phase one by one: LDS is reused below
     ++it;
-#if BORE_LAG_PRIO
     if (threadIdx.x == 0) __hip_atomic_fetch_add(prog, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#endif
     if (it >= target) break;
     // ---- the next row: delivered while we were busy, or within wait_ticks, or not our business ----
     if (threadIdx.x == 0) {
@@ -256,7 +247,6 @@ __global__ __launch_bounds__(BORE_THREADS, OCC) void iteration_kernel(const Iter
         if (__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) break;
         __builtin_amdgcn_s_sleep(16);
       }
-#if BORE_LAG_PRIO
       // A loop more than 3/4 of an iteration AHEAD of the grid's mean spends its slack here, asleep, and
       // leaves the CU's issue slots to its partner (the region ends with the slowest loop: a leader gains
       // nothing by arriving early): until the mean has come within 3/4 of an iteration, 500 us at most per
@@ -271,7 +261,6 @@ __global__ __launch_bounds__(BORE_THREADS, OCC) void iteration_kernel(const Iter
           __builtin_amdgcn_s_sleep(64);
         }
       }
-#endif
       // (after this store the workgroup touches nothing of the loop: the host may relaunch it)
       if (!go) __hip_atomic_store(pa->parked + lid, it, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
       s_go4[0] = go;
@@ -318,6 +307,15 @@ __global__ __launch_bounds__(BORE_THREADS, OCC) void queue_kernel(const IterArgs
 #endif
       const unsigned long long t =
           __hip_atomic_fetch_add(pa->q_head, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef BORE_QUEUE_STALL_TEST
+      // (test build, tools/queue_stall_test.sh: the workgroup that draws ticket BORE_QUEUE_STALL_TEST sits on it,
+      // its entry UNREAD, for ~25 ms -- some ten thousand tickets of everybody else -- while the host's ring, which the
+      // same macro shrinks to the smallest legal size, comes round to that slot again and again.  What keeps the entry
+      // from being overwritten under it is the host's rule that a slot is written again only once the entry it held
+      // has been ANSWERED: bore_engine.hip, async_run_queue's push.)
+      if (t == (unsigned long long)(BORE_QUEUE_STALL_TEST))
+        for (int z = 0; z < 8000; ++z) __builtin_amdgcn_s_sleep(127);
+#endif
       // Waiting for entry t.  Round 4: every waiting workgroup polled the entry's sequence number in pinned memory --
       // a read over the bus every ~2 us from each of them.  With hundreds of workgroups idle (fewer ready loops than
       // workgroups; the end of every run) those reads saturate the link, and everything else that crosses it -- the
@@ -384,30 +382,47 @@ __global__ __launch_bounds__(BORE_THREADS, OCC) void queue_kernel(const IterArgs
 // its), uploads the block to d_args and launches.
 // Returns BORE_E_UNSUPPORTED when the model is not static shape 1: the caller falls back to the
 // launch chain.
-static int iteration_supported(const bore_mlp_desc *desc) {
-  return desc->compute == BORE_COMPUTE_F32 && bore_kernel_flavour(desc, true) == 1;
+// The static shape whose fused kernels run the model, or 0 (the caller keeps the launch chain).  Shape 5 only at its
+// 16 compiled inputs: with fewer the fit runs zero-padded through a repacked copy (fit_padded), which the fused
+// kernel has no phase for.
+static int iteration_shape(const bore_mlp_desc *desc) {
+  if (desc->compute != BORE_COMPUTE_F32) return 0;
+  const int f = bore_kernel_flavour(desc, true);
+  if (f == 1) return 1;
+  if (f == 5 && desc->input_dim == 16 && bore_flavour_built(5)) return 5;
+  return 0;
 }
+static int iteration_supported(const bore_mlp_desc *desc) { return iteration_shape(desc) != 0; }
 
 // Loops (workgroups) of the fused kernels one CU holds at a time with `lds_bytes` of dynamic LDS each: what the
 // runtime's occupancy query says (registers, waves), and no more than the LDS allows at its allocation granularity
 // -- 1 280 B on gfx950, which the query does not apply: at 54 240 B it answers 3 where the hardware places 2, and
 // a resident grid sized by that answer waits for workgroups that never start (331 k it/s instead of 560 k).
-static int iteration_loops_per_cu(size_t lds_bytes, int *per_cu_out) {
+static int iteration_loops_per_cu(int shape, size_t lds_bytes, int *per_cu_out) {
   static thread_local size_t seen_bytes = ~(size_t)0;
-  static thread_local int seen_per_cu = 0, seen_dev = -1;
+  static thread_local int seen_per_cu = 0, seen_dev = -1, seen_shape = 0;
   int dev = 0;
   HIP_TRY(hipGetDevice(&dev));
-  if (seen_bytes != lds_bytes || seen_dev != dev) {  // (per device: a thread may drive several)
-    int per_cu = 0, q_per_cu = 0;
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, iteration_kernel<1, true, 3>, BORE_THREADS, lds_bytes));
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&q_per_cu, queue_kernel<1, 3>, BORE_THREADS, lds_bytes));
+  if (seen_bytes != lds_bytes || seen_dev != dev || seen_shape != shape) {  // (per device: a thread may drive several)
+    int per_cu = 0, q_per_cu = 0, most = 3;
+#if BORE_ON_5
+    if (shape == 5) {  // (one build: two loops per CU, the whole register file of two waves per SIMD)
+      HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, iteration_kernel<5, true, 2>, BORE_THREADS, lds_bytes));
+      HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&q_per_cu, queue_kernel<5, 2>, BORE_THREADS, lds_bytes));
+      most = 2;
+    } else
+#endif
+    {
+      HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, iteration_kernel<1, true, 3>, BORE_THREADS, lds_bytes));
+      HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&q_per_cu, queue_kernel<1, 3>, BORE_THREADS, lds_bytes));
+    }
     if (q_per_cu < per_cu) per_cu = q_per_cu;
     const size_t granule = 1280, static_bytes = 16;  // (s_go4 / s_q4)
     const size_t each = (lds_bytes + static_bytes + granule - 1) / granule * granule;
     const int by_lds = (int)(BORE_LDS_BYTES / each);
     if (by_lds < per_cu) per_cu = by_lds;
-    if (per_cu > 3) per_cu = 3;  // (what the kernels are compiled for)
-    seen_bytes = lds_bytes; seen_dev = dev; seen_per_cu = per_cu;
+    if (per_cu > most) per_cu = most;  // (what the kernels are compiled for)
+    seen_bytes = lds_bytes; seen_dev = dev; seen_per_cu = per_cu; seen_shape = shape;
   }
   *per_cu_out = seen_per_cu;
   return 0;
@@ -439,8 +454,9 @@ static int iteration_launch(const bore_mlp_desc *desc, int n_slots, float *theta
   if ((rc = lbfgsb_build(desc, n_slots, theta, transform, 1, x0, num_starts, low, high, opts, x, fun,
                          jac, info, h->b, lb, sb, blocks)))
     return rc;
-  if (sf != 1 || ss != 1 || sb != 1 || blocks != 1)
-    return fail(BORE_E_UNSUPPORTED, "iteration_launch: static shape 1 only");
+  const int shape = iteration_shape(desc);
+  if (!shape || sf != shape || ss != shape || sb != shape || blocks != 1)
+    return fail(BORE_E_UNSUPPORTED, "iteration_launch: static shape 1, or 5 at 16 inputs, one workgroup per loop");
   h->X_seen = X_seen; h->y_seen = y_seen; h->X32 = X32; h->z = z;
   h->x_new = x_new; h->y_new = y_new;
   h->stamps = reinterpret_cast<long long *>(g_batch->stamps);
@@ -460,13 +476,22 @@ static int iteration_launch(const bore_mlp_desc *desc, int n_slots, float *theta
   floats = floats > lb ? floats : lb;
   const size_t labels_floats = 2 * ((size_t)cap + 2);
   floats = floats > labels_floats ? floats : labels_floats;
-  if ((rc = allow_lds(iteration_kernel<1, true, 2>, floats * 4)) || (rc = allow_lds(iteration_kernel<1, true, 3>, floats * 4)) ||
-      (rc = allow_lds(iteration_kernel<1, false, 2>, floats * 4)) || (rc = allow_lds(queue_kernel<1, 2>, floats * 4)) ||
-      (rc = allow_lds(queue_kernel<1, 3>, floats * 4)))
-    return rc;
+  if (shape == 1) {
+    if ((rc = allow_lds(iteration_kernel<1, true, 2>, floats * 4)) || (rc = allow_lds(iteration_kernel<1, true, 3>, floats * 4)) ||
+        (rc = allow_lds(iteration_kernel<1, false, 2>, floats * 4)) || (rc = allow_lds(queue_kernel<1, 2>, floats * 4)) ||
+        (rc = allow_lds(queue_kernel<1, 3>, floats * 4)))
+      return rc;
+  }
+#if BORE_ON_5
+  if (shape == 5) {
+    if ((rc = allow_lds(iteration_kernel<5, true, 2>, floats * 4)) || (rc = allow_lds(iteration_kernel<5, false, 2>, floats * 4)) ||
+        (rc = allow_lds(queue_kernel<5, 2>, floats * 4)))
+      return rc;
+  }
+#endif
   if (per_cu_out) {  // (a question, not a launch: how many loops of this model one CU holds)
     *per_cu_out = 0;
-    return iteration_loops_per_cu(floats * 4, per_cu_out);
+    return iteration_loops_per_cu(shape, floats * 4, per_cu_out);
   }
   if (queue_wgs > 0) {  // the work-queue form: a fixed grid, fed by the host through q_ring
     if (!q_ring || !q_head || !q_tail_host || !g_batch->ynew || !g_batch->abort_flag)
@@ -476,6 +501,11 @@ static int iteration_launch(const bore_mlp_desc *desc, int n_slots, float *theta
     HIP_TRY(hipMemcpyAsync(const_cast<IterArgs *>(d_args), h, sizeof(IterArgs), hipMemcpyHostToDevice,
                            (hipStream_t)stream));
     // (no more workgroups than two per CU: the kernel with the whole register file)
+#if BORE_ON_5
+    if (shape == 5)
+      hipLaunchKernelGGL((queue_kernel<5, 2>), dim3(queue_wgs), dim3(BORE_THREADS), floats * 4, (hipStream_t)stream, d_args);
+    else
+#endif
     if (queue_wgs <= 2 * device_cus())
       hipLaunchKernelGGL((queue_kernel<1, 2>), dim3(queue_wgs), dim3(BORE_THREADS), floats * 4, (hipStream_t)stream, d_args);
     else
@@ -485,7 +515,7 @@ static int iteration_launch(const bore_mlp_desc *desc, int n_slots, float *theta
   }
   if (h->wait_ticks > 0) {  // waiting workgroups hold their slots: only when all of them fit at once
     int per_cu = 0;
-    if ((rc = iteration_loops_per_cu(floats * 4, &per_cu))) return rc;
+    if ((rc = iteration_loops_per_cu(shape, floats * 4, &per_cu))) return rc;
     if (getenv("BORE_ASYNC_DEBUG"))
       fprintf(stderr, "[bore] fused kernel: %zu B of LDS per loop (fit %zu, screen %zu, restarts %zu, labels %zu), %d loops per CU\n", floats * 4, lf * 4, ls * 4, lb * 4, labels_floats * 4, per_cu);
     if (g_batch->resident_loops > per_cu * device_cus()) h->wait_ticks = 0;
@@ -493,6 +523,18 @@ static int iteration_launch(const bore_mlp_desc *desc, int n_slots, float *theta
   // h heads the caller's staging block (arguments | per-slot inputs | index lists): one upload
   HIP_TRY(hipMemcpyAsync(const_cast<IterArgs *>(d_args), h, upload_bytes, hipMemcpyHostToDevice,
                          (hipStream_t)stream));
+#if BORE_ON_5
+  if (shape == 5) {
+    if (h->wait_ticks > 0)
+      hipLaunchKernelGGL((iteration_kernel<5, true, 2>), dim3(n_slots), dim3(BORE_THREADS), floats * 4,
+                         (hipStream_t)stream, d_args);
+    else
+      hipLaunchKernelGGL((iteration_kernel<5, false, 2>), dim3(n_slots), dim3(BORE_THREADS), floats * 4,
+                         (hipStream_t)stream, d_args);
+    HIP_TRY(hipGetLastError());
+    return 0;
+  }
+#endif
   if (h->wait_ticks > 0 && g_batch->resident_loops > 2 * device_cus())  // (three loops per CU: see iteration_kernel)
     hipLaunchKernelGGL((iteration_kernel<1, true, 3>), dim3(n_slots), dim3(BORE_THREADS), floats * 4,
                        (hipStream_t)stream, d_args);

@@ -651,58 +651,8 @@ LB_HD double projgr(int n, const double *l, const double *u, const int *nbd, con
   return sb;
 }
 
-// ---- heap of breakpoints -------------------------------------------------------------
-// t[0..n) with companion iorder; iheap == 0 builds the heap first.  On exit the least
-// element sits in t[n-1] and t[0..n-1) is a heap again.
-LB_HD void hpsolb(int n, double *t, int *iorder, int iheap) {
-  if (iheap == 0) {
-    for (int k = 2; k <= n; ++k) {
-      const double ddum = t[k - 1];
-      const int indxin = iorder[k - 1];
-      int i = k;
-      while (i > 1) {
-        const int j = i / 2;
-        if (ddum < t[j - 1]) {
-          t[i - 1] = t[j - 1];
-          iorder[i - 1] = iorder[j - 1];
-          i = j;
-        } else {
-          break;
-        }
-      }
-      t[i - 1] = ddum;
-      iorder[i - 1] = indxin;
-    }
-  }
-  if (n > 1) {
-    int i = 1;
-    const double out = t[0];
-    const int indxou = iorder[0];
-    const double ddum = t[n - 1];
-    const int indxin = iorder[n - 1];
-    for (;;) {
-      int j = i + i;
-      if (j <= n - 1) {
-        if (t[j] < t[j - 1]) j = j + 1;
-        if (t[j - 1] < ddum) {
-          t[i - 1] = t[j - 1];
-          iorder[i - 1] = iorder[j - 1];
-          i = j;
-          continue;
-        }
-      }
-      break;
-    }
-    t[i - 1] = ddum;
-    iorder[i - 1] = indxin;
-    t[n - 1] = out;
-    iorder[n - 1] = indxou;
-  }
-}
+// (the heap of breakpoints of the published code -- hpsolb -- is gone: see cauchy's tie rule)
 
-// The three once-per-iteration routines below are real (non-inlined) device functions, so that
-// the per-evaluation path (line search) stays a few KB of code.  They take the scalars they
-// need BY VALUE (the caller's State stays in registers) and return theirs packed in an int.
 struct IterArgs {
   int n, m, col, head, nfree, nenter, ileave, updatd, iupdat;
   double theta, sbgnrm;
@@ -940,9 +890,8 @@ LB_HDN int cauchy(const IterArgs s, const Work w, const double *l, const double 
     // One variable per lane above: breakpoint k of the list sits in lane k's registers and the next one is the
     // smallest still there -- a wave minimum (ties: the lowest list position) instead of the heap in the workspace,
     // whose every step is a dependent LDS round trip made by all 64 lanes together (building it for the second
-    // breakpoint and sifting: 4.2 k cycles per breakpoint at n = 32, 21 k of cauchy's 35 k per call).  The heap hands
-    // out the breakpoints in ascending order too; where two are EQUAL its order is an accident of its shape, so the
-    // host build may then differ in the last bits (exactly equal breakpoints: not seen in any test or run).
+    // breakpoint and sifting: 4.2 k cycles per breakpoint at n = 32, 21 k of cauchy's 35 k per call).  The forms
+    // without a variable per lane (host build, one problem per lane) scan for the same entry: see below.
     const bool in_lanes = VL && cp.nl > 1 && n <= cp.nl && m <= cp.nl;
     double t_l = 0.0;
     int o_l = 0;
@@ -971,19 +920,27 @@ LB_HDN int cauchy(const IterArgs s, const Work w, const double *l, const double 
         alive = alive && cp.lane != lp;
       } else
 #endif
-      if (iter == 1) {
-        tj = bkmin;
-        ibp = iorder[ibkmin - 1];
-      } else {
-        if (iter == 2) {
-          if (ibkmin != nbreak) {
-            t[ibkmin - 1] = t[nbreak - 1];
-            iorder[ibkmin - 1] = iorder[nbreak - 1];
+      {
+        // ONE tie rule in every form: the next breakpoint is the smallest still in the list, and among
+        // EQUAL ones the lowest list position -- what the wave minimum above takes.  The published code's heap hands
+        // the breakpoints out in ascending order too, but where two are exactly equal (symmetric gradients and bounds)
+        // its order is an accident of the heap's shape; a host build with the heap could then differ from the device
+        // in the last bits.  A taken entry is marked with -1 (breakpoints are >= 0).
+        int best = ibkmin - 1;
+        if (iter > 1) {
+          best = -1;
+          double tb = 0.0;
+          for (int k = 0; k < nbreak; ++k) {
+            const double tk = t[k];
+            if (tk != -1.0 && (best < 0 || tk < tb)) {  // (!= : a NaN entry still counts as present)
+              best = k;
+              tb = tk;
+            }
           }
         }
-        hpsolb(nleft, t, iorder, iter - 2);
-        tj = t[nleft - 1];
-        ibp = iorder[nleft - 1];
+        tj = iter == 1 ? bkmin : t[best];
+        ibp = iorder[best];
+        t[best] = -1.0;
       }
       CK_MARK(21);
       const double dt = tj - tj0;

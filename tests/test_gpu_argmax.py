@@ -3,7 +3,7 @@ in-kernel multi-start L-BFGS-B, through the C-ABI on an MI355X."""
 import numpy as np
 import pytest
 import torch
-from scipy.optimize import Bounds
+from scipy.optimize import Bounds, minimize
 
 import lbfgsb_host as H
 from bore_amd import _lib, ops, sampling
@@ -148,6 +148,45 @@ def test_device_lbfgsb_equals_host_build_and_tracks_scipy(gpu, D, units, acts, t
     assert n_same_scipy >= MIN_SAME[D] * L * R
     # (32-D, random 128-128-1 nets: 17 of 20 within 2e-5, the others end 1e-5 .. 1e-4 apart)
     assert np.median(dfun) < 1e-6 and np.mean(np.array(dfun) < 2e-5) >= (0.8 if D == 32 else 0.9)
+
+
+def test_equal_breakpoints_take_the_same_order_on_the_device_and_in_the_host_build(gpu, monkeypatch):
+    """with exactly EQUAL breakpoints (symmetric gradients and bounds) the published code's heap hands them
+    out in an order that is an accident of its shape; every form here -- a variable per lane (wave minimum), one problem
+    per lane, the host build -- takes the lowest list position among equals, so the device still equals the host build
+    bit for bit.  A net whose first-layer rows are all alike has the same gradient in every input; starts with all
+    components equal (or equal in pairs) then have equal breakpoints in every Cauchy search."""
+    rs = np.random.RandomState(77)
+    D, units, acts = 6, [32, 32, 1], ["relu", "relu", "sigmoid"]
+    desc = _lib.make_desc(D, units, acts)
+    p = rand_model(rs, D, units)
+    p[0][:] = p[0][0:1]                                   # W1: every input row the same
+    th = dev(pack(p)[None])
+    X0 = np.concatenate([np.repeat(rs.uniform(0.05, 0.95, size=(10, 1)), D, axis=1),
+                         np.repeat(rs.uniform(0.05, 0.95, size=(6, 3)), 2, axis=1)])[None]      # [1][16][6]
+    lo, hi = np.zeros(D), np.ones(D)
+    opts = dict(maxiter=200, ftol=1e-9)
+
+    def fg_gpu(xx):
+        v, g = ops.mlp_value_and_input_grad(desc, th, dev(np.atleast_2d(xx)[None]), "identity", True)
+        return v.cpu().numpy()[0, 0], g.cpu().numpy()[0, 0]
+
+    v0, g0 = fg_gpu(X0[0, 0])
+    assert np.all(g0 == g0[0]) and g0[0] != 0.0          # the premise: equal gradient components, equal breakpoints
+    outs = []
+    for grid in ("4194304", "0"):                         # one problem per wave / one per lane
+        monkeypatch.setenv("BORE_LBFGSB_COOP_GRID", grid)
+        outs.append([t.cpu().numpy() for t in ops.lbfgsb_minimize(desc, th, dev(X0), lo, hi, "identity", True, **opts)])
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)
+    x, fun, jac, info = outs[0]
+    assert info[0, :, 0].max() >= 1                       # (the searches did move)
+    for r in range(X0.shape[1]):
+        h = H.minimize(fg_gpu, X0[0, r], (lo, hi), **opts)
+        assert np.array_equal(h.x, x[0, r]) and h.fun == fun[0, r] and (h.nit, h.nfev, h.status) == tuple(info[0, r, :3])
+        s = minimize(lambda xx: tuple(np.float64(a) if i == 0 else a for i, a in enumerate(fg_gpu(xx))), X0[0, r], jac=True,
+                     method="L-BFGS-B", bounds=Bounds(lo, hi), options=opts)
+        assert abs(s.fun - fun[0, r]) < 1e-6              # SciPy's heap may order the ties otherwise: same optimum
 
 
 def test_lbfgsb_one_problem_per_lane_mode_equals_one_per_wave(gpu):
@@ -354,6 +393,38 @@ def test_async_engine_equals_lockstep_engine(gpu, dedup):
     # without a launch -- two run() calls need two launches, parked loops a few more)
     assert 2 <= sa["fit_launches"] and sa["argmax_ms"] > 0
     assert sa["phase_iterations"] == 37 * 15 and sa["phase_ns_fit"] > 0 and sa["phase_ns_lbfgsb"] > 0
+
+
+@pytest.mark.parametrize("loops,queue", [(23, "0"), (40, "1")])
+def test_async_engine_runs_the_plugins_default_network_fused(gpu, monkeypatch, loops, queue):
+    """Round 6: the network the reference's only in-repo caller builds -- D -> 32-32-32-1, elu x3
+    + a linear output, transform sigmoid, 5 restarts, gamma 1/3 (bore/plugins/hpbandster/base.py:23-33 ->
+    bore/models.py:16-19) -- has the fused loop kernel at its 16 compiled inputs: resident workgroups (BORE_ASYNC_QUEUE
+    = 0) and the work queue (= 1), five restarts per loop in one workgroup.  Same trajectories and weights as the
+    lock-step engine's five-launch chain, bit for bit."""
+    from bore_amd.engine import NativeEngine
+    monkeypatch.setenv("BORE_ASYNC_QUEUE", queue)
+    obj = lambda X: np.sum((X - 0.4) ** 2, axis=-1) + 0.1 * np.sin(5.0 * X.sum(axis=-1))
+    kw = dict(input_dim=16, units=(32, 32, 32, 1), acts=("elu", "elu", "elu", "linear"), transform="sigmoid", gamma=1.0 / 3.0,
+              epochs=12, num_samples=128, num_starts=5, n_init=20, objective=obj)
+    a = NativeEngine(np.arange(100, 100 + loops), async_loops=True, **kw)
+    b = NativeEngine(np.arange(100, 100 + loops), groups=2, **kw)
+    a.run(4)
+    a.run(3)
+    b.run(7)
+    Xa, ya = a.observations()
+    Xb, yb = b.observations()
+    assert Xa.shape == (loops, 27, 16) and np.array_equal(Xa, Xb) and np.array_equal(ya, yb)
+    for u, v in zip(a.state(), b.state()):
+        assert np.array_equal(u, v)
+    sa, sb = a.take_stats(), b.take_stats()
+    assert sa["phase_iterations"] == loops * 7 and sa["phase_ns_fit"] > 0      # (the fused kernel's in-kernel stamps)
+    assert sa["fit_ms"] == 0.0 and sb["fit_ms"] > 0                             # fused: ONE kernel; lock-step: the chain
+    assert sa["none_results"] == sb["none_results"] and sa["n_fg_requests"] == sb["n_fg_requests"]
+    # fewer inputs than the static shape's 16: no fused kernel (the fit would run zero-padded): the launch chain
+    c = NativeEngine(np.arange(5), async_loops=True, **dict(kw, input_dim=6))
+    c.run(2)
+    assert c.take_stats()["fit_ms"] > 0
 
 
 def test_async_engine_launch_chain_for_other_models(gpu):
