@@ -237,7 +237,7 @@ def test_tools_and_committed_measurements_are_readable():
     for path in scripts:
         py_compile.compile(path, doraise=True)
     import bench
-    assert bench.TRAFFIC_FILE.startswith(os.path.join("profiles", "r5")) and bench.SWEEP_FILE.startswith(os.path.join("profiles", "r5"))
+    assert bench.TRAFFIC_FILE.startswith(os.path.join("profiles", "r6")) and bench.SWEEP_FILE.startswith(os.path.join("profiles", "r6"))
     traffic = json.load(open(os.path.join(root, bench.TRAFFIC_FILE)))
     assert traffic["iteration_kernel"]["hbm_bytes_per_model"] > 0
     # the PMC pass names the kernel sources it was collected on; bench.py compares with the tree it times
@@ -246,12 +246,18 @@ def test_tools_and_committed_measurements_are_readable():
     assert set(sweep["it_per_s"]) >= {"64", "512", "768", "1024", "4096"}
     # (round 5: per (kernel, grid) counter passes; per config and phase the 256-loop launch's bytes and its kernel)
     assert 0.0 < traffic["iteration_kernel"]["issue_slot_utilisation"] < 1.0
-    for cfg in ("cfg2_hartmann6_32-32-1_R256", "cfg3_hpo16_64-64-64-1_R1024", "cfg5_nas32_128-128-1_bf16_R4096", "plugin_default_D16"):
+    for cfg in ("cfg2_hartmann6_32-32-1_R256", "cfg3_hpo16_64-64-64-1_R1024", "cfg5_nas32_128-128-1_bf16_R4096", "plugin_default_D16",
+                "plugin_D16_transform_identity"):
         for phase in ("fit", "screen", "fg"):
             e = traffic["configs"][cfg][phase]
             assert e["hbm_bytes_per_launch"] > 0 and e["kernel"] and e["avg_ns_kernel_trace"] > 0
-    line = json.loads(open(os.path.join(root, "profiles", "r5", "bench_driver_form.json")).read().strip().splitlines()[-1])
+    # (round 6: the committed record is the side file of the driver-form run -- the line itself is the compact one)
+    line = json.loads(open(os.path.join(root, "profiles", "r6", "bench_driver_form.json")).read().strip().splitlines()[-1])
     assert line["configs"]["plugin_default_D16"]["many_loops"]["loops"] == 256
+    assert line["configs"]["plugin_default_D16_engine_256_loops"]["schedule"] == "fused loop kernel"
+    assert line["configs"]["cfg2_hartmann6_32-32-1_R256"]["many_loops"]["roofline_fp64_optimiser"] is not None
+    compact = json.loads(bench.compact_line(line, "bench_detail_n1.json"))
+    assert len(json.dumps(compact)) < 4096 and compact["roofline"]["kernel"] == "iteration_kernel"
     for cfg in ("cfg2_hartmann6_32-32-1_R256", "cfg3_hpo16_64-64-64-1_R1024", "cfg5_nas32_128-128-1_bf16_R4096"):
         reps = line["configs"][cfg]["many_loops"]["ms_reps"]
         assert reps["n"] >= 5 and reps["min"]["lbfgsb"] <= line["configs"][cfg]["many_loops"]["ms"]["lbfgsb"] <= reps["max"]["lbfgsb"]
