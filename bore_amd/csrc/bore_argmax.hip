@@ -1336,7 +1336,10 @@ static int lbfgsb_build(const bore_mlp_desc *desc, int n_models, const float *th
   if (!g_batch && PB <= wmax && num_starts > PB && q_env != 0) {
     // (the 32-32-1 flavour stages 6 KB of weights and runs two workgroups per CU: finer shares -- 32 per CU
     // over the launch -- measured best there, profiles/r4/ab_log.txt; the wide flavours stage 40 - 50 KB)
-    const long long want = q_env > 0 ? q_env : ((flavour == 2 || flavour == 5) && wmax == 4 ? 32LL : 4LL) * device_cus();
+    // (round 6, tools/ab_restarts.py on fixed inputs, profiles/r6/ab_queue_shares.txt: 4 per CU is the best or within
+    // 0.2 % of it for the twelve- / eight-wave float32 kernels; 32->128-128-1 in bfloat16 gains 4 % from 8 per CU)
+    const long long want = q_env > 0 ? q_env
+                                     : ((flavour == 2 || flavour == 5) && wmax == 4 ? 32LL : (flavour == 4 ? 8LL : 4LL)) * device_cus();
     long long per_model = (want + n_models - 1) / n_models;
     const long long most = (num_starts + slots - 1) / slots;
     if (per_model > most) per_model = most;

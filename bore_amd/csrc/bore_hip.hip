@@ -46,22 +46,22 @@ __device__ int g_stamp_on;
 // top of the next epoch, 13 -> shuffle chosen, 14 -> step loop top; 15 mid-step barrier -> the wave's
 // weight-gradient task done (5 then holds what follows it: the next step size, the l2 sums).
 #ifdef BORE_FIT_MARKS
-__device__ unsigned long long g_fit_acc[4][32];
-__shared__ unsigned g_fit_lds[4][32];
+__device__ unsigned long long g_fit_acc[8][32];  // (eight waves: fit_kernel_w8)
+__shared__ unsigned g_fit_lds[8][32];
 #define FIT_MARK_DECL long long fm_last = clock64()
 #define FIT_MARK(i)                                                                                    \
   do {                                                                                                 \
     const long long fm_now = clock64();                                                                \
     if ((threadIdx.x & 63) == 0) {                                                                     \
-      __hip_atomic_fetch_add(&g_fit_lds[(threadIdx.x >> 6) & 3][i], (unsigned)(fm_now - fm_last), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
-      __hip_atomic_fetch_add(&g_fit_lds[(threadIdx.x >> 6) & 3][16 + (i)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
+      __hip_atomic_fetch_add(&g_fit_lds[(threadIdx.x >> 6) & 7][i], (unsigned)(fm_now - fm_last), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
+      __hip_atomic_fetch_add(&g_fit_lds[(threadIdx.x >> 6) & 7][16 + (i)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
     }                                                                                                  \
     fm_last = fm_now;                                                                                  \
   } while (0)
 extern "C" int bore_debug_fit_marks(unsigned long long *out, int reset) {
-  int rc = (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fit_acc), sizeof(unsigned long long) * 128);
+  int rc = (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fit_acc), sizeof(unsigned long long) * 256);
   if (reset) {
-    unsigned long long z[128] = {0};
+    unsigned long long z[256] = {0};
     rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(g_fit_acc), z, sizeof(z));
   }
   return rc;
@@ -983,8 +983,13 @@ __device__ __forceinline__ void fit_body(const FitArgs &a, const long long slot,
   // loop-invariant addresses instead of the perm -> row -> operand chain.  (The slot is private to
   // its lane: no synchronisation; LDS rather than a register carried around the loop, which the
   // compiler rotated with copies that waited for the request at once.)  Same permutations, same rows.
-  const bool pipe_perm = SHAPE > 0 && !WIDE && !a.perm && PG >= 2 && blockDim.x == BORE_THREADS &&
-                         a.data_in_lds && N - (steps - 1) * a.B <= 16 * (BORE_THREADS / 64 - 1);
+  // Round 6: the eight-wave kernel too -- its fifth wave never has rows, so every data set of up to 128 rows qualifies;
+  // before, it drew the shuffles of two epochs with the whole workgroup at the top of every other epoch: 2.1 k cycles
+  // per epoch of 16->32-32-32-1 at N 100, 1.07 k of a 13.5 k-cycle step (profiles/r6/ab_log.txt).
+  const bool pipe_perm = SHAPE > 0 && !WIDE && !a.perm && PG >= 2 && a.data_in_lds &&
+                         ((blockDim.x == BORE_THREADS && N - (steps - 1) * a.B <= 16 * (BORE_THREADS / 64 - 1)) ||
+                          (NW == 8 && blockDim.x == 2 * BORE_THREADS));
+  const int draw_wave = NW == 8 && blockDim.x == 2 * BORE_THREADS ? BORE_THREADS / 64 : BORE_THREADS / 64 - 1;
   // The shuffles of the pipelined form are drawn by the fourth wave, two epochs ahead, during an epoch's
   // last step (make_perm_wave_buckets: ~1 k cycles at 100 rows; round 3's all-pairs count took ~6 k there,
   // more than a step's front half, and the workgroup drew the shuffles of 65..112 rows at the top of every
@@ -998,7 +1003,8 @@ __device__ __forceinline__ void fit_body(const FitArgs &a, const long long slot,
   const bool ahead = NW == 8 && a.perm_ahead && !a.perm && PG == 1 && blockDim.x == 2 * BORE_THREADS;
   constexpr int PRE_KC = RegNet<(SHAPE > 0 ? SHAPE : 1), 1>::KC0;
   static_assert(WIDE || SHAPE <= 0 || (PRE_KC + 1) * BORE_THREADS <= BORE_FIT_STAGE_FLOATS_OF(SHAPE), "stage region");
-  float *stage = smem + a.o_stage + tid;  // [PRE_KC + 1][BORE_THREADS]: inputs 4 kc + q4, then the label
+  // [PRE_KC + 1][BORE_THREADS]: inputs 4 kc + q4, then the label (the waves past the fourth own no rows and park none)
+  float *stage = smem + a.o_stage + (tid & (BORE_THREADS - 1));
   // (pipe_perm) request this lane's share of row `srow`: every address valid, dead shares zeroed at the store
   auto request_row = [&](float (&gx)[PRE_KC], float &gz, const int srow) {  // (pipe_perm: the data is in LDS)
 #pragma unroll
@@ -1021,7 +1027,7 @@ __device__ __forceinline__ void fit_body(const FitArgs &a, const long long slot,
   bool first_step = true;
   __syncthreads();
 #ifdef BORE_FIT_MARKS
-  if (lane < 32) g_fit_lds[wv & 3][lane] = 0;
+  if (lane < 32) g_fit_lds[wv & 7][lane] = 0;
 #endif
   FIT_MARK_DECL;
 
@@ -1030,7 +1036,7 @@ __device__ __forceinline__ void fit_body(const FitArgs &a, const long long slot,
     const bool live0 = wv * 16 + m16 < min(a.B, N);
     float gx[PRE_KC], gz;
     request_row(gx, gz, perm_all[live0 ? wv * 16 + m16 : 0]);
-    park_row(gx, gz, live0);
+    if (wv < BORE_THREADS / 64) park_row(gx, gz, live0);
   }
 
   // (the epochs in two instantiations -- rows parked ahead or gathered in the step -- chosen once: tested
@@ -1255,10 +1261,12 @@ __device__ __forceinline__ void fit_body(const FitArgs &a, const long long slot,
           misc[0] = 0.f;  // consumed; re-accumulated from the updated weights below
         }
       } else if constexpr (PIPE) {  // a wave without rows in this step may have some in the next
-        float gx[PRE_KC], gz;
-        request_row(gx, gz, src);
-        park_row(gx, gz, live_n);
-        if (wv == BORE_THREADS / 64 - 1 && s == steps - 1 && e + 2 < a.epochs) {
+        if (wv < BORE_THREADS / 64) {
+          float gx[PRE_KC], gz;
+          request_row(gx, gz, src);
+          park_row(gx, gz, live_n);
+        }
+        if (wv == draw_wave && s == steps - 1 && e + 2 < a.epochs) {
           // (an opaque copy keeps the epoch's hash in THIS wave's branch: wave-uniform scalar code is
           // otherwise hoisted in front of every wave's step)
           long long draw_epoch = epoch0 + e + 2;
@@ -1479,7 +1487,7 @@ __device__ __forceinline__ void fit_body(const FitArgs &a, const long long slot,
   }
   if (tid == 0) a.at[model] = t0 + (long long)a.epochs * steps;
 #ifdef BORE_FIT_MARKS
-  if (lane < 32) atomicAdd(&g_fit_acc[wv & 3][lane], (unsigned long long)g_fit_lds[wv & 3][lane]);
+  if (lane < 32) atomicAdd(&g_fit_acc[wv & 7][lane], (unsigned long long)g_fit_lds[wv & 7][lane]);
 #endif
 }
 
@@ -1563,7 +1571,7 @@ __global__ __launch_bounds__(BORE_THREADS) void fit_bf16_kernel(const FitBf16Arg
   bool first_step = true;
   __syncthreads();
 #ifdef BORE_FIT_MARKS
-  if (lane < 32) g_fit_lds[wv & 3][lane] = 0;
+  if (lane < 32) g_fit_lds[wv & 7][lane] = 0;
 #endif
   FIT_MARK_DECL;
 
@@ -1745,7 +1753,7 @@ __global__ __launch_bounds__(BORE_THREADS) void fit_bf16_mfma_kernel(const FitBf
   bool first_step = true;
   __syncthreads();
 #ifdef BORE_FIT_MARKS
-  if (lane < 32) g_fit_lds[wv & 3][lane] = 0;
+  if (lane < 32) g_fit_lds[wv & 7][lane] = 0;
 #endif
   FIT_MARK_DECL;
   // The float32 MASTER weights live in registers for the launch: the lane's four of each of this wave's tiles

@@ -131,7 +131,7 @@ struct RegNet {
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) v[t][r] = act_fwd<DELTAS == 1>(A, v[t][r]);  // (DELTAS == 1: the fit's network)
+      for (int r = 0; r < 4; ++r) v[t][r] = act_fwd<DELTAS == 1 && !BF16>(A, v[t][r]);  // (DELTAS == 1: the fit's network)
   }
   template <int NT>
   static __device__ __forceinline__ void act_tiles_rt(int a, float (&v)[T][4]) {
@@ -285,7 +285,7 @@ struct RegNet {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const bool valid = 16 * t + 4 * q + r < L.w[l];
-          h[l][t][r] = valid ? rnd(act_fwd<DELTAS == 1>(a, acc[r] + bias[r])) : 0.f;
+          h[l][t][r] = valid ? rnd(act_fwd<DELTAS == 1 && !BF16>(a, acc[r] + bias[r])) : 0.f;
         }
       }
     }

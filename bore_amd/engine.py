@@ -69,6 +69,13 @@ def lbfgsb_opts(options):
                            float(o["ftol"]), float(o["gtol"]))
 
 
+# engines whose close() came while some engine of this process was inside run() (see NativeEngine.close)
+_RUN_DEPTH = [0]
+_DEFERRED = []
+import threading as _threading_run
+_RUN_LOCK = _threading_run.Lock()       # (ShardedEngine runs its engines on several threads)
+
+
 class NativeEngine:
     """The replica engine with its host loop in C++ (``bore_engine_*``, bore_amd/csrc/
     bore_engine.hip): same loops, same streams of random numbers, same kernels and the same
@@ -147,10 +154,21 @@ class NativeEngine:
     def close(self):
         """Free the engine's device memory, pinned memory and streams now.  (The callback closure refers
         back to the engine: without this an engine lives until the cycle collector runs, and the streams of
-        several dead engines share the process's hardware queues with the live one's.)"""
+        several dead engines share the process's hardware queues with the live one's.)
+
+        NOT while any engine of the process is inside ``run``: ``bore_engine_destroy`` frees device memory, which waits
+        for the device to be idle -- and a running engine's resident / work-queue kernel waits on its CUs for objective
+        values that the host, stuck in the free, would never deliver (found in round 6: the cycle collector finalised a
+        dead engine from INSIDE another engine's objective callback and the run hung).  Such a close is deferred to the
+        end of the outermost ``run``."""
         h, self._h = getattr(self, "_h", None), None
         if h:
-            _lib.lib().bore_engine_destroy(h)
+            with _RUN_LOCK:
+                defer = _RUN_DEPTH[0] > 0
+                if defer:
+                    _DEFERRED.append(h)
+            if not defer:
+                _lib.lib().bore_engine_destroy(h)
 
     def __del__(self):
         try:
@@ -159,7 +177,16 @@ class NativeEngine:
             pass
 
     def run(self, n_steps):
-        rc = _lib.lib().bore_engine_run(self._h, int(n_steps))
+        with _RUN_LOCK:
+            _RUN_DEPTH[0] += 1
+        try:
+            rc = _lib.lib().bore_engine_run(self._h, int(n_steps))
+        finally:
+            with _RUN_LOCK:
+                _RUN_DEPTH[0] -= 1
+                late = [_DEFERRED.pop() for _ in range(len(_DEFERRED))] if _RUN_DEPTH[0] == 0 else []
+            for h in late:                      # (engines closed or collected while a run was in progress)
+                _lib.lib().bore_engine_destroy(h)
         if self._error is not None:             # the objective raised: the engine stopped
             e, self._error = self._error, None
             raise e

@@ -468,6 +468,11 @@ int bore_engine_observations(bore_engine *engine, double *X, double *y);
 int bore_engine_state(bore_engine *engine, float *theta, float *adam_m, float *adam_v,
                       int64_t *adam_t);
 int bore_engine_get_stats(bore_engine *engine, bore_engine_stats *out, int reset);
+/* Frees the engine's device and pinned memory and its streams.  NOT from inside an objective callback, nor from
+ * another thread while ANY engine of the process is inside bore_engine_run on the same device: freeing device memory
+ * waits for the device to be idle, and a running engine's resident / work-queue kernel waits on its CUs for objective
+ * values that the host, stuck in the free, would never deliver.  (The Python wrapper defers such a close to the end of
+ * the outermost run: bore_amd.engine.NativeEngine.close.) */
 void bore_engine_destroy(bore_engine *engine);
 
 #ifdef __cplusplus

@@ -425,6 +425,38 @@ def test_async_engine_runs_the_plugins_default_network_fused(gpu, monkeypatch, l
     c = NativeEngine(np.arange(5), async_loops=True, **dict(kw, input_dim=6))
     c.run(2)
     assert c.take_stats()["fit_ms"] > 0
+    for eng in (a, b, c):
+        eng.close()
+
+
+def test_an_engine_collected_inside_another_engines_callback_does_not_hang_the_run(gpu):
+    """Round 6: `bore_engine_destroy` frees device memory, which waits for an idle device; a resident kernel waits on
+    its CUs for objective values.  An engine finalised (cycle collector, or an explicit close) from INSIDE another
+    engine's objective callback therefore used to hang the run.  The close is now deferred to the end of the run."""
+    import gc
+    from bore_amd import engine as E
+    from bore_amd.engine import NativeEngine
+    dead = NativeEngine(np.arange(4), async_loops=True, epochs=5, num_samples=32, objective="branin01")
+    dead.run(1)
+    calls, armed = [], [False]
+
+    def objective(X):
+        nonlocal dead
+        if armed[0] and dead is not None:    # first call of the live engine's run: drop the other engine here
+            assert E._RUN_DEPTH[0] == 1
+            dead.close()                     # (what __del__ does when the collector runs here)
+            assert len(E._DEFERRED) == 1     # deferred, not destroyed under the running kernel
+            dead = None
+            gc.collect()
+        calls.append(len(X))
+        return np.sum((X - 0.3) ** 2, axis=-1)
+
+    live = NativeEngine(np.arange(10, 16), async_loops=True, epochs=5, num_samples=32, objective=objective)
+    calls.clear()                            # (the constructor evaluated the initial design)
+    armed[0] = True
+    live.run(3)                              # used to hang here
+    assert len(calls) >= 1 and dead is None and not E._DEFERRED and E._RUN_DEPTH[0] == 0
+    live.close()
 
 
 def test_async_engine_launch_chain_for_other_models(gpu):

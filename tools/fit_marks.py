@@ -15,7 +15,7 @@ warm = int(sys.argv[3]) if len(sys.argv) > 3 else 5
 eng = NativeEngine(np.arange(L), async_loops=True)
 eng.run(warm)
 eng.take_stats()
-buf = (C.c_ulonglong * 128)()
+buf = (C.c_ulonglong * 256)()
 lib.bore_debug_fit_marks(buf, 1)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
@@ -24,7 +24,7 @@ torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 st = eng.take_stats()
 lib.bore_debug_fit_marks(buf, 0)
-a = np.array(buf, dtype=np.float64).reshape(4, 32)
+a = np.array(buf, dtype=np.float64).reshape(8, 32)
 names = ["gather+requests", "forward", "loss+delta", "backward+copies", "wait mid barrier", "dW+Adam phase", "wait end barrier",
          "step loop top -> step", "  task: requests", "  task: matrix chain", "  task: Adam+stores", "(a mark itself)", "(end barrier -> epoch top)", "(epoch top -> shuffle chosen)", "(-> step loop top)", "(mid barrier -> own task done)"]
 n_steps = a[:, 16 + 5].max()          # every wave passes mark 5 once per Adam step

@@ -23,7 +23,7 @@ X = torch.from_numpy(rs.uniform(size=(L, N, D)).astype(np.float32)).cuda()
 z = torch.from_numpy((rs.uniform(size=(L, N)) < 0.25).astype(np.float32)).cuda()
 ops.mlp_fit(desc, th, m, v, t, X, z, 2, 64, seed=3, want_loss=False)
 torch.cuda.synchronize()
-buf = (C.c_ulonglong * 128)()
+buf = (C.c_ulonglong * 256)()
 _lib.lib().bore_debug_fit_marks(buf, 1)
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
@@ -31,13 +31,13 @@ ops.mlp_fit(desc, th, m, v, t, X, z, E, 64, seed=3, epoch0=2, want_loss=False)
 e1.record()
 torch.cuda.synchronize()
 _lib.lib().bore_debug_fit_marks(buf, 0)
-a = np.array(buf, dtype=np.float64).reshape(4, 32)
+a = np.array(buf, dtype=np.float64).reshape(8, 32)
 names = ["gather+requests", "forward", "loss+delta", "backward+copies", "wait mid barrier", "dW+Adam phase", "wait end barrier",
          "step loop top -> step", "  task: requests", "  task: matrix chain", "  task: Adam+stores", "(a mark itself)", "(end barrier -> epoch top)",
          "(epoch top -> shuffle chosen)", "(-> step loop top)", "(mid barrier -> own task done)"]
 n_steps = a[:, 16 + 5].max()
 print(f"{D}->{'-'.join(map(str, units))}, N {N}, {L} loops, {E} epochs: {1e3 * e0.elapsed_time(e1) / (E * ((N + 63) // 64)):.2f} us per Adam step (marks build); {n_steps:.0f} steps marked")
 for i, nm in enumerate(names):
-    print(f"  {nm:30s} " + "  ".join(f"{a[w, i] / max(a[w, 16 + i], 1):7.0f} ({a[w, 16 + i] / max(n_steps, 1):4.2f})" for w in range(4)))
-print("  sum of 0..7 per step           " + "  ".join(f"{sum(a[w, i] for i in range(8)) / max(n_steps, 1):7.0f}       " for w in range(4)))
-print("  12..14 per step                " + "  ".join(f"{sum(a[w, i] for i in (12, 13, 14)) / max(n_steps, 1):7.0f}       " for w in range(4)))
+    print(f"  {nm:30s} " + "  ".join(f"{a[w, i] / max(a[w, 16 + i], 1):7.0f} ({a[w, 16 + i] / max(n_steps, 1):4.2f})" for w in range(8) if a[w, 16 + 7] > 0))
+print("  sum of 0..7 per step           " + "  ".join(f"{sum(a[w, i] for i in range(8)) / max(n_steps, 1):7.0f}       " for w in range(8) if a[w, 16 + 7] > 0))
+print("  12..14 per step                " + "  ".join(f"{sum(a[w, i] for i in (12, 13, 14)) / max(n_steps, 1):7.0f}       " for w in range(8) if a[w, 16 + 7] > 0))
