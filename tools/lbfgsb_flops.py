@@ -4,7 +4,7 @@ operation counted (tests/native/lbfgsb_flops.cpp: `double` replaced by a countin
 driven on the DEVICE-trained network of one loop of the config -- f / g of every evaluation come from the GPU
 (bore_mlp_value_and_input_grad), the starts from the screening kernel -- for a sample of the restarts.  The counted
 run must ask for exactly the evaluations the device's own restart of the same start asks for (same header, same
-operations; checked).  Writes profiles/r5/optimiser_flops.json, which bench.py's restart roofline reads.
+operations; checked).  Writes profiles/r6/optimiser_flops.json, which bench.py's restart roofline reads.
 usage (GPU box): python tools/lbfgsb_flops.py [restarts per config]"""
 import ctypes as C, json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -75,5 +75,5 @@ for name, c in CONFIGS.items():
          "network_flops_per_evaluation_fwd_bwd": 4.0 * sum(i * o for i, o in zip([D] + units[:-1], units)), **launch}
     out["configs"][name] = e
     print(name, json.dumps(e), flush=True)
-os.makedirs(os.path.join(ROOT, "gpurun_out", "r5"), exist_ok=True)
-json.dump(out, open(os.path.join(ROOT, "gpurun_out", "r5", "optimiser_flops.json"), "w"), indent=1)
+os.makedirs(os.path.join(ROOT, "gpurun_out", "r6"), exist_ok=True)
+json.dump(out, open(os.path.join(ROOT, "gpurun_out", "r6", "optimiser_flops.json"), "w"), indent=1)
