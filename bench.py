@@ -980,7 +980,7 @@ def run_rank(args):
                        "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"),
                        # how long a loop's workgroup waits on its CU for the objective value
                        # before it gives the slot up (0 = one launch per loop-iteration)
-                       "resident_wait_us": float(os.environ.get("BORE_ASYNC_RESIDENT_US", 2000)),
+                       "resident_wait_us": 2000.0,      # (bore_engine_cfg::resident_wait_us: the library's default)
                        "N_start": int(r["n_start"]),
                        "N_end": int(r["n_end"]), "parallelism": f"replica-shard x{world}"},
             "roofline": dominant,

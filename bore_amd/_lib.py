@@ -72,7 +72,9 @@ class EngineCfg(C.Structure):
                 ("num_starts", C.c_int32), ("num_samples", C.c_int32), ("transform", C.c_int32),
                 ("deduplicate", C.c_int32), ("async_loops", C.c_int32), ("seed", C.c_uint64),
                 ("gamma", C.c_double), ("adam", AdamCfg), ("lbfgsb", LbfgsbOpts),
-                ("low", C.POINTER(C.c_double)), ("high", C.POINTER(C.c_double))]
+                ("low", C.POINTER(C.c_double)), ("high", C.POINTER(C.c_double)),
+                ("resident_wait_us", C.c_int32), ("worker_streams", C.c_int32), ("work_queue", C.c_int32),
+                ("reserved", C.c_int32)]
 
 
 class EngineStats(C.Structure):

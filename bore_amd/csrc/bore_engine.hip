@@ -362,7 +362,7 @@ int async_alloc(bore_engine *e, int64_t cap) {
 
 // How many loops of this engine's model one CU holds (the fused kernels' registers and the LDS their phases need at
 // the current record capacity: iteration_launch asked without launching), and from that the schedule: all loops
-// resident, or -- more loops than resident workgroups -- the work queue.  BORE_ASYNC_QUEUE = 0 / 1 forces the
+// resident, or -- more loops than resident workgroups -- the work queue.  bore_engine_cfg::work_queue = 0 / 1 forces the
 // launch-per-batch schedule of round 3 / the queue (tests, A/B).  Called when the engine is created and whenever
 // the records have grown (a longer data set in LDS may cost a loop per CU).
 static int async_decide_schedule(bore_engine *e) {
@@ -391,7 +391,7 @@ static int async_decide_schedule(bore_engine *e) {
   }
   if (per_cu < 1) return fail(BORE_E_UNSUPPORTED, "engine: the fused kernel does not fit a compute unit with records of %lld rows", (long long)A.cap);
   A.per_cu = per_cu;
-  const int forced = getenv("BORE_ASYNC_QUEUE") ? atoi(getenv("BORE_ASYNC_QUEUE")) : -1;
+  const int forced = c.work_queue;
   const int resident_cap = per_cu * device_cus();
   A.queue = forced < 0 ? L > resident_cap : forced != 0;
   if (A.queue) {
@@ -472,9 +472,9 @@ int async_create(bore_engine *e, const double *X0, const double *y0) {
   A.done_ids.assign(L, 0);
   A.fused = iteration_supported(&e->desc);
   // Residency: a loop's workgroup stays on its CU between iterations and waits this long for the
-  // objective value before it gives its slot up (BORE_ASYNC_RESIDENT_US; 0 = one iteration per
+  // objective value before it gives its slot up (bore_engine_cfg::resident_wait_us; 0 = one iteration per
   // launch).  Dropped by the launcher when the device cannot hold all loops at once.
-  const double resident_us = getenv("BORE_ASYNC_RESIDENT_US") ? atof(getenv("BORE_ASYNC_RESIDENT_US")) : 2000.0;
+  const double resident_us = e->cfg.resident_wait_us < 0 ? 2000.0 : (double)e->cfg.resident_wait_us;
   A.wait_ticks = A.fused && resident_us > 0 ? (int64_t)(resident_us * 1e3 / A.ns_per_tick) : 0;
   // Worker streams: a dozen independent single-kernel launches in flight when fused (each stream
   // needs its own hardware queue -- streams sharing one serialise, which halves the throughput --
@@ -484,7 +484,7 @@ int async_create(bore_engine *e, const double *X0, const double *y0) {
     const int queues = getenv("GPU_MAX_HW_QUEUES") ? atoi(getenv("GPU_MAX_HW_QUEUES")) : 4;
     if (n_workers > queues - 2) n_workers = queues - 2 > 2 ? queues - 2 : 2;
   }
-  if (getenv("BORE_ASYNC_WORKERS")) n_workers = atoi(getenv("BORE_ASYNC_WORKERS"));
+  if (e->cfg.worker_streams > 0) n_workers = e->cfg.worker_streams;
   A.workers.resize(n_workers > 0 ? n_workers : 1);
   for (Worker &w : A.workers) {
     HIP_TRY(hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking));

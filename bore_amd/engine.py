@@ -86,10 +86,14 @@ class NativeEngine:
     def __init__(self, loop_ids, input_dim=2, units=(16, 16, 1), acts=("relu", "relu", "sigmoid"),
                  transform="identity", gamma=0.25, epochs=200, batch_size=64, num_starts=3,
                  num_samples=1024, n_init=10, objective=branin01, options=None, device=None,
-                 seed=0, groups=4, deduplicate=False, async_loops=False):
+                 seed=0, groups=4, deduplicate=False, async_loops=False, resident_wait_us=None,
+                 worker_streams=None, work_queue=None):
         """async_loops: every loop advances on its own (a loop re-enters the next launch as soon
         as ITS restarts are done instead of waiting for the slowest loop of its group); same
-        trajectories, tested.  Needs num_starts <= 4."""
+        trajectories, tested.  Needs num_starts <= 16.  Its knobs (None = the library's default; bore_engine_cfg,
+        ABI 12 -- environment variables until round 5): ``resident_wait_us`` how long a loop's workgroup waits on its
+        CU for the objective value before it parks (0: one launch per loop-iteration), ``worker_streams``,
+        ``work_queue`` False / True: never / always the persistent work-queue launch (default: by size)."""
         self.device = device or _lib.require_gpu()
         self.loop_ids = np.asarray(loop_ids, dtype=np.int64)
         self.L = L = len(self.loop_ids)
@@ -140,7 +144,10 @@ class NativeEngine:
                              _lib.TRANSFORM[tr.name], int(bool(deduplicate)), int(bool(async_loops)),
                              int(seed) & (2 ** 64 - 1), float(gamma),
                              _lib.AdamCfg(1e-3, 0.9, 0.999, 1e-7),
-                             lbfgsb_opts(dict(options or dict(maxiter=1000, ftol=1e-9))), lo_p, hi_p)
+                             lbfgsb_opts(dict(options or dict(maxiter=1000, ftol=1e-9))), lo_p, hi_p,
+                             -1 if resident_wait_us is None else int(resident_wait_us),
+                             0 if worker_streams is None else int(worker_streams),
+                             -1 if work_queue is None else int(bool(work_queue)), 0)
         self.n_groups = cfg.groups
         th = np.ascontiguousarray(th)
         X0, y0 = np.ascontiguousarray(X0, dtype=np.float64), np.ascontiguousarray(y0, dtype=np.float64)
@@ -230,8 +237,6 @@ class NativeEngine:
         return X[np.arange(self.L), i], y[np.arange(self.L), i]
 
 
-import threading as _threading
-_ENV_LOCK = _threading.Lock()
 
 
 class ShardedEngine:
@@ -249,27 +254,13 @@ class ShardedEngine:
     whole device as its own), and the worker streams are divided among them."""
 
     def __init__(self, loop_ids, shards=2, **kw):
-        import os
         ids = np.asarray(loop_ids, dtype=np.int64)
         shards = int(max(1, min(shards, len(ids))))
-        # (bore_engine_create reads these three from the environment: the swap is process-wide, so engines are
-        # created under a lock and what the user had set comes back afterwards)
-        _ENV_LOCK.acquire()
-        saved = {k: os.environ.get(k) for k in ("BORE_ASYNC_RESIDENT_US", "BORE_ASYNC_WORKERS", "BORE_ASYNC_QUEUE")}
-        try:
-            if shards > 1:      # (read by bore_engine_create)
-                os.environ["BORE_ASYNC_RESIDENT_US"] = "0"
-                os.environ["BORE_ASYNC_WORKERS"] = str(max(2, 12 // shards))
-                # (each engine's work-queue kernel would hold the whole device until its run ends)
-                os.environ["BORE_ASYNC_QUEUE"] = "0"
-            self.engines = [NativeEngine(part, **kw) for part in np.array_split(ids, shards)]
-        finally:
-            for k, v in saved.items():
-                if v is None:
-                    os.environ.pop(k, None)
-                else:
-                    os.environ[k] = v
-            _ENV_LOCK.release()
+        if shards > 1:
+            # (no resident workgroups: each engine would count the whole device as its own; no work queue: its
+            # kernel would hold the device until the run ends; the worker streams divided among the shards)
+            kw = dict(kw, resident_wait_us=0, worker_streams=max(2, 12 // shards), work_queue=False)
+        self.engines = [NativeEngine(part, **kw) for part in np.array_split(ids, shards)]
         e0 = self.engines[0]
         self.loop_ids, self.L, self.D, self.P = ids, len(ids), e0.D, e0.P
         self.n_groups = e0.n_groups

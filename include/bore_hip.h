@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define BORE_ABI_VERSION 11
+#define BORE_ABI_VERSION 12
 #define BORE_MAX_LAYERS 8
 #define BORE_BATCH_MAX 64 /* rows per tile == wavefront width */
 #define BORE_DIM_MAX 64   /* largest input dimension for the by-value bound arrays */
@@ -415,6 +415,14 @@ typedef struct bore_engine_cfg {
   bore_adam_cfg adam;
   bore_lbfgsb_opts lbfgsb;
   const double *low, *high; /* HOST fp64 [D]: the search box (copied) */
+  /* ABI 12 (round 6; were the environment variables BORE_ASYNC_RESIDENT_US / _WORKERS / _QUEUE).  Asynchronous schedule: */
+  int32_t resident_wait_us; /* how long a loop's workgroup waits on its CU for the objective value before it parks:
+                               < 0 the default (2000), 0 = one launch per loop-iteration */
+  int32_t worker_streams;   /* <= 0 the default (12 single-kernel launches in flight when fused, bounded by
+                               GPU_MAX_HW_QUEUES - 2; 4 launch chains otherwise) */
+  int32_t work_queue;       /* < 0 by size (more loops than the device holds at once), 0 never (the launch-per-batch
+                               schedule of round 3), 1 always (one persistent launch fed by the host) */
+  int32_t reserved;         /* 0 */
 } bore_engine_cfg;
 
 /* Sums since creation / the last reset (HIP-event durations of the two big kernels, the

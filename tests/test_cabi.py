@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol(built):
     raw = ctypes.CDLL(_lib.LIB_PATH)
     for name in header_functions():
         assert hasattr(raw, name), name
-    assert built.bore_abi_version() == 11
+    assert built.bore_abi_version() == 12
 
 
 def test_library_carries_the_digest_of_its_sources(built):
@@ -84,3 +84,26 @@ def test_reading_the_built_digest_does_not_load_the_library():
             "assert 'libbore_hip' not in open('/proc/self/maps').read()")
     r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr[-1500:]
+
+
+def test_ctypes_structures_have_the_headers_layout(tmp_path):
+    """The ctypes mirrors of the C structures (bore_amd._lib) against the header as a C compiler lays it out: sizes and
+    the offsets of the fields added last (ABI 12: bore_engine_cfg's resident_wait_us / worker_streams / work_queue)."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "bore_hip.h"\n'
+                   'int main(void) { printf("%zu %zu %zu %zu %zu %zu %zu\\n", sizeof(bore_engine_cfg), '
+                   'offsetof(bore_engine_cfg, low), offsetof(bore_engine_cfg, resident_wait_us), '
+                   'offsetof(bore_engine_cfg, work_queue), sizeof(bore_engine_stats), sizeof(bore_lbfgsb_opts), '
+                   'sizeof(bore_adam_cfg)); return 0; }\n')
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", os.path.join(root, "include"), str(src), "-o", str(exe)], check=True)
+    got = [int(v) for v in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()]
+    want = [ctypes.sizeof(_lib.EngineCfg), _lib.EngineCfg.low.offset, _lib.EngineCfg.resident_wait_us.offset,
+            _lib.EngineCfg.work_queue.offset, ctypes.sizeof(_lib.EngineStats), ctypes.sizeof(_lib.LbfgsbOpts),
+            ctypes.sizeof(_lib.AdamCfg)]
+    assert got == want, (got, want)

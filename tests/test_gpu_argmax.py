@@ -395,19 +395,18 @@ def test_async_engine_equals_lockstep_engine(gpu, dedup):
     assert sa["phase_iterations"] == 37 * 15 and sa["phase_ns_fit"] > 0 and sa["phase_ns_lbfgsb"] > 0
 
 
-@pytest.mark.parametrize("loops,queue", [(23, "0"), (40, "1")])
+@pytest.mark.parametrize("loops,queue", [(23, False), (40, True)])
 def test_async_engine_runs_the_plugins_default_network_fused(gpu, monkeypatch, loops, queue):
     """Round 6: the network the reference's only in-repo caller builds -- D -> 32-32-32-1, elu x3
     + a linear output, transform sigmoid, 5 restarts, gamma 1/3 (bore/plugins/hpbandster/base.py:23-33 ->
-    bore/models.py:16-19) -- has the fused loop kernel at its 16 compiled inputs: resident workgroups (BORE_ASYNC_QUEUE
-    = 0) and the work queue (= 1), five restarts per loop in one workgroup.  Same trajectories and weights as the
+    bore/models.py:16-19) -- has the fused loop kernel at its 16 compiled inputs: resident workgroups (work_queue
+    False) and the work queue (True), five restarts per loop in one workgroup.  Same trajectories and weights as the
     lock-step engine's five-launch chain, bit for bit."""
     from bore_amd.engine import NativeEngine
-    monkeypatch.setenv("BORE_ASYNC_QUEUE", queue)
     obj = lambda X: np.sum((X - 0.4) ** 2, axis=-1) + 0.1 * np.sin(5.0 * X.sum(axis=-1))
     kw = dict(input_dim=16, units=(32, 32, 32, 1), acts=("elu", "elu", "elu", "linear"), transform="sigmoid", gamma=1.0 / 3.0,
               epochs=12, num_samples=128, num_starts=5, n_init=20, objective=obj)
-    a = NativeEngine(np.arange(100, 100 + loops), async_loops=True, **kw)
+    a = NativeEngine(np.arange(100, 100 + loops), async_loops=True, work_queue=queue, **kw)
     b = NativeEngine(np.arange(100, 100 + loops), groups=2, **kw)
     a.run(4)
     a.run(3)
@@ -728,9 +727,7 @@ def test_work_queue_engine_equals_lockstep_engine(gpu, monkeypatch, dedup):
     would be natural for them (the queue, not the grid, hands out the work) and with the duplicate filter."""
     from bore_amd.engine import NativeEngine
     kw = dict(epochs=20, num_samples=64, deduplicate=dedup)
-    monkeypatch.setenv("BORE_ASYNC_QUEUE", "1")
-    a = NativeEngine(np.arange(3, 40), async_loops=True, objective="branin01", **kw)
-    monkeypatch.delenv("BORE_ASYNC_QUEUE")
+    a = NativeEngine(np.arange(3, 40), async_loops=True, objective="branin01", work_queue=True, **kw)
     b = NativeEngine(np.arange(3, 40), groups=3, **kw)
     a.run(5)
     a.run(1)
@@ -817,7 +814,6 @@ def test_resident_workgroups_park_and_resume_with_a_slow_objective(gpu, monkeypa
     and as with an objective that answers at once (no parking)."""
     import time
     from bore_amd.engine import NativeEngine, branin01
-    monkeypatch.setenv("BORE_ASYNC_RESIDENT_US", "150")
     calls = []
 
     def slow(X):
@@ -826,7 +822,7 @@ def test_resident_workgroups_park_and_resume_with_a_slow_objective(gpu, monkeypa
         return branin01(X)
 
     kw = dict(epochs=20, num_samples=64)
-    a = NativeEngine(np.arange(5, 30), async_loops=True, objective=slow, **kw)
+    a = NativeEngine(np.arange(5, 30), async_loops=True, objective=slow, resident_wait_us=150, **kw)
     b = NativeEngine(np.arange(5, 30), groups=2, **kw)
     a.run(6)
     b.run(6)
@@ -835,8 +831,7 @@ def test_resident_workgroups_park_and_resume_with_a_slow_objective(gpu, monkeypa
         assert np.array_equal(u, v)
     st = a.take_stats()
     assert st["batches"] > 6                   # parked loops came back through later launches
-    monkeypatch.setenv("BORE_ASYNC_RESIDENT_US", "0")   # one launch per loop-iteration (inlined kernel)
-    c = NativeEngine(np.arange(5, 30), async_loops=True, **kw)
+    c = NativeEngine(np.arange(5, 30), async_loops=True, resident_wait_us=0, **kw)   # one launch per loop-iteration (inlined kernel)
     c.run(6)
     assert np.array_equal(c.X, b.X) and np.array_equal(c.state()[0], b.state()[0])
 
