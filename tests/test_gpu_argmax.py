@@ -977,3 +977,29 @@ def test_screen_split_over_workgroups_gives_the_same_bits(gpu, monkeypatch, D, u
         assert np.array_equal(u, v)
     for u, v in zip(outs[0][:3], outs[0][3:]):      # sampled == in-memory candidates
         assert np.array_equal(u, v)
+
+
+def test_flags_by_fenced_store_where_the_link_has_no_host_atomics(gpu):
+    """the resident kernels publish a loop's flag by a system-scope atomic exchange on pinned memory only
+    where the link does host-native atomics; elsewhere -- forced here with BORE_ASYNC_DEBUG=2, in a process of its own
+    because the choice is made once per device and process -- by a release store behind a system-scope fence.  Same
+    trajectories as the lock-step engine, resident and work-queue schedules."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import numpy as np\n"
+        "from bore_amd.engine import NativeEngine\n"
+        "kw = dict(epochs=20, num_samples=64)\n"
+        "b = NativeEngine(np.arange(3, 40), groups=3, **kw); b.run(9)\n"
+        "for q in (False, True):\n"
+        "    a = NativeEngine(np.arange(3, 40), async_loops=True, objective='branin01', work_queue=q, **kw)\n"
+        "    a.run(5); a.run(4)\n"
+        "    assert np.array_equal(a.observations()[0], b.observations()[0]) and np.array_equal(a.state()[0], b.state()[0])\n"
+        "    a.close()\n"
+        "print('same trajectories')\n")
+    env = dict(os.environ, BORE_ASYNC_DEBUG="2", PYTHONPATH=root)
+    p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300, cwd=root)
+    assert p.returncode == 0 and "same trajectories" in p.stdout, p.stderr[-2000:]
+    assert "flags by fenced release store" in p.stderr           # (the engine says which path it took)
