@@ -245,7 +245,11 @@ def test_eight_wave_fit_gives_the_same_bits(gpu, monkeypatch, D, units, acts):
     rs = np.random.RandomState(11)
     desc = _lib.make_desc(D, units, acts)
     # (129..512 rows: the fifth wave draws every epoch's shuffle but the first one epoch ahead, a stage per step)
-    for N, L, E in ((256, 3, 6), (100, 2, 5), (30, 1, 9), (150, 1, 4), (512, 1, 3), (600, 1, 3)):
+    # (round 6: up to 128 rows the eight-wave kernel parks its rows a step ahead and its fifth wave draws the shuffles
+    # two epochs ahead, whatever the last step's size -- the four-wave kernel only when its fourth wave is free then:
+    # 1, 50, 64, 65, 113 and 128 rows are the sizes at which the two kernels take different forms or a step is full)
+    for N, L, E in ((256, 3, 6), (100, 2, 5), (30, 1, 9), (150, 1, 4), (512, 1, 3), (600, 1, 3),
+                    (1, 1, 3), (50, 2, 5), (64, 1, 4), (65, 1, 4), (113, 1, 4), (128, 2, 5)):
         th0 = np.stack([pack(rand_model(rs, D, units)) for _ in range(L)])
         X = dev(rs.uniform(size=(L, N, D)), torch.float32)
         z = dev((rs.uniform(size=(L, N)) < 0.25).astype(np.float32))
