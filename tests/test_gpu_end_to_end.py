@@ -534,6 +534,12 @@ def _wide_chain_teacher_forced(name, D2, U2, A2, compute, L, T, R, NS, E, N0, se
                 assert bf16_logit_ulps[-1] <= 8.0 and fit_loss_rel[-1] <= 0.02, (name, it, l, bf16_logit_ulps[-1], fit_loss_rel[-1])
                 assert n_other <= max(3, 0.1 * n_bad), (name, it, l, n_bad, n_other)
                 assert theta_within[-1] >= 0.93, (name, it, l, theta_within[-1])
+                # (0.97 -- the floor before round 5, what every run so far has measured above -- stays the
+                # recorded EXPECTATION: a run below it passes but says so, so that a drift is seen before it reaches 0.93)
+                if theta_within[-1] < 0.97:
+                    import warnings
+                    warnings.warn(f"{name} iteration {it} loop {l}: share of bfloat16-fit weights within tolerance "
+                                  f"{theta_within[-1]:.4f} < 0.97 (expected 0.975 - 1.0; hard floor 0.93)")
             else:
                 assert err.max() <= 1.0, (name, it, l, float(err.max()))
             Xc = sampling.uniform_candidates(5, 1, NS, lo, hi, model_index0=100 + l, draw_index=it)[0]
