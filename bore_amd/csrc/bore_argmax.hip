@@ -750,7 +750,7 @@ __device__ __forceinline__ void lbfgsb_body(const LbfgsbArgs &a, const long long
     // subspace minimisation comes -- as the zeroed LDS would have been found -- not 6.4 KB of writes per problem)
     if (my_big) wk.vm = lbfgsb::LB_BIG_LAZY;
     const double *x0 = a.x0 + (model * a.R + p0 + myp) * (long long)D;
-    lbfgsb::lbfgsb_init(st, wk, D, a.opt.m, x0, blo, bhi, bnbd);
+    lbfgsb::lbfgsb_init(st, wk, D, a.opt.m, x0, blo, bhi, bnbd, cp);
 #ifdef BORE_STAMPS
     st.lb_last = clock64();
 #endif
@@ -931,7 +931,9 @@ __device__ __forceinline__ void lbfgsb_body(const LbfgsbArgs &a, const long long
       const int rc = lbfgsb::lbfgsb_advance<SHAPE != 1>(st, wk, blo, bhi, bnbd, a.opt, cp);
       if (rc == lbfgsb::LB_NEED_FG) {
         float *row = tile + L.aoff[0] + myrow * L.lda[0];
-        for (int d = 0; d < D; ++d) row[d] = (float)wk.x[d];  // Keras autocast fp64 -> fp32
+        // Keras autocast fp64 -> fp32 (a wave's single problem: a component per lane -- cp = {lane, 64} -- else the
+        // lane's own problem, every component)
+        for (int d = cp.lane; d < D; d += cp.nl) row[d] = (float)wk.x[d];
         pending = 1;
       } else {
         done = true;
@@ -968,14 +970,14 @@ __device__ __forceinline__ void lbfgsb_body(const LbfgsbArgs &a, const long long
       if (pending) {  // lane s < 16 owns row s: its value is already in this lane
         st.f = (double)Tv;
         const float *g = tile + BORE_BATCH_MAX * L.lda[0] + myrow * L.lda[0];
-        for (int d = 0; d < D; ++d) wk.g[d] = (double)g[d];
+        for (int d = cp.lane; d < D; d += cp.nl) wk.g[d] = (double)g[d];
       }
     } else {
       fg_rowblock(L, n_lay, th, tile, wv, a.transform, a.sign, vals);
       if (pending) {
         st.f = (double)vals[myrow];
         const float *g = tile + L.doff[0] + myrow * L.lda[0];
-        for (int d = 0; d < D; ++d) wk.g[d] = (double)g[d];
+        for (int d = cp.lane; d < D; d += cp.nl) wk.g[d] = (double)g[d];
       }
     }
     wave_lds_sync();
@@ -1017,12 +1019,25 @@ __device__ __forceinline__ void lbfgsb_body(const LbfgsbArgs &a, const long long
     st.task = lbfgsb::T_STOP;
     st.msg = lbfgsb::M_MAXFUN;
   }
-  if (myp >= 0 && (!coop || lane == 0)) {  // (coop: one lane reports the shared problem)
+  // (round 6, the 32-input shape: the shared problem's point and gradient go out a component per lane -- one lane
+  // walking 32 components was 64 dependent LDS round trips at the end of every problem of BASELINE config 5, whose
+  // restarts last one iteration: 20.4 -> 19.7 ms.  Not for the narrower shapes: 16->64-64-64-1 14.35 -> 15.0 ms with it,
+  // profiles/r6/ab_log.txt)
+  constexpr bool OUT_PER_LANE = SHAPE == 4;
+  if (OUT_PER_LANE && myp >= 0 && coop) {
     const long long q = model * a.R + p0 + myq;
-    for (int d = 0; d < D; ++d) {
+    for (int d = lane; d < D; d += 64) {
       a.x[q * D + d] = wk.x[d];
       a.jac[q * D + d] = wk.g[d];
     }
+  }
+  if (myp >= 0 && (!coop || lane == 0)) {  // (coop: one lane reports the shared problem)
+    const long long q = model * a.R + p0 + myq;
+    if (!(OUT_PER_LANE && coop))
+      for (int d = 0; d < D; ++d) {
+        a.x[q * D + d] = wk.x[d];
+        a.jac[q * D + d] = wk.g[d];
+      }
     a.fun[q] = st.f;
     int *inf = a.info + q * 5;
     inf[0] = st.nit; inf[1] = st.nfev; inf[2] = st.status; inf[3] = st.task; inf[4] = st.msg;

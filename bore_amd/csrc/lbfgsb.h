@@ -1796,12 +1796,14 @@ LB_HD void finish(State &s, int task, int msg) {
 
 // Initialise a problem.  x0 is clipped into the box (scipy does that before the solver
 // sees it).  nbd[i]: 0 unbounded, 1 lower, 2 both, 3 upper.
+// (c: the lanes of a wave that runs ONE problem share the loop over the variables -- round 6: done by every lane alike it
+// was 32 dependent LDS round trips per problem of BASELINE config 5, whose restarts last one iteration)
 LB_HD void lbfgsb_init(State &s, const Work &w, int n, int m, const double *x0, const double *l,
-                       const double *u, const int *nbd) {
+                       const double *u, const int *nbd, const Coop c = Coop{0, 1}) {
   s = State{};
   s.n = n;
   s.m = m;
-  for (int i = 0; i < n; ++i) {
+  for (int i = c.lane; i < n; i += c.nl) {
     double xi = x0[i];
     if (nbd[i] == 1 || nbd[i] == 2) xi = fmax(xi, l[i]);
     if (nbd[i] == 2 || nbd[i] == 3) xi = fmin(xi, u[i]);
@@ -1882,6 +1884,20 @@ LB_HD int lbfgsb_advance(State &s, const Work &w, const double *l, const double 
     if (n <= 0) { finish(s, T_ERROR, M_N_LE_0); return LB_DONE; }
     if (m <= 0) { finish(s, T_ERROR, M_M_LE_0); return LB_DONE; }
     if (opt.factr < 0.0) { finish(s, T_ERROR, M_FACTR_NEG); return LB_DONE; }
+    if (VL && coop.nl > 1 && n <= coop.nl) {  // one variable per lane; the FIRST offending variable names the error
+      bool bad = false, empty = false;
+      if (coop.lane < n) {
+        const int nb = nbd[coop.lane];
+        bad = nb < 0 || nb > 3;
+        empty = nb == 2 && l[coop.lane] > u[coop.lane];
+      }
+      const unsigned long long mb = lanes_ballot(bad), me = lanes_ballot(empty);
+      if (mb | me) {
+        const unsigned long long first = (mb | me) & (0ull - (mb | me));  // lowest set bit
+        finish(s, T_ERROR, (mb & first) ? M_INVALID_NBD : M_NO_FEASIBLE);
+        return LB_DONE;
+      }
+    } else
     for (int i = 0; i < n; ++i) {
       if (nbd[i] < 0 || nbd[i] > 3) { finish(s, T_ERROR, M_INVALID_NBD); return LB_DONE; }
       if (nbd[i] == 2 && l[i] > u[i]) { finish(s, T_ERROR, M_NO_FEASIBLE); return LB_DONE; }
