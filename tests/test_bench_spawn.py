@@ -162,3 +162,18 @@ def test_failed_rank_fails_the_run():
     p = _run("--gpus", "2", "--steps", "1", "--warmup", "0", "--cpu-seconds", "0")
     assert p.returncode != 0
     assert "rank 0 exited" in p.stderr or "rank 1 exited" in p.stderr
+
+
+def test_under_torch_distributed_run_as_the_driver_launches_n_ranks(tmp_path):
+    """The driver's N > 1 form: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N ...` -- every rank runs the script, rank 0 alone prints, and what it prints last
+    is the compact record."""
+    port = str(29000 + os.getpid() % 2000)
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", port, os.path.join(ROOT, "bench.py"), "--gpus", "2",
+                        "--dry-run", "--steps", "2", "--warmup", "0", "--detail-dir", str(tmp_path)],
+                       env=_plain_env(), capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d, full = _record(p, tmp_path)
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["loops_per_gpu"] == 256
+    assert full["ranks"]["backend_world_size"] == 2 and "efficiency" in d
